@@ -1,0 +1,504 @@
+#!/usr/bin/env python3
+"""Golden-vector generator (TEST INFRASTRUCTURE — runs only in the build container).
+
+Imports the *real* reference (pollen-robotics/reachy2_symbolic_ik, mounted read-only
+at /root/reference) and records inputs + expected outputs of the analytic solve path
+as small .npz fixtures under tests/golden/.  Nothing of the reference's source is
+written to the repo: only numbers.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py [--out tests/golden]
+
+Environment used for the committed fixtures: Python 3.10.12, numpy 2.2.6,
+scipy 1.15.3 (the reference pins scipy==1.8.0, not installable offline; see
+DESIGN.md "oracle pinning").
+
+Reference entry points exercised (file:line in /root/reference/src/reachy2_symbolic_ik):
+  SymbolicIK.__init__                 symbolic_ik.py:26-83
+  SymbolicIK.is_reachable             symbolic_ik.py:121-282
+  SymbolicIK.is_reachable_no_limits   symbolic_ik.py:85-119
+  SymbolicIK.get_joints               symbolic_ik.py:697-863
+  SymbolicIK.get_elbow_position       symbolic_ik.py:684-695
+  ControlIK.__init__                  control_ik.py:28-160
+  ControlIK.symbolic_inverse_kinematics (discrete, continuous)  control_ik.py:162-497
+
+Canonical semantics: every recorded get_joints() is preceded by a FRESH
+is_reachable() on the same solver object.
+"""
+import argparse
+import contextlib
+import io
+import os
+import sys
+import time as _time
+
+import numpy as np
+
+REF_SRC = "/root/reference/src"
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF_SRC)
+
+from scipy.spatial.transform import Rotation as R  # noqa: E402
+
+import reachy2_symbolic_ik.control_ik as ref_control_mod  # noqa: E402
+from reachy2_symbolic_ik.control_ik import ControlIK  # noqa: E402
+from reachy2_symbolic_ik.symbolic_ik import SymbolicIK  # noqa: E402
+
+# state string <-> uint8 code (shared with include/rsik.h, keep in sync)
+STATE_CODES = {
+    "reachable": 0,
+    "Pose out of reach": 1,
+    "Backward pose": 2,
+    "wrist out of range": 3,
+    "limited by wrist": 4,
+    "out of reach - should not happen": 5,
+    "limited by shoulder": 6,
+    "": 7,
+}
+
+ARMS = ["r_arm", "l_arm"]
+SHOULDER = {"r_arm": np.array([0.0, -0.2, 0.0]), "l_arm": np.array([0.0, 0.2, 0.0])}
+NAN = float("nan")
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def make_solver(arm, singularity_offset=0.03):
+    return quiet(SymbolicIK, arm=arm, singularity_offset=singularity_offset)
+
+
+def mirror_pose(pos, eul):
+    """r <-> l mirror rule (src/example/test_random_reachability.py:156-166)."""
+    return np.array([pos[0], -pos[1], pos[2]]), np.array([-eul[0], eul[1], -eul[2]])
+
+
+def solve_symbolic(solver, pos, eul, theta=None, theta_u=None, prev=None):
+    """One canonical solve: fresh is_reachable, then ONE get_joints.
+
+    theta policy: explicit theta, or interval[0] (theta_u None), or a point inside the
+    interval at fraction theta_u in [0,1).
+    Returns dict of plain numbers (NaN where the reference returns [] / None).
+    """
+    pose = np.array([np.array(pos, dtype=float), np.array(eul, dtype=float)])
+    ok, interval, fn, state = solver.is_reachable(pose)
+    out = {
+        "reachable": np.uint8(bool(ok)),
+        "state": np.uint8(STATE_CODES[state]),
+        "interval": np.array([NAN, NAN]),
+        "theta": NAN,
+        "joints": np.full(7, NAN),
+        "elbow": np.full(3, NAN),
+        "elbow_len": np.uint8(0),
+    }
+    if ok:
+        out["interval"] = np.array(interval, dtype=float)
+        if theta is None:
+            if theta_u is None:
+                theta = float(interval[0])
+            else:
+                a, b = float(interval[0]), float(interval[1])
+                if a > b:
+                    b += 2 * np.pi
+                theta = a + theta_u * (b - a)
+        out["theta"] = theta
+        if prev is None:
+            joints, elbow = fn(theta)
+        else:
+            joints, elbow = fn(theta, list(prev))
+        out["joints"] = np.array(joints, dtype=float)
+        out["elbow"] = np.array(elbow[:3], dtype=float)
+        out["elbow_len"] = np.uint8(len(elbow))  # Q2: 4 normally, 3 if projection fired
+    return out
+
+
+def stack(dicts):
+    keys = dicts[0].keys()
+    return {k: np.stack([np.asarray(d[k]) for d in dicts]) for k in keys}
+
+
+def random_poses(rng, arm, n):
+    pos = SHOULDER[arm] + rng.uniform(-0.7, 0.7, size=(n, 3))
+    eul = rng.uniform(-np.pi, np.pi, size=(n, 3))
+    return pos, eul
+
+
+def reachable_poses(rng, solver, arm, n):
+    """Rejection-sample poses whose is_reachable state is 'reachable'."""
+    P, E = [], []
+    while len(P) < n:
+        pos, eul = random_poses(rng, arm, 4096)
+        for p, e in zip(pos, eul):
+            ok, _, _, _ = solver.is_reachable(np.array([p, e]))
+            if ok:
+                P.append(p)
+                E.append(e)
+                if len(P) == n:
+                    break
+    return np.array(P), np.array(E)
+
+
+def pose_to_matrix(pos, eul):
+    M = np.eye(4)
+    M[:3, :3] = R.from_euler("xyz", eul).as_matrix()
+    M[:3, 3] = pos
+    return M
+
+
+# ----------------------------------------------------------------------------------------
+# G0: per-arm constants
+# ----------------------------------------------------------------------------------------
+def gen_constants(out):
+    data = {}
+    for arm in ARMS:
+        for tag, so in (("dflt", 0.03), ("ctrl", -1.01)):
+            s = make_solver(arm, so)
+            p = f"{arm}_{tag}_"
+            data[p + "shoulder_position"] = np.array(s.shoulder_position, dtype=float)
+            data[p + "shoulder_orientation_offset"] = np.array(s.shoulder_orientation_offset, dtype=float)
+            data[p + "upper_arm_size"] = np.float64(s.upper_arm_size)
+            data[p + "forearm_size"] = np.float64(s.forearm_size)
+            data[p + "tip_position"] = np.array(s.tip_position, dtype=float)
+            data[p + "gripper_size"] = np.float64(s.gripper_size)
+            data[p + "max_arm_length"] = np.float64(s.max_arm_length)
+            data[p + "shoulder_wrist_min_distance"] = np.float64(s.shoulder_wrist_min_distance)
+            data[p + "elbow_singularity_position"] = np.array(s.elbow_singularity_position, dtype=float)
+            data[p + "wrist_singularity_position"] = np.array(s.wrist_singularity_position, dtype=float)
+            data[p + "singularity_offset"] = np.float64(s.singularity_offset)
+            data[p + "singularity_limit_coeff"] = np.float64(s.singularity_limit_coeff)
+            data[p + "wrist_limit"] = np.float64(s.wrist_limit)
+            data[p + "backward_limit"] = np.float64(s.backward_limit)
+            data[p + "projection_margin"] = np.float64(s.projection_margin)
+            data[p + "normal_vector_margin"] = np.float64(s.normal_vector_margin)
+            data[p + "elbow_limit"] = np.float64(s.elbow_limit)
+    # URDF-derived parameters (utils.py:661-690) for the host-side parser test
+    c = quiet(ControlIK, urdf_path="../config_files/reachy2.urdf")
+    for arm in ARMS:
+        s = c.symbolic_ik_solver[arm]
+        p = f"{arm}_urdf_"
+        data[p + "shoulder_position"] = np.array(s.shoulder_position, dtype=float)
+        data[p + "shoulder_orientation_offset"] = np.array(s.shoulder_orientation_offset, dtype=float)
+        data[p + "upper_arm_size"] = np.float64(s.upper_arm_size)
+        data[p + "forearm_size"] = np.float64(s.forearm_size)
+        data[p + "tip_position"] = np.array(s.tip_position, dtype=float)
+        data[p + "elbow_singularity_position"] = np.array(s.elbow_singularity_position, dtype=float)
+        data[p + "wrist_limit"] = np.float64(s.wrist_limit)
+        data[p + "previous_theta_init"] = np.float64(c.previous_theta[arm])
+        data[p + "preferred_theta"] = np.float64(c.preferred_theta[arm])
+        data[p + "previous_sol"] = np.array(c.previous_sol[arm], dtype=float)
+    np.savez_compressed(os.path.join(out, "g0_constants.npz"), **data)
+
+
+# ----------------------------------------------------------------------------------------
+# G1: known-answer catalogue
+# ----------------------------------------------------------------------------------------
+def catalogue():
+    d2r = np.radians
+    cat = []
+    # tests/test_ik.py:17-79 (r_arm, default solver) — the reference's own unit-test poses
+    t_ik = [
+        ([0.4, 0.2, 0.1], [d2r(-60), d2r(-90), d2r(20)]),
+        ([0.3, -0.2, -0.3], [d2r(0), d2r(-90), d2r(0)]),
+        ([0.02, -0.2, -0.65], [0.0, 0.0, 0.0]),
+        ([0.0, -0.2, -0.65], [0.0, 0.0, 0.0]),
+        ([0.87, -0.2, -0.0], [0.0, -np.pi / 2, 0.0]),
+        ([0.35, -0.2, -0.28], [0.0, -np.pi / 2, 0.0]),
+    ]
+    for p, e in t_ik:
+        cat.append(("r_arm", p, e))
+    # README.md:73-74 and src/benchmark/ik_benchmarks.py:13-14
+    cat.append(("r_arm", [0.55, -0.3, -0.15], [0, -np.pi / 2, 0]))
+    cat.append(("r_arm", [0.3, -0.1, 0.1], [d2r(20), d2r(-50), d2r(20)]))
+    # src/example/test_go_to.py:169-213 labelled poses (r list; l list is its mirror)
+    go_to_r = [
+        ([0.0001, -0.2, -0.6599], [0, 0, 0]),
+        ([0.38, -0.2, -0.28], [0, -np.pi / 2, 0]),
+        ([0.66, -0.2, -0.0], [0, -np.pi / 2, 0]),
+        ([0.30, -0.2, -0.28], [0.0, 0.0, np.pi / 3]),
+        ([0.0, -0.85, -0.0], [-np.pi / 2, 0, 0]),
+        ([0.0, -0.58, -0.28], [-np.pi / 2, -np.pi / 2, 0]),
+        ([0.15, 0.35, -0.10], [np.pi / 3, -np.pi / 2, 0]),
+        ([0.10, 0.20, -0.22], [np.pi / 3, -np.pi / 2, 0]),
+        ([0.0, -0.2, -0.66], [0.0, 0.0, -np.pi / 3]),
+        ([0.001, -0.2, -0.68], [0.0, 0.0, -np.pi / 3]),
+        ([0.001, -0.2, -0.659], [0.0, np.pi / 2, 0.0]),
+        ([0.38, -0.2, -0.28], [0.0, np.pi / 2, 0.0]),
+        ([0.1, -0.2, 0.0], [0.0, np.pi, 0.0]),
+        ([0.38, -0.2, -0.28], [0.0, 0.0, 0.0]),
+        ([0.1, 0.2, -0.1], [0.0, -np.pi / 2, np.pi / 2]),
+        ([0.0, -0.2, -0.66], [0, 0, 0]),
+    ]
+    for p, e in go_to_r:
+        cat.append(("r_arm", p, e))
+    for p, e in go_to_r:
+        pl, el = mirror_pose(np.array(p, dtype=float), np.array(e, dtype=float))
+        cat.append(("l_arm", list(pl), list(el)))
+    # mirrors of the test_ik / README / benchmark poses for the l arm
+    for p, e in t_ik + [([0.55, -0.3, -0.15], [0, -np.pi / 2, 0]), ([0.3, -0.1, 0.1], [d2r(20), d2r(-50), d2r(20)])]:
+        pl, el = mirror_pose(np.array(p, dtype=float), np.array(e, dtype=float))
+        cat.append(("l_arm", list(pl), list(el)))
+    # geometric edge cases: fully extended arm along +x, min-distance reduce, backward shift of wrist
+    cat.append(("r_arm", [0.66, -0.2, 0.0], [0.0, -np.pi / 2, 0.0]))
+    cat.append(("r_arm", [0.2, -0.2, -0.05], [0.0, -np.pi / 2, 0.0]))
+    cat.append(("r_arm", [0.15, -0.25, -0.1], [0.0, -np.pi / 2, 0.3]))
+    cat.append(("r_arm", [0.05, -0.2, -0.5], [0.0, 0.3, 0.0]))
+    cat.append(("r_arm", [0.03, -0.3, -0.45], [0.2, 0.6, -0.1]))
+    cat.append(("l_arm", [0.2, 0.2, -0.05], [0.0, -np.pi / 2, 0.0]))
+    cat.append(("l_arm", [0.05, 0.2, -0.5], [0.0, 0.3, 0.0]))
+    return cat
+
+
+def control_call(ctrl, arm, M, nb, mode, current_joints=None, preferred_theta=None):
+    ctrl.nb_search_points = nb
+    kw = {}
+    if current_joints is not None:
+        kw["current_joints"] = list(current_joints)
+    if preferred_theta is not None:
+        kw["preferred_theta"] = preferred_theta
+    j, ok, st = quiet(ctrl.symbolic_inverse_kinematics, arm, M, "discrete", constrained_mode=mode, **kw)
+    assert not ctrl.emergency_stop
+    return np.array(j, dtype=float), np.uint8(bool(ok)), np.uint8(STATE_CODES[st])
+
+
+def gen_catalogue(out):
+    cat = catalogue()
+    solvers = {(arm, so): make_solver(arm, so) for arm in ARMS for so in (0.03, -1.01)}
+    ctrl = quiet(ControlIK, urdf_path="../config_files/reachy2.urdf")
+    rows03, rows101 = [], []
+    arm_id, pos, eul, Ms = [], [], [], []
+    cj = {k: [] for k in ("u20", "u64", "l20", "l64")}
+    cf = {k: [] for k in cj}
+    cs = {k: [] for k in cj}
+    for arm, p, e in cat:
+        arm_id.append(ARMS.index(arm))
+        pos.append(np.array(p, dtype=float))
+        eul.append(np.array(e, dtype=float))
+        rows03.append(solve_symbolic(solvers[(arm, 0.03)], p, e))
+        rows101.append(solve_symbolic(solvers[(arm, -1.01)], p, e))
+        M = pose_to_matrix(p, e)
+        Ms.append(M)
+        for key, nb, mode in (("u20", 20, "unconstrained"), ("u64", 64, "unconstrained"),
+                              ("l20", 20, "low_elbow"), ("l64", 64, "low_elbow")):
+            j, ok, st = control_call(ctrl, arm, M, nb, mode)
+            cj[key].append(j)
+            cf[key].append(ok)
+            cs[key].append(st)
+    data = {"arm": np.array(arm_id, dtype=np.uint8), "pos": np.array(pos), "eul": np.array(eul), "M": np.array(Ms)}
+    for k, v in stack(rows03).items():
+        data["so003_" + k] = v
+    for k, v in stack(rows101).items():
+        data["so101_" + k] = v
+    for k in cj:
+        data[f"ctrl_{k}_joints"] = np.array(cj[k])
+        data[f"ctrl_{k}_reachable"] = np.array(cf[k], dtype=np.uint8)
+        data[f"ctrl_{k}_state"] = np.array(cs[k], dtype=np.uint8)
+    np.savez_compressed(os.path.join(out, "g1_catalogue.npz"), **data)
+
+
+# ----------------------------------------------------------------------------------------
+# G2: random sweep, all outcomes
+# ----------------------------------------------------------------------------------------
+def gen_sweep(out, n=20000):
+    rng = np.random.default_rng(0)
+    data = {}
+    for arm in ARMS:
+        solver = make_solver(arm, 0.03)
+        pos, eul = random_poses(rng, arm, n)
+        rows = [solve_symbolic(solver, p, e) for p, e in zip(pos, eul)]
+        data[f"{arm}_pos"] = pos
+        data[f"{arm}_eul"] = eul
+        for k, v in stack(rows).items():
+            data[f"{arm}_{k}"] = v
+    np.savez_compressed(os.path.join(out, "g2_sweep.npz"), **data)
+
+
+# ----------------------------------------------------------------------------------------
+# G3: reachable only, two theta policies, two singularity offsets, prev joints
+# ----------------------------------------------------------------------------------------
+def gen_reachable(out, n=4096):
+    rng = np.random.default_rng(1)
+    data = {}
+    for arm in ARMS:
+        base = make_solver(arm, 0.03)
+        pos, eul = reachable_poses(rng, base, arm, n)
+        tu = rng.uniform(0.0, 1.0, size=n)
+        data[f"{arm}_pos"] = pos
+        data[f"{arm}_eul"] = eul
+        data[f"{arm}_theta_u"] = tu
+        for tag, so in (("so003", 0.03), ("so101", -1.01)):
+            solver = make_solver(arm, so)
+            rows0 = [solve_symbolic(solver, p, e) for p, e in zip(pos, eul)]
+            rows1 = [solve_symbolic(solver, p, e, theta_u=u) for p, e, u in zip(pos, eul, tu)]
+            for k, v in stack(rows0).items():
+                data[f"{arm}_{tag}_i0_{k}"] = v
+            for k, v in stack(rows1).items():
+                data[f"{arm}_{tag}_in_{k}"] = v
+    np.savez_compressed(os.path.join(out, "g3_reachable.npz"), **data)
+
+
+# ----------------------------------------------------------------------------------------
+# G4: ControlIK discrete
+# ----------------------------------------------------------------------------------------
+def gen_control(out, n_uniform=1024, n_reach=1024, n_var=512):
+    rng = np.random.default_rng(2)
+    data = {}
+    for dvt_tag, is_dvt in (("std", False), ("dvt", True)):
+        ctrl = quiet(ControlIK, urdf_path="../config_files/reachy2.urdf", is_dvt=is_dvt)
+        for arm in ARMS:
+            solver = ctrl.symbolic_ik_solver[arm]
+            pu, eu = random_poses(rng, arm, n_uniform)
+            pr, er = reachable_poses(rng, solver, arm, n_reach)
+            pos = np.concatenate([pu, pr])
+            eul = np.concatenate([eu, er])
+            Ms = np.array([pose_to_matrix(p, e) for p, e in zip(pos, eul)])
+            pre = f"{dvt_tag}_{arm}_"
+            data[pre + "M"] = Ms
+            combos = [("u20", 20, "unconstrained"), ("u64", 64, "unconstrained"),
+                      ("l20", 20, "low_elbow"), ("l64", 64, "low_elbow")]
+            if is_dvt:
+                combos = combos[:2]
+            for key, nb, mode in combos:
+                res = [control_call(ctrl, arm, M, nb, mode) for M in Ms]
+                data[pre + key + "_joints"] = np.array([r[0] for r in res])
+                data[pre + key + "_reachable"] = np.array([r[1] for r in res], dtype=np.uint8)
+                data[pre + key + "_state"] = np.array([r[2] for r in res], dtype=np.uint8)
+            if not is_dvt:
+                # argument variations: explicit current_joints and preferred_theta (r-arm convention)
+                idx = rng.choice(len(Ms), size=n_var, replace=False)
+                curj = rng.uniform(-1.0, 1.0, size=(n_var, 7))
+                pth = rng.uniform(-np.pi, np.pi, size=n_var)
+                res = [control_call(ctrl, arm, Ms[i], 20, "unconstrained", current_joints=c, preferred_theta=t)
+                       for i, c, t in zip(idx, curj, pth)]
+                data[pre + "var_idx"] = idx.astype(np.int64)
+                data[pre + "var_current_joints"] = curj
+                data[pre + "var_preferred_theta"] = pth
+                data[pre + "var_joints"] = np.array([r[0] for r in res])
+                data[pre + "var_reachable"] = np.array([r[1] for r in res], dtype=np.uint8)
+                data[pre + "var_state"] = np.array([r[2] for r in res], dtype=np.uint8)
+    np.savez_compressed(os.path.join(out, "g4_control_discrete.npz"), **data)
+
+
+# ----------------------------------------------------------------------------------------
+# G5: elbow positions + is_reachable_no_limits (helpers used by theta search / continuous)
+# ----------------------------------------------------------------------------------------
+def gen_helpers(out, n=2048):
+    rng = np.random.default_rng(3)
+    data = {}
+    for arm in ARMS:
+        solver = make_solver(arm, 0.03)
+        pr, er = reachable_poses(rng, solver, arm, n // 2)
+        pu, eu = random_poses(rng, arm, n // 2)
+        pos = np.concatenate([pr, pu])
+        eul = np.concatenate([er, eu])
+        thetas = rng.uniform(-np.pi, np.pi, size=(len(pos), 4))
+        elb = np.full((len(pos), 4, 3), NAN)
+        nl_joints = np.full((len(pos), 7), NAN)
+        nl_elbow = np.full((len(pos), 3), NAN)
+        nl_ok = np.zeros(len(pos), dtype=np.uint8)
+        for i, (p, e) in enumerate(zip(pos, eul)):
+            pose = np.array([p, e])
+            ok, _, _, _ = solver.is_reachable(pose)
+            if ok:
+                for k in range(4):
+                    elb[i, k] = solver.get_elbow_position(thetas[i, k])[:3]
+            ok2, itv, fn = solver.is_reachable_no_limits(pose)
+            nl_ok[i] = bool(ok2)
+            if ok2:
+                j, el = fn(thetas[i, 0])
+                nl_joints[i] = j
+                nl_elbow[i] = el[:3]
+        data[f"{arm}_pos"] = pos
+        data[f"{arm}_eul"] = eul
+        data[f"{arm}_thetas"] = thetas
+        data[f"{arm}_elbow_at_theta"] = elb
+        data[f"{arm}_nolimits_ok"] = nl_ok
+        data[f"{arm}_nolimits_joints"] = nl_joints
+        data[f"{arm}_nolimits_elbow"] = nl_elbow
+    np.savez_compressed(os.path.join(out, "g5_helpers.npz"), **data)
+
+
+# ----------------------------------------------------------------------------------------
+# G6: ControlIK continuous over pose trajectories, deterministic fake clock
+# ----------------------------------------------------------------------------------------
+class FakeClock:
+    def __init__(self, t0=1000.0):
+        self.t = t0
+
+    def time(self):
+        return self.t
+
+
+def trajectory_pose(t, arm):
+    """Task-space generator shaped like tests/test_sdk.py:38-63 (data, not code)."""
+    x0, y0, z0 = 0.65, -0.2, 0.0
+    r0, p0, w0 = 0.0, -np.pi / 2, 0.0
+    amp = [0.35, 0.35, 0.35, np.pi / 6, np.pi / 6, np.pi / 6]
+    freq = [0.6, 0.34, 0.78, 0.18, 0.31, 0.47]
+    v = [c + a * np.sin(f * t) for c, a, f in zip((x0, y0, z0, r0, p0, w0), amp, freq)]
+    pos, eul = np.array(v[:3]), np.array(v[3:])
+    if arm == "l_arm":
+        pos, eul = mirror_pose(pos, eul)
+    return pos, eul
+
+
+def gen_continuous(out, n_traj=6, n_steps=400):
+    rng = np.random.default_rng(4)
+    data = {}
+    real_time = ref_control_mod.time
+    for arm in ARMS:
+        phases = rng.uniform(0.0, 40.0, size=n_traj)
+        Ms = np.zeros((n_traj, n_steps, 4, 4))
+        J = np.zeros((n_traj, n_steps, 7))
+        F = np.zeros((n_traj, n_steps), dtype=np.uint8)
+        S = np.zeros((n_traj, n_steps), dtype=np.uint8)
+        TH = np.zeros((n_traj, n_steps))
+        ES = np.zeros((n_traj, n_steps), dtype=np.uint8)
+        for k in range(n_traj):
+            clock = FakeClock()
+            ref_control_mod.time = clock
+            try:
+                ctrl = quiet(ControlIK, urdf_path="../config_files/reachy2.urdf")
+                for i in range(n_steps):
+                    t = i / 120.0 + 11.0 + phases[k]
+                    pos, eul = trajectory_pose(t, arm)
+                    M = pose_to_matrix(pos, eul)
+                    Ms[k, i] = M
+                    clock.t += 1.0 / 120.0
+                    j, ok, st = quiet(ctrl.symbolic_inverse_kinematics, arm, M, "continuous", d_theta_max=0.01)
+                    J[k, i] = np.array(j, dtype=float)
+                    F[k, i] = bool(ok)
+                    S[k, i] = STATE_CODES.get(st, 255)
+                    TH[k, i] = ctrl.previous_theta[arm]
+                    ES[k, i] = bool(ctrl.emergency_stop)
+            finally:
+                ref_control_mod.time = real_time
+        data[f"{arm}_phase"] = phases
+        data[f"{arm}_M"] = Ms
+        data[f"{arm}_joints"] = J
+        data[f"{arm}_reachable"] = F
+        data[f"{arm}_state"] = S
+        data[f"{arm}_previous_theta"] = TH
+        data[f"{arm}_emergency_stop"] = ES
+    np.savez_compressed(os.path.join(out, "g6_control_continuous.npz"), **data)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    out = os.path.abspath(args.out)
+    os.makedirs(out, exist_ok=True)
+    steps = [("g0", gen_constants), ("g1", gen_catalogue), ("g2", gen_sweep), ("g3", gen_reachable),
+             ("g4", gen_control), ("g5", gen_helpers), ("g6", gen_continuous)]
+    for name, fn in steps:
+        if args.only and name not in args.only.split(","):
+            continue
+        t0 = _time.time()
+        fn(out)
+        print(f"{name}: done in {_time.time() - t0:.1f}s", flush=True)
+
+
+if __name__ == "__main__":
+    main()

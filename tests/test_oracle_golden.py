@@ -1,0 +1,243 @@
+"""Pins the CPU checker (oracle/) against golden vectors recorded from the real reference.
+
+Bars: reachability flags and state codes bit-exact; intervals / joints / elbows within 1e-9
+(north-star tolerance is 1e-6 rad; the restatement is expected to agree to ~1e-12).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+TOL = 1e-9
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def angle_close(a, b, tol=TOL):
+    """compare angles that the reference does not wrap consistently only up to rounding (no 2pi folding!)."""
+    return np.nanmax(np.abs(a - b)) if a.size else 0.0
+
+
+@pytest.fixture(scope="module")
+def arms():
+    return {(a, so): orc.Arm(a, so) for a in ("r_arm", "l_arm") for so in (0.03, -1.01)}
+
+
+def test_constants(golden_dir):
+    g = load(golden_dir, "g0_constants.npz")
+    for arm in ("r_arm", "l_arm"):
+        for tag, so in (("dflt", 0.03), ("ctrl", -1.01)):
+            a = orc.Arm(arm, so)
+            for f in ("shoulder_position", "shoulder_orientation_offset", "upper_arm_size", "forearm_size", "tip_position",
+                      "gripper_size", "max_arm_length", "shoulder_wrist_min_distance", "elbow_singularity_position",
+                      "wrist_singularity_position", "singularity_offset", "singularity_limit_coeff", "wrist_limit",
+                      "backward_limit", "projection_margin", "normal_vector_margin", "elbow_limit"):
+                np.testing.assert_allclose(a.field(f), g[f"{arm}_{tag}_{f}"], rtol=0, atol=2e-16, err_msg=f"{arm} {tag} {f}")
+
+
+def _singular_rows(g, prefix):
+    """Fully extended arm (elbow pitch == 0 to rounding): elbow yaw and wrist yaw rotate about the same
+    axis, the reference's split between them is decided by 1e-17-level rounding noise (atan2 of two
+    ~1e-17 numbers).  Only j2 + j6 is defined there; those rows are compared through that sum."""
+    j = g[prefix + "joints"]
+    return np.abs(j[:, 3]) < 1e-12
+
+
+def _check_symbolic(res, g, prefix, n_expected=None):
+    reach = g[prefix + "reachable"]
+    np.testing.assert_array_equal(res["reachable"], reach)
+    np.testing.assert_array_equal(res["state"], g[prefix + "state"])
+    m = reach.astype(bool)
+    assert np.all(np.isnan(res["joints"][~m]))
+    assert np.all(np.isnan(res["interval"][~m]))
+    sing = _singular_rows(g, prefix) & m
+    for k in ("interval", "joints", "elbow"):
+        mm = m & ~sing if k == "joints" else m
+        err = np.max(np.abs(res[k][mm] - g[prefix + k][mm])) if mm.any() else 0.0
+        assert err < TOL, f"{prefix}{k}: max err {err}"
+    if sing.any():
+        a, b = res["joints"][sing], g[prefix + "joints"][sing]
+        assert np.max(np.abs(a[:, [0, 1, 3, 4, 5]] - b[:, [0, 1, 3, 4, 5]])) < TOL
+        assert np.max(np.abs((a[:, 2] + a[:, 6]) - (b[:, 2] + b[:, 6]))) < TOL
+    # Q2: reference returns a 3-vector elbow exactly when the projection branch fired
+    np.testing.assert_array_equal(res["projected"][m], (g[prefix + "elbow_len"][m] == 3).astype(np.uint8))
+
+
+def test_catalogue_symbolic(golden_dir, arms):
+    g = load(golden_dir, "g1_catalogue.npz")
+    for tag, so in (("so003_", 0.03), ("so101_", -1.01)):
+        res = orc.solve_batch(arms[("r_arm", so)], arms[("l_arm", so)], g["pos"], g["eul"], arm_id=g["arm"])
+        _check_symbolic(res, g, tag)
+
+
+def test_reference_unit_test_poses(golden_dir, arms):
+    """tests/test_ik.py:17-79 of the reference: flags / shapes on six r_arm poses."""
+    g = load(golden_dir, "g1_catalogue.npz")
+    res = orc.solve_batch(arms[("r_arm", 0.03)], arms[("l_arm", 0.03)], g["pos"][:6], g["eul"][:6])
+    assert list(res["reachable"]) == [0, 1, 1, 0, 0, 1]
+    assert np.all(res["interval"][2] == [-np.pi, np.pi])
+    assert res["interval"][1][0] >= -np.pi and res["interval"][1][1] <= np.pi
+    # README pose spot values
+    np.testing.assert_allclose(res_readme(arms)["interval"][0], [2.189523775249914, -0.223936328755258], atol=1e-12)
+
+
+def res_readme(arms):
+    return orc.solve_batch(arms[("r_arm", 0.03)], arms[("l_arm", 0.03)], np.array([[0.55, -0.3, -0.15]]),
+                           np.array([[0, -np.pi / 2, 0]]))
+
+
+def test_random_sweep_all_outcomes(golden_dir, arms):
+    g = load(golden_dir, "g2_sweep.npz")
+    for i, arm in enumerate(("r_arm", "l_arm")):
+        n = len(g[f"{arm}_pos"])
+        res = orc.solve_batch(arms[("r_arm", 0.03)], arms[("l_arm", 0.03)], g[f"{arm}_pos"], g[f"{arm}_eul"],
+                              arm_id=np.full(n, i, dtype=np.uint8), nthreads=4)
+        _check_symbolic(res, g, f"{arm}_")
+        # every outcome class must be present in the sweep
+        assert set(np.unique(g[f"{arm}_state"])) >= {0, 1, 2, 3, 4}
+
+
+def test_reachable_two_thetas(golden_dir, arms):
+    g = load(golden_dir, "g3_reachable.npz")
+    for i, arm in enumerate(("r_arm", "l_arm")):
+        n = len(g[f"{arm}_pos"])
+        aid = np.full(n, i, dtype=np.uint8)
+        for tag, so in (("so003", 0.03), ("so101", -1.01)):
+            res = orc.solve_batch(arms[("r_arm", so)], arms[("l_arm", so)], g[f"{arm}_pos"], g[f"{arm}_eul"], arm_id=aid,
+                                  nthreads=4)
+            _check_symbolic(res, g, f"{arm}_{tag}_i0_")
+            res = orc.solve_batch(arms[("r_arm", so)], arms[("l_arm", so)], g[f"{arm}_pos"], g[f"{arm}_eul"], arm_id=aid,
+                                  theta_policy=2, theta_in=g[f"{arm}_theta_u"], nthreads=4)
+            _check_symbolic(res, g, f"{arm}_{tag}_in_")
+            # explicit-theta policy reproduces the same numbers
+            res = orc.solve_batch(arms[("r_arm", so)], arms[("l_arm", so)], g[f"{arm}_pos"], g[f"{arm}_eul"], arm_id=aid,
+                                  theta_policy=1, theta_in=g[f"{arm}_{tag}_in_theta"], nthreads=4)
+            _check_symbolic(res, g, f"{arm}_{tag}_in_")
+        # projection branch must actually be exercised with offset 0.03 and never with -1.01 (Q18)
+        assert (g[f"{arm}_so003_i0_elbow_len"] == 3).mean() > 0.1
+        assert (g[f"{arm}_so101_i0_elbow_len"] == 3).sum() == 0
+
+
+def _ctrl_arms(is_dvt=False):
+    so = 0.03 if is_dvt else -1.01
+    return orc.Arm("r_arm", so), orc.Arm("l_arm", so)
+
+
+MODES = {"u20": (20, 0), "u64": (64, 0), "l20": (20, 1), "l64": (64, 1)}
+
+
+def test_catalogue_control_discrete(golden_dir):
+    g = load(golden_dir, "g1_catalogue.npz")
+    ar, al = _ctrl_arms()
+    for key, (nb, mode) in MODES.items():
+        res = orc.control_discrete_batch(ar, al, g["M"], arm_id=g["arm"], nb_search_points=nb, constrained_mode=mode)
+        np.testing.assert_array_equal(res["reachable"], g[f"ctrl_{key}_reachable"])
+        np.testing.assert_array_equal(res["state"], g[f"ctrl_{key}_state"])
+        assert np.max(np.abs(res["joints"] - g[f"ctrl_{key}_joints"])) < 1e-7, key
+    # README spot value, nb=20 unconstrained
+    M = np.eye(4)
+    from scipy.spatial.transform import Rotation as R
+    M[:3, :3] = R.from_euler("xyz", [0, -np.pi / 2, 0]).as_matrix()
+    M[:3, 3] = [0.55, -0.3, -0.15]
+    res = orc.control_discrete_batch(ar, al, M[None])
+    np.testing.assert_allclose(res["joints"][0], [-0.602816657693155, -0.324538165592665, 0.008828077832103,
+                                                  -1.048669758375133, 0.024186782799737, 0.143971244612599,
+                                                  -0.531677295547562], atol=1e-9)
+
+
+def test_random_control_discrete(golden_dir):
+    g = load(golden_dir, "g4_control_discrete.npz")
+    for dvt_tag, is_dvt in (("std", False), ("dvt", True)):
+        ar, al = _ctrl_arms(is_dvt)
+        for i, arm in enumerate(("r_arm", "l_arm")):
+            pre = f"{dvt_tag}_{arm}_"
+            M = g[pre + "M"]
+            aid = np.full(len(M), i, dtype=np.uint8)
+            for key, (nb, mode) in MODES.items():
+                if pre + key + "_joints" not in g:
+                    continue
+                res = orc.control_discrete_batch(ar, al, M, arm_id=aid, nb_search_points=nb, constrained_mode=mode, nthreads=4)
+                np.testing.assert_array_equal(res["reachable"], g[pre + key + "_reachable"], err_msg=pre + key)
+                np.testing.assert_array_equal(res["state"], g[pre + key + "_state"], err_msg=pre + key)
+                err = np.max(np.abs(res["joints"] - g[pre + key + "_joints"]))
+                assert err < 1e-7, f"{pre}{key}: {err}"
+                assert res["emergency"].sum() == 0
+            if dvt_tag == "std":
+                idx = g[pre + "var_idx"]
+                # per-pose preferred_theta: run one call per distinct value (batch API takes a scalar)
+                out_j = np.zeros((len(idx), 7)); out_f = np.zeros(len(idx), np.uint8); out_s = np.zeros(len(idx), np.uint8)
+                for k, (ii, cj, pt) in enumerate(zip(idx, g[pre + "var_current_joints"], g[pre + "var_preferred_theta"])):
+                    r = orc.control_discrete_batch(ar, al, M[ii][None], arm_id=aid[:1], nb_search_points=20, preferred_theta=pt,
+                                                   current_joints=cj[None])
+                    out_j[k], out_f[k], out_s[k] = r["joints"][0], r["reachable"][0], r["state"][0]
+                np.testing.assert_array_equal(out_f, g[pre + "var_reachable"])
+                np.testing.assert_array_equal(out_s, g[pre + "var_state"])
+                assert np.max(np.abs(out_j - g[pre + "var_joints"])) < 1e-7
+
+
+def test_helpers_elbow_and_no_limits(golden_dir, arms):
+    g = load(golden_dir, "g5_helpers.npz")
+    for arm in ("r_arm", "l_arm"):
+        sv = orc.Solver(arms[(arm, 0.03)])
+        pos, eul, th = g[f"{arm}_pos"], g[f"{arm}_eul"], g[f"{arm}_thetas"]
+        for i in range(0, len(pos), 3):
+            ok, _, _ = sv.is_reachable(pos[i], eul[i])
+            exp = g[f"{arm}_elbow_at_theta"][i]
+            assert ok == (not np.isnan(exp[0, 0]))
+            if ok:
+                for k in range(4):
+                    assert np.max(np.abs(sv.get_elbow_position(th[i, k]) - exp[k])) < TOL
+            assert sv.is_reachable_no_limits(pos[i], eul[i]) == bool(g[f"{arm}_nolimits_ok"][i])
+            j, e, _ = sv.get_joints(th[i, 0])
+            assert np.max(np.abs(j - g[f"{arm}_nolimits_joints"][i])) < TOL
+            assert np.max(np.abs(e - g[f"{arm}_nolimits_elbow"][i])) < TOL
+
+
+def test_previous_theta_init_Q15(golden_dir):
+    """ControlIK.__init__'s accidental 2x7 broadcast (control_ik.py:152-158)."""
+    g = load(golden_dir, "g0_constants.npz")
+    cur = np.array([[0.0, 0.2617993877991494, -0.17453292519943295, 0, 0, 0, 0],
+                    [0.0, -0.2617993877991494, 0.17453292519943295, 0, 0, 0, 0]])
+    for arm, y in (("r_arm", -0.2), ("l_arm", 0.2)):
+        a = orc.Arm(arm, -1.01)
+        sv = orc.Solver(a)
+        assert sv.is_reachable_no_limits([0, y, -0.66], [0, 0, 0])
+        th = sv.best_theta_to_current_joints(cur, g[f"{arm}_urdf_preferred_theta"])
+        assert abs(th - g[f"{arm}_urdf_previous_theta_init"]) < 1e-9
+
+
+def test_control_continuous(golden_dir):
+    g = load(golden_dir, "g6_control_continuous.npz")
+    g0 = load(golden_dir, "g0_constants.npz")
+    pref_arg = -4 * np.pi / 6
+    for arm, y in (("r_arm", -0.2), ("l_arm", 0.2)):
+        a = orc.Arm(arm, -1.01)
+        Ms, J, F, S = g[f"{arm}_M"], g[f"{arm}_joints"], g[f"{arm}_reachable"], g[f"{arm}_state"]
+        TH = g[f"{arm}_previous_theta"]
+        pose0 = np.eye(4); pose0[:3, 3] = [0, y, -0.66]
+        for k in range(Ms.shape[0]):
+            cs = orc.ContinuousState(g0[f"{arm}_urdf_previous_theta_init"], g0[f"{arm}_urdf_previous_sol"])
+            prev_pose = pose0
+            for i in range(Ms.shape[1]):
+                cur = cs.previous_sol
+                j, ok, st = orc.control_continuous_step(a, cs, Ms[k, i], timed_out=(i == 0), preferred_theta_arg=pref_arg,
+                                                        preferred_theta_self=g0[f"{arm}_urdf_preferred_theta"],
+                                                        constrained_mode=0, current_joints=cur, current_pose=prev_pose)
+                prev_pose = Ms[k, i]
+                assert ok == bool(F[k, i]), (arm, k, i)
+                assert st == S[k, i], (arm, k, i)
+                assert np.max(np.abs(j - J[k, i])) < 1e-7, (arm, k, i)
+                assert abs(cs.previous_theta - TH[k, i]) < 1e-9
+            assert not cs.emergency_stop
+
+
+def test_python_float_mod_semantics():
+    L = orc.lib()
+    rng = np.random.default_rng(7)
+    for a in np.concatenate([rng.uniform(-20, 20, 200), [0.0, -0.0, 2 * np.pi, -2 * np.pi, np.pi, -np.pi]]):
+        for b in (2 * np.pi, -2 * np.pi):
+            assert L.orc_pymod(float(a), b) == float(a) % b
