@@ -1,0 +1,198 @@
+/*
+ * rsik.h — C ABI of the MI355X-native batched analytic IK solver for the Reachy 2 arms.
+ *
+ * This is the drop-in boundary for ONE path of pollen-robotics/reachy2_symbolic_ik:
+ *   SymbolicIK.is_reachable + theta_to_joints_func (= SymbolicIK.get_joints)
+ *   ControlIK.symbolic_inverse_kinematics, control_type "discrete" (and "continuous" as state-carrying steps)
+ *
+ * The reference has no FFI: its boundary is the Python API of two classes
+ * (src/reachy2_symbolic_ik/symbolic_ik.py:25-863, control_ik.py:27-497).  Each entry point below
+ * cites the reference interface it replaces.  Plain C: pointers and sizes only, no C++/torch types.
+ *
+ * Conventions
+ *   - Every function returns an int status: RSIK_OK (0) or a negative RSIK_E_* code;
+ *     rsik_last_error(ctx) gives the message.  Unreachable poses are DATA (reachable/state
+ *     arrays), never errors — the reference returns (False, [], None, state) rather than raising
+ *     (symbolic_ik.py:130-132,161,263).
+ *   - All `const double*` / `double*` / `uint8_t*` batch arguments are DEVICE pointers (HBM) owned
+ *     by the caller unless the name ends in `_host`.  The library never frees or retains them.
+ *   - Work is enqueued on the context's HIP stream (rsik_set_stream) and is asynchronous;
+ *     rsik_sync waits for it.
+ *   - Angles in radians, lengths in metres, everything IEEE float64.
+ *   - Rows of unreachable poses in joints / interval / elbow are filled with NaN.
+ */
+#ifndef RSIK_H
+#define RSIK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSIK_ABI_VERSION 1
+
+/* ---- status codes ---- */
+#define RSIK_OK 0
+#define RSIK_E_INVALID (-1)   /* bad argument (null pointer, bad enum, n < 0 ...) */
+#define RSIK_E_NO_DEVICE (-2) /* no usable HIP device / device id out of range */
+#define RSIK_E_HIP (-3)       /* a HIP runtime call failed; see rsik_last_error */
+#define RSIK_E_NOT_SET (-4)   /* arm constants were not uploaded for an arm the call needs */
+
+/* ---- per-pose state codes (uint8); strings are the reference's own ---- */
+#define RSIK_STATE_REACHABLE 0           /* "reachable"                         symbolic_ik.py:234 */
+#define RSIK_STATE_POSE_OUT_OF_REACH 1   /* "Pose out of reach"                 symbolic_ik.py:300 */
+#define RSIK_STATE_BACKWARD_POSE 2       /* "Backward pose"                     symbolic_ik.py:306 */
+#define RSIK_STATE_WRIST_OUT_OF_RANGE 3  /* "wrist out of range"                symbolic_ik.py:159 */
+#define RSIK_STATE_LIMITED_BY_WRIST 4    /* "limited by wrist"                  symbolic_ik.py:262 */
+#define RSIK_STATE_SHOULD_NOT_HAPPEN 5   /* "out of reach - should not happen"  symbolic_ik.py:281 */
+#define RSIK_STATE_LIMITED_BY_SHOULDER 6 /* "limited by shoulder"               control_ik.py:363,452 */
+#define RSIK_STATE_EMPTY 7               /* ""  (continuous mode, reachable)    control_ik.py:297 */
+#define RSIK_STATE_EMERGENCY 8           /* emergency stop latched              control_ik.py:205-210 */
+
+/* ---- arms ---- */
+#define RSIK_ARM_R 0
+#define RSIK_ARM_L 1
+
+/* ---- theta policies for rsik_solve (which elbow angle get_joints is evaluated at) ---- */
+#define RSIK_THETA_INTERVAL0 0 /* theta = interval[0]  (README.md:85, ik_benchmarks.py:27-31) */
+#define RSIK_THETA_EXPLICIT 1  /* theta = theta_in[i] */
+#define RSIK_THETA_FRACTION 2  /* theta = i0 + theta_in[i] * (i1' - i0), i1' = i1 (+2pi if wrapped) */
+#define RSIK_THETA_NONE 3      /* is_reachable only: joints/elbow are not written */
+
+/* ---- constrained modes (control_ik.py:225-232) ---- */
+#define RSIK_MODE_UNCONSTRAINED 0
+#define RSIK_MODE_LOW_ELBOW 1
+
+/*
+ * Per-arm constant block: a flat array of RSIK_ARM_CONSTS_COUNT doubles computed once on the host
+ * from SymbolicIK.__init__'s arguments (symbolic_ik.py:26-83, utils.py:26-43) plus the
+ * pose-independent parts of get_joints / make_elbow_projection (symbolic_ik.py:728-738, 653-672).
+ * Offsets:
+ */
+enum {
+    RSIK_C_SHOULDER = 0,      /* [3] shoulder_position                                   */
+    RSIK_C_UPPER_ARM = 3,     /* upper_arm_size u                                         */
+    RSIK_C_FOREARM = 4,       /* forearm_size f                                           */
+    RSIK_C_TIPL = 5,          /* [3] wrist offset in the goal frame (-tip_x, tip_y, tip_z) symbolic_ik.py:422 */
+    RSIK_C_MAX_LEN = 8,       /* max_arm_length                                           */
+    RSIK_C_MIN_DIST = 9,      /* shoulder_wrist_min_distance                              */
+    RSIK_C_BACKWARD = 10,     /* backward_limit                                           */
+    RSIK_C_PROJ_MARGIN = 11,  /* projection_margin                                        */
+    RSIK_C_NORMAL_MARGIN = 12,/* normal_vector_margin                                     */
+    RSIK_C_UPF = 13,          /* u + f                                                    */
+    RSIK_C_WRIST_R = 14,      /* sin(radians(wrist_limit)) * f          symbolic_ik.py:413 */
+    RSIK_C_WRIST_AX = 15,     /* sqrt(f^2 - r^2)                        symbolic_ik.py:414 */
+    RSIK_C_MST = 16,          /* [9] M_shoulder_torso row-major         symbolic_ik.py:728-736 */
+    RSIK_C_TSH = 25,          /* [3] P_shoulder_torso = -M_shoulder_torso . s  symbolic_ik.py:737 */
+    RSIK_C_ES = 28,           /* [3] elbow_singularity_position                           */
+    RSIK_C_SING_OFFSET = 31,  /* singularity_offset                                       */
+    RSIK_C_SING_COEFF = 32,   /* singularity_limit_coeff                                  */
+    RSIK_C_ELBOW_LIMIT = 33,  /* radians(elbow_limit)                                     */
+    RSIK_C_SIDE = 34,         /* +1 r_arm, -1 l_arm                                       */
+    RSIK_C_PLANE_P = 35,      /* [3] P_limits                           symbolic_ik.py:657 */
+    RSIK_C_PLANE_N = 38,      /* [3] v3 (unit plane normal)             symbolic_ik.py:668-669 */
+    RSIK_C_PROJ_CENTER = 41,  /* [3] projected_center                   symbolic_ik.py:671 */
+    RSIK_C_PROJ_RADIUS = 44,  /* radius (NaN if the plane misses the shoulder sphere)  symbolic_ik.py:672 */
+    RSIK_C_TIP_Z = 45,        /* tip_position[2]                        symbolic_ik.py:837 */
+    RSIK_ARM_CONSTS_COUNT = 46
+};
+
+typedef struct rsik_ctx rsik_ctx;
+
+/* ---- lifecycle ---- */
+int rsik_abi_version(void);
+int rsik_arm_consts_count(void);
+/* Number of HIP devices visible; 0 when there is none (never fails). */
+int rsik_device_count(void);
+/* Creates a context bound to one GPU.  Replaces constructing SymbolicIK / ControlIK objects
+ * (symbolic_ik.py:26, control_ik.py:28): constants are uploaded separately with rsik_set_arm. */
+int rsik_create(int device_id, rsik_ctx **out);
+int rsik_destroy(rsik_ctx *ctx);
+/* Message of the last failing call on this context ("" if none).  ctx == NULL: last rsik_create failure. */
+const char *rsik_last_error(const rsik_ctx *ctx);
+/* Use the caller's hipStream_t (e.g. torch's current stream) for all launches; NULL = default stream. */
+int rsik_set_stream(rsik_ctx *ctx, void *hip_stream);
+int rsik_sync(rsik_ctx *ctx);
+/* Uploads one arm's constant block (host pointer).  Replaces SymbolicIK.__init__ (symbolic_ik.py:26-83). */
+int rsik_set_arm(rsik_ctx *ctx, int arm, const double *consts_host, int count);
+
+/* ---- device memory helpers for hosts without their own allocator (torch users do not need them) ---- */
+int rsik_malloc(rsik_ctx *ctx, size_t bytes, void **dev_ptr);
+int rsik_free(rsik_ctx *ctx, void *dev_ptr);
+int rsik_memcpy_h2d(rsik_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int rsik_memcpy_d2h(rsik_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+/*
+ * rsik_solve — fused SymbolicIK.is_reachable (symbolic_ik.py:121-282) + one call of the returned
+ * theta_to_joints_func = SymbolicIK.get_joints (symbolic_ik.py:697-863) per pose, canonical
+ * "fresh is_reachable, then exactly one get_joints" semantics.
+ *
+ *   n            number of poses
+ *   pose_soa     6 device arrays of n doubles: px, py, pz, roll, pitch, yaw — the reference's
+ *                goal_pose = [[x,y,z],[roll,pitch,yaw]], extrinsic xyz Euler (README.md:73-75)
+ *   arm          device array of n uint8 (RSIK_ARM_R / RSIK_ARM_L) or NULL
+ *   arm_uniform  arm used for every pose when arm == NULL
+ *   theta_policy RSIK_THETA_*;  theta_in: device array of n doubles for EXPLICIT / FRACTION, else NULL
+ *   previous_joints_host  7 doubles (host) or NULL for zeros — get_joints' previous_joints argument
+ *   joints       [n,7] row-major or NULL      (shoulder_pitch, shoulder_roll, elbow_yaw, elbow_pitch,
+ *                                               wrist_roll, wrist_pitch, wrist_yaw)
+ *   interval     [n,2] or NULL                 theta interval, i0 > i1 means wrap-around (README.md:83-84)
+ *   elbow        [n,3] or NULL                 elbow position returned by get_joints
+ *   reachable    [n] uint8 or NULL
+ *   state        [n] uint8 RSIK_STATE_* or NULL
+ */
+int rsik_solve(rsik_ctx *ctx, int64_t n, const double *const pose_soa[6], const uint8_t *arm, int arm_uniform,
+               int theta_policy, const double *theta_in, const double *previous_joints_host, double *joints,
+               double *interval, double *elbow, uint8_t *reachable, uint8_t *state);
+
+/*
+ * rsik_control_discrete — ControlIK.symbolic_inverse_kinematics(name, M, "discrete", ...)
+ * (control_ik.py:162-274 -> symbolic_inverse_kinematics_discrete :409-462 -> safety_checks :464-497),
+ * which is a pure function of its inputs and constructor-time constants.
+ *
+ *   m12_soa          12 device arrays of n doubles: R00,R01,R02,R10,...,R22 (row-major rotation of the
+ *                    4x4 goal matrix M) then tx,ty,tz (M[:3,3])
+ *   arm/arm_uniform  as above (name "r_arm"/"l_arm")
+ *   nb_search_points ControlIK.nb_search_points (control_ik.py:64), >= 2
+ *   preferred_theta  the preferred_theta argument (r-arm convention; mirrored for l inside, control_ik.py:252)
+ *   constrained_mode RSIK_MODE_*
+ *   previous_sol_host 14 doubles: ControlIK.previous_sol["r_arm"], ["l_arm"] (control_ik.py:136,140)
+ *   current_joints   [n,7] device or NULL (=> previous_sol of the pose's arm, control_ik.py:237-238)
+ *   orbita3d_max_angle  wrist cone half-angle in radians (control_ik.py:84)
+ *   joints [n,7], reachable [n], state [n] as above; emergency [n] uint8 or NULL: 1 where
+ *   multiturn_safety_check tripped (utils.py:535-568).
+ */
+int rsik_control_discrete(rsik_ctx *ctx, int64_t n, const double *const m12_soa[12], const uint8_t *arm,
+                          int arm_uniform, int nb_search_points, double preferred_theta, int constrained_mode,
+                          const double *previous_sol_host, const double *current_joints, double orbita3d_max_angle,
+                          double *joints, uint8_t *reachable, uint8_t *state, uint8_t *emergency);
+
+/*
+ * Solver-state entry points: the scalar drop-in API.  A SymbolicIK object keeps self.goal_pose,
+ * self.wrist_position and self.intersection_circle between is_reachable() and the closure it returns
+ * (symbolic_ik.py:143-144,185,235), and get_joints() mutates them when the elbow projection fires
+ * (symbolic_ik.py:714-718).  That state lives in a caller-owned device array, one row of
+ * RSIK_SOLVER_STATE_STRIDE doubles per solver instance:
+ *   0-2 goal position, 3-5 goal euler, 6-8 wrist position, 9-11 circle centre, 12 circle radius,
+ *   13-15 circle normal, 16-18 elbow position of the last get_joints, 19 projection flag, 20-23 reserved.
+ */
+#define RSIK_SOLVER_STATE_STRIDE 24
+
+/* SymbolicIK.is_reachable (no_limits == 0, symbolic_ik.py:121-282) or is_reachable_no_limits
+ * (no_limits != 0, symbolic_ik.py:85-119).  Only the fields the reference would have assigned are
+ * written into solver_state (an early "Pose out of reach" leaves the row untouched). */
+int rsik_reach_state(rsik_ctx *ctx, int64_t n, const double *const pose_soa[6], const uint8_t *arm, int arm_uniform,
+                     int no_limits, double *solver_state, double *interval, uint8_t *reachable, uint8_t *state);
+/* SymbolicIK.get_joints(theta, previous_joints) on stored state (symbolic_ik.py:697-863); updates the
+ * row like the reference updates self.  previous_joints: [n,7] device or NULL for zeros. */
+int rsik_joints_from_state(rsik_ctx *ctx, int64_t n, double *solver_state, const uint8_t *arm, int arm_uniform,
+                           const double *theta, const double *previous_joints, double *joints, double *elbow);
+/* SymbolicIK.get_elbow_position(theta) on stored state (symbolic_ik.py:684-695). */
+int rsik_elbow_from_state(rsik_ctx *ctx, int64_t n, const double *solver_state, const double *theta, double *elbow);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSIK_H */

@@ -1,0 +1,76 @@
+"""ctypes binding of the C ABI declared in include/rsik.h (csrc/librsik_hip.so).
+
+There is no CPU fallback: if the HIP library is missing or no GPU is present the product
+path raises.  (`load()` itself works on a GPU-less machine so the symbol table can be checked.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librsik_hip.so")
+
+RSIK_OK = 0
+RSIK_E_INVALID, RSIK_E_NO_DEVICE, RSIK_E_HIP, RSIK_E_NOT_SET = -1, -2, -3, -4
+
+THETA_INTERVAL0, THETA_EXPLICIT, THETA_FRACTION, THETA_NONE = 0, 1, 2, 3
+MODE_UNCONSTRAINED, MODE_LOW_ELBOW = 0, 1
+MODES = {"unconstrained": MODE_UNCONSTRAINED, "low_elbow": MODE_LOW_ELBOW}
+
+_vp = C.c_void_p
+_dp = C.POINTER(C.c_double)
+
+# name -> (restype, argtypes); every symbol include/rsik.h declares
+PROTOTYPES = {
+    "rsik_abi_version": (C.c_int, []),
+    "rsik_arm_consts_count": (C.c_int, []),
+    "rsik_device_count": (C.c_int, []),
+    "rsik_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "rsik_destroy": (C.c_int, [_vp]),
+    "rsik_last_error": (C.c_char_p, [_vp]),
+    "rsik_set_stream": (C.c_int, [_vp, _vp]),
+    "rsik_sync": (C.c_int, [_vp]),
+    "rsik_set_arm": (C.c_int, [_vp, C.c_int, _dp, C.c_int]),
+    "rsik_malloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    "rsik_free": (C.c_int, [_vp, _vp]),
+    "rsik_memcpy_h2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "rsik_memcpy_d2h": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "rsik_solve": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp), _vp, C.c_int, C.c_int, _vp, _dp, _vp, _vp, _vp, _vp, _vp]),
+    "rsik_control_discrete": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp), _vp, C.c_int, C.c_int, C.c_double, C.c_int, _dp,
+                                        _vp, C.c_double, _vp, _vp, _vp, _vp]),
+    "rsik_reach_state": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp), _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    "rsik_joints_from_state": (C.c_int, [_vp, C.c_int64, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "rsik_elbow_from_state": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp]),
+}
+
+SOLVER_STATE_STRIDE = 24
+
+
+class RsikError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"rsik error {code}: {message}")
+        self.code = code
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Loads the HIP library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  reachy2_symbolic_ik_amd has no CPU fallback."
+            )
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if lib.rsik_abi_version() != 1:
+            raise ImportError("librsik_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib

@@ -1,0 +1,265 @@
+"""Device-side driver: owns one rsik context per GPU and hands torch-owned HBM buffers to the C ABI.
+
+PyTorch is used for device memory, streams and torch.distributed only; all arithmetic happens in
+the hand-written HIP kernels behind include/rsik.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _abi
+from .constants import ARM_CONSTS_COUNT
+
+_F64 = torch.float64
+_U8 = torch.uint8
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class HipSolver:
+    """One context = one GPU.  Methods enqueue on torch's current stream and return torch tensors."""
+
+    def __init__(self, device: int | torch.device | None = None) -> None:
+        self.lib = _abi.load()
+        if self.lib.rsik_device_count() <= 0 or not torch.cuda.is_available():
+            raise RuntimeError(
+                "reachy2_symbolic_ik_amd: no MI355X/HIP device visible — this package has no CPU fallback"
+            )
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+        index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", index)
+        h = C.c_void_p()
+        rc = self.lib.rsik_create(index, C.byref(h))
+        if rc != _abi.RSIK_OK:
+            raise _abi.RsikError(rc, (self.lib.rsik_last_error(None) or b"").decode())
+        self._h = h
+        self._arms_set = [False, False]
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self.lib.rsik_destroy(self._h)
+            self._h = None
+
+    def __del__(self) -> None:  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int) -> None:
+        if rc != _abi.RSIK_OK:
+            raise _abi.RsikError(rc, (self.lib.rsik_last_error(self._h) or b"").decode())
+
+    def _bind_stream(self) -> None:
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        self._check(self.lib.rsik_set_stream(self._h, C.c_void_p(s)))
+
+    def set_arm(self, arm_id: int, consts: np.ndarray) -> None:
+        c = np.ascontiguousarray(consts, dtype=np.float64)
+        if c.shape != (ARM_CONSTS_COUNT,):
+            raise ValueError(f"expected {ARM_CONSTS_COUNT} constants, got {c.shape}")
+        self._check(self.lib.rsik_set_arm(self._h, int(arm_id), c.ctypes.data_as(C.POINTER(C.c_double)), c.size))
+        self._arms_set[arm_id] = True
+
+    def synchronize(self) -> None:
+        self._check(self.lib.rsik_sync(self._h))
+
+    # ------------------------------------------------------------------ checks
+    def _dev_f64(self, t: torch.Tensor, shape: Sequence[int], name: str) -> torch.Tensor:
+        if not isinstance(t, torch.Tensor):
+            t = torch.as_tensor(np.asarray(t, dtype=np.float64))
+        t = t.to(device=self.device, dtype=_F64)
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+        return t.contiguous()
+
+    def _dev_u8(self, t, n: int, name: str) -> torch.Tensor:
+        if not isinstance(t, torch.Tensor):
+            t = torch.as_tensor(np.asarray(t, dtype=np.uint8))
+        t = t.to(device=self.device, dtype=_U8)
+        if tuple(t.shape) != (n,):
+            raise ValueError(f"{name}: expected shape ({n},), got {tuple(t.shape)}")
+        return t.contiguous()
+
+    # ------------------------------------------------------------------ rsik_solve
+    def solve(
+        self,
+        pose_soa: torch.Tensor,
+        arm: Optional[torch.Tensor] = None,
+        arm_uniform: int = 0,
+        theta_policy: int = _abi.THETA_INTERVAL0,
+        theta_in: Optional[torch.Tensor] = None,
+        previous_joints: Optional[Sequence[float]] = None,
+        want_elbow: bool = True,
+        out: Optional[Dict[str, torch.Tensor]] = None,
+    ) -> Dict[str, torch.Tensor]:
+        """pose_soa: [6, n] float64 (rows px,py,pz,roll,pitch,yaw).  Returns joints [n,7], interval [n,2],
+        elbow [n,3], reachable [n] u8, state [n] u8 (device tensors, asynchronous on the current stream)."""
+        if pose_soa.dim() != 2 or pose_soa.shape[0] != 6:
+            raise ValueError("pose_soa must have shape [6, n]")
+        n = int(pose_soa.shape[1])
+        pose_soa = self._dev_f64(pose_soa, (6, n), "pose_soa")
+        if arm is not None:
+            arm = self._dev_u8(arm, n, "arm")
+        if theta_policy in (_abi.THETA_EXPLICIT, _abi.THETA_FRACTION):
+            if theta_in is None:
+                raise ValueError("theta_in is required for this theta policy")
+            theta_in = self._dev_f64(theta_in, (n,), "theta_in")
+        else:
+            theta_in = None
+        if out is None:
+            out = {}
+        dev = self.device
+        none = theta_policy == _abi.THETA_NONE
+        joints = None if none else out.get("joints", None)
+        if not none and joints is None:
+            joints = torch.empty((n, 7), dtype=_F64, device=dev)
+        elbow = None
+        if not none and want_elbow:
+            elbow = out.get("elbow", None)
+            if elbow is None:
+                elbow = torch.empty((n, 3), dtype=_F64, device=dev)
+        interval = out.get("interval", None)
+        if interval is None:
+            interval = torch.empty((n, 2), dtype=_F64, device=dev)
+        reachable = out.get("reachable", None)
+        if reachable is None:
+            reachable = torch.empty((n,), dtype=_U8, device=dev)
+        state = out.get("state", None)
+        if state is None:
+            state = torch.empty((n,), dtype=_U8, device=dev)
+        cols = (C.c_void_p * 6)(*[pose_soa[k].data_ptr() for k in range(6)])
+        prev = None
+        if previous_joints is not None:
+            pj = np.ascontiguousarray(previous_joints, dtype=np.float64)
+            if pj.shape != (7,):
+                raise ValueError("previous_joints must have 7 entries")
+            prev = pj.ctypes.data_as(C.POINTER(C.c_double))
+        with torch.cuda.device(self.device):
+            self._bind_stream()
+            self._check(
+                self.lib.rsik_solve(self._h, n, cols, _ptr(arm), int(arm_uniform), int(theta_policy), _ptr(theta_in), prev,
+                                    _ptr(joints), _ptr(interval), _ptr(elbow), _ptr(reachable), _ptr(state))
+            )
+        res = {"interval": interval, "reachable": reachable, "state": state}
+        if joints is not None:
+            res["joints"] = joints
+        if elbow is not None:
+            res["elbow"] = elbow
+        return res
+
+    # ------------------------------------------------------------------ rsik_control_discrete
+    def control_discrete(
+        self,
+        m12_soa: torch.Tensor,
+        arm: Optional[torch.Tensor] = None,
+        arm_uniform: int = 0,
+        nb_search_points: int = 20,
+        preferred_theta: float = -4 * np.pi / 6,
+        constrained_mode: int = _abi.MODE_UNCONSTRAINED,
+        previous_sol: Optional[np.ndarray] = None,
+        current_joints: Optional[torch.Tensor] = None,
+        orbita3d_max_angle: float = float(np.deg2rad(42.5)),
+        out: Optional[Dict[str, torch.Tensor]] = None,
+    ) -> Dict[str, torch.Tensor]:
+        """m12_soa: [12, n] float64 (R row-major, then translation)."""
+        if m12_soa.dim() != 2 or m12_soa.shape[0] != 12:
+            raise ValueError("m12_soa must have shape [12, n]")
+        n = int(m12_soa.shape[1])
+        m12_soa = self._dev_f64(m12_soa, (12, n), "m12_soa")
+        if nb_search_points < 2:
+            raise ValueError("nb_search_points must be >= 2")
+        if arm is not None:
+            arm = self._dev_u8(arm, n, "arm")
+        if current_joints is not None:
+            current_joints = self._dev_f64(current_joints, (n, 7), "current_joints")
+        ps = np.ascontiguousarray(previous_sol, dtype=np.float64)
+        if ps.shape != (2, 7):
+            raise ValueError("previous_sol must have shape (2, 7)")
+        if out is None:
+            out = {}
+        dev = self.device
+        joints = out.get("joints", None)
+        if joints is None:
+            joints = torch.empty((n, 7), dtype=_F64, device=dev)
+        reachable = out.get("reachable", None)
+        if reachable is None:
+            reachable = torch.empty((n,), dtype=_U8, device=dev)
+        state = out.get("state", None)
+        if state is None:
+            state = torch.empty((n,), dtype=_U8, device=dev)
+        emergency = out.get("emergency", None)
+        if emergency is None:
+            emergency = torch.empty((n,), dtype=_U8, device=dev)
+        cols = (C.c_void_p * 12)(*[m12_soa[k].data_ptr() for k in range(12)])
+        with torch.cuda.device(self.device):
+            self._bind_stream()
+            self._check(
+                self.lib.rsik_control_discrete(self._h, n, cols, _ptr(arm), int(arm_uniform), int(nb_search_points),
+                                               float(preferred_theta), int(constrained_mode),
+                                               ps.ctypes.data_as(C.POINTER(C.c_double)), _ptr(current_joints),
+                                               float(orbita3d_max_angle), _ptr(joints), _ptr(reachable), _ptr(state),
+                                               _ptr(emergency))
+            )
+        return {"joints": joints, "reachable": reachable, "state": state, "emergency": emergency}
+
+    # ------------------------------------------------------------------ solver-state entry points
+    def new_solver_state(self, n: int) -> torch.Tensor:
+        return torch.zeros((n, _abi.SOLVER_STATE_STRIDE), dtype=_F64, device=self.device)
+
+    def reach_state(self, pose_soa: torch.Tensor, solver_state: torch.Tensor, arm: Optional[torch.Tensor] = None,
+                    arm_uniform: int = 0, no_limits: bool = False) -> Dict[str, torch.Tensor]:
+        n = int(pose_soa.shape[1])
+        pose_soa = self._dev_f64(pose_soa, (6, n), "pose_soa")
+        self._check_state(solver_state, n)
+        if arm is not None:
+            arm = self._dev_u8(arm, n, "arm")
+        interval = torch.empty((n, 2), dtype=_F64, device=self.device)
+        reachable = torch.empty((n,), dtype=_U8, device=self.device)
+        state = torch.empty((n,), dtype=_U8, device=self.device)
+        cols = (C.c_void_p * 6)(*[pose_soa[k].data_ptr() for k in range(6)])
+        with torch.cuda.device(self.device):
+            self._bind_stream()
+            self._check(self.lib.rsik_reach_state(self._h, n, cols, _ptr(arm), int(arm_uniform), int(bool(no_limits)),
+                                                  _ptr(solver_state), _ptr(interval), _ptr(reachable), _ptr(state)))
+        return {"interval": interval, "reachable": reachable, "state": state}
+
+    def joints_from_state(self, solver_state: torch.Tensor, theta: torch.Tensor, arm: Optional[torch.Tensor] = None,
+                          arm_uniform: int = 0, previous_joints: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        n = int(solver_state.shape[0])
+        self._check_state(solver_state, n)
+        theta = self._dev_f64(theta, (n,), "theta")
+        if arm is not None:
+            arm = self._dev_u8(arm, n, "arm")
+        if previous_joints is not None:
+            previous_joints = self._dev_f64(previous_joints, (n, 7), "previous_joints")
+        joints = torch.empty((n, 7), dtype=_F64, device=self.device)
+        elbow = torch.empty((n, 3), dtype=_F64, device=self.device)
+        with torch.cuda.device(self.device):
+            self._bind_stream()
+            self._check(self.lib.rsik_joints_from_state(self._h, n, _ptr(solver_state), _ptr(arm), int(arm_uniform),
+                                                        _ptr(theta), _ptr(previous_joints), _ptr(joints), _ptr(elbow)))
+        return {"joints": joints, "elbow": elbow}
+
+    def elbow_from_state(self, solver_state: torch.Tensor, theta: torch.Tensor) -> torch.Tensor:
+        n = int(solver_state.shape[0])
+        self._check_state(solver_state, n)
+        theta = self._dev_f64(theta, (n,), "theta")
+        elbow = torch.empty((n, 3), dtype=_F64, device=self.device)
+        with torch.cuda.device(self.device):
+            self._bind_stream()
+            self._check(self.lib.rsik_elbow_from_state(self._h, n, _ptr(solver_state), _ptr(theta), _ptr(elbow)))
+        return elbow
+
+    def _check_state(self, solver_state: torch.Tensor, n: int) -> None:
+        if (not isinstance(solver_state, torch.Tensor) or solver_state.dtype != _F64 or solver_state.device != self.device
+                or tuple(solver_state.shape) != (n, _abi.SOLVER_STATE_STRIDE) or not solver_state.is_contiguous()):
+            raise ValueError(f"solver_state must be a contiguous float64 [{n}, {_abi.SOLVER_STATE_STRIDE}] tensor on {self.device}")

@@ -1,0 +1,269 @@
+"""ControlIK — drop-in for reachy2_symbolic_ik.control_ik.ControlIK (control_ik.py:27-497) on MI355X.
+
+`symbolic_inverse_kinematics(name, M, "discrete", ...)` keeps the reference signature and return
+tuple; `symbolic_inverse_kinematics_batch` is the MI355X-native form (matrices laid out SoA in HBM,
+wave-cooperative theta sweep in the kernel).  No CPU fallback.
+"""
+from __future__ import annotations
+
+import copy
+import os
+from typing import Any, Dict, Optional, Tuple
+
+import numpy as np
+import numpy.typing as npt
+import torch
+
+from . import _abi
+from .backend import HipSolver
+from .constants import ARM_IDS, STATE_STRINGS, get_ik_parameters_from_urdf
+from .symbolic_ik import SymbolicIK
+
+DEFAULT_CURRENT_JOINTS = [
+    [0.0, 0.2617993877991494, -0.17453292519943295, 0.0, 0.0, 0.0, 0.0],
+    [0.0, -0.2617993877991494, 0.17453292519943295, 0.0, 0.0, 0.0, 0.0],
+]
+DEFAULT_CURRENT_POSE = [
+    np.array([[1, 0, 0, 0], [0, 1, 0, -0.2], [0, 0, 1, -0.66], [0, 0, 0, 1]]),
+    np.array([[1, 0, 0, 0], [0, 1, 0, 0.2], [0, 0, 1, -0.66], [0, 0, 0, 1]]),
+]
+
+
+def matrices_to_m12_soa(M: Any, device: torch.device) -> torch.Tensor:
+    """[n,4,4] homogeneous matrices (or an already packed [12,n]) -> contiguous [12,n] float64 on `device`
+    (rows R00..R22 row-major, then tx, ty, tz)."""
+    t = M if isinstance(M, torch.Tensor) else torch.as_tensor(np.asarray(M, dtype=np.float64))
+    t = t.to(device=device, dtype=torch.float64)
+    if t.dim() == 2 and t.shape[0] == 12:
+        return t.contiguous()
+    if t.dim() == 2 and tuple(t.shape) == (4, 4):
+        t = t.unsqueeze(0)
+    if not (t.dim() == 3 and tuple(t.shape[1:]) == (4, 4)):
+        raise ValueError("M must have shape [n,4,4], [4,4] or [12,n]")
+    rot = t[:, :3, :3].reshape(t.shape[0], 9)
+    tr = t[:, :3, 3]
+    return torch.cat([rot, tr], dim=1).t().contiguous()
+
+
+def angle_diff(a: float, b: float) -> float:
+    """utils.py:486-490."""
+    d = a - b
+    return ((d + np.pi) % (2 * np.pi)) - np.pi
+
+
+def get_best_theta_to_current_joints(get_joints: Any, nb_search_points: int, current_joints: Any, arm: str,
+                                     preferred_theta: float) -> Tuple[float, str]:
+    """utils.py:267-331: ternary search over the whole circle for the theta whose joints are closest to
+    `current_joints`.  `current_joints` is used exactly as handed over — including ControlIK.__init__'s
+    list-of-both-arms form (control_ik.py:152-158), which NumPy broadcasting turns into a 2x7 comparison (Q15)."""
+    current_joints = copy.deepcopy(current_joints)
+    low, high = (-np.pi, np.pi) if arm != "l_arm" else (0, 2 * np.pi)
+    tolerance = 0.01
+
+    def distance(joints: Any) -> float:
+        return float(np.linalg.norm([angle_diff(joints[i], np.asarray(current_joints[i])) for i in range(len(current_joints))]))
+
+    joints, _ = get_joints(preferred_theta)
+    if distance(joints) < tolerance:
+        return preferred_theta, "preferred_theta worked!"
+    while (high - low) > tolerance:
+        mid1 = low + (high - low) / 3
+        mid2 = high - (high - low) / 3
+        j1, _ = get_joints(mid1)
+        j2, _ = get_joints(mid2)
+        if distance(j1) < distance(j2):
+            high = mid2
+        else:
+            low = mid1
+    best_theta = (low + high) / 2
+    get_joints(best_theta)  # utils.py:324 (the reference evaluates it once more; state-mutating, Q1)
+    return best_theta, f" \n low = {low}, high = {high}"
+
+
+class ControlIK:
+    def __init__(
+        self,
+        current_joints: list = DEFAULT_CURRENT_JOINTS,
+        current_pose: list = DEFAULT_CURRENT_POSE,
+        logger: Any = None,
+        urdf: str = "",
+        urdf_path: str = "",
+        reachy_model: str = "full_kit",
+        is_dvt: bool = False,
+        device: Any = None,
+        solver: Optional[HipSolver] = None,
+    ) -> None:
+        self.symbolic_ik_solver: Dict[str, SymbolicIK] = {}
+        self.last_call_t: Dict[str, float] = {}
+        self.call_timeout = 0.2
+        self.nb_search_points = 20
+        self.emergency_state = ""
+        self.emergency_stop = False
+        self.init = True
+        self.logger = logger
+        if is_dvt:
+            self.singularity_offset = 0.03
+            if self.logger is not None:
+                self.logger.info("DVT mode activated", throttle_duration_sec=0.1)
+            else:
+                print("DVT mode activated")
+        else:
+            self.singularity_offset = -1.01
+        self.singularity_limit_coeff = 1.0
+        self.preferred_theta: Dict[str, float] = {}
+        self.previous_theta: Dict[str, float] = {}
+        self.previous_sol: Dict[str, npt.NDArray[np.float64]] = {}
+        self.previous_pose: Dict[str, npt.NDArray[np.float64]] = {}
+        self.orbita3D_max_angle = np.deg2rad(42.5)
+
+        if urdf_path == "" and urdf == "":
+            raise ValueError("No URDF provided")
+        if urdf_path != "" and urdf == "":
+            urdf_path = os.path.join(os.path.dirname(__file__), urdf_path)
+            if os.path.isfile(urdf_path) and os.path.getsize(urdf_path) > 0:
+                with open(urdf_path, "r") as fh:
+                    urdf = fh.read()
+            if urdf == "":
+                raise ValueError("Empty URDF file")
+        if reachy_model in ("full_kit", "headless"):
+            arms = ["r", "l"]
+        elif reachy_model == "starter_kit_right":
+            arms = ["r"]
+        elif reachy_model == "starter_kit_left":
+            arms = ["l"]
+        elif reachy_model == "mini":
+            arms = []
+        else:
+            raise ValueError(f"Unknown Reachy model {reachy_model}")
+        try:
+            ik_parameters = get_ik_parameters_from_urdf(urdf, arms)
+        except Exception as e:
+            raise ValueError(f"Error while parsing URDF: {e}")
+
+        self._solver = solver if solver is not None else (HipSolver(device) if arms else None)
+        for prefix in arms:
+            arm = f"{prefix}_arm"
+            if ik_parameters != {}:
+                self.symbolic_ik_solver[arm] = SymbolicIK(
+                    arm=arm, ik_parameters=ik_parameters, singularity_offset=self.singularity_offset,
+                    singularity_limit_coeff=self.singularity_limit_coeff, solver=self._solver)
+            else:
+                self.symbolic_ik_solver[arm] = SymbolicIK(
+                    arm=arm, wrist_limit=np.rad2deg(self.orbita3D_max_angle), singularity_offset=self.singularity_offset,
+                    singularity_limit_coeff=self.singularity_limit_coeff, solver=self._solver)
+            preferred_theta = -4 * np.pi / 6
+            k = 0 if prefix == "r" else 1
+            self.preferred_theta[arm] = preferred_theta if prefix == "r" else -np.pi - preferred_theta
+            self.previous_sol[arm] = np.array(current_joints[k])
+            self.previous_pose[arm] = current_pose[k]
+            pose_tuple = self._matrix_to_pose(self.previous_pose[arm])
+            _, _, theta_to_joints_func = self.symbolic_ik_solver[arm].is_reachable_no_limits(pose_tuple)
+            best_prev_theta, _ = get_best_theta_to_current_joints(theta_to_joints_func, 20, current_joints, arm,
+                                                                  self.preferred_theta[arm])
+            self.previous_theta[arm] = best_prev_theta
+            self.last_call_t[arm] = 0.0
+
+    # ------------------------------------------------------------------ helpers
+    @staticmethod
+    def _matrix_to_pose(M: npt.NDArray[np.float64]) -> npt.NDArray[np.float64]:
+        """control_ik.py:212-217 / 142-147: identity shortcut, else extrinsic xyz Euler angles of M[:3,:3]."""
+        M = np.asarray(M, dtype=np.float64)
+        if np.allclose(M[:3, :3], np.eye(3)):
+            return np.array([M[:3, 3], [0, 0, 0]], dtype=np.float64)
+        from scipy.spatial.transform import Rotation
+
+        return np.array([M[:3, 3], Rotation.from_matrix(M[:3, :3]).as_euler("xyz")])
+
+    def _previous_sol_2x7(self) -> np.ndarray:
+        ps = np.zeros((2, 7))
+        for arm, k in ARM_IDS.items():
+            if arm in self.previous_sol:
+                ps[k] = self.previous_sol[arm]
+        return ps
+
+    def _upload_arms(self) -> None:
+        for s in self.symbolic_ik_solver.values():
+            s._upload()
+
+    # ------------------------------------------------------------------ reference API
+    def symbolic_inverse_kinematics(
+        self,
+        name: str,
+        M: npt.NDArray[np.float64],
+        control_type: str,
+        current_joints: list = [],
+        constrained_mode: str = "unconstrained",
+        current_pose: npt.NDArray[np.float64] = np.array([]),
+        d_theta_max: float = 0.01,
+        preferred_theta: float = -4 * np.pi / 6,
+    ) -> Tuple[npt.NDArray[np.float64], bool, str]:
+        """control_ik.py:162-274."""
+        if control_type == "unfreeze":
+            self.emergency_stop = False
+            self.emergency_state = ""
+            self.init = True
+            if self.logger is not None:
+                self.logger.info(f"{name} Unfreeze", throttle_duration_sec=1.0)
+            else:
+                print(f"{name} Unfreeze")
+        if self.emergency_stop:
+            if self.logger is not None:
+                self.logger.info(f"{name} Emergency state: {self.emergency_state}", throttle_duration_sec=1.0)
+            else:
+                print(f"{name} Emergency state: {self.emergency_state}")
+            return self.previous_sol[name], False, self.emergency_state
+        if constrained_mode not in _abi.MODES:
+            # the reference leaves interval_limit unbound here (control_ik.py:225-232)
+            raise UnboundLocalError("local variable 'interval_limit' referenced before assignment")
+        if current_joints == []:
+            current_joints = self.previous_sol[name].tolist()
+        if control_type == "continuous" or control_type == "unfreeze":
+            raise NotImplementedError("continuous mode: use symbolic_inverse_kinematics_continuous_batch (state-carrying kernel)")
+        elif control_type == "discrete":
+            M = np.asarray(M, dtype=np.float64)
+            res = self.symbolic_inverse_kinematics_batch(
+                name, M.reshape(1, 4, 4), constrained_mode=constrained_mode,
+                current_joints=np.asarray(current_joints, dtype=np.float64).reshape(1, 7), preferred_theta=preferred_theta)
+            ik_joints = res["joints"][0].cpu().numpy().tolist()
+            is_reachable = bool(res["reachable"].item())
+            state = STATE_STRINGS[int(res["state"].item())]
+            if bool(res["emergency"].item()):
+                self.emergency_stop = True
+                self.emergency_state += "\nEMERGENCY STOP: multiturn limit reached"
+        else:
+            raise ValueError(f"Unknown type {control_type}")
+        self.previous_pose[name] = M
+        return ik_joints, is_reachable, state
+
+    # ------------------------------------------------------------------ MI355X-native batch API
+    def symbolic_inverse_kinematics_batch(
+        self,
+        name: Any,
+        M: Any,
+        constrained_mode: str = "unconstrained",
+        current_joints: Any = None,
+        preferred_theta: float = -4 * np.pi / 6,
+        out: Optional[Dict[str, torch.Tensor]] = None,
+    ) -> Dict[str, torch.Tensor]:
+        """Discrete-mode IK for a batch of goal matrices.
+
+        name: "r_arm" / "l_arm" for a single-arm batch, or a uint8 tensor/array [n] of arm ids (0 = r, 1 = l).
+        M: [n,4,4] or packed SoA [12,n].  current_joints: [n,7] or None (=> previous_sol of the pose's arm).
+        Returns device tensors joints [n,7], reachable [n], state [n], emergency [n].
+        """
+        if constrained_mode not in _abi.MODES:
+            raise UnboundLocalError("local variable 'interval_limit' referenced before assignment")
+        m12 = matrices_to_m12_soa(M, self._solver.device)
+        arm_t, arm_uniform = None, 0
+        if isinstance(name, str):
+            if name not in self.symbolic_ik_solver:
+                raise KeyError(name)
+            arm_uniform = ARM_IDS[name]
+        else:
+            arm_t = name
+        self._upload_arms()
+        return self._solver.control_discrete(
+            m12, arm=arm_t, arm_uniform=arm_uniform, nb_search_points=int(self.nb_search_points),
+            preferred_theta=float(preferred_theta), constrained_mode=_abi.MODES[constrained_mode],
+            previous_sol=self._previous_sol_2x7(), current_joints=current_joints,
+            orbita3d_max_angle=float(self.orbita3D_max_angle), out=out)

@@ -1,0 +1,507 @@
+// rsik_device.hpp — per-pose analytic IK math for gfx950 (one pose per lane, IEEE float64).
+//
+// Not a translation of the reference's 4x4-matrix / scipy formulation: every frame is reduced
+// to the 3-vectors that are actually consumed, all rotations about a joint axis are built from
+// normalised vector components (no sin/cos of an angle that was just produced by atan2), and the
+// least-squares plane/plane line of symbolic_ik.py:570-606 is replaced by its closed form.
+// Decision points (threshold comparisons that fix the reachability flag / state / interval
+// orientation) keep the reference's operand order so flags stay bit-exact; they are marked [D].
+//
+// Reference citations: S: = src/reachy2_symbolic_ik/symbolic_ik.py, U: = utils.py, C: = control_ik.py.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rsik.h"
+
+namespace rsik {
+
+constexpr double kPi = 3.141592653589793;  // == math.pi
+constexpr double kTwoPi = 2 * kPi;
+
+struct ArmC {
+    double v[RSIK_ARM_CONSTS_COUNT];
+};
+
+struct V3 {
+    double x, y, z;
+};
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ V3 operator/(V3 a, double s) { return {a.x / s, a.y / s, a.z / s}; }
+__device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ double norm(V3 a) { return sqrt(dot(a, a)); }
+
+// numpy.isclose(a, b), default rtol/atol: |a-b| <= 1e-8 + 1e-5*|b|
+__device__ __forceinline__ bool np_isclose(double a, double b) { return fabs(a - b) <= (1e-8 + 1e-5 * fabs(b)); }
+
+// Python float modulo `a % (2*pi)` (result in [0, 2pi)).  CPython computes fmod(a, b) (exact) and adds b
+// when the signs differ.  For the small quotients on this path a - q*2pi is exactly representable, so one
+// fma reproduces fmod bit for bit; the two fix-ups only fire when a*(1/2pi) rounded across an integer.
+__device__ __forceinline__ double pymod_2pi(double a) {
+    double q = floor(a * 0.15915494309189535);
+    double m = fma(-q, kTwoPi, a);
+    if (m < 0) m += kTwoPi;
+    if (m >= kTwoPi) m -= kTwoPi;
+    return m;
+}
+// U:486-490
+__device__ __forceinline__ double angle_diff(double a, double b) {
+    double d = a - b;
+    return pymod_2pi(d + kPi) - kPi;
+}
+// U:468-474
+__device__ __forceinline__ bool is_valid_angle(double angle, double i0, double i1) {
+    if (pymod_2pi(i0) == pymod_2pi(i1)) return true;
+    if (i0 < i1) return (i0 <= angle) && (angle <= i1);
+    return (i0 <= angle) || (angle <= i1);
+}
+
+// Goal rotation R = Rz(yaw) Ry(pitch) Rx(roll)  (scipy from_euler("xyz"), extrinsic; S:420).
+struct Rot {
+    double m[9];  // row-major
+    __device__ __forceinline__ V3 apply(V3 v) const {
+        return {m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z,
+                m[6] * v.x + m[7] * v.y + m[8] * v.z};
+    }
+    __device__ __forceinline__ V3 col0() const { return {m[0], m[3], m[6]}; }
+};
+__device__ __forceinline__ Rot rot_from_euler(double roll, double pitch, double yaw) {
+    double sa, ca, sb, cb, sc, cc;
+    sincos(roll, &sa, &ca);
+    sincos(pitch, &sb, &cb);
+    sincos(yaw, &sc, &cc);
+    Rot r;
+    r.m[0] = cc * cb; r.m[1] = cc * sb * sa - sc * ca; r.m[2] = cc * sb * ca + sc * sa;
+    r.m[3] = sc * cb; r.m[4] = sc * sb * sa + cc * ca; r.m[5] = sc * sb * ca - cc * sa;
+    r.m[6] = -sb;     r.m[7] = cb * sa;                r.m[8] = cb * ca;
+    return r;
+}
+
+// Columns of utils.rotation_matrix_from_vector(n) (U:59-81): the rotation taking e_x to n/|n|.
+// c0 is only needed for the "which side of the wrist-limit plane" tests.
+struct Frame {
+    V3 c0, c1, c2;
+};
+__device__ __forceinline__ Frame frame_from_normal(V3 n) {
+    double nn = norm(n);
+    V3 u = n / nn;
+    Frame F;
+    // [D] colinear special cases, numpy.isclose semantics with the tolerance scaled by the 2nd argument
+    bool yz = np_isclose(0.0, u.y) && np_isclose(0.0, u.z);
+    if (yz && np_isclose(1.0, u.x)) {
+        F.c0 = {1, 0, 0}; F.c1 = {0, 1, 0}; F.c2 = {0, 0, 1};
+        return F;
+    }
+    if (yz && np_isclose(1.0, -u.x)) {
+        F.c0 = {-1, 0, 0}; F.c1 = {0, 1, 0}; F.c2 = {0, 0, -1};
+        return F;
+    }
+    // Rodrigues I + K + K^2 (1-c)/s^2 with v = e_x x u = (0, -u_z, u_y)
+    double s2 = u.z * u.z + u.y * u.y;
+    double h = (1 - u.x) / s2;
+    double yzh = (u.y * u.z) * h;
+    F.c0 = {1 - s2 * h, u.y, u.z};
+    F.c1 = {-u.y, 1 - (u.y * u.y) * h, -yzh};
+    F.c2 = {-u.z, -yzh, 1 - (u.z * u.z) * h};
+    return F;
+}
+
+// Result of the is_reachable stage: what SymbolicIK leaves on `self` for get_joints (Q1).
+struct Reach {
+    int state;     // RSIK_STATE_*
+    bool ok;
+    double i0, i1; // theta interval
+    V3 pos;        // self.goal_pose[0]
+    V3 w;          // self.wrist_position
+    V3 c2;         // intersection circle centre
+    double r2;     // radius
+    V3 n2;         // circle normal (self.intersection_circle[2])
+    V3 a1, a2;     // circle frame axes: elbow(theta) = c2 + r2 cos(theta) a1 + r2 sin(theta) a2
+    int stage;     // how far self.* was updated: 0 nothing, 1 goal_pose + wrist_position, 2 + intersection_circle
+};
+
+template <class Acc>
+__device__ __forceinline__ V3 cvec(const Acc& A, int off) {
+    return {A(off), A(off + 1), A(off + 2)};
+}
+
+// S:418-425 — wrist = T_torso_goal . (-tip_x, tip_y, tip_z, 1)
+template <class Acc>
+__device__ __forceinline__ V3 wrist_position(const Acc& A, const Rot& Rg, V3 pos) {
+    V3 tl = cvec(A, RSIK_C_TIPL);
+    return Rg.apply(tl) + pos;
+}
+
+// SymbolicIK.is_reachable (S:121-282) including is_pose_in_robot_reach (S:284-307),
+// reduce_goal_pose_no_limits (S:337-349), get_intersection_circle (S:366-399),
+// get_limitation_wrist_circle (S:401-416) and are_circles_linked (S:427-568).
+// NO_LIMITS = true gives SymbolicIK.is_reachable_no_limits (S:85-119): never fails on reach, interval [-pi, pi].
+template <bool NO_LIMITS, class Acc>
+__device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
+    Reach r;
+    r.ok = false;
+    r.i0 = r.i1 = __builtin_nan("");
+    const V3 s = cvec(A, RSIK_C_SHOULDER);
+    const double u = A(RSIK_C_UPPER_ARM), f = A(RSIK_C_FOREARM);
+    const double bl = A(RSIK_C_BACKWARD), pm = A(RSIK_C_PROJ_MARGIN), upf = A(RSIK_C_UPF);
+
+    // [D] S:284-307
+    V3 gp = pos_in;
+    V3 dv = gp - s;
+    double d = norm(dv);
+    int st = RSIK_STATE_REACHABLE;
+    if (d > A(RSIK_C_MAX_LEN)) {
+        double nd = d + pm;
+        gp = s + (dv / nd) * A(RSIK_C_MAX_LEN);
+        st = RSIK_STATE_POSE_OUT_OF_REACH;
+    }
+    if (gp.x < bl) {
+        gp.x = bl;
+        st = RSIK_STATE_BACKWARD_POSE;
+    }
+    r.state = st;
+    r.stage = 0;
+    r.pos = gp; r.w = gp; r.c2 = gp; r.n2 = gp; r.a1 = gp; r.a2 = gp; r.r2 = 0.0;
+    if (!NO_LIMITS && st != RSIK_STATE_REACHABLE) return r;
+    r.stage = 1;
+
+    V3 w = wrist_position(A, Rg, gp);
+    // [D] S:146-153 / S:94-98
+    if (w.x < bl) {
+        double diff = bl - w.x;
+        gp.x = gp.x + diff;
+        if (NO_LIMITS) w = wrist_position(A, Rg, gp);
+        else w.x = w.x + diff;
+    }
+    V3 P = w - s;
+    double dsw = norm(P);
+    V3 self_pos = gp;  // what ends up in self.goal_pose (differs from the local only in the NO_LIMITS far case, Q4)
+    if (NO_LIMITS) {
+        if (dsw > upf) {  // S:102-105: self.wrist_position moved onto the sphere, self.goal_pose shifted
+            double nd = fabs(dsw) + pm;
+            V3 nw = s + ((w - s) / nd) * upf;
+            self_pos = gp + (nw - w);
+            w = nw;
+        }
+    } else {
+        if (dsw > upf) {  // [D] S:157-161
+            r.state = RSIK_STATE_WRIST_OUT_OF_RANGE;
+            r.pos = gp; r.w = w;
+            return r;
+        }
+    }
+    if (dsw < A(RSIK_C_MIN_DIST)) {  // [D] S:166-171 / S:107-112
+        double nd = fabs(dsw) + pm;
+        V3 nw = s + ((w - s) / nd) * A(RSIK_C_MIN_DIST);
+        gp = gp + (nw - w);
+        w = wrist_position(A, Rg, gp);
+        self_pos = gp;
+    }
+
+    // S:366-399 intersection circle of the shoulder sphere (radius u) and the wrist sphere (radius f)
+    P = w - s;
+    d = sqrt(P.x * P.x + P.y * P.y + P.z * P.z);
+    r.pos = self_pos;
+    r.w = w;
+    if (d > upf) {  // [D] S:374
+        r.state = RSIK_STATE_SHOULD_NOT_HAPPEN;
+        return r;
+    }
+    V3 n2 = P / d;
+    double d2 = d * d, k = d2 - f * f + u * u;
+    double r2 = 1 / (2 * d) * sqrt(4 * d2 * (u * u) - k * k);
+    V3 c2 = s + n2 * (k / (2 * d));
+    Frame F2 = frame_from_normal(n2);
+    r.c2 = c2; r.r2 = r2; r.n2 = n2; r.a1 = F2.c1; r.a2 = F2.c2;
+    r.stage = 2;
+    if (NO_LIMITS) {
+        r.ok = true; r.state = RSIK_STATE_REACHABLE; r.i0 = -kPi; r.i1 = kPi;
+        return r;
+    }
+
+    // S:401-416 wrist-limit circle (cone of half-angle wrist_limit around the hand axis)
+    V3 n1 = w - gp;
+    double nn1 = norm(n1);
+    V3 c1 = w + (n1 / nn1) * A(RSIK_C_WRIST_AX);
+    double r1 = A(RSIK_C_WRIST_R);
+
+    // S:427-509 are_circles_linked, wrist-centred coordinates
+    V3 p1 = c1 - w, p2 = c2 - w;
+    Frame F1 = frame_from_normal(n1);
+    // [D] x of T_limitation_torso . p = c0.p + (-c0).p1
+    double tlx = (-F1.c0.x) * p1.x + (-F1.c0.y) * p1.y + (-F1.c0.z) * p1.z;
+    bool side_ok = (F1.c0.x * p2.x + F1.c0.y * p2.y + F1.c0.z * p2.z + tlx) > 0;
+    r.state = side_ok ? RSIK_STATE_REACHABLE : RSIK_STATE_LIMITED_BY_WRIST;
+    r.ok = side_ok;
+    r.i0 = side_ok ? -kPi : __builtin_nan("");
+    r.i1 = side_ok ? kPi : __builtin_nan("");
+
+    V3 N1 = n1 / nn1;
+    V3 N2 = n2 / norm(n2);
+    const double mg = A(RSIK_C_NORMAL_MARGIN);
+    // [D] S:475-483 parallel planes
+    bool par = (fabs(N2.x - N1.x) < mg && fabs(N2.y - N1.y) < mg && fabs(N2.z - N1.z) < mg) ||
+               (fabs(N2.x + N1.x) < mg && fabs(N2.y + N1.y) < mg && fabs(N2.z + N1.z) < mg);
+    if (par) return r;
+
+    // S:588-606 + S:570-586: line of intersection of the two planes.  The reference solves
+    // [v1, -v2] t = p2 - p1 by least squares; since v1, v2, (p2-p1 minus its v-part) are coplanar the
+    // minimiser is the exact intersection: t0 = N2.b / (N2.v1), t1 = N1.b / -(N1.v2), both denominators = |N1 x N2|.
+    V3 cr = cross(N1, N2);
+    double nv = norm(cr);
+    V3 v = cr / nv;
+    V3 v1 = cross(v, N1);
+    V3 b = p2 - p1;
+    double t0 = dot(N2, b) / nv;
+    double t1 = dot(N1, b) / nv;
+    if (np_isclose(t1, t0)) return r;  // [D] S:582-583 (Q7)
+    V3 q = v1 * t0 + p1;
+
+    // S:608-645 circle 1 (centre p1, radius r1) with the line (q, v)
+    V3 wv = q - p1;
+    double qa = dot(v, v);
+    double qb = 2 * dot(v, wv);
+    double qc = dot(wv, wv) - r1 * r1;
+    double disc = qb * qb - 4 * qa * qc;
+    if (disc < 0) return r;  // [D]
+
+    // S:511-568 angles of the intersection points in the circle-2 frame
+    V3 a1 = F2.c1, a2 = F2.c2;
+    double oy = -dot(a1, p2), oz = -dot(a2, p2);  // translation of T_intersection_torso
+    r.ok = true;
+    r.state = RSIK_STATE_REACHABLE;
+    if (disc == 0) {  // [D] tangent: interval [a, a] (Q8)
+        double t = -qb / (2 * qa);
+        V3 p = q + v * t;
+        double ang = atan2(dot(a2, p) + oz, dot(a1, p) + oy);
+        r.i0 = ang; r.i1 = ang;
+        return r;
+    }
+    double sq = sqrt(disc);
+    double ta = (-qb + sq) / (2 * qa), tb = (-qb - sq) / (2 * qa);
+    V3 pa = q + v * ta, pb = q + v * tb;
+    double ang1 = atan2(dot(a2, pa) + oz, dot(a1, pa) + oy);
+    double ang2 = atan2(dot(a2, pb) + oz, dot(a1, pb) + oy);
+    if (ang2 < ang1) { double t = ang1; ang1 = ang2; ang2 = t; }
+    double am = (ang1 + ang2) / 2;
+    double sm, cm;
+    sincos(am, &sm, &cm);
+    double ty = cm * r2, tz = sm * r2;
+    V3 tp = {a1.x * ty + a2.x * tz + p2.x, a1.y * ty + a2.y * tz + p2.y, a1.z * ty + a2.z * tz + p2.z};
+    bool inside = (F1.c0.x * tp.x + F1.c0.y * tp.y + F1.c0.z * tp.z + tlx) > 0;  // [D] S:564
+    r.i0 = inside ? ang1 : ang2;
+    r.i1 = inside ? ang2 : ang1;
+    return r;
+}
+
+// S:684-695
+__device__ __forceinline__ V3 elbow_on_circle(const Reach& r, double ct, double st) {
+    double y = r.r2 * ct, z = r.r2 * st;
+    return {r.a1.x * y + r.a2.x * z + r.c2.x, r.a1.y * y + r.a2.y * z + r.c2.y, r.a1.z * y + r.a2.z * z + r.c2.z};
+}
+
+// [D] S:708-713 / U:459-464: elbow above the singularity plane
+template <class Acc>
+__device__ __forceinline__ bool above_singularity_plane(const Acc& A, V3 e) {
+    return e.z > (e.x - A(RSIK_C_ES)) * A(RSIK_C_SING_COEFF) + A(RSIK_C_ES + 2) - A(RSIK_C_SING_OFFSET);
+}
+// U:443-465 (effective predicate, Q10)
+template <class Acc>
+__device__ __forceinline__ bool is_elbow_ok(const Acc& A, V3 e) {
+    bool ok = e.y * A(RSIK_C_SIDE) < -0.2;
+    return ok && (e.z < (e.x - A(RSIK_C_ES)) * A(RSIK_C_SING_COEFF) + A(RSIK_C_ES + 2) - A(RSIK_C_SING_OFFSET));
+}
+
+struct JointsOut {
+    double j[7];
+    V3 elbow;
+    bool projected;
+    // unit vectors of the wrist angles, for ControlIK.safety_checks without re-evaluating sin/cos
+    double c4, s4, c5, s5, c6, s6;
+};
+
+// SymbolicIK.get_joints (S:697-863).  Mutates r.pos / r.w like the reference mutates self (Q1).
+//
+// Derivation (see DESIGN.md "joint chain"): with q = M_shoulder_torso.(e - s),
+//   G = Rz(-sr) Ry(-sp) has rows  q/|q|, (-q_y c, rho/|q|, -q_y s)/... , (-s, 0, c)   with (c, s) = (q_x, q_z)/rho
+// so no trigonometric function of a computed joint angle is ever evaluated; the same holds for the
+// elbow (H) and wrist (K) frames.  Exact-zero singularities fall back to previous_joints (S:751-753, 782-784).
+template <class Acc>
+__device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, double theta, const double* prev) {
+    JointsOut o;
+    double st, ct;
+    sincos(theta, &st, &ct);
+    V3 e = elbow_on_circle(r, ct, st);
+    o.projected = false;
+    if (above_singularity_plane(A, e)) {  // S:708-718 -> make_elbow_projection S:647-682
+        V3 Pl = cvec(A, RSIK_C_PLANE_P), v3 = cvec(A, RSIK_C_PLANE_N), pc = cvec(A, RSIK_C_PROJ_CENTER);
+        double dist = dot(e - Pl, v3);
+        V3 pe = e - v3 * dist;
+        V3 V = pe - pc;
+        V3 ne = pc + (V / norm(V)) * A(RSIK_C_PROJ_RADIUS);
+        r.pos = r.pos + (ne - e);
+        e = ne;
+        r.w = wrist_position(A, Rg, r.pos);
+        o.projected = true;
+    }
+    o.elbow = e;
+    const double u = A(RSIK_C_UPPER_ARM), f = A(RSIK_C_FOREARM);
+    // shoulder frame: x = M_shoulder_torso . p + P_shoulder_torso (S:728-741)
+    auto to_shoulder = [&](V3 p) -> V3 {
+        return {A(RSIK_C_MST + 0) * p.x + A(RSIK_C_MST + 1) * p.y + A(RSIK_C_MST + 2) * p.z + A(RSIK_C_TSH + 0),
+                A(RSIK_C_MST + 3) * p.x + A(RSIK_C_MST + 4) * p.y + A(RSIK_C_MST + 5) * p.z + A(RSIK_C_TSH + 1),
+                A(RSIK_C_MST + 6) * p.x + A(RSIK_C_MST + 7) * p.y + A(RSIK_C_MST + 8) * p.z + A(RSIK_C_TSH + 2)};
+    };
+    V3 q = to_shoulder(e);
+    // shoulder pitch / roll (S:751-766)
+    double cphi, sphi, sp;
+    double rho = sqrt(q.x * q.x + q.z * q.z);
+    if (q.x == 0 && q.z == 0) {  // [D] exact singularity: keep the previous pitch
+        sp = prev[0];
+        double s_, c_;
+        sincos(sp, &s_, &c_);
+        cphi = c_; sphi = -s_;
+    } else {
+        sp = -atan2(q.z, q.x);
+        cphi = q.x / rho; sphi = q.z / rho;
+    }
+    double sr = atan2(q.y, rho);
+    double L = sqrt(rho * rho + q.y * q.y);
+    double cr = rho / L, srs = q.y / L;
+    // G = Rz(-sr) Ry(-sp): rows g0, g1, g2
+    V3 g0 = {cr * cphi, srs, cr * sphi};
+    V3 g1 = {-srs * cphi, cr, -srs * sphi};
+    V3 g2 = {-sphi, 0.0, cphi};
+    auto to_elbow = [&](V3 p) -> V3 {  // T_elbow_torso (S:776-777)
+        V3 a = to_shoulder(p);
+        return {dot(g0, a) - u, dot(g1, a), dot(g2, a)};
+    };
+    // elbow yaw / pitch (S:780-797)
+    V3 pw = to_elbow(r.w);
+    double sigma = sqrt(pw.y * pw.y + pw.z * pw.z);
+    double ey, ca, sa;
+    if (pw.y == 0 && pw.z == 0) {  // [D] exact singularity
+        ey = prev[2];
+        sincos(ey, &sa, &ca);
+    } else {
+        ey = -kPi / 2 + atan2(pw.z, -pw.y);
+        ca = pw.z / sigma; sa = pw.y / sigma;
+    }
+    double ep = -atan2(sigma, pw.x);
+    double lam = sqrt(sigma * sigma + pw.x * pw.x);
+    double cchi = pw.x / lam, schi = sigma / lam;
+    // H = Ry(-ep) Rx(ey)
+    V3 h0 = {cchi, schi * sa, schi * ca};
+    V3 h1 = {0.0, ca, -sa};
+    V3 h2 = {-schi, cchi * sa, cchi * ca};
+    auto to_wrist = [&](V3 p) -> V3 {  // T_wrist_torso (S:805-806)
+        V3 a = to_elbow(p);
+        return {dot(h0, a) - f, dot(h1, a), dot(h2, a)};
+    };
+    // wrist roll / pitch (S:808-826)
+    V3 tl = cvec(A, RSIK_C_TIPL);
+    V3 ptip = Rg.apply(V3{tl.x, tl.y, 0.0}) + r.pos;
+    V3 t = to_wrist(ptip);
+    double tau = sqrt(t.x * t.x + t.y * t.y);
+    double wr, cw, sw;
+    if (tau == 0) {
+        wr = kPi - atan2(t.y, -t.x);
+        if (wr > kPi) wr = wr - kTwoPi;
+        sincos(wr, &sw, &cw);
+    } else {
+        wr = kPi - atan2(t.y, -t.x);
+        if (wr > kPi) wr = wr - kTwoPi;
+        cw = t.x / tau; sw = t.y / tau;
+    }
+    double wp = atan2(t.z, tau);
+    double mu = sqrt(tau * tau + t.z * t.z);
+    double cp = tau / mu, spp = t.z / mu;
+    // K = Ry(wp) Rz(-wr); only rows 1, 2 are needed for the yaw
+    V3 k1 = {-sw, cw, 0.0};
+    V3 k2 = {-spp * cw, -spp * sw, cp};
+    // wrist yaw (S:839-848): direction of the goal frame's x axis seen from the tip frame
+    V3 xg = Rg.col0();
+    V3 xs = {A(RSIK_C_MST + 0) * xg.x + A(RSIK_C_MST + 1) * xg.y + A(RSIK_C_MST + 2) * xg.z,
+             A(RSIK_C_MST + 3) * xg.x + A(RSIK_C_MST + 4) * xg.y + A(RSIK_C_MST + 5) * xg.z,
+             A(RSIK_C_MST + 6) * xg.x + A(RSIK_C_MST + 7) * xg.y + A(RSIK_C_MST + 8) * xg.z};
+    V3 xe = {dot(g0, xs), dot(g1, xs), dot(g2, xs)};
+    V3 xw = {dot(h0, xe), dot(h1, xe), dot(h2, xe)};
+    double gy = dot(k1, xw), gz = dot(k2, xw);
+    double wy = -atan2(gy, gz);
+
+    o.j[0] = sp; o.j[1] = sr; o.j[2] = ey; o.j[3] = ep; o.j[4] = wr; o.j[5] = -wp; o.j[6] = -wy;
+    const double el = A(RSIK_C_ELBOW_LIMIT);  // S:853-861
+    if (o.j[3] > el) o.j[3] = el;
+    if (o.j[3] < -el) o.j[3] = -el;
+    double gn = sqrt(gy * gy + gz * gz);
+    o.c4 = cw; o.s4 = sw; o.c5 = cp; o.s5 = -spp;
+    o.c6 = gz / gn; o.s6 = gy / gn;
+    return o;
+}
+
+// U:93-112 limit_theta_to_interval (previous_theta is normalised by the reference but never used, Q12)
+__device__ __forceinline__ double limit_theta_to_interval(double theta, double l0, double l1) {
+    theta = pymod_2pi(theta);
+    if (theta > kPi) theta -= kTwoPi;
+    if (is_valid_angle(theta, l0, l1)) return theta;
+    double posDiff = angle_diff(theta, l1);
+    double negDiff = angle_diff(theta, l0);
+    if (fabs(posDiff) < fabs(negDiff)) return l1;
+    return l0;
+}
+
+// ControlIK.safety_checks (C:464-497):
+//   utils.limit_orbita3d_joints (U:508-519): wrist triple as intrinsic XYZ -> ZYZ (alpha, beta, gamma), clamp
+//   beta to the Orbita3D cone, back to XYZ (scipy gimbal conventions: beta within 1e-7 of 0 or pi => gamma := 0);
+//   utils.allow_multiturn (U:493-505); utils.multiturn_safety_check (U:535-568).
+// The wrist angles enter as unit vectors (c, s) so no sin/cos is evaluated for joints that came out of atan2.
+__device__ __forceinline__ bool safety_checks(double (&j)[7], double ca, double sa, double cb, double sb, double cc,
+                                              double sc, const double* prev, double max_angle, double cos_max,
+                                              double sin_max) {
+    // W = Rx(a) Ry(b) Rz(c)
+    double W00 = cb * cc, W01 = -cb * sc, W02 = sb;
+    double W10 = ca * sc + sa * sb * cc, W12 = -sa * cb;
+    double W20 = sa * sc - ca * sb * cc, W21 = sa * cc + ca * sb * sc, W22 = ca * cb;
+    double sbeta = sqrt(W02 * W02 + W12 * W12);  // sin(beta) >= 0, beta in [0, pi]
+    double beta = atan2(sbeta, W22);
+    double cal, sal, cga, sga;  // cos/sin of alpha, gamma
+    if (fabs(beta) <= 1e-7) {
+        double h = sqrt(W00 * W00 + W10 * W10);
+        cal = W00 / h; sal = W10 / h; cga = 1.0; sga = 0.0;
+    } else if (fabs(beta - kPi) <= 1e-7) {
+        double h = sqrt(W00 * W00 + W10 * W10);
+        cal = -W00 / h; sal = -W10 / h; cga = 1.0; sga = 0.0;
+    } else {
+        cal = W02 / sbeta; sal = W12 / sbeta;
+        double h = sqrt(W20 * W20 + W21 * W21);
+        cga = -W20 / h; sga = W21 / h;
+    }
+    double cbe = W22 / sqrt(sbeta * sbeta + W22 * W22), sbe = sbeta / sqrt(sbeta * sbeta + W22 * W22);
+    if (beta > max_angle) { cbe = cos_max; sbe = sin_max; }  // beta >= 0 so only the upper clamp can act
+    // W' = Rz(alpha) Ry(beta') Rz(gamma); intrinsic XYZ angles of W'
+    double V02 = cal * sbe, V12 = sal * sbe, V22 = cbe;
+    double V01 = -cal * cbe * sga - sal * cga, V00 = cal * cbe * cga - sal * sga;
+    j[4] = atan2(-V12, V22);
+    j[5] = asin(V02);
+    j[6] = atan2(-V01, V00);
+    bool emergency = false;
+#pragma unroll
+    for (int k = 0; k < 7; k++) j[k] = prev[k] + angle_diff(j[k], prev[k]);
+    const double lim = 6 * kPi;
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        if (k == 0 || k == 2 || k == 6) {
+            if (j[k] > lim) { j[k] = lim; emergency = true; }
+            if (j[k] < -lim) { j[k] = -lim; emergency = true; }
+        }
+    }
+    return emergency;
+}
+
+}  // namespace rsik

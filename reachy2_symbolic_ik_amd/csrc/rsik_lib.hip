@@ -1,0 +1,717 @@
+// rsik_lib.hip — HIP kernels (gfx950) and the C ABI of include/rsik.h.
+//
+// Kernel shape: one pose per lane, 256-thread workgroups (4 wave64), SoA float64 inputs so that
+// every global load is a fully coalesced 512-B wave access; the [n,7] / [n,3] row outputs are
+// transposed through LDS so that each wave writes its 3584-B / 1536-B slab with unit-stride stores.
+// Per-arm constants travel in the kernarg segment (scalar loads, wave-uniform).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "rsik_device.hpp"
+
+namespace rsik {
+
+constexpr int kBlock = 256;
+
+struct SolveArgs {
+    int64_t n;
+    const double* in[6];
+    const uint8_t* arm;
+    int theta_policy;
+    const double* theta_in;
+    double prev[7];
+    double* joints;
+    double* interval;
+    double* elbow;
+    uint8_t* reachable;
+    uint8_t* state;
+    ArmC arms[2];  // uniform launch: arms[0] is the arm; mixed launch: arms[0] = r, arms[1] = l
+};
+
+template <bool MIXED>
+struct Acc {
+    const ArmC* a;
+    bool isl;
+    __device__ __forceinline__ double operator()(int i) const {
+        if constexpr (MIXED) return isl ? a[1].v[i] : a[0].v[i];
+        else return a[0].v[i];
+    }
+};
+
+// Writes ROWxW doubles per lane as a contiguous [64*W] slab per wave (row-major [n,W] output).
+template <int W>
+__device__ __forceinline__ void store_rows(double* __restrict__ out, int64_t wave_base, int64_t n, int lane,
+                                           double* __restrict__ lds_wave, const double (&vals)[W]) {
+#pragma unroll
+    for (int k = 0; k < W; k++) lds_wave[lane * W + k] = vals[k];
+    // same-wave LDS exchange: the wave executes in lock-step, only the LDS counter must drain
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    int64_t rows = n - wave_base;
+    if (rows > 64) rows = 64;
+    const int64_t total = rows * W;
+    double* dst = out + wave_base * W;
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+        int idx = k * 64 + lane;
+        if (idx < total) dst[idx] = lds_wave[idx];
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <bool MIXED>
+__global__ __launch_bounds__(kBlock) void solve_kernel(const SolveArgs K) {
+    __shared__ double lds[kBlock / 64][64 * 7];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t wave_base = (int64_t)blockIdx.x * kBlock + wave * 64;
+    const bool live = i < K.n;
+    const int64_t ii = live ? i : (K.n - 1);  // tail lanes recompute the last pose; stores are masked
+
+    Acc<MIXED> A{K.arms, false};
+    if constexpr (MIXED) A.isl = K.arm[ii] != 0;
+
+    V3 pos = {K.in[0][ii], K.in[1][ii], K.in[2][ii]};
+    Rot Rg = rot_from_euler(K.in[3][ii], K.in[4][ii], K.in[5][ii]);
+
+    Reach r = reach<false>(A, pos, Rg);
+
+    const double nan = __builtin_nan("");
+    double jv[7] = {nan, nan, nan, nan, nan, nan, nan};
+    double ev[3] = {nan, nan, nan};
+    if (K.theta_policy != RSIK_THETA_NONE && r.ok) {
+        double theta = r.i0;
+        if (K.theta_policy == RSIK_THETA_EXPLICIT) theta = K.theta_in[ii];
+        else if (K.theta_policy == RSIK_THETA_FRACTION) {
+            double a = r.i0, b = r.i1;
+            if (a > b) b += kTwoPi;
+            theta = a + K.theta_in[ii] * (b - a);
+        }
+        JointsOut o = joints_from_theta(A, r, Rg, theta, K.prev);
+#pragma unroll
+        for (int k = 0; k < 7; k++) jv[k] = o.j[k];
+        ev[0] = o.elbow.x; ev[1] = o.elbow.y; ev[2] = o.elbow.z;
+    }
+    if (K.theta_policy != RSIK_THETA_NONE) {
+        if (K.joints) store_rows<7>(K.joints, wave_base, K.n, lane, lds[wave], jv);
+        if (K.elbow) store_rows<3>(K.elbow, wave_base, K.n, lane, lds[wave], ev);
+    }
+    if (live) {
+        if (K.interval) {
+            double2 iv = {r.i0, r.i1};
+            reinterpret_cast<double2*>(K.interval)[i] = iv;
+        }
+        if (K.reachable) K.reachable[i] = r.ok ? 1 : 0;
+        if (K.state) K.state[i] = (uint8_t)r.state;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// ControlIK discrete mode (C:162-274, C:409-497)
+// ------------------------------------------------------------------------------------------
+struct DiscreteArgs {
+    int64_t n;
+    const double* in[12];
+    const uint8_t* arm;
+    int nb;
+    int log2p;            // sweep sub-group width P = 1 << log2p  (P = pow2ceil(min(nb, 64)))
+    double pref[2];       // preferred theta per arm slot (already mirrored for l, C:252)
+    double lim[2][2];     // interval_limit per arm slot (C:225-250)
+    double prev_sol[2][7];
+    const double* current_joints;
+    double max_angle, cos_max, sin_max;
+    double* joints;
+    uint8_t* reachable;
+    uint8_t* state;
+    uint8_t* emergency;
+    ArmC arms[2];
+};
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr int kGeo = 13;  // staged doubles per pose: c2(3) a1(3) a2(3) r2 a step b
+
+// utils.get_best_discrete_theta (U:334-396) for the poses of one wave that need the grid.
+// Lane-per-pose has already staged the circle geometry of its pose in LDS; here the wave walks the set
+// bits of `mask` and gives every selected pose a P-lane sub-group: lane k evaluates theta_k, elbow-ok
+// (U:443-465) and |angle_diff(theta_k, preferred)|, a segmented xor-butterfly keeps the lexicographic
+// minimum of (distance, k) = the reference's "first strict minimum" (U:381-388), the sub-group leader
+// posts the winner.  nb > 64 is handled by extra rounds of the same lanes.
+template <bool MIXED>
+__device__ __forceinline__ void sweep_theta_grid(const DiscreteArgs& K, uint64_t mask, int lane, bool my_isl,
+                                                 const double (*geo)[64], double* res) {
+    const int P = 1 << K.log2p;
+    const int G = 64 >> K.log2p;
+    const int sub = lane >> K.log2p;
+    const int k0 = lane & (P - 1);
+    const int rounds = (K.nb + 63) >> 6;
+    const double inf = __builtin_inf();
+    while (mask) {
+        int p = -1;
+        uint64_t m = mask;
+        for (int g = 0; g < G; g++) {
+            if (m) {
+                int bit = __builtin_ctzll(m);
+                if (g == sub) p = bit;
+                m &= m - 1;
+            }
+        }
+        mask = m;
+        double best_d = inf;
+        int best_k = 0x7fffffff;
+        double ga = 0, gstep = 0, gb = 0;
+        int src = p < 0 ? lane : p;
+        bool isl = MIXED ? (__shfl((int)my_isl, src) != 0) : false;
+        Acc<MIXED> A{K.arms, isl};
+        const int slot = MIXED ? (isl ? 1 : 0) : 0;
+        if (p >= 0) {
+            V3 c2 = {geo[0][p], geo[1][p], geo[2][p]};
+            V3 a1 = {geo[3][p], geo[4][p], geo[5][p]};
+            V3 a2 = {geo[6][p], geo[7][p], geo[8][p]};
+            double r2 = geo[9][p];
+            ga = geo[10][p]; gstep = geo[11][p]; gb = geo[12][p];
+            const double pref = K.pref[slot];
+            for (int rd = 0; rd < rounds; rd++) {
+                int k = k0 + (rd << 6);
+                if (k < K.nb) {
+                    double th = (k == K.nb - 1) ? gb : ((double)k * gstep + ga);  // np.linspace (Q11)
+                    double st, ct;
+                    sincos(th, &st, &ct);
+                    double y = r2 * ct, z = r2 * st;
+                    V3 e = {a1.x * y + a2.x * z + c2.x, a1.y * y + a2.y * z + c2.y, a1.z * y + a2.z * z + c2.z};
+                    if (is_elbow_ok(A, e)) {
+                        double dist = fabs(angle_diff(th, pref));
+                        if (dist < best_d) { best_d = dist; best_k = k; }
+                    }
+                }
+            }
+        }
+        for (int off = P >> 1; off >= 1; off >>= 1) {
+            double od = __shfl_xor(best_d, off);
+            int ok = __shfl_xor(best_k, off);
+            if (od < best_d || (od == best_d && ok < best_k)) { best_d = od; best_k = ok; }
+        }
+        if (p >= 0 && k0 == 0) {
+            double th = __builtin_nan("");
+            if (best_k != 0x7fffffff) th = (best_k == K.nb - 1) ? gb : ((double)best_k * gstep + ga);
+            res[p] = th;
+        }
+    }
+}
+
+template <bool MIXED>
+__global__ __launch_bounds__(kBlock) void control_discrete_kernel(const DiscreteArgs K) {
+    __shared__ double lds_out[kBlock / 64][64 * 7];
+    __shared__ double lds_geo[kBlock / 64][kGeo][64];
+    __shared__ double lds_res[kBlock / 64][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t wave_base = (int64_t)blockIdx.x * kBlock + wave * 64;
+    const bool live = i < K.n;
+    const int64_t ii = live ? i : (K.n - 1);
+
+    Acc<MIXED> A{K.arms, false};
+    if constexpr (MIXED) A.isl = K.arm[ii] != 0;
+    const int slot = MIXED ? (A.isl ? 1 : 0) : 0;
+
+    // C:212-217: M -> pose.  np.allclose(R, I) snaps to the identity; otherwise the reference's Euler
+    // round trip reproduces R to rounding, so R is consumed directly (Q6).
+    Rot Rg;
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rg.m[k] = K.in[k][ii];
+    {
+        bool eye = true;
+#pragma unroll
+        for (int k = 0; k < 9; k++) eye = eye && np_isclose(Rg.m[k], (k % 4 == 0) ? 1.0 : 0.0);
+        if (eye) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) Rg.m[k] = (k % 4 == 0) ? 1.0 : 0.0;
+        }
+    }
+    V3 pos = {K.in[9][ii], K.in[10][ii], K.in[11][ii]};
+
+    Reach r = reach<false>(A, pos, Rg);
+    const double pref = K.pref[slot];
+    bool found = false;
+    double theta = 0.0;
+    bool need = false;
+    if (r.ok) {  // U:357-364 preferred-theta shortcut
+        if (is_valid_angle(pref, r.i0, r.i1)) {
+            double st, ct;
+            sincos(pref, &st, &ct);
+            if (is_elbow_ok(A, elbow_on_circle(r, ct, st))) { found = true; theta = pref; }
+        }
+        need = !found;
+    }
+    if (need) {  // U:366-375 grid end points
+        double a, b;
+        if (fabs(fabs(r.i0) + fabs(r.i1) - kTwoPi) < 0.00001) { a = kPi / 2; b = kPi / 2 + kTwoPi; }
+        else if (r.i0 < r.i1) { a = r.i0; b = r.i1; }
+        else { a = r.i0; b = r.i1 + kTwoPi; }
+        double step = (b - a) / (double)(K.nb - 1);
+        double (*g)[64] = lds_geo[wave];
+        g[0][lane] = r.c2.x; g[1][lane] = r.c2.y; g[2][lane] = r.c2.z;
+        g[3][lane] = r.a1.x; g[4][lane] = r.a1.y; g[5][lane] = r.a1.z;
+        g[6][lane] = r.a2.x; g[7][lane] = r.a2.y; g[8][lane] = r.a2.z;
+        g[9][lane] = r.r2; g[10][lane] = a; g[11][lane] = step; g[12][lane] = b;
+    }
+    wave_lds_sync();
+    const uint64_t mask = __ballot(need);
+    sweep_theta_grid<MIXED>(K, mask, lane, A.isl, lds_geo[wave], lds_res[wave]);
+    wave_lds_sync();
+    int st_code = r.state;
+    if (need) {
+        double th = lds_res[wave][lane];
+        if (th == th) { found = true; theta = th; }
+        else st_code = RSIK_STATE_LIMITED_BY_SHOULDER;  // C:451-452
+    }
+
+    const double* prev = K.prev_sol[slot];
+    double jv[7];
+    double c4, s4, c5, s5, c6, s6;
+    if (found) {  // C:454-456
+        theta = limit_theta_to_interval(theta, K.lim[slot][0], K.lim[slot][1]);
+        JointsOut o = joints_from_theta(A, r, Rg, theta, prev);
+#pragma unroll
+        for (int k = 0; k < 7; k++) jv[k] = o.j[k];
+        c4 = o.c4; s4 = o.s4; c5 = o.c5; s5 = o.s5; c6 = o.c6; s6 = o.s6;
+    } else {  // C:457-458
+#pragma unroll
+        for (int k = 0; k < 7; k++) jv[k] = K.current_joints ? K.current_joints[ii * 7 + k] : prev[k];
+        sincos(jv[4], &s4, &c4);
+        sincos(jv[5], &s5, &c5);
+        sincos(jv[6], &s6, &c6);
+    }
+    bool em = safety_checks(jv, c4, s4, c5, s5, c6, s6, prev, K.max_angle, K.cos_max, K.sin_max);
+    store_rows<7>(K.joints, wave_base, K.n, lane, lds_out[wave], jv);
+    if (live) {
+        if (K.reachable) K.reachable[i] = found ? 1 : 0;
+        if (K.state) K.state[i] = (uint8_t)st_code;
+        if (K.emergency) K.emergency[i] = em ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Solver-state kernels: the scalar drop-in API (SymbolicIK objects keep `self.goal_pose`,
+// `self.wrist_position`, `self.intersection_circle` between is_reachable() and the returned closure, Q1).
+// State row layout (RSIK_SOLVER_STATE_STRIDE doubles):
+//   0-2 goal position, 3-5 goal euler, 6-8 wrist, 9-11 circle centre, 12 radius, 13-15 circle normal,
+//   16-18 elbow position of the last get_joints, 19 projection-fired flag, 20-23 reserved.
+// ------------------------------------------------------------------------------------------
+struct StateArgs {
+    int64_t n;
+    const double* in[6];
+    const uint8_t* arm;
+    int no_limits;
+    double* solver_state;
+    const double* theta;
+    const double* prev;  // [n,7] device or NULL
+    double* joints;
+    double* interval;
+    double* elbow;
+    uint8_t* reachable;
+    uint8_t* state;
+    ArmC arms[2];
+};
+
+template <bool MIXED>
+__global__ __launch_bounds__(kBlock) void reach_state_kernel(const StateArgs K) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= K.n) return;
+    Acc<MIXED> A{K.arms, false};
+    if constexpr (MIXED) A.isl = K.arm[i] != 0;
+    V3 pos = {K.in[0][i], K.in[1][i], K.in[2][i]};
+    double e0 = K.in[3][i], e1 = K.in[4][i], e2 = K.in[5][i];
+    Rot Rg = rot_from_euler(e0, e1, e2);
+    Reach r = K.no_limits ? reach<true>(A, pos, Rg) : reach<false>(A, pos, Rg);
+    double* S = K.solver_state + i * RSIK_SOLVER_STATE_STRIDE;
+    if (r.stage >= 1) {
+        S[0] = r.pos.x; S[1] = r.pos.y; S[2] = r.pos.z; S[3] = e0; S[4] = e1; S[5] = e2;
+        S[6] = r.w.x; S[7] = r.w.y; S[8] = r.w.z;
+    }
+    if (r.stage >= 2) {
+        S[9] = r.c2.x; S[10] = r.c2.y; S[11] = r.c2.z; S[12] = r.r2;
+        S[13] = r.n2.x; S[14] = r.n2.y; S[15] = r.n2.z;
+    }
+    if (K.interval) { K.interval[2 * i] = r.i0; K.interval[2 * i + 1] = r.i1; }
+    if (K.reachable) K.reachable[i] = r.ok ? 1 : 0;
+    if (K.state) K.state[i] = (uint8_t)r.state;
+}
+
+__device__ __forceinline__ Reach reach_from_state(const double* S) {
+    Reach r;
+    r.ok = true; r.state = RSIK_STATE_REACHABLE; r.stage = 2; r.i0 = -kPi; r.i1 = kPi;
+    r.pos = {S[0], S[1], S[2]};
+    r.w = {S[6], S[7], S[8]};
+    r.c2 = {S[9], S[10], S[11]};
+    r.r2 = S[12];
+    r.n2 = {S[13], S[14], S[15]};
+    Frame F = frame_from_normal(r.n2);  // S:686: get_elbow_position rebuilds the frame from the stored normal
+    r.a1 = F.c1; r.a2 = F.c2;
+    return r;
+}
+
+template <bool MIXED>
+__global__ __launch_bounds__(kBlock) void joints_state_kernel(const StateArgs K) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= K.n) return;
+    Acc<MIXED> A{K.arms, false};
+    if constexpr (MIXED) A.isl = K.arm[i] != 0;
+    double* S = K.solver_state + i * RSIK_SOLVER_STATE_STRIDE;
+    Reach r = reach_from_state(S);
+    Rot Rg = rot_from_euler(S[3], S[4], S[5]);
+    double prev[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) prev[k] = K.prev ? K.prev[i * 7 + k] : 0.0;
+    JointsOut o = joints_from_theta(A, r, Rg, K.theta[i], prev);
+#pragma unroll
+    for (int k = 0; k < 7; k++) K.joints[i * 7 + k] = o.j[k];
+    S[0] = r.pos.x; S[1] = r.pos.y; S[2] = r.pos.z;
+    S[6] = r.w.x; S[7] = r.w.y; S[8] = r.w.z;
+    S[16] = o.elbow.x; S[17] = o.elbow.y; S[18] = o.elbow.z;
+    S[19] = o.projected ? 1.0 : 0.0;
+    if (K.elbow) { K.elbow[3 * i] = o.elbow.x; K.elbow[3 * i + 1] = o.elbow.y; K.elbow[3 * i + 2] = o.elbow.z; }
+}
+
+__global__ __launch_bounds__(kBlock) void elbow_state_kernel(const StateArgs K) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= K.n) return;
+    const double* S = K.solver_state + i * RSIK_SOLVER_STATE_STRIDE;
+    Reach r = reach_from_state(S);
+    double st, ct;
+    sincos(K.theta[i], &st, &ct);
+    V3 e = elbow_on_circle(r, ct, st);
+    K.elbow[3 * i] = e.x; K.elbow[3 * i + 1] = e.y; K.elbow[3 * i + 2] = e.z;
+}
+
+}  // namespace rsik
+
+// =====================================================================================
+// C ABI
+// =====================================================================================
+struct rsik_ctx {
+    int device;
+    hipStream_t stream;
+    bool have_arm[2];
+    rsik::ArmC arms[2];
+    std::string err;
+};
+
+static thread_local std::string g_create_err;
+
+static int fail(rsik_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    else g_create_err = msg;
+    return code;
+}
+static int hip_fail(rsik_ctx* ctx, hipError_t e, const char* what) {
+    return fail(ctx, RSIK_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define RSIK_HIP(ctx, call)                                   \
+    do {                                                      \
+        hipError_t e_ = (call);                               \
+        if (e_ != hipSuccess) return hip_fail(ctx, e_, #call); \
+    } while (0)
+
+extern "C" {
+
+int rsik_abi_version(void) { return RSIK_ABI_VERSION; }
+int rsik_arm_consts_count(void) { return RSIK_ARM_CONSTS_COUNT; }
+
+int rsik_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int rsik_create(int device_id, rsik_ctx** out) {
+    if (!out) return fail(nullptr, RSIK_E_INVALID, "rsik_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(nullptr, RSIK_E_NO_DEVICE, "rsik_create: no HIP device available");
+    if (device_id < 0 || device_id >= n) return fail(nullptr, RSIK_E_NO_DEVICE, "rsik_create: device id out of range");
+    rsik_ctx* c = new (std::nothrow) rsik_ctx();
+    if (!c) return fail(nullptr, RSIK_E_INVALID, "rsik_create: out of host memory");
+    c->device = device_id;
+    c->stream = nullptr;
+    c->have_arm[0] = c->have_arm[1] = false;
+    *out = c;
+    return RSIK_OK;
+}
+
+int rsik_destroy(rsik_ctx* ctx) {
+    delete ctx;
+    return RSIK_OK;
+}
+
+const char* rsik_last_error(const rsik_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int rsik_set_stream(rsik_ctx* ctx, void* hip_stream) {
+    if (!ctx) return RSIK_E_INVALID;
+    ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    return RSIK_OK;
+}
+
+int rsik_sync(rsik_ctx* ctx) {
+    if (!ctx) return RSIK_E_INVALID;
+    RSIK_HIP(ctx, hipSetDevice(ctx->device));
+    RSIK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RSIK_OK;
+}
+
+int rsik_set_arm(rsik_ctx* ctx, int arm, const double* consts_host, int count) {
+    if (!ctx) return RSIK_E_INVALID;
+    if (arm != RSIK_ARM_R && arm != RSIK_ARM_L) return fail(ctx, RSIK_E_INVALID, "rsik_set_arm: arm must be 0 (r) or 1 (l)");
+    if (!consts_host || count != RSIK_ARM_CONSTS_COUNT)
+        return fail(ctx, RSIK_E_INVALID, "rsik_set_arm: expected RSIK_ARM_CONSTS_COUNT doubles");
+    std::memcpy(ctx->arms[arm].v, consts_host, sizeof(double) * RSIK_ARM_CONSTS_COUNT);
+    ctx->have_arm[arm] = true;
+    return RSIK_OK;
+}
+
+int rsik_malloc(rsik_ctx* ctx, size_t bytes, void** dev_ptr) {
+    if (!ctx || !dev_ptr) return RSIK_E_INVALID;
+    RSIK_HIP(ctx, hipSetDevice(ctx->device));
+    RSIK_HIP(ctx, hipMalloc(dev_ptr, bytes));
+    return RSIK_OK;
+}
+int rsik_free(rsik_ctx* ctx, void* dev_ptr) {
+    if (!ctx) return RSIK_E_INVALID;
+    RSIK_HIP(ctx, hipSetDevice(ctx->device));
+    RSIK_HIP(ctx, hipFree(dev_ptr));
+    return RSIK_OK;
+}
+int rsik_memcpy_h2d(rsik_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
+    if (!ctx) return RSIK_E_INVALID;
+    RSIK_HIP(ctx, hipSetDevice(ctx->device));
+    RSIK_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    RSIK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RSIK_OK;
+}
+int rsik_memcpy_d2h(rsik_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes) {
+    if (!ctx) return RSIK_E_INVALID;
+    RSIK_HIP(ctx, hipSetDevice(ctx->device));
+    RSIK_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    RSIK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RSIK_OK;
+}
+
+static int check_arms(rsik_ctx* ctx, const uint8_t* arm, int arm_uniform, const char* who) {
+    if (arm) {
+        if (!ctx->have_arm[0] || !ctx->have_arm[1])
+            return fail(ctx, RSIK_E_NOT_SET, std::string(who) + ": per-pose arm ids need both arms' constants (rsik_set_arm)");
+    } else {
+        if (arm_uniform != RSIK_ARM_R && arm_uniform != RSIK_ARM_L)
+            return fail(ctx, RSIK_E_INVALID, std::string(who) + ": arm_uniform must be 0 (r) or 1 (l)");
+        if (!ctx->have_arm[arm_uniform])
+            return fail(ctx, RSIK_E_NOT_SET, std::string(who) + ": constants of the requested arm were not uploaded");
+    }
+    return RSIK_OK;
+}
+
+int rsik_solve(rsik_ctx* ctx, int64_t n, const double* const pose_soa[6], const uint8_t* arm, int arm_uniform,
+               int theta_policy, const double* theta_in, const double* previous_joints_host, double* joints,
+               double* interval, double* elbow, uint8_t* reachable, uint8_t* state) {
+    if (!ctx) return RSIK_E_INVALID;
+    if (n < 0) return fail(ctx, RSIK_E_INVALID, "rsik_solve: n < 0");
+    if (theta_policy < RSIK_THETA_INTERVAL0 || theta_policy > RSIK_THETA_NONE)
+        return fail(ctx, RSIK_E_INVALID, "rsik_solve: unknown theta_policy");
+    if ((theta_policy == RSIK_THETA_EXPLICIT || theta_policy == RSIK_THETA_FRACTION) && !theta_in && n > 0)
+        return fail(ctx, RSIK_E_INVALID, "rsik_solve: theta_in is required for this theta_policy");
+    int rc = check_arms(ctx, arm, arm_uniform, "rsik_solve");
+    if (rc != RSIK_OK) return rc;
+    if (n == 0) return RSIK_OK;
+    if (!pose_soa) return fail(ctx, RSIK_E_INVALID, "rsik_solve: pose_soa is NULL");
+    rsik::SolveArgs K;
+    K.n = n;
+    for (int k = 0; k < 6; k++) {
+        if (!pose_soa[k]) return fail(ctx, RSIK_E_INVALID, "rsik_solve: a pose_soa column is NULL");
+        K.in[k] = pose_soa[k];
+    }
+    K.arm = arm;
+    K.theta_policy = theta_policy;
+    K.theta_in = theta_in;
+    for (int k = 0; k < 7; k++) K.prev[k] = previous_joints_host ? previous_joints_host[k] : 0.0;
+    K.joints = joints; K.interval = interval; K.elbow = elbow; K.reachable = reachable; K.state = state;
+    if (arm) { K.arms[0] = ctx->arms[0]; K.arms[1] = ctx->arms[1]; }
+    else { K.arms[0] = ctx->arms[arm_uniform]; K.arms[1] = ctx->arms[arm_uniform]; }
+    RSIK_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t blocks = (n + rsik::kBlock - 1) / rsik::kBlock;
+    if (blocks > 0x7fffffffLL) return fail(ctx, RSIK_E_INVALID, "rsik_solve: n too large for one launch");
+    dim3 grid((unsigned)blocks), block(rsik::kBlock);
+    if (arm) hipLaunchKernelGGL(rsik::solve_kernel<true>, grid, block, 0, ctx->stream, K);
+    else hipLaunchKernelGGL(rsik::solve_kernel<false>, grid, block, 0, ctx->stream, K);
+    RSIK_HIP(ctx, hipGetLastError());
+    return RSIK_OK;
+}
+
+// Python float modulo (sign of the divisor), used for the l-arm limit wrap (C:243-250).
+static double host_pymod(double a, double b) {
+    double m = std::fmod(a, b);
+    if (m != 0.0) {
+        if ((b < 0) != (m < 0)) m += b;
+    } else {
+        m = std::copysign(0.0, b);
+    }
+    return m;
+}
+
+// C:225-252: interval_limit per constrained mode, mirrored and re-wrapped for the left arm.
+static void control_limits(int arm, int constrained_mode, double preferred_theta, double lim[2], double* pref) {
+    const double pi = rsik::kPi;
+    if (constrained_mode == RSIK_MODE_UNCONSTRAINED) { lim[0] = 3 * pi / 4; lim[1] = -2 * pi / 6; }
+    else { lim[0] = -4 * pi / 5; lim[1] = 0; }
+    if (arm == RSIK_ARM_L) {
+        double a = -pi - lim[1], b = -pi - lim[0];
+        lim[0] = a; lim[1] = b;
+        if (lim[0] < -pi) lim[0] = host_pymod(lim[0], 2 * pi);
+        if (lim[1] < -pi) lim[1] = host_pymod(lim[1], 2 * pi);
+        if (lim[0] > pi) lim[0] = host_pymod(lim[0], -2 * pi);
+        if (lim[1] > pi) lim[1] = host_pymod(lim[1], -2 * pi);
+        preferred_theta = -pi - preferred_theta;
+    }
+    *pref = preferred_theta;
+}
+
+static int launch_dims(rsik_ctx* ctx, int64_t n, dim3* grid, const char* who) {
+    const int64_t blocks = (n + rsik::kBlock - 1) / rsik::kBlock;
+    if (blocks > 0x7fffffffLL) return fail(ctx, RSIK_E_INVALID, std::string(who) + ": n too large for one launch");
+    *grid = dim3((unsigned)blocks);
+    return RSIK_OK;
+}
+
+int rsik_control_discrete(rsik_ctx* ctx, int64_t n, const double* const m12_soa[12], const uint8_t* arm,
+                          int arm_uniform, int nb_search_points, double preferred_theta, int constrained_mode,
+                          const double* previous_sol_host, const double* current_joints, double orbita3d_max_angle,
+                          double* joints, uint8_t* reachable, uint8_t* state, uint8_t* emergency) {
+    if (!ctx) return RSIK_E_INVALID;
+    if (n < 0) return fail(ctx, RSIK_E_INVALID, "rsik_control_discrete: n < 0");
+    if (nb_search_points < 2) return fail(ctx, RSIK_E_INVALID, "rsik_control_discrete: nb_search_points must be >= 2");
+    if (constrained_mode != RSIK_MODE_UNCONSTRAINED && constrained_mode != RSIK_MODE_LOW_ELBOW)
+        return fail(ctx, RSIK_E_INVALID, "rsik_control_discrete: unknown constrained_mode");
+    if (!previous_sol_host) return fail(ctx, RSIK_E_INVALID, "rsik_control_discrete: previous_sol_host is NULL");
+    int rc = check_arms(ctx, arm, arm_uniform, "rsik_control_discrete");
+    if (rc != RSIK_OK) return rc;
+    if (n == 0) return RSIK_OK;
+    if (!m12_soa || !joints) return fail(ctx, RSIK_E_INVALID, "rsik_control_discrete: m12_soa / joints is NULL");
+    rsik::DiscreteArgs K;
+    K.n = n;
+    for (int k = 0; k < 12; k++) {
+        if (!m12_soa[k]) return fail(ctx, RSIK_E_INVALID, "rsik_control_discrete: an m12_soa column is NULL");
+        K.in[k] = m12_soa[k];
+    }
+    K.arm = arm;
+    K.nb = nb_search_points;
+    int lg = 0;
+    while ((1 << lg) < nb_search_points && lg < 6) lg++;
+    K.log2p = lg;
+    for (int slot = 0; slot < 2; slot++) {
+        const int a = arm ? slot : arm_uniform;
+        control_limits(a, constrained_mode, preferred_theta, K.lim[slot], &K.pref[slot]);
+        for (int k = 0; k < 7; k++) K.prev_sol[slot][k] = previous_sol_host[7 * a + k];
+        K.arms[slot] = ctx->arms[a];
+    }
+    K.current_joints = current_joints;
+    K.max_angle = orbita3d_max_angle;
+    K.cos_max = std::cos(orbita3d_max_angle);
+    K.sin_max = std::sin(orbita3d_max_angle);
+    K.joints = joints; K.reachable = reachable; K.state = state; K.emergency = emergency;
+    RSIK_HIP(ctx, hipSetDevice(ctx->device));
+    dim3 grid, block(rsik::kBlock);
+    rc = launch_dims(ctx, n, &grid, "rsik_control_discrete");
+    if (rc != RSIK_OK) return rc;
+    if (arm) hipLaunchKernelGGL(rsik::control_discrete_kernel<true>, grid, block, 0, ctx->stream, K);
+    else hipLaunchKernelGGL(rsik::control_discrete_kernel<false>, grid, block, 0, ctx->stream, K);
+    RSIK_HIP(ctx, hipGetLastError());
+    return RSIK_OK;
+}
+
+static int fill_state_args(rsik_ctx* ctx, rsik::StateArgs* K, int64_t n, const uint8_t* arm, int arm_uniform,
+                           const char* who) {
+    if (n < 0) return fail(ctx, RSIK_E_INVALID, std::string(who) + ": n < 0");
+    int rc = check_arms(ctx, arm, arm_uniform, who);
+    if (rc != RSIK_OK) return rc;
+    std::memset(K, 0, sizeof *K);
+    K->n = n;
+    K->arm = arm;
+    for (int slot = 0; slot < 2; slot++) K->arms[slot] = ctx->arms[arm ? slot : arm_uniform];
+    return RSIK_OK;
+}
+
+int rsik_reach_state(rsik_ctx* ctx, int64_t n, const double* const pose_soa[6], const uint8_t* arm, int arm_uniform,
+                     int no_limits, double* solver_state, double* interval, uint8_t* reachable, uint8_t* state) {
+    if (!ctx) return RSIK_E_INVALID;
+    rsik::StateArgs K;
+    int rc = fill_state_args(ctx, &K, n, arm, arm_uniform, "rsik_reach_state");
+    if (rc != RSIK_OK) return rc;
+    if (n == 0) return RSIK_OK;
+    if (!pose_soa || !solver_state) return fail(ctx, RSIK_E_INVALID, "rsik_reach_state: pose_soa / solver_state is NULL");
+    for (int k = 0; k < 6; k++) {
+        if (!pose_soa[k]) return fail(ctx, RSIK_E_INVALID, "rsik_reach_state: a pose_soa column is NULL");
+        K.in[k] = pose_soa[k];
+    }
+    K.no_limits = no_limits ? 1 : 0;
+    K.solver_state = solver_state; K.interval = interval; K.reachable = reachable; K.state = state;
+    RSIK_HIP(ctx, hipSetDevice(ctx->device));
+    dim3 grid, block(rsik::kBlock);
+    rc = launch_dims(ctx, n, &grid, "rsik_reach_state");
+    if (rc != RSIK_OK) return rc;
+    if (arm) hipLaunchKernelGGL(rsik::reach_state_kernel<true>, grid, block, 0, ctx->stream, K);
+    else hipLaunchKernelGGL(rsik::reach_state_kernel<false>, grid, block, 0, ctx->stream, K);
+    RSIK_HIP(ctx, hipGetLastError());
+    return RSIK_OK;
+}
+
+int rsik_joints_from_state(rsik_ctx* ctx, int64_t n, double* solver_state, const uint8_t* arm, int arm_uniform,
+                           const double* theta, const double* previous_joints, double* joints, double* elbow) {
+    if (!ctx) return RSIK_E_INVALID;
+    rsik::StateArgs K;
+    int rc = fill_state_args(ctx, &K, n, arm, arm_uniform, "rsik_joints_from_state");
+    if (rc != RSIK_OK) return rc;
+    if (n == 0) return RSIK_OK;
+    if (!solver_state || !theta || !joints)
+        return fail(ctx, RSIK_E_INVALID, "rsik_joints_from_state: solver_state / theta / joints is NULL");
+    K.solver_state = solver_state; K.theta = theta; K.prev = previous_joints; K.joints = joints; K.elbow = elbow;
+    RSIK_HIP(ctx, hipSetDevice(ctx->device));
+    dim3 grid, block(rsik::kBlock);
+    rc = launch_dims(ctx, n, &grid, "rsik_joints_from_state");
+    if (rc != RSIK_OK) return rc;
+    if (arm) hipLaunchKernelGGL(rsik::joints_state_kernel<true>, grid, block, 0, ctx->stream, K);
+    else hipLaunchKernelGGL(rsik::joints_state_kernel<false>, grid, block, 0, ctx->stream, K);
+    RSIK_HIP(ctx, hipGetLastError());
+    return RSIK_OK;
+}
+
+int rsik_elbow_from_state(rsik_ctx* ctx, int64_t n, const double* solver_state, const double* theta, double* elbow) {
+    if (!ctx) return RSIK_E_INVALID;
+    if (n < 0) return fail(ctx, RSIK_E_INVALID, "rsik_elbow_from_state: n < 0");
+    if (n == 0) return RSIK_OK;
+    if (!solver_state || !theta || !elbow)
+        return fail(ctx, RSIK_E_INVALID, "rsik_elbow_from_state: solver_state / theta / elbow is NULL");
+    rsik::StateArgs K;
+    std::memset(&K, 0, sizeof K);
+    K.n = n;
+    K.solver_state = const_cast<double*>(solver_state); K.theta = theta; K.elbow = elbow;
+    RSIK_HIP(ctx, hipSetDevice(ctx->device));
+    dim3 grid, block(rsik::kBlock);
+    int rc = launch_dims(ctx, n, &grid, "rsik_elbow_from_state");
+    if (rc != RSIK_OK) return rc;
+    hipLaunchKernelGGL(rsik::elbow_state_kernel, grid, block, 0, ctx->stream, K);
+    RSIK_HIP(ctx, hipGetLastError());
+    return RSIK_OK;
+}
+
+}  // extern "C"

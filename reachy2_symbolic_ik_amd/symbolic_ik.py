@@ -1,0 +1,188 @@
+"""SymbolicIK — drop-in for reachy2_symbolic_ik.symbolic_ik.SymbolicIK (symbolic_ik.py:25-863) on MI355X.
+
+Same constructor signature, public attributes, return tuples and state strings as the reference;
+every solve runs in the HIP kernels behind include/rsik.h (no CPU path).  The scalar methods
+(`is_reachable`, `get_joints`, ...) are batch-of-one calls that keep the reference's per-instance
+state semantics in a one-row device state array; the `*_batch` methods are the
+MI355X-native interface for pose batches laid out SoA in HBM.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import numpy.typing as npt
+import torch
+
+from . import _abi
+from .backend import HipSolver
+from .constants import ARM_IDS, STATE_STRINGS, ArmGeometry, default_ik_parameters
+
+_THETA_POLICIES = {"interval0": _abi.THETA_INTERVAL0, "explicit": _abi.THETA_EXPLICIT, "fraction": _abi.THETA_FRACTION,
+                   "none": _abi.THETA_NONE}
+
+
+def poses_to_soa(poses: Any, device: torch.device) -> torch.Tensor:
+    """[n,2,3] (position, xyz-euler) or [6,n] -> contiguous [6,n] float64 on `device`."""
+    t = poses if isinstance(poses, torch.Tensor) else torch.as_tensor(np.asarray(poses, dtype=np.float64))
+    t = t.to(device=device, dtype=torch.float64)
+    if t.dim() == 3 and tuple(t.shape[1:]) == (2, 3):
+        t = t.reshape(t.shape[0], 6).t()
+    elif not (t.dim() == 2 and t.shape[0] == 6):
+        raise ValueError("poses must have shape [n,2,3] or [6,n]")
+    return t.contiguous()
+
+
+class SymbolicIK:
+    def __init__(
+        self,
+        arm: str = "r_arm",
+        ik_parameters: Dict[str, Any] = {},
+        elbow_limit: int = 127,
+        wrist_limit: np.float64 = np.float64(42.5),
+        projection_margin: float = 1e-8,
+        backward_limit: float = 0.02,
+        normal_vector_margin: float = 1e-7,
+        singularity_offset: float = 0.03,
+        singularity_limit_coeff: float = 1.0,
+        device: Any = None,
+        solver: Optional[HipSolver] = None,
+    ) -> None:
+        if ik_parameters == {}:
+            print("Using default parameters")
+            ik_parameters = default_ik_parameters()
+        self._geom = ArmGeometry(arm, ik_parameters, elbow_limit, wrist_limit, projection_margin, backward_limit,
+                                 normal_vector_margin, singularity_offset, singularity_limit_coeff)
+        g = self._geom
+        # public attributes of the reference (symbolic_ik.py:55-83)
+        self.arm = arm
+        self.shoulder_position = g.shoulder_position
+        self.shoulder_orientation_offset = g.shoulder_orientation_offset
+        self.upper_arm_size = g.upper_arm_size
+        self.forearm_size = g.forearm_size
+        self.tip_position = g.tip_position
+        self.gripper_size = g.gripper_size
+        self.max_arm_length = g.max_arm_length
+        self.torso_pose = np.array([0.0, 0.0, 0.0])
+        self.projection_margin = projection_margin
+        self.normal_vector_margin = normal_vector_margin
+        self.backward_limit = backward_limit
+        self.elbow_limit = elbow_limit
+        self.shoulder_wrist_min_distance = g.shoulder_wrist_min_distance
+        self.wrist_limit = wrist_limit
+        self.singularity_offset = singularity_offset
+        self.singularity_limit_coeff = singularity_limit_coeff
+        self.elbow_singularity_position = g.elbow_singularity_position
+        self.wrist_singularity_position = g.wrist_singularity_position
+
+        self.arm_id = ARM_IDS[arm]
+        self.consts = g.pack()
+        self._solver = solver if solver is not None else HipSolver(device)
+        self._solver.set_arm(self.arm_id, self.consts)
+        self._state = self._solver.new_solver_state(1)  # one SymbolicIK instance = one row of solver state
+
+    # ------------------------------------------------------------------ scalar drop-in API
+    @property
+    def solver(self) -> HipSolver:
+        return self._solver
+
+    def _upload(self) -> None:
+        # several SymbolicIK objects may share one context; make sure *this* arm's constants are current
+        self._solver.set_arm(self.arm_id, self.consts)
+
+    def _sync_attributes(self) -> None:
+        s = self._state[0].cpu().numpy()
+        self.goal_pose = np.array([s[0:3], s[3:6]])
+        self.wrist_position = s[6:9].copy()
+        self.intersection_circle = (s[9:12].copy(), float(s[12]), s[13:16].copy())
+
+    def _reach_scalar(self, goal_pose: Any, no_limits: bool):
+        pose = np.asarray([np.asarray(goal_pose[0], dtype=np.float64), np.asarray(goal_pose[1], dtype=np.float64)])
+        soa = torch.as_tensor(pose.reshape(6, 1)).to(self._solver.device)
+        self._upload()
+        r = self._solver.reach_state(soa, self._state, arm_uniform=self.arm_id, no_limits=no_limits)
+        ok = bool(r["reachable"].item())
+        code = int(r["state"].item())
+        interval = r["interval"][0].cpu().numpy()
+        self._sync_attributes()
+        return ok, interval, code
+
+    def is_reachable(self, goal_pose: npt.NDArray[np.float64]) -> Tuple[bool, npt.NDArray[np.float64], Optional[Any], str]:
+        """symbolic_ik.py:121-282."""
+        ok, interval, code = self._reach_scalar(goal_pose, no_limits=False)
+        if not ok:
+            return False, np.array([]), None, STATE_STRINGS[code]
+        return True, interval, self.get_joints, STATE_STRINGS[code]
+
+    def is_reachable_no_limits(self, goal_pose: npt.NDArray[np.float64]) -> Tuple[bool, npt.NDArray[np.float64], Optional[Any]]:
+        """symbolic_ik.py:85-119."""
+        ok, interval, _ = self._reach_scalar(goal_pose, no_limits=True)
+        if not ok:
+            return False, np.array([]), None
+        return True, np.array([-np.pi, np.pi]), self.get_joints
+
+    def get_joints(
+        self, theta: float, previous_joints: Sequence[float] = [0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0]
+    ) -> Tuple[npt.NDArray[np.float64], npt.NDArray[np.float64]]:
+        """symbolic_ik.py:697-863 — reads and (when the elbow projection fires) updates the state left by the
+        last is_reachable*() call, exactly like the reference's bound method."""
+        self._upload()
+        th = torch.tensor([float(theta)], dtype=torch.float64, device=self._solver.device)
+        pj = torch.as_tensor(np.asarray(previous_joints, dtype=np.float64).reshape(1, 7)).to(self._solver.device)
+        r = self._solver.joints_from_state(self._state, th, arm_uniform=self.arm_id, previous_joints=pj)
+        joints = r["joints"][0].cpu().numpy()
+        s = self._state[0].cpu().numpy()
+        self._sync_attributes()
+        if s[19] != 0.0:  # Q2: 3 components after a projection, [x, y, z, 1] otherwise
+            self.elbow_position = s[16:19].copy()
+        else:
+            self.elbow_position = np.array([s[16], s[17], s[18], 1.0])
+        return joints, self.elbow_position
+
+    def get_elbow_position(self, theta: float) -> npt.NDArray[np.float64]:
+        """symbolic_ik.py:684-695."""
+        th = torch.tensor([float(theta)], dtype=torch.float64, device=self._solver.device)
+        e = self._solver.elbow_from_state(self._state, th)[0].cpu().numpy()
+        return np.array([e[0], e[1], e[2], 1.0])
+
+    def get_wrist_position(self, goal_pose: npt.NDArray[np.float64]) -> npt.NDArray[np.float64]:
+        """symbolic_ik.py:418-425 (host arithmetic: a single 3x3 product, not on the solve path)."""
+        from .constants import euler_xyz_extrinsic
+
+        R = euler_xyz_extrinsic(np.asarray(goal_pose[1], dtype=np.float64))
+        tl = np.array([-self.tip_position[0], self.tip_position[1], self.tip_position[2]])
+        return R @ tl + np.asarray(goal_pose[0], dtype=np.float64)
+
+    # ------------------------------------------------------------------ batched API (MI355X-native)
+    def solve_batch(
+        self,
+        poses: Any,
+        theta: Any = "interval0",
+        previous_joints: Optional[Sequence[float]] = None,
+        want_elbow: bool = True,
+        out: Optional[Dict[str, torch.Tensor]] = None,
+    ) -> Dict[str, torch.Tensor]:
+        """Fused is_reachable + get_joints for a batch of poses of this arm.
+
+        poses: [n,2,3] or SoA [6,n].  theta: "interval0" (the reference's README/benchmark convention),
+        "none" (reachability only), ("explicit", tensor[n]) or ("fraction", tensor[n]).
+        Returns device tensors: joints [n,7], interval [n,2], elbow [n,3], reachable [n] u8, state [n] u8.
+        """
+        soa = poses_to_soa(poses, self._solver.device)
+        theta_in = None
+        if isinstance(theta, str):
+            policy = _THETA_POLICIES[theta]
+        else:
+            policy = _THETA_POLICIES[theta[0]]
+            theta_in = theta[1]
+        self._upload()
+        return self._solver.solve(soa, arm_uniform=self.arm_id, theta_policy=policy, theta_in=theta_in,
+                                  previous_joints=previous_joints, want_elbow=want_elbow, out=out)
+
+    def is_reachable_batch(self, poses: Any) -> Dict[str, torch.Tensor]:
+        return self.solve_batch(poses, theta="none")
+
+    @staticmethod
+    def state_strings(codes: Any) -> list:
+        c = codes.cpu().numpy() if isinstance(codes, torch.Tensor) else np.asarray(codes)
+        return [STATE_STRINGS[int(k)] for k in c]

@@ -1,0 +1,171 @@
+"""CPU-side tests: the C-ABI library loads and exports every symbol include/rsik.h declares (no compute
+calls without a GPU), and the host logic (constants, URDF, limits, packing, error behaviour)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from reachy2_symbolic_ik_amd import _abi, build
+
+    build.build()
+    return _abi.load()
+
+
+def test_header_symbols_exported(lib):
+    from reachy2_symbolic_ik_amd import _abi
+
+    hdr = open(os.path.join(ROOT, "include", "rsik.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(rsik_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 18
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/rsik.h but not exported"
+    assert declared == set(_abi.PROTOTYPES), "python prototypes out of sync with include/rsik.h"
+
+
+def test_header_constants_match_python(lib):
+    from reachy2_symbolic_ik_amd import _abi, constants
+
+    hdr = open(os.path.join(ROOT, "include", "rsik.h")).read()
+    enum = dict((k, int(v)) for k, v in re.findall(r"(RSIK_C_[A-Z_]+|RSIK_ARM_CONSTS_COUNT)\s*=\s*(\d+)", hdr))
+    assert enum["RSIK_ARM_CONSTS_COUNT"] == constants.ARM_CONSTS_COUNT == lib.rsik_arm_consts_count()
+    for py, c in (("C_SHOULDER", "RSIK_C_SHOULDER"), ("C_TIPL", "RSIK_C_TIPL"), ("C_MST", "RSIK_C_MST"), ("C_TSH", "RSIK_C_TSH"),
+                  ("C_ES", "RSIK_C_ES"), ("C_SIDE", "RSIK_C_SIDE"), ("C_PLANE_P", "RSIK_C_PLANE_P"),
+                  ("C_PROJ_RADIUS", "RSIK_C_PROJ_RADIUS"), ("C_TIP_Z", "RSIK_C_TIP_Z"), ("C_WRIST_AX", "RSIK_C_WRIST_AX")):
+        assert getattr(constants, py) == enum[c]
+    states = dict((int(v), k) for k, v in re.findall(r"#define (RSIK_STATE_[A-Z_]+) (\d+)", hdr))
+    assert len(states) == 9 and len(constants.STATE_STRINGS) == 9
+    assert int(re.search(r"#define RSIK_SOLVER_STATE_STRIDE (\d+)", hdr).group(1)) == _abi.SOLVER_STATE_STRIDE
+    assert lib.rsik_abi_version() == int(re.search(r"#define RSIK_ABI_VERSION (\d+)", hdr).group(1))
+
+
+def test_no_gpu_fails_loudly(lib):
+    """Without a GPU the product must refuse to run rather than fall back to any CPU path."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert lib.rsik_device_count() == 0
+    h = C.c_void_p()
+    assert lib.rsik_create(0, C.byref(h)) == -2  # RSIK_E_NO_DEVICE
+    assert b"no HIP device" in lib.rsik_last_error(None)
+    from reachy2_symbolic_ik_amd import ControlIK, SymbolicIK
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        SymbolicIK()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ControlIK(urdf_path="config_files/reachy2_ik_minimal.urdf")
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "reachy2_symbolic_ik_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.lower(), f"{f} mentions the checker: the product must not depend on it"
+
+
+def test_packed_constants_against_reference_goldens(golden_dir):
+    from reachy2_symbolic_ik_amd import constants as K
+
+    g = np.load(os.path.join(golden_dir, "g0_constants.npz"))
+    for arm in ("r_arm", "l_arm"):
+        for tag, so in (("dflt", 0.03), ("ctrl", -1.01)):
+            geo = K.ArmGeometry(arm, K.default_ik_parameters(), singularity_offset=so)
+            c = geo.pack()
+            assert c.shape == (K.ARM_CONSTS_COUNT,)
+            p = f"{arm}_{tag}_"
+            np.testing.assert_array_equal(c[K.C_SHOULDER:K.C_SHOULDER + 3], g[p + "shoulder_position"])
+            assert c[K.C_MAX_LEN] == g[p + "max_arm_length"] and c[K.C_MIN_DIST] == g[p + "shoulder_wrist_min_distance"]
+            assert c[K.C_BACKWARD] == g[p + "backward_limit"] and c[K.C_PROJ_MARGIN] == g[p + "projection_margin"]
+            np.testing.assert_allclose(c[K.C_ES:K.C_ES + 3], g[p + "elbow_singularity_position"], rtol=0, atol=1e-16)
+            np.testing.assert_allclose(geo.wrist_singularity_position, g[p + "wrist_singularity_position"], rtol=0, atol=1e-16)
+            assert c[K.C_SIDE] == (1.0 if arm == "r_arm" else -1.0)
+            assert c[K.C_ELBOW_LIMIT] == np.radians(127) and c[K.C_SING_OFFSET] == so
+            # M_shoulder_torso is a rotation, P_shoulder_torso = -M s
+            MsT = c[K.C_MST:K.C_MST + 9].reshape(3, 3)
+            np.testing.assert_allclose(MsT @ MsT.T, np.eye(3), atol=1e-15)
+            np.testing.assert_allclose(c[K.C_TSH:K.C_TSH + 3], -MsT @ geo.shoulder_position, atol=1e-17)
+            # projection plane: unit normal, centre on the plane, radius NaN exactly when the plane misses the sphere (Q18)
+            v3 = c[K.C_PLANE_N:K.C_PLANE_N + 3]
+            assert abs(np.linalg.norm(v3) - 1) < 1e-15
+            assert abs(np.dot(c[K.C_PROJ_CENTER:K.C_PROJ_CENTER + 3] - c[K.C_PLANE_P:K.C_PLANE_P + 3], v3)) < 1e-15
+            assert np.isnan(c[K.C_PROJ_RADIUS]) == (so == -1.01)
+    with pytest.raises(ValueError, match="arm should be either 'r_arm' or 'l_arm'"):
+        K.ArmGeometry("x_arm", K.default_ik_parameters())
+
+
+def test_urdf_parameters(golden_dir):
+    from reachy2_symbolic_ik_amd import constants as K
+
+    g = np.load(os.path.join(golden_dir, "g0_constants.npz"))
+    urdf = open(os.path.join(ROOT, "reachy2_symbolic_ik_amd", "config_files", "reachy2_ik_minimal.urdf")).read()
+    p = K.get_ik_parameters_from_urdf(urdf, ["r", "l"])
+    for arm in ("r_arm", "l_arm"):
+        a = arm[0]
+        np.testing.assert_array_equal(p[f"{a}_shoulder_position"], g[f"{arm}_urdf_shoulder_position"])
+        np.testing.assert_array_equal(p[f"{a}_shoulder_orientation"], g[f"{arm}_urdf_shoulder_orientation_offset"])
+        assert p[f"{a}_upper_arm_size"] == g[f"{arm}_urdf_upper_arm_size"] and p[f"{a}_forearm_size"] == g[f"{arm}_urdf_forearm_size"]
+        np.testing.assert_array_equal(p[f"{a}_tip_position"], g[f"{arm}_urdf_tip_position"])
+    assert K.get_ik_parameters_from_urdf(urdf, []) == {}
+    assert set(K.get_ik_parameters_from_urdf(urdf, ["r"])) == {k for k in p if k.startswith("r_")}
+
+
+def test_interval_limits():
+    from reachy2_symbolic_ik_amd.constants import interval_limit_for
+
+    lim, pref = interval_limit_for("r_arm", "unconstrained", -4 * np.pi / 6)
+    np.testing.assert_array_equal(lim, [3 * np.pi / 4, -2 * np.pi / 6]) and pref == -4 * np.pi / 6
+    lim, pref = interval_limit_for("l_arm", "unconstrained", -4 * np.pi / 6)
+    np.testing.assert_allclose(lim, [-2 * np.pi / 3, np.pi / 4], atol=1e-15)  # SURVEY a-16
+    assert pref == -np.pi - (-4 * np.pi / 6)
+    lim, _ = interval_limit_for("l_arm", "low_elbow", 0.0)
+    np.testing.assert_allclose(lim, [-np.pi, -np.pi / 5], atol=1e-15)
+    lim, _ = interval_limit_for("r_arm", "low_elbow", 0.0)
+    np.testing.assert_array_equal(lim, [-4 * np.pi / 5, 0])
+
+
+def test_control_constructor_errors():
+    """control_ik.py:86-112 error behaviour is host logic and must not need a GPU."""
+    from reachy2_symbolic_ik_amd import ControlIK
+
+    with pytest.raises(ValueError, match="No URDF provided"):
+        ControlIK()
+    with pytest.raises(ValueError, match="Empty URDF file"):
+        ControlIK(urdf_path="config_files/does_not_exist.urdf")
+    with pytest.raises(ValueError, match="Unknown Reachy model bogus"):
+        ControlIK(urdf_path="config_files/reachy2_ik_minimal.urdf", reachy_model="bogus")
+    with pytest.raises(ValueError, match="Error while parsing URDF"):
+        ControlIK(urdf="<robot><joint></robot>")
+    c = ControlIK(urdf_path="config_files/reachy2_ik_minimal.urdf", reachy_model="mini")  # no arms: no GPU needed
+    assert c.symbolic_ik_solver == {} and c.nb_search_points == 20 and c.singularity_offset == -1.01
+
+
+def test_packing_helpers():
+    import torch
+
+    from reachy2_symbolic_ik_amd.control_ik import matrices_to_m12_soa
+    from reachy2_symbolic_ik_amd.symbolic_ik import poses_to_soa
+
+    rng = np.random.default_rng(0)
+    M = rng.normal(size=(5, 4, 4))
+    m12 = matrices_to_m12_soa(M, torch.device("cpu"))
+    assert m12.shape == (12, 5) and m12.is_contiguous()
+    np.testing.assert_array_equal(m12[:9].numpy().T.reshape(5, 3, 3), M[:, :3, :3])
+    np.testing.assert_array_equal(m12[9:].numpy().T, M[:, :3, 3])
+    assert matrices_to_m12_soa(M[0], torch.device("cpu")).shape == (12, 1)
+    poses = rng.normal(size=(7, 2, 3))
+    s = poses_to_soa(poses, torch.device("cpu"))
+    assert s.shape == (6, 7)
+    np.testing.assert_array_equal(s.numpy()[:3].T, poses[:, 0])
+    np.testing.assert_array_equal(s.numpy()[3:].T, poses[:, 1])
+    with pytest.raises(ValueError):
+        poses_to_soa(np.zeros((3, 5)), torch.device("cpu"))

@@ -1,0 +1,366 @@
+"""GPU parity tests (run with -m gpu on an MI355X): HIP kernels, through the C ABI, against
+(a) golden vectors recorded from the real reference and (b) the CPU checker (oracle/) on seeded inputs.
+
+Bars (north star): reachability flags and state codes bit-exact; joints / intervals / elbows within
+1e-6 rad (observed ~1e-12; asserted at 1e-9 so that regressions show).
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-9          # asserted (north-star bar: 1e-6 rad)
+NORTH_STAR_TOL = 1e-6
+URDF = "config_files/reachy2_ik_minimal.urdf"
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle as o
+
+    return o
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def make_symbolic(so):
+    import contextlib
+    import io
+
+    from reachy2_symbolic_ik_amd import HipSolver, SymbolicIK
+
+    solver = HipSolver(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        r = SymbolicIK("r_arm", singularity_offset=so, solver=solver)
+        l = SymbolicIK("l_arm", singularity_offset=so, solver=solver)
+    return solver, r, l
+
+
+def soa(pos, eul, torch):
+    return torch.as_tensor(np.concatenate([pos.T, eul.T], axis=0)).cuda()
+
+
+def to_np(res):
+    return {k: v.cpu().numpy() for k, v in res.items()}
+
+
+def singular_rows(j):
+    return np.abs(j[:, 3]) < 1e-12
+
+
+def check_symbolic(res, g, prefix, tol=TOL):
+    reach = g[prefix + "reachable"]
+    np.testing.assert_array_equal(res["reachable"], reach)
+    np.testing.assert_array_equal(res["state"], g[prefix + "state"])
+    m = reach.astype(bool)
+    assert np.all(np.isnan(res["joints"][~m])) and np.all(np.isnan(res["interval"][~m]))
+    sing = singular_rows(g[prefix + "joints"]) & m
+    for k in ("interval", "joints", "elbow"):
+        mm = m & ~sing if k == "joints" else m
+        err = np.max(np.abs(res[k][mm] - g[prefix + k][mm])) if mm.any() else 0.0
+        assert err < tol, f"{prefix}{k}: max err {err}"
+    if sing.any():  # fully extended arm: only j2 + j6 is defined (see tests/test_oracle_golden.py)
+        a, b = res["joints"][sing], g[prefix + "joints"][sing]
+        assert np.max(np.abs(a[:, [0, 1, 3, 4, 5]] - b[:, [0, 1, 3, 4, 5]])) < tol
+        assert np.max(np.abs((a[:, 2] + a[:, 6]) - (b[:, 2] + b[:, 6]))) < 1e-7
+
+
+# ------------------------------------------------------------------------------------------ rsik_solve
+@pytest.mark.parametrize("tag,so", [("so003_", 0.03), ("so101_", -1.01)])
+def test_catalogue_mixed_arms(golden_dir, torch_mod, tag, so):
+    """G1 known-answer catalogue (reference unit-test / README / benchmark / go_to poses), r and l mixed in one
+    launch through the per-pose arm byte."""
+    from reachy2_symbolic_ik_amd import _abi
+
+    g = load(golden_dir, "g1_catalogue.npz")
+    solver, r, l = make_symbolic(so)
+    res = to_np(solver.solve(soa(g["pos"], g["eul"], torch_mod), arm=torch_mod.as_tensor(g["arm"]).cuda(),
+                             theta_policy=_abi.THETA_INTERVAL0))
+    check_symbolic(res, g, tag)
+
+
+def test_reference_unit_test_poses_scalar_api(golden_dir, torch_mod, capsys):
+    """The reference's own tests/test_ik.py:12-79, run against the drop-in class."""
+    from reachy2_symbolic_ik_amd import SymbolicIK
+
+    symbolic_ik = SymbolicIK()
+    assert "Using default parameters" in capsys.readouterr().out
+    result = symbolic_ik.is_reachable([[0.4, 0.2, 0.1], [np.radians(-60), np.radians(-90), np.radians(20)]])
+    assert not result[0] and len(result[1]) == 0 and result[2] is None
+    result = symbolic_ik.is_reachable([[0.3, -0.2, -0.3], [0.0, np.radians(-90), 0.0]])
+    assert result[0] and result[1][0] >= -np.pi and result[1][1] <= np.pi and result[2] is not None
+    joints, elbow_position = result[2](result[1][0])
+    assert len(joints) == 7
+    result = symbolic_ik.is_reachable([[0.02, -0.2, -0.65], [0.0, 0.0, 0.0]])
+    assert result[0] and np.all(result[1] == [-np.pi, np.pi]) and result[2] is not None
+    joints, elbow_position = result[2](0)
+    assert len(joints) == 7
+    assert not symbolic_ik.is_reachable([[0.0, -0.2, -0.65], [0.0, 0.0, 0.0]])[0]
+    assert not symbolic_ik.is_reachable([[0.87, -0.2, -0.0], [0.0, -np.pi / 2, 0.0]])[0]
+    assert symbolic_ik.is_reachable([[0.35, -0.2, -0.28], [0.0, -np.pi / 2, 0.0]])[0]
+    # README example with its recorded values
+    ok, interval, fn, state = symbolic_ik.is_reachable(np.array([[0.55, -0.3, -0.15], [0, -np.pi / 2, 0]]))
+    assert ok and state == "reachable"
+    np.testing.assert_allclose(interval, [2.189523775249914, -0.223936328755258], atol=1e-12)
+    joints, elbow = fn(interval[0])
+    np.testing.assert_allclose(joints, [-1.52495747419263, -0.684394520135058, -3.931173030050867, -1.048669758375133,
+                                        -0.44045940371327, 0.617944472775118, -2.281740790978251], atol=1e-11)
+    assert len(elbow) in (3, 4)
+    with pytest.raises(ValueError, match="arm should be either"):
+        SymbolicIK(arm="middle_arm")
+
+
+def test_random_sweep_all_outcomes(golden_dir, torch_mod):
+    """G2: 20 000 uniform poses per arm, every outcome class (backward / out of reach / wrist ...)."""
+    g = load(golden_dir, "g2_sweep.npz")
+    solver, r, l = make_symbolic(0.03)
+    for ik, arm in ((r, "r_arm"), (l, "l_arm")):
+        res = to_np(ik.solve_batch(soa(g[f"{arm}_pos"], g[f"{arm}_eul"], torch_mod)))
+        check_symbolic(res, g, f"{arm}_")
+
+
+@pytest.mark.parametrize("tag,so", [("so003", 0.03), ("so101", -1.01)])
+def test_reachable_theta_policies(golden_dir, torch_mod, tag, so):
+    """G3: reachable poses, theta = interval[0], a fraction inside the interval, and the same theta given explicitly;
+    singularity_offset 0.03 exercises the elbow-projection branch (~35 % of poses), -1.01 never does."""
+    g = load(golden_dir, "g3_reachable.npz")
+    solver, r, l = make_symbolic(so)
+    for ik, arm in ((r, "r_arm"), (l, "l_arm")):
+        p = soa(g[f"{arm}_pos"], g[f"{arm}_eul"], torch_mod)
+        check_symbolic(to_np(ik.solve_batch(p)), g, f"{arm}_{tag}_i0_")
+        tu = torch_mod.as_tensor(g[f"{arm}_theta_u"]).cuda()
+        check_symbolic(to_np(ik.solve_batch(p, theta=("fraction", tu))), g, f"{arm}_{tag}_in_")
+        th = torch_mod.as_tensor(np.nan_to_num(g[f"{arm}_{tag}_in_theta"])).cuda()
+        check_symbolic(to_np(ik.solve_batch(p, theta=("explicit", th))), g, f"{arm}_{tag}_in_")
+        none = to_np(ik.is_reachable_batch(p))
+        np.testing.assert_array_equal(none["reachable"], g[f"{arm}_{tag}_i0_reachable"])
+        assert "joints" not in none
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 256, 257, 1000])
+def test_ragged_sizes_match_checker(torch_mod, orc, n):
+    """Tail handling of the 256-thread blocks / 64-lane row transposes: any n, outputs must not bleed."""
+    rng = np.random.default_rng(100 + n)
+    pos = np.array([0.25, -0.2, -0.15]) + rng.uniform(-0.25, 0.25, size=(n, 3))
+    eul = np.array([0, -np.pi / 2, 0]) + rng.uniform(-0.8, 0.8, size=(n, 3))
+    solver, r, l = make_symbolic(0.03)
+    import torch
+
+    guard = 3
+    joints = torch.full((n + guard, 7), 777.0, dtype=torch.float64, device="cuda")
+    elbow = torch.full((n + guard, 3), 777.0, dtype=torch.float64, device="cuda")
+    out = {"joints": joints[:n], "elbow": elbow[:n]}
+    res = to_np(r.solve_batch(soa(pos, eul, torch_mod), out=out))
+    ref = orc.solve_batch(orc.Arm("r_arm", 0.03), orc.Arm("l_arm", 0.03), pos, eul)
+    np.testing.assert_array_equal(res["reachable"], ref["reachable"])
+    np.testing.assert_array_equal(res["state"], ref["state"])
+    m = ref["reachable"].astype(bool)
+    assert m.sum() > 0 or n < 3
+    for k in ("joints", "interval", "elbow"):
+        if m.any():
+            assert np.max(np.abs(res[k][m] - ref[k][m])) < TOL
+    assert torch.all(joints[n:] == 777.0) and torch.all(elbow[n:] == 777.0), "store ran past the end of the batch"
+
+
+def test_empty_batch(torch_mod):
+    solver, r, l = make_symbolic(0.03)
+    res = r.solve_batch(torch_mod.zeros((6, 0), dtype=torch_mod.float64, device="cuda"))
+    assert res["joints"].shape == (0, 7) and res["reachable"].shape == (0,)
+
+
+def test_config2_full_size_against_checker(torch_mod, orc):
+    """BASELINE config 2 at full size: 1 048 576 reachable r_arm poses, theta = interval[0], checked pose by pose
+    against the CPU checker (OpenMP), plus the r<->l mirror property on the same batch."""
+    from bench import make_config2_poses
+
+    pos, eul = make_config2_poses(1 << 20, seed=20250204)
+    solver, r, l = make_symbolic(0.03)
+    res = to_np(r.solve_batch(soa(pos, eul, torch_mod)))
+    ref = orc.solve_batch(orc.Arm("r_arm", 0.03), orc.Arm("l_arm", 0.03), pos, eul, nthreads=max(1, os.cpu_count() or 1))
+    np.testing.assert_array_equal(res["reachable"], ref["reachable"])
+    np.testing.assert_array_equal(res["state"], ref["state"])
+    assert res["reachable"].all()
+    for k in ("joints", "interval", "elbow"):
+        err = np.max(np.abs(res[k] - ref[k]))
+        assert err < NORTH_STAR_TOL, (k, err)
+        assert np.quantile(np.abs(res[k] - ref[k]), 0.9999) < 1e-9
+    # mirror property (test_random_reachability.py:156-166,248): l pose = (x,-y,z; -roll,pitch,-yaw)
+    posl = pos * np.array([1, -1, 1]); eull = eul * np.array([-1, 1, -1])
+    resl = to_np(l.solve_batch(soa(posl, eull, torch_mod)))
+    np.testing.assert_array_equal(resl["reachable"], res["reachable"])
+    # theta_l = -pi - theta_r differs from interval[0] of the mirrored interval, so compare through explicit thetas
+    th_r = res["interval"][:, 0]
+    th_l = torch_mod.as_tensor(-np.pi - th_r).cuda()
+    resl = to_np(l.solve_batch(soa(posl, eull, torch_mod), theta=("explicit", th_l)))
+    sign = np.array([1, -1, -1, 1, -1, 1, -1])
+    d = np.abs(resl["joints"] - res["joints"] * sign)
+    d = np.minimum(d, np.abs(d - 2 * np.pi))  # wrist roll wraps at +-pi
+    assert np.quantile(d, 0.9999) < 1e-9 and np.max(d) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------ solver-state (scalar API)
+def test_scalar_state_semantics_Q1(golden_dir, torch_mod, orc):
+    """get_joints is stateful like the reference's bound method: a second call after an elbow projection starts from
+    the moved goal pose.  Checked call-for-call against the CPU checker's solver object."""
+    g = load(golden_dir, "g3_reachable.npz")
+    solver, r, l = make_symbolic(0.03)
+    proj = np.where(g["r_arm_so003_i0_elbow_len"] == 3)[0][:8]
+    plain = np.where(g["r_arm_so003_i0_elbow_len"] == 4)[0][:8]
+    sv = orc.Solver(orc.Arm("r_arm", 0.03))
+    for i in list(proj) + list(plain):
+        pos, eul = g["r_arm_pos"][i], g["r_arm_eul"][i]
+        ok, interval, fn, state = r.is_reachable(np.array([pos, eul]))
+        oko, itvo, _ = sv.is_reachable(pos, eul)
+        assert ok and oko and np.max(np.abs(interval - itvo)) < TOL
+        np.testing.assert_allclose(r.wrist_position, sv.buf[6:9], atol=1e-12)
+        np.testing.assert_allclose(r.intersection_circle[0], sv.buf[9:12], atol=1e-12)
+        for rep in range(3):
+            j, e = fn(interval[0])
+            jo, eo, pr = sv.get_joints(interval[0])
+            assert np.max(np.abs(j - jo)) < TOL, (i, rep)
+            assert len(e) == (3 if pr else 4) and np.max(np.abs(e[:3] - eo)) < TOL
+            np.testing.assert_allclose(r.goal_pose[0], sv.buf[0:3], atol=1e-12)
+        e4 = r.get_elbow_position(0.3)
+        assert len(e4) == 4 and np.max(np.abs(e4[:3] - sv.get_elbow_position(0.3))) < TOL
+
+
+def test_helpers_elbow_and_no_limits(golden_dir, torch_mod):
+    g = load(golden_dir, "g5_helpers.npz")
+    solver, r, l = make_symbolic(0.03)
+    for ik, arm in ((r, "r_arm"), (l, "l_arm")):
+        pos, eul, th = g[f"{arm}_pos"], g[f"{arm}_eul"], g[f"{arm}_thetas"]
+        for i in list(range(0, 60)) + list(range(1024, 1084)):
+            ok, _, fn, _ = ik.is_reachable(np.array([pos[i], eul[i]]))
+            exp = g[f"{arm}_elbow_at_theta"][i]
+            assert ok == (not np.isnan(exp[0, 0]))
+            if ok:
+                for k in range(4):
+                    assert np.max(np.abs(ik.get_elbow_position(th[i, k])[:3] - exp[k])) < TOL
+            ok2, itv, fn2 = ik.is_reachable_no_limits(np.array([pos[i], eul[i]]))
+            assert ok2 == bool(g[f"{arm}_nolimits_ok"][i]) and np.all(itv == [-np.pi, np.pi])
+            j, e = fn2(th[i, 0])
+            assert np.max(np.abs(j - g[f"{arm}_nolimits_joints"][i])) < TOL
+            assert np.max(np.abs(e[:3] - g[f"{arm}_nolimits_elbow"][i])) < TOL
+
+
+# ------------------------------------------------------------------------------------------ rsik_control_discrete
+MODES = {"u20": (20, "unconstrained"), "u64": (64, "unconstrained"), "l20": (20, "low_elbow"), "l64": (64, "low_elbow")}
+
+
+def make_control(is_dvt=False):
+    import contextlib
+    import io
+
+    from reachy2_symbolic_ik_amd import ControlIK
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        return ControlIK(urdf_path=URDF, is_dvt=is_dvt)
+
+
+def test_control_catalogue_mixed(golden_dir, torch_mod):
+    g = load(golden_dir, "g1_catalogue.npz")
+    c = make_control()
+    arm = torch_mod.as_tensor(g["arm"]).cuda()
+    for key, (nb, mode) in MODES.items():
+        c.nb_search_points = nb
+        res = to_np(c.symbolic_inverse_kinematics_batch(arm, g["M"], constrained_mode=mode))
+        np.testing.assert_array_equal(res["reachable"], g[f"ctrl_{key}_reachable"], err_msg=key)
+        np.testing.assert_array_equal(res["state"], g[f"ctrl_{key}_state"], err_msg=key)
+        err = np.max(np.abs(res["joints"] - g[f"ctrl_{key}_joints"]))
+        assert err < 1e-7, (key, err)  # catalogue holds exact gimbal-lock orientations (pitch = -pi/2): Euler round trip
+        assert res["emergency"].sum() == 0
+
+
+def test_control_scalar_readme(torch_mod):
+    """README.md:96-123 example through the drop-in ControlIK."""
+    from scipy.spatial.transform import Rotation as R
+
+    c = make_control()
+    M = np.eye(4)
+    M[:3, :3] = R.from_euler("xyz", [0, -np.pi / 2, 0]).as_matrix()
+    M[:3, 3] = [0.55, -0.3, -0.15]
+    joints, ok, state = c.symbolic_inverse_kinematics("r_arm", M, "discrete")
+    assert ok and state == "reachable" and len(joints) == 7
+    np.testing.assert_allclose(joints, [-0.602816657693155, -0.324538165592665, 0.008828077832103, -1.048669758375133,
+                                        0.024186782799737, 0.143971244612599, -0.531677295547562], atol=1e-9)
+    assert c.previous_pose["r_arm"] is M
+    with pytest.raises(ValueError, match="Unknown type"):
+        c.symbolic_inverse_kinematics("r_arm", M, "bogus")
+
+
+@pytest.mark.parametrize("dvt_tag,is_dvt", [("std", False), ("dvt", True)])
+def test_control_random(golden_dir, torch_mod, dvt_tag, is_dvt):
+    """G4: random goal matrices (half uniform, half wrist-reachable), both arms, 20 / 64 search points, both
+    constrained modes, DVT and non-DVT singularity offsets."""
+    g = load(golden_dir, "g4_control_discrete.npz")
+    c = make_control(is_dvt)
+    for arm in ("r_arm", "l_arm"):
+        pre = f"{dvt_tag}_{arm}_"
+        M = g[pre + "M"]
+        for key, (nb, mode) in MODES.items():
+            if pre + key + "_joints" not in g:
+                continue
+            c.nb_search_points = nb
+            res = to_np(c.symbolic_inverse_kinematics_batch(arm, M, constrained_mode=mode))
+            np.testing.assert_array_equal(res["reachable"], g[pre + key + "_reachable"], err_msg=pre + key)
+            np.testing.assert_array_equal(res["state"], g[pre + key + "_state"], err_msg=pre + key)
+            err = np.max(np.abs(res["joints"] - g[pre + key + "_joints"]))
+            assert err < TOL, (pre + key, err)
+            assert set(np.unique(res["state"])) >= {0, 6}, "sweep hit and sweep miss must both occur"
+        if dvt_tag == "std":
+            c.nb_search_points = 20
+            idx = g[pre + "var_idx"]
+            for k in range(0, len(idx), 4):
+                j, ok, st = c.symbolic_inverse_kinematics(arm, M[idx[k]], "discrete",
+                                                          current_joints=list(g[pre + "var_current_joints"][k]),
+                                                          preferred_theta=float(g[pre + "var_preferred_theta"][k]))
+                assert ok == bool(g[pre + "var_reachable"][k])
+                from reachy2_symbolic_ik_amd import STATE_STRINGS
+                assert st == STATE_STRINGS[g[pre + "var_state"][k]]
+                assert np.max(np.abs(np.array(j) - g[pre + "var_joints"][k])) < TOL
+
+
+@pytest.mark.parametrize("nb", [2, 3, 10, 20, 33, 64, 65, 100, 200])
+def test_control_grid_sizes_match_checker(golden_dir, torch_mod, orc, nb):
+    """The wave-cooperative sweep packs 64/pow2ceil(nb) poses per round and needs extra rounds above 64 points."""
+    g = load(golden_dir, "g4_control_discrete.npz")
+    c = make_control()
+    c.nb_search_points = nb
+    ar, al = orc.Arm("r_arm", -1.01), orc.Arm("l_arm", -1.01)
+    M = np.concatenate([g["std_r_arm_M"][900:1300], g["std_l_arm_M"][900:1300]])
+    arm = np.concatenate([np.zeros(400, np.uint8), np.ones(400, np.uint8)])
+    res = to_np(c.symbolic_inverse_kinematics_batch(torch_mod.as_tensor(arm).cuda(), M))
+    ref = orc.control_discrete_batch(ar, al, M, arm_id=arm, nb_search_points=nb)
+    np.testing.assert_array_equal(res["reachable"], ref["reachable"])
+    np.testing.assert_array_equal(res["state"], ref["state"])
+    assert np.max(np.abs(res["joints"] - ref["joints"])) < TOL
+
+
+def test_config3_full_size_against_checker(torch_mod, orc):
+    """BASELINE config 3 at full size: 262 144 wrist-reachable goal matrices, 64-point sweep."""
+    from bench import make_config3_matrices
+
+    M = make_config3_matrices(1 << 18, seed=20250204)
+    c = make_control()
+    c.nb_search_points = 64
+    res = to_np(c.symbolic_inverse_kinematics_batch("r_arm", M))
+    ref = orc.control_discrete_batch(orc.Arm("r_arm", -1.01), orc.Arm("l_arm", -1.01), M, nb_search_points=64,
+                                     nthreads=max(1, os.cpu_count() or 1))
+    np.testing.assert_array_equal(res["reachable"], ref["reachable"])
+    np.testing.assert_array_equal(res["state"], ref["state"])
+    err = np.abs(res["joints"] - ref["joints"])
+    assert np.max(err) < NORTH_STAR_TOL and np.quantile(err, 0.9999) < 1e-9
+    frac = np.bincount(res["state"], minlength=7) / len(M)
+    assert frac[0] > 0.5 and frac[6] > 0.1  # both the sweep-hit and the sweep-miss populations are large
