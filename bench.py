@@ -54,7 +54,7 @@ def make_config2_poses(n, seed=20250204, device=0):
     while have < n:
         pos = SHOULDER_R + rng.uniform(-0.7, 0.7, size=(chunk, 3))
         eul = rng.uniform(-np.pi, np.pi, size=(chunk, 3))
-        soa = torch.as_tensor(np.concatenate([pos.T, eul.T], axis=0)).to(ik.solver.device)
+        soa = torch.as_tensor(np.ascontiguousarray(np.concatenate([pos.T, eul.T], axis=0))).to(ik.solver.device)
         ok = ik.is_reachable_batch(soa)["reachable"].cpu().numpy().astype(bool)
         P.append(pos[ok])
         E.append(eul[ok])
@@ -77,7 +77,7 @@ def make_config3_matrices(n, seed=20250204, device=0):
     while have < n:
         pos = SHOULDER_R + rng.uniform(-0.7, 0.7, size=(chunk, 3))
         eul = rng.uniform(-np.pi, np.pi, size=(chunk, 3))
-        soa = torch.as_tensor(np.concatenate([pos.T, eul.T], axis=0)).to(ik.solver.device)
+        soa = torch.as_tensor(np.ascontiguousarray(np.concatenate([pos.T, eul.T], axis=0))).to(ik.solver.device)
         ok = ik.is_reachable_batch(soa)["reachable"].cpu().numpy().astype(bool)
         P.append(pos[ok])
         E.append(eul[ok])
@@ -100,32 +100,48 @@ def cpu_baseline(config, inputs, seconds):
     on a bounded sample of the SAME workload.  Reported baseline, not the target."""
     from oracle import oracle as orc
 
-    cores = max(1, min(orc.lib().orc_max_threads(), os.cpu_count() or 1))
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    avail = max(1, min(avail, orc.lib().orc_max_threads()))
     if config == 2:
         pos, eul = inputs
         m = min(len(pos), 1 << 18)
+        pos, eul = np.ascontiguousarray(pos[:m]), np.ascontiguousarray(eul[:m])
         ar, al = orc.Arm("r_arm", 0.03), orc.Arm("l_arm", 0.03)
-        run = lambda: orc.solve_batch(ar, al, pos[:m], eul[:m], nthreads=cores)  # noqa: E731
+        run = lambda nt: orc.solve_batch(ar, al, pos, eul, nthreads=nt)  # noqa: E731
     else:
-        M = inputs
-        m = min(len(M), 1 << 17)
+        M = np.ascontiguousarray(inputs[: min(len(inputs), 1 << 17)])
+        m = len(M)
         ar, al = orc.Arm("r_arm", -1.01), orc.Arm("l_arm", -1.01)
-        run = lambda: orc.control_discrete_batch(ar, al, M[:m], nb_search_points=64, nthreads=cores)  # noqa: E731
-    run()
-    t0 = time.perf_counter()
-    passes = 0
-    while True:
-        run()
-        passes += 1
-        el = time.perf_counter() - t0
-        if el >= seconds or passes >= 1000:
-            break
+        run = lambda nt: orc.control_discrete_batch(ar, al, M, nb_search_points=64, nthreads=nt)  # noqa: E731
+
+    def rate(nt, budget):
+        run(nt)
+        t0 = time.perf_counter()
+        passes = 0
+        while True:
+            run(nt)
+            passes += 1
+            el = time.perf_counter() - t0
+            if el >= budget or passes >= 2000:
+                return passes * m / el, passes, el
+
+    # the host may expose more logical CPUs than the container's CPU quota: probe a few thread counts briefly,
+    # then spend the remaining budget on the best one
+    cands = sorted({c for c in (1, 8, 16, 32, 64, 128, avail) if c <= avail})
+    probe = {c: rate(c, 0.7)[0] for c in cands}
+    best = max(probe, key=probe.get)
+    value, passes, el = rate(best, max(1.0, seconds - 0.7 * len(cands)))
     return {
-        "value": passes * m / el,
+        "value": value,
         "unit": "solves/s",
-        "cores": cores,
+        "cores": best,
         "kind": "port",
-        "sample": f"first {m} poses of the workload x {passes} passes ({el:.1f} s, OpenMP {cores} threads, gcc -O2 no-FMA)",
+        "single_thread": probe[1],
+        "sample": f"first {m} poses of the workload x {passes} passes ({el:.1f} s) with OpenMP {best} threads "
+                  f"(best of {cands}; 1 thread: {probe[1]:.0f} solves/s); C restatement built gcc -O2 -ffp-contract=off",
     }
 
 
@@ -165,14 +181,16 @@ def main():
         pos, eul = make_config2_poses(n, seed=20250204 + rank, device=local_rank)
         inputs = (pos, eul)
         ik = _quiet(SymbolicIK, "r_arm", device=local_rank)
-        soa = torch.as_tensor(np.concatenate([pos.T, eul.T], axis=0)).to(dev)
+        soa = torch.as_tensor(np.ascontiguousarray(np.concatenate([pos.T, eul.T], axis=0))).to(dev)
+        assert soa.is_contiguous()
         out = {
             "joints": torch.empty((n, 7), dtype=torch.float64, device=dev),
             "interval": torch.empty((n, 2), dtype=torch.float64, device=dev),
             "reachable": torch.empty((n,), dtype=torch.uint8, device=dev),
             "state": torch.empty((n,), dtype=torch.uint8, device=dev),
         }
-        step_kernel = lambda: ik.solve_batch(soa, want_elbow=False, out=out)  # noqa: E731
+        plan = ik.solve_batch(soa, want_elbow=False, out=out, plan_only=True)
+        step_kernel = plan["launch"]  # one rsik_solve call with pre-bound arguments
         workload = f"config2: r_arm is_reachable + theta_to_joints_func(interval[0]), {n} random reachable poses per GPU"
         kernel_name = "solve_kernel"
     else:
@@ -189,7 +207,8 @@ def main():
             "state": torch.empty((n,), dtype=torch.uint8, device=dev),
             "emergency": torch.empty((n,), dtype=torch.uint8, device=dev),
         }
-        step_kernel = lambda: ctrl.symbolic_inverse_kinematics_batch("r_arm", m12, out=out)  # noqa: E731
+        plan = ctrl.symbolic_inverse_kinematics_batch("r_arm", m12, out=out, plan_only=True)
+        step_kernel = plan["launch"]  # one rsik_control_discrete call with pre-bound arguments
         workload = f"config3: r_arm ControlIK discrete, 64-point theta sweep, {n} wrist-reachable goal matrices per GPU"
         kernel_name = "control_discrete_kernel"
 

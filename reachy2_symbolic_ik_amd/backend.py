@@ -100,9 +100,11 @@ class HipSolver:
         previous_joints: Optional[Sequence[float]] = None,
         want_elbow: bool = True,
         out: Optional[Dict[str, torch.Tensor]] = None,
+        plan_only: bool = False,
     ) -> Dict[str, torch.Tensor]:
         """pose_soa: [6, n] float64 (rows px,py,pz,roll,pitch,yaw).  Returns joints [n,7], interval [n,2],
-        elbow [n,3], reachable [n] u8, state [n] u8 (device tensors, asynchronous on the current stream)."""
+        elbow [n,3], reachable [n] u8, state [n] u8 (device tensors, asynchronous on the current stream).
+        plan_only=True launches nothing and adds res["launch"], a zero-overhead re-launch callable (see plan())."""
         if pose_soa.dim() != 2 or pose_soa.shape[0] != 6:
             raise ValueError("pose_soa must have shape [6, n]")
         n = int(pose_soa.shape[1])
@@ -143,18 +145,37 @@ class HipSolver:
             if pj.shape != (7,):
                 raise ValueError("previous_joints must have 7 entries")
             prev = pj.ctypes.data_as(C.POINTER(C.c_double))
-        with torch.cuda.device(self.device):
-            self._bind_stream()
-            self._check(
-                self.lib.rsik_solve(self._h, n, cols, _ptr(arm), int(arm_uniform), int(theta_policy), _ptr(theta_in), prev,
-                                    _ptr(joints), _ptr(interval), _ptr(elbow), _ptr(reachable), _ptr(state))
-            )
+        cargs = (n, cols, _ptr(arm), int(arm_uniform), int(theta_policy), _ptr(theta_in), prev,
+                 _ptr(joints), _ptr(interval), _ptr(elbow), _ptr(reachable), _ptr(state))
         res = {"interval": interval, "reachable": reachable, "state": state}
+        if plan_only:
+            res["launch"] = self.plan("rsik_solve", *cargs)
+            res["_keepalive"] = (pose_soa, arm, theta_in, cols, prev)
+        else:
+            with torch.cuda.device(self.device):
+                self._bind_stream()
+                self._check(self.lib.rsik_solve(self._h, *cargs))
         if joints is not None:
             res["joints"] = joints
         if elbow is not None:
             res["elbow"] = elbow
         return res
+
+    def plan(self, fn_name: str, *args):
+        """Binds one C-ABI call with all its arguments once; the returned callable re-issues exactly that launch on the
+        stream that was current at planning time (a few microseconds of host time per call — the hot loop of a
+        caller that re-solves resident buffers, e.g. bench.py).  Keep the tensors alive while the plan is used."""
+        fn = getattr(self.lib, fn_name)
+        with torch.cuda.device(self.device):
+            self._bind_stream()
+        h, check = self._h, self._check
+
+        def launch() -> None:
+            rc = fn(h, *args)
+            if rc != _abi.RSIK_OK:
+                check(rc)
+
+        return launch
 
     # ------------------------------------------------------------------ rsik_control_discrete
     def control_discrete(
@@ -169,6 +190,7 @@ class HipSolver:
         current_joints: Optional[torch.Tensor] = None,
         orbita3d_max_angle: float = float(np.deg2rad(42.5)),
         out: Optional[Dict[str, torch.Tensor]] = None,
+        plan_only: bool = False,
     ) -> Dict[str, torch.Tensor]:
         """m12_soa: [12, n] float64 (R row-major, then translation)."""
         if m12_soa.dim() != 2 or m12_soa.shape[0] != 12:
@@ -200,16 +222,18 @@ class HipSolver:
         if emergency is None:
             emergency = torch.empty((n,), dtype=_U8, device=dev)
         cols = (C.c_void_p * 12)(*[m12_soa[k].data_ptr() for k in range(12)])
-        with torch.cuda.device(self.device):
-            self._bind_stream()
-            self._check(
-                self.lib.rsik_control_discrete(self._h, n, cols, _ptr(arm), int(arm_uniform), int(nb_search_points),
-                                               float(preferred_theta), int(constrained_mode),
-                                               ps.ctypes.data_as(C.POINTER(C.c_double)), _ptr(current_joints),
-                                               float(orbita3d_max_angle), _ptr(joints), _ptr(reachable), _ptr(state),
-                                               _ptr(emergency))
-            )
-        return {"joints": joints, "reachable": reachable, "state": state, "emergency": emergency}
+        cargs = (n, cols, _ptr(arm), int(arm_uniform), int(nb_search_points), float(preferred_theta), int(constrained_mode),
+                 ps.ctypes.data_as(C.POINTER(C.c_double)), _ptr(current_joints), float(orbita3d_max_angle), _ptr(joints),
+                 _ptr(reachable), _ptr(state), _ptr(emergency))
+        res = {"joints": joints, "reachable": reachable, "state": state, "emergency": emergency}
+        if plan_only:
+            res["launch"] = self.plan("rsik_control_discrete", *cargs)
+            res["_keepalive"] = (m12_soa, arm, current_joints, cols, ps)
+        else:
+            with torch.cuda.device(self.device):
+                self._bind_stream()
+                self._check(self.lib.rsik_control_discrete(self._h, *cargs))
+        return res
 
     # ------------------------------------------------------------------ solver-state entry points
     def new_solver_state(self, n: int) -> torch.Tensor:

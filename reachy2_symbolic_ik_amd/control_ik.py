@@ -244,6 +244,7 @@ class ControlIK:
         current_joints: Any = None,
         preferred_theta: float = -4 * np.pi / 6,
         out: Optional[Dict[str, torch.Tensor]] = None,
+        plan_only: bool = False,
     ) -> Dict[str, torch.Tensor]:
         """Discrete-mode IK for a batch of goal matrices.
 
@@ -266,4 +267,4 @@ class ControlIK:
             m12, arm=arm_t, arm_uniform=arm_uniform, nb_search_points=int(self.nb_search_points),
             preferred_theta=float(preferred_theta), constrained_mode=_abi.MODES[constrained_mode],
             previous_sol=self._previous_sol_2x7(), current_joints=current_joints,
-            orbita3d_max_angle=float(self.orbita3D_max_angle), out=out)
+            orbita3d_max_angle=float(self.orbita3D_max_angle), out=out, plan_only=plan_only)

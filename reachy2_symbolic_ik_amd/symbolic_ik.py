@@ -161,6 +161,7 @@ class SymbolicIK:
         previous_joints: Optional[Sequence[float]] = None,
         want_elbow: bool = True,
         out: Optional[Dict[str, torch.Tensor]] = None,
+        plan_only: bool = False,
     ) -> Dict[str, torch.Tensor]:
         """Fused is_reachable + get_joints for a batch of poses of this arm.
 
@@ -177,7 +178,7 @@ class SymbolicIK:
             theta_in = theta[1]
         self._upload()
         return self._solver.solve(soa, arm_uniform=self.arm_id, theta_policy=policy, theta_in=theta_in,
-                                  previous_joints=previous_joints, want_elbow=want_elbow, out=out)
+                                  previous_joints=previous_joints, want_elbow=want_elbow, out=out, plan_only=plan_only)
 
     def is_reachable_batch(self, poses: Any) -> Dict[str, torch.Tensor]:
         return self.solve_batch(poses, theta="none")

@@ -49,7 +49,7 @@ def make_symbolic(so):
 
 
 def soa(pos, eul, torch):
-    return torch.as_tensor(np.concatenate([pos.T, eul.T], axis=0)).cuda()
+    return torch.as_tensor(np.ascontiguousarray(np.concatenate([pos.T, eul.T], axis=0))).cuda()
 
 
 def to_np(res):
