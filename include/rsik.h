@@ -192,6 +192,12 @@ int rsik_joints_from_state(rsik_ctx *ctx, int64_t n, double *solver_state, const
 /* SymbolicIK.get_elbow_position(theta) on stored state (symbolic_ik.py:684-695). */
 int rsik_elbow_from_state(rsik_ctx *ctx, int64_t n, const double *solver_state, const double *theta, double *elbow);
 
+/* Test hook: evaluates the kernels' own elementary functions (csrc/rsik_math.hpp) on device arrays so their
+ * accuracy can be measured against the host libm.  op: 0 reciprocal, 1 sqrt (out0, out1 two variants),
+ * 2 reciprocal sqrt, 3 atan2(a, b), 4 sincos(a) -> out0 = sin, out1 = cos, 5 out0 = a mod 2pi (Python
+ * semantics), out1 = angle_diff(a, b) (utils.py:486-490).  Not part of the reference surface. */
+int rsik_debug_math(rsik_ctx *ctx, int op, int64_t n, const double *a, const double *b, double *out0, double *out1);
+
 #ifdef __cplusplus
 }
 #endif

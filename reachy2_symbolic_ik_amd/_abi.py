@@ -42,6 +42,7 @@ PROTOTYPES = {
     "rsik_reach_state": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp), _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "rsik_joints_from_state": (C.c_int, [_vp, C.c_int64, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     "rsik_elbow_from_state": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp]),
+    "rsik_debug_math": (C.c_int, [_vp, C.c_int, C.c_int64, _vp, _vp, _vp, _vp]),
 }
 
 SOLVER_STATE_STRIDE = 24

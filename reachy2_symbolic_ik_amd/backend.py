@@ -287,3 +287,17 @@ class HipSolver:
         if (not isinstance(solver_state, torch.Tensor) or solver_state.dtype != _F64 or solver_state.device != self.device
                 or tuple(solver_state.shape) != (n, _abi.SOLVER_STATE_STRIDE) or not solver_state.is_contiguous()):
             raise ValueError(f"solver_state must be a contiguous float64 [{n}, {_abi.SOLVER_STATE_STRIDE}] tensor on {self.device}")
+
+    # ------------------------------------------------------------------ test hook
+    def debug_math(self, op: int, a: torch.Tensor, b: Optional[torch.Tensor] = None):
+        """Evaluates the kernels' own elementary functions (csrc/rsik_math.hpp) on device arrays (rsik_debug_math)."""
+        n = int(a.numel())
+        a = self._dev_f64(a, (n,), "a")
+        if b is not None:
+            b = self._dev_f64(b, (n,), "b")
+        o0 = torch.empty((n,), dtype=_F64, device=self.device)
+        o1 = torch.empty((n,), dtype=_F64, device=self.device)
+        with torch.cuda.device(self.device):
+            self._bind_stream()
+            self._check(self.lib.rsik_debug_math(self._h, int(op), n, _ptr(a), _ptr(b), _ptr(o0), _ptr(o1)))
+        return o0, o1

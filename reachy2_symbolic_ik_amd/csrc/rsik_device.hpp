@@ -14,6 +14,7 @@
 #include <stdint.h>
 
 #include "../../include/rsik.h"
+#include "rsik_math.hpp"
 
 namespace rsik {
 
@@ -30,12 +31,20 @@ struct V3 {
 __device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 __device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 __device__ __forceinline__ V3 operator*(V3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
-__device__ __forceinline__ V3 operator/(V3 a, double s) { return {a.x / s, a.y / s, a.z / s}; }
 __device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ __forceinline__ V3 cross(V3 a, V3 b) {
     return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
-__device__ __forceinline__ double norm(V3 a) { return sqrt(dot(a, a)); }
+__device__ __forceinline__ double norm(V3 a) { return sqrt_cr(dot(a, a)); }
+// |a| (correctly rounded) and a/|a| through one v_rsq_f64 sequence instead of a sqrt and three IEEE divisions
+__device__ __forceinline__ V3 normalized(V3 a, double& len) {
+    double rs;
+    sqrt_rsqrt(dot(a, a), len, rs);
+    return a * rs;
+}
+__device__ __forceinline__ V3 normalized(V3 a) {
+    return a * rsqrt_fast(dot(a, a));
+}
 
 // numpy.isclose(a, b), default rtol/atol: |a-b| <= 1e-8 + 1e-5*|b|
 __device__ __forceinline__ bool np_isclose(double a, double b) { return fabs(a - b) <= (1e-8 + 1e-5 * fabs(b)); }
@@ -73,9 +82,9 @@ struct Rot {
 };
 __device__ __forceinline__ Rot rot_from_euler(double roll, double pitch, double yaw) {
     double sa, ca, sb, cb, sc, cc;
-    sincos(roll, &sa, &ca);
-    sincos(pitch, &sb, &cb);
-    sincos(yaw, &sc, &cc);
+    fast_sincos(roll, &sa, &ca);
+    fast_sincos(pitch, &sb, &cb);
+    fast_sincos(yaw, &sc, &cc);
     Rot r;
     r.m[0] = cc * cb; r.m[1] = cc * sb * sa - sc * ca; r.m[2] = cc * sb * ca + sc * sa;
     r.m[3] = sc * cb; r.m[4] = sc * sb * sa + cc * ca; r.m[5] = sc * sb * ca - cc * sa;
@@ -89,8 +98,7 @@ struct Frame {
     V3 c0, c1, c2;
 };
 __device__ __forceinline__ Frame frame_from_normal(V3 n) {
-    double nn = norm(n);
-    V3 u = n / nn;
+    V3 u = normalized(n);
     Frame F;
     // [D] colinear special cases, numpy.isclose semantics with the tolerance scaled by the 2nd argument
     bool yz = np_isclose(0.0, u.y) && np_isclose(0.0, u.z);
@@ -104,7 +112,7 @@ __device__ __forceinline__ Frame frame_from_normal(V3 n) {
     }
     // Rodrigues I + K + K^2 (1-c)/s^2 with v = e_x x u = (0, -u_z, u_y)
     double s2 = u.z * u.z + u.y * u.y;
-    double h = (1 - u.x) / s2;
+    double h = (1 - u.x) * fast_rcp(s2);
     double yzh = (u.y * u.z) * h;
     F.c0 = {1 - s2 * h, u.y, u.z};
     F.c1 = {-u.y, 1 - (u.y * u.y) * h, -yzh};
@@ -158,7 +166,7 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
     int st = RSIK_STATE_REACHABLE;
     if (d > A(RSIK_C_MAX_LEN)) {
         double nd = d + pm;
-        gp = s + (dv / nd) * A(RSIK_C_MAX_LEN);
+        gp = s + (dv * fast_rcp(nd)) * A(RSIK_C_MAX_LEN);
         st = RSIK_STATE_POSE_OUT_OF_REACH;
     }
     if (gp.x < bl) {
@@ -185,7 +193,7 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
     if (NO_LIMITS) {
         if (dsw > upf) {  // S:102-105: self.wrist_position moved onto the sphere, self.goal_pose shifted
             double nd = fabs(dsw) + pm;
-            V3 nw = s + ((w - s) / nd) * upf;
+            V3 nw = s + ((w - s) * fast_rcp(nd)) * upf;
             self_pos = gp + (nw - w);
             w = nw;
         }
@@ -198,7 +206,7 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
     }
     if (dsw < A(RSIK_C_MIN_DIST)) {  // [D] S:166-171 / S:107-112
         double nd = fabs(dsw) + pm;
-        V3 nw = s + ((w - s) / nd) * A(RSIK_C_MIN_DIST);
+        V3 nw = s + ((w - s) * fast_rcp(nd)) * A(RSIK_C_MIN_DIST);
         gp = gp + (nw - w);
         w = wrist_position(A, Rg, gp);
         self_pos = gp;
@@ -206,17 +214,19 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
 
     // S:366-399 intersection circle of the shoulder sphere (radius u) and the wrist sphere (radius f)
     P = w - s;
-    d = sqrt(P.x * P.x + P.y * P.y + P.z * P.z);
+    d = sqrt_cr(P.x * P.x + P.y * P.y + P.z * P.z);
     r.pos = self_pos;
     r.w = w;
     if (d > upf) {  // [D] S:374
         r.state = RSIK_STATE_SHOULD_NOT_HAPPEN;
         return r;
     }
-    V3 n2 = P / d;
+    const double inv_d = fast_rcp(d);
+    V3 n2 = P * inv_d;
     double d2 = d * d, k = d2 - f * f + u * u;
-    double r2 = 1 / (2 * d) * sqrt(4 * d2 * (u * u) - k * k);
-    V3 c2 = s + n2 * (k / (2 * d));
+    // the radicand is exactly 0 for a fully extended arm (Q23): keep the library sqrt (handles +0) there
+    double r2 = (0.5 * inv_d) * sqrt(4 * d2 * (u * u) - k * k);
+    V3 c2 = s + n2 * (k * (0.5 * inv_d));
     Frame F2 = frame_from_normal(n2);
     r.c2 = c2; r.r2 = r2; r.n2 = n2; r.a1 = F2.c1; r.a2 = F2.c2;
     r.stage = 2;
@@ -227,8 +237,8 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
 
     // S:401-416 wrist-limit circle (cone of half-angle wrist_limit around the hand axis)
     V3 n1 = w - gp;
-    double nn1 = norm(n1);
-    V3 c1 = w + (n1 / nn1) * A(RSIK_C_WRIST_AX);
+    V3 N1 = normalized(n1);
+    V3 c1 = w + N1 * A(RSIK_C_WRIST_AX);
     double r1 = A(RSIK_C_WRIST_R);
 
     // S:427-509 are_circles_linked, wrist-centred coordinates
@@ -242,8 +252,7 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
     r.i0 = side_ok ? -kPi : __builtin_nan("");
     r.i1 = side_ok ? kPi : __builtin_nan("");
 
-    V3 N1 = n1 / nn1;
-    V3 N2 = n2 / norm(n2);
+    V3 N2 = normalized(n2);
     const double mg = A(RSIK_C_NORMAL_MARGIN);
     // [D] S:475-483 parallel planes
     bool par = (fabs(N2.x - N1.x) < mg && fabs(N2.y - N1.y) < mg && fabs(N2.z - N1.z) < mg) ||
@@ -254,12 +263,12 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
     // [v1, -v2] t = p2 - p1 by least squares; since v1, v2, (p2-p1 minus its v-part) are coplanar the
     // minimiser is the exact intersection: t0 = N2.b / (N2.v1), t1 = N1.b / -(N1.v2), both denominators = |N1 x N2|.
     V3 cr = cross(N1, N2);
-    double nv = norm(cr);
-    V3 v = cr / nv;
+    const double inv_nv = rsqrt_fast(dot(cr, cr));
+    V3 v = cr * inv_nv;
     V3 v1 = cross(v, N1);
     V3 b = p2 - p1;
-    double t0 = dot(N2, b) / nv;
-    double t1 = dot(N1, b) / nv;
+    double t0 = dot(N2, b) * inv_nv;
+    double t1 = dot(N1, b) * inv_nv;
     if (np_isclose(t1, t0)) return r;  // [D] S:582-583 (Q7)
     V3 q = v1 * t0 + p1;
 
@@ -276,22 +285,23 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
     double oy = -dot(a1, p2), oz = -dot(a2, p2);  // translation of T_intersection_torso
     r.ok = true;
     r.state = RSIK_STATE_REACHABLE;
+    const double inv_2qa = fast_rcp(2 * qa);
     if (disc == 0) {  // [D] tangent: interval [a, a] (Q8)
-        double t = -qb / (2 * qa);
+        double t = -qb * inv_2qa;
         V3 p = q + v * t;
-        double ang = atan2(dot(a2, p) + oz, dot(a1, p) + oy);
+        double ang = fast_atan2(dot(a2, p) + oz, dot(a1, p) + oy);
         r.i0 = ang; r.i1 = ang;
         return r;
     }
-    double sq = sqrt(disc);
-    double ta = (-qb + sq) / (2 * qa), tb = (-qb - sq) / (2 * qa);
+    double sq = sqrt_cr(disc);
+    double ta = (-qb + sq) * inv_2qa, tb = (-qb - sq) * inv_2qa;
     V3 pa = q + v * ta, pb = q + v * tb;
-    double ang1 = atan2(dot(a2, pa) + oz, dot(a1, pa) + oy);
-    double ang2 = atan2(dot(a2, pb) + oz, dot(a1, pb) + oy);
+    double ang1 = fast_atan2(dot(a2, pa) + oz, dot(a1, pa) + oy);
+    double ang2 = fast_atan2(dot(a2, pb) + oz, dot(a1, pb) + oy);
     if (ang2 < ang1) { double t = ang1; ang1 = ang2; ang2 = t; }
     double am = (ang1 + ang2) / 2;
     double sm, cm;
-    sincos(am, &sm, &cm);
+    fast_sincos(am, &sm, &cm);
     double ty = cm * r2, tz = sm * r2;
     V3 tp = {a1.x * ty + a2.x * tz + p2.x, a1.y * ty + a2.y * tz + p2.y, a1.z * ty + a2.z * tz + p2.z};
     bool inside = (F1.c0.x * tp.x + F1.c0.y * tp.y + F1.c0.z * tp.z + tlx) > 0;  // [D] S:564
@@ -336,7 +346,7 @@ template <class Acc>
 __device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, double theta, const double* prev) {
     JointsOut o;
     double st, ct;
-    sincos(theta, &st, &ct);
+    fast_sincos(theta, &st, &ct);
     V3 e = elbow_on_circle(r, ct, st);
     o.projected = false;
     if (above_singularity_plane(A, e)) {  // S:708-718 -> make_elbow_projection S:647-682
@@ -344,7 +354,7 @@ __device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, do
         double dist = dot(e - Pl, v3);
         V3 pe = e - v3 * dist;
         V3 V = pe - pc;
-        V3 ne = pc + (V / norm(V)) * A(RSIK_C_PROJ_RADIUS);
+        V3 ne = pc + normalized(V) * A(RSIK_C_PROJ_RADIUS);
         r.pos = r.pos + (ne - e);
         e = ne;
         r.w = wrist_position(A, Rg, r.pos);
@@ -360,20 +370,21 @@ __device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, do
     };
     V3 q = to_shoulder(e);
     // shoulder pitch / roll (S:751-766)
-    double cphi, sphi, sp;
-    double rho = sqrt(q.x * q.x + q.z * q.z);
+    double cphi, sphi, sp, rho;
     if (q.x == 0 && q.z == 0) {  // [D] exact singularity: keep the previous pitch
         sp = prev[0];
         double s_, c_;
         sincos(sp, &s_, &c_);
-        cphi = c_; sphi = -s_;
+        cphi = c_; sphi = -s_; rho = 0.0;
     } else {
-        sp = -atan2(q.z, q.x);
-        cphi = q.x / rho; sphi = q.z / rho;
+        double irho;
+        sqrt_rsqrt(q.x * q.x + q.z * q.z, rho, irho);
+        sp = -fast_atan2(q.z, q.x);
+        cphi = q.x * irho; sphi = q.z * irho;
     }
-    double sr = atan2(q.y, rho);
-    double L = sqrt(rho * rho + q.y * q.y);
-    double cr = rho / L, srs = q.y / L;
+    double sr = fast_atan2(q.y, rho);
+    const double iL = rsqrt_fast(rho * rho + q.y * q.y);
+    double cr = rho * iL, srs = q.y * iL;
     // G = Rz(-sr) Ry(-sp): rows g0, g1, g2
     V3 g0 = {cr * cphi, srs, cr * sphi};
     V3 g1 = {-srs * cphi, cr, -srs * sphi};
@@ -384,18 +395,20 @@ __device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, do
     };
     // elbow yaw / pitch (S:780-797)
     V3 pw = to_elbow(r.w);
-    double sigma = sqrt(pw.y * pw.y + pw.z * pw.z);
-    double ey, ca, sa;
+    double sigma, ey, ca, sa;
     if (pw.y == 0 && pw.z == 0) {  // [D] exact singularity
         ey = prev[2];
         sincos(ey, &sa, &ca);
+        sigma = 0.0;
     } else {
-        ey = -kPi / 2 + atan2(pw.z, -pw.y);
-        ca = pw.z / sigma; sa = pw.y / sigma;
+        double isig;
+        sqrt_rsqrt(pw.y * pw.y + pw.z * pw.z, sigma, isig);
+        ey = -kPi / 2 + fast_atan2(pw.z, -pw.y);
+        ca = pw.z * isig; sa = pw.y * isig;
     }
-    double ep = -atan2(sigma, pw.x);
-    double lam = sqrt(sigma * sigma + pw.x * pw.x);
-    double cchi = pw.x / lam, schi = sigma / lam;
+    double ep = -fast_atan2(sigma, pw.x);
+    const double ilam = rsqrt_fast(sigma * sigma + pw.x * pw.x);
+    double cchi = pw.x * ilam, schi = sigma * ilam;
     // H = Ry(-ep) Rx(ey)
     V3 h0 = {cchi, schi * sa, schi * ca};
     V3 h1 = {0.0, ca, -sa};
@@ -408,20 +421,20 @@ __device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, do
     V3 tl = cvec(A, RSIK_C_TIPL);
     V3 ptip = Rg.apply(V3{tl.x, tl.y, 0.0}) + r.pos;
     V3 t = to_wrist(ptip);
-    double tau = sqrt(t.x * t.x + t.y * t.y);
-    double wr, cw, sw;
-    if (tau == 0) {
-        wr = kPi - atan2(t.y, -t.x);
-        if (wr > kPi) wr = wr - kTwoPi;
+    double tau, wr, cw, sw;
+    wr = kPi - fast_atan2(t.y, -t.x);
+    if (wr > kPi) wr = wr - kTwoPi;
+    if (t.x == 0 && t.y == 0) {
         sincos(wr, &sw, &cw);
+        tau = 0.0;
     } else {
-        wr = kPi - atan2(t.y, -t.x);
-        if (wr > kPi) wr = wr - kTwoPi;
-        cw = t.x / tau; sw = t.y / tau;
+        double itau;
+        sqrt_rsqrt(t.x * t.x + t.y * t.y, tau, itau);
+        cw = t.x * itau; sw = t.y * itau;
     }
-    double wp = atan2(t.z, tau);
-    double mu = sqrt(tau * tau + t.z * t.z);
-    double cp = tau / mu, spp = t.z / mu;
+    double wp = fast_atan2(t.z, tau);
+    const double imu = rsqrt_fast(tau * tau + t.z * t.z);
+    double cp = tau * imu, spp = t.z * imu;
     // K = Ry(wp) Rz(-wr); only rows 1, 2 are needed for the yaw
     V3 k1 = {-sw, cw, 0.0};
     V3 k2 = {-spp * cw, -spp * sw, cp};
@@ -433,15 +446,15 @@ __device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, do
     V3 xe = {dot(g0, xs), dot(g1, xs), dot(g2, xs)};
     V3 xw = {dot(h0, xe), dot(h1, xe), dot(h2, xe)};
     double gy = dot(k1, xw), gz = dot(k2, xw);
-    double wy = -atan2(gy, gz);
+    double wy = -fast_atan2(gy, gz);
 
     o.j[0] = sp; o.j[1] = sr; o.j[2] = ey; o.j[3] = ep; o.j[4] = wr; o.j[5] = -wp; o.j[6] = -wy;
     const double el = A(RSIK_C_ELBOW_LIMIT);  // S:853-861
     if (o.j[3] > el) o.j[3] = el;
     if (o.j[3] < -el) o.j[3] = -el;
-    double gn = sqrt(gy * gy + gz * gz);
+    const double ign = rsqrt_fast(gy * gy + gz * gz);
     o.c4 = cw; o.s4 = sw; o.c5 = cp; o.s5 = -spp;
-    o.c6 = gz / gn; o.s6 = gy / gn;
+    o.c6 = gz * ign; o.s6 = gy * ign;
     return o;
 }
 
@@ -469,27 +482,29 @@ __device__ __forceinline__ bool safety_checks(double (&j)[7], double ca, double 
     double W10 = ca * sc + sa * sb * cc, W12 = -sa * cb;
     double W20 = sa * sc - ca * sb * cc, W21 = sa * cc + ca * sb * sc, W22 = ca * cb;
     double sbeta = sqrt(W02 * W02 + W12 * W12);  // sin(beta) >= 0, beta in [0, pi]
-    double beta = atan2(sbeta, W22);
+    double beta = fast_atan2(sbeta, W22);
     double cal, sal, cga, sga;  // cos/sin of alpha, gamma
     if (fabs(beta) <= 1e-7) {
-        double h = sqrt(W00 * W00 + W10 * W10);
-        cal = W00 / h; sal = W10 / h; cga = 1.0; sga = 0.0;
+        double ih = rsqrt_fast(W00 * W00 + W10 * W10);
+        cal = W00 * ih; sal = W10 * ih; cga = 1.0; sga = 0.0;
     } else if (fabs(beta - kPi) <= 1e-7) {
-        double h = sqrt(W00 * W00 + W10 * W10);
-        cal = -W00 / h; sal = -W10 / h; cga = 1.0; sga = 0.0;
+        double ih = rsqrt_fast(W00 * W00 + W10 * W10);
+        cal = -W00 * ih; sal = -W10 * ih; cga = 1.0; sga = 0.0;
     } else {
-        cal = W02 / sbeta; sal = W12 / sbeta;
-        double h = sqrt(W20 * W20 + W21 * W21);
-        cga = -W20 / h; sga = W21 / h;
+        double isb = fast_rcp(sbeta);
+        cal = W02 * isb; sal = W12 * isb;
+        double ih = rsqrt_fast(W20 * W20 + W21 * W21);
+        cga = -W20 * ih; sga = W21 * ih;
     }
-    double cbe = W22 / sqrt(sbeta * sbeta + W22 * W22), sbe = sbeta / sqrt(sbeta * sbeta + W22 * W22);
+    const double inb = rsqrt_fast(sbeta * sbeta + W22 * W22);
+    double cbe = W22 * inb, sbe = sbeta * inb;
     if (beta > max_angle) { cbe = cos_max; sbe = sin_max; }  // beta >= 0 so only the upper clamp can act
     // W' = Rz(alpha) Ry(beta') Rz(gamma); intrinsic XYZ angles of W'
     double V02 = cal * sbe, V12 = sal * sbe, V22 = cbe;
     double V01 = -cal * cbe * sga - sal * cga, V00 = cal * cbe * cga - sal * sga;
-    j[4] = atan2(-V12, V22);
-    j[5] = asin(V02);
-    j[6] = atan2(-V01, V00);
+    j[4] = fast_atan2(-V12, V22);
+    j[5] = fast_atan2(V02, sqrt(fma(-V02, V02, 1.0)));  // asin(V02); |V02| <= sin(max_angle) after the clamp
+    j[6] = fast_atan2(-V01, V00);
     bool emergency = false;
 #pragma unroll
     for (int k = 0; k < 7; k++) j[k] = prev[k] + angle_diff(j[k], prev[k]);

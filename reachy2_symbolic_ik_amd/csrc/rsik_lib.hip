@@ -396,6 +396,24 @@ __global__ __launch_bounds__(kBlock) void elbow_state_kernel(const StateArgs K) 
     K.elbow[3 * i] = e.x; K.elbow[3 * i + 1] = e.y; K.elbow[3 * i + 2] = e.z;
 }
 
+// Unit-test hook for rsik_math.hpp (rsik_debug_math): op 0 rcp, 1 sqrt_cr, 2 rsqrt, 3 atan2(a,b), 4 sincos(a), 5 a % 2pi
+__global__ void debug_math_kernel(int op, int64_t n, const double* a, const double* b, double* o0, double* o1) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double x = a[i], r0 = 0.0, r1 = 0.0;
+    switch (op) {
+        case 0: r0 = fast_rcp(x); break;
+        case 1: sqrt_rsqrt(x, r0, r1); r1 = sqrt_cr(x); break;
+        case 2: r0 = rsqrt_fast(x); break;
+        case 3: r0 = fast_atan2(x, b[i]); break;
+        case 4: fast_sincos(x, &r0, &r1); break;
+        case 5: r0 = pymod_2pi(x); r1 = angle_diff(x, b[i]); break;
+        default: break;
+    }
+    o0[i] = r0;
+    if (o1) o1[i] = r1;
+}
+
 }  // namespace rsik
 
 // =====================================================================================
@@ -710,6 +728,20 @@ int rsik_elbow_from_state(rsik_ctx* ctx, int64_t n, const double* solver_state, 
     int rc = launch_dims(ctx, n, &grid, "rsik_elbow_from_state");
     if (rc != RSIK_OK) return rc;
     hipLaunchKernelGGL(rsik::elbow_state_kernel, grid, block, 0, ctx->stream, K);
+    RSIK_HIP(ctx, hipGetLastError());
+    return RSIK_OK;
+}
+
+int rsik_debug_math(rsik_ctx* ctx, int op, int64_t n, const double* a, const double* b, double* out0, double* out1) {
+    if (!ctx) return RSIK_E_INVALID;
+    if (n < 0 || op < 0 || op > 5) return fail(ctx, RSIK_E_INVALID, "rsik_debug_math: bad op or n");
+    if (n == 0) return RSIK_OK;
+    if (!a || !out0 || ((op == 3 || op == 5) && !b)) return fail(ctx, RSIK_E_INVALID, "rsik_debug_math: NULL operand");
+    RSIK_HIP(ctx, hipSetDevice(ctx->device));
+    dim3 grid, block(rsik::kBlock);
+    int rc = launch_dims(ctx, n, &grid, "rsik_debug_math");
+    if (rc != RSIK_OK) return rc;
+    hipLaunchKernelGGL(rsik::debug_math_kernel, grid, block, 0, ctx->stream, op, n, a, b, out0, out1);
     RSIK_HIP(ctx, hipGetLastError());
     return RSIK_OK;
 }

@@ -74,7 +74,8 @@ def check_symbolic(res, g, prefix, tol=TOL):
     if sing.any():  # fully extended arm: only j2 + j6 is defined (see tests/test_oracle_golden.py)
         a, b = res["joints"][sing], g[prefix + "joints"][sing]
         assert np.max(np.abs(a[:, [0, 1, 3, 4, 5]] - b[:, [0, 1, 3, 4, 5]])) < tol
-        assert np.max(np.abs((a[:, 2] + a[:, 6]) - (b[:, 2] + b[:, 6]))) < 1e-7
+        dsum = (a[:, 2] + a[:, 6]) - (b[:, 2] + b[:, 6])  # defined modulo 2 pi only (elbow yaw is not wrapped, Q3)
+        assert np.max(np.abs(dsum - 2 * np.pi * np.round(dsum / (2 * np.pi)))) < 1e-7
 
 
 # ------------------------------------------------------------------------------------------ rsik_solve
@@ -364,3 +365,36 @@ def test_config3_full_size_against_checker(torch_mod, orc):
     assert np.max(err) < NORTH_STAR_TOL and np.quantile(err, 0.9999) < 1e-9
     frac = np.bincount(res["state"], minlength=7) / len(M)
     assert frac[0] > 0.5 and frac[6] > 0.1  # both the sweep-hit and the sweep-miss populations are large
+
+
+# ------------------------------------------------------------------------------------------ csrc/rsik_math.hpp
+def test_device_math_accuracy(torch_mod):
+    """The kernels' own rcp / sqrt / rsqrt / atan2 / sincos / python-modulo against the host libm (float64)."""
+    from reachy2_symbolic_ik_amd import HipSolver
+
+    hs = HipSolver(0)
+    rng = np.random.default_rng(5)
+    n = 1 << 18
+    t = lambda x: torch_mod.as_tensor(np.ascontiguousarray(x)).cuda()  # noqa: E731
+    x = np.concatenate([rng.uniform(1e-6, 10.0, n // 2), 10.0 ** rng.uniform(-12, 6, n // 2)])
+    r, _ = hs.debug_math(0, t(x))
+    assert np.max(np.abs(r.cpu().numpy() * x - 1.0)) < 4.5e-16
+    s, s2 = hs.debug_math(1, t(x))
+    np.testing.assert_array_equal(s.cpu().numpy(), np.sqrt(x))   # correctly rounded
+    np.testing.assert_array_equal(s2.cpu().numpy(), np.sqrt(x))
+    rs, _ = hs.debug_math(2, t(x))
+    assert np.max(np.abs(rs.cpu().numpy() * np.sqrt(x) - 1.0)) < 4.5e-16
+    yy = np.concatenate([rng.normal(size=n - 8), [0.0, 0.0, -0.0, 1.0, -1.0, 0.0, 1e-300, 3.0]])
+    xx = np.concatenate([rng.normal(size=n - 8), [0.0, -0.0, -0.0, 0.0, 0.0, -2.0, 1.0, 3.0]])
+    a, _ = hs.debug_math(3, t(yy), t(xx))
+    assert np.max(np.abs(a.cpu().numpy() - np.arctan2(yy, xx))) < 4.5e-16
+    ang = np.concatenate([rng.uniform(-4 * np.pi, 4 * np.pi, n // 2), rng.uniform(-1e4, 1e4, n // 2 - 4),
+                          [0.0, np.pi / 2, -np.pi, np.pi]])
+    sn, cs = hs.debug_math(4, t(ang))
+    assert np.max(np.abs(sn.cpu().numpy() - np.sin(ang))) < 3e-16
+    assert np.max(np.abs(cs.cpu().numpy() - np.cos(ang))) < 3e-16
+    aa = np.concatenate([rng.uniform(-30, 30, n - 6), [0.0, 2 * np.pi, -2 * np.pi, np.pi, -np.pi, 4 * np.pi]])
+    bb = rng.uniform(-8, 8, n)
+    m, ad = hs.debug_math(5, t(aa), t(bb))
+    np.testing.assert_array_equal(m.cpu().numpy(), aa % (2 * np.pi))   # Python float modulo, bit for bit
+    np.testing.assert_array_equal(ad.cpu().numpy(), ((aa - bb + np.pi) % (2 * np.pi)) - np.pi)
