@@ -96,7 +96,11 @@ enum {
     RSIK_C_PROJ_CENTER = 41,  /* [3] projected_center                   symbolic_ik.py:671 */
     RSIK_C_PROJ_RADIUS = 44,  /* radius (NaN if the plane misses the shoulder sphere)  symbolic_ik.py:672 */
     RSIK_C_TIP_Z = 45,        /* tip_position[2]                        symbolic_ik.py:837 */
-    RSIK_ARM_CONSTS_COUNT = 46
+    RSIK_C_INV_U = 46,        /* 1 / upper_arm_size        (lengths that hold by construction) */
+    RSIK_C_INV_F = 47,        /* 1 / forearm_size                                          */
+    RSIK_C_INV_TIPZ = 48,     /* 1 / |tip_position[2]|                                     */
+    RSIK_C_INV_GRIP = 49,     /* 1 / gripper_size = 1 / |tip_position|                     */
+    RSIK_ARM_CONSTS_COUNT = 50
 };
 
 typedef struct rsik_ctx rsik_ctx;

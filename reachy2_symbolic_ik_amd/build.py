@@ -11,8 +11,9 @@ SOURCES = ["rsik_lib.hip"]
 DEPS = ["rsik_lib.hip", "rsik_device.hpp", os.path.join("..", "..", "include", "rsik.h")]
 OUT = os.path.join(CSRC, "librsik_hip.so")
 
-# -ffp-contract=off: decision points of the reach test keep the reference's (NumPy, no FMA) rounding;
-# fma() is written explicitly where it is wanted.
+# -ffp-contract=off: the compiler never fuses on its own (HIP's default "fast" mode fuses in the backend and ignores
+# `#pragma clang fp contract`), so decision points of the reach test keep the reference's NumPy (unfused) rounding;
+# everywhere else fused multiply-adds are written out explicitly (rsik_device.hpp: dot, cross, madd, ...).
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
 
 

@@ -18,7 +18,8 @@ import numpy as np
 C_SHOULDER, C_UPPER_ARM, C_FOREARM, C_TIPL, C_MAX_LEN, C_MIN_DIST, C_BACKWARD = 0, 3, 4, 5, 8, 9, 10
 C_PROJ_MARGIN, C_NORMAL_MARGIN, C_UPF, C_WRIST_R, C_WRIST_AX, C_MST, C_TSH, C_ES = 11, 12, 13, 14, 15, 16, 25, 28
 C_SING_OFFSET, C_SING_COEFF, C_ELBOW_LIMIT, C_SIDE, C_PLANE_P, C_PLANE_N = 31, 32, 33, 34, 35, 38
-C_PROJ_CENTER, C_PROJ_RADIUS, C_TIP_Z, ARM_CONSTS_COUNT = 41, 44, 45, 46
+C_PROJ_CENTER, C_PROJ_RADIUS, C_TIP_Z = 41, 44, 45
+C_INV_U, C_INV_F, C_INV_TIPZ, C_INV_GRIP, ARM_CONSTS_COUNT = 46, 47, 48, 49, 50
 
 ARM_IDS = {"r_arm": 0, "l_arm": 1}
 
@@ -155,6 +156,11 @@ class ArmGeometry:
         c[C_PROJ_CENTER:C_PROJ_CENTER + 3] = pc
         c[C_PROJ_RADIUS] = pr
         c[C_TIP_Z] = self.tip_position[2]
+        with np.errstate(divide="ignore"):
+            c[C_INV_U] = 1.0 / self.upper_arm_size
+            c[C_INV_F] = 1.0 / self.forearm_size
+            c[C_INV_TIPZ] = 1.0 / abs(self.tip_position[2])
+            c[C_INV_GRIP] = 1.0 / self.gripper_size
         return c
 
 

@@ -31,11 +31,17 @@ struct V3 {
 __device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 __device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 __device__ __forceinline__ V3 operator*(V3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
-__device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// The translation unit is compiled with -ffp-contract=off: fused multiply-adds are written out where the
+// rounding of the reference (NumPy, unfused) does not matter; decision points use the *_d forms.
+__device__ __forceinline__ double dot(V3 a, V3 b) { return fma(a.x, b.x, fma(a.y, b.y, a.z * b.z)); }
 __device__ __forceinline__ V3 cross(V3 a, V3 b) {
-    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+    return {fma(a.y, b.z, -(a.z * b.y)), fma(a.z, b.x, -(a.x * b.z)), fma(a.x, b.y, -(a.y * b.x))};
 }
-__device__ __forceinline__ double norm(V3 a) { return sqrt_cr(dot(a, a)); }
+// a * s + b
+__device__ __forceinline__ V3 madd(V3 a, double s, V3 b) { return {fma(a.x, s, b.x), fma(a.y, s, b.y), fma(a.z, s, b.z)}; }
+// Decision points are evaluated with the reference's (NumPy, unfused) rounding.
+__device__ __forceinline__ double dot_d(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ double norm(V3 a) { return sqrt_cr(dot_d(a, a)); }
 // |a| (correctly rounded) and a/|a| through one v_rsq_f64 sequence instead of a sqrt and three IEEE divisions
 __device__ __forceinline__ V3 normalized(V3 a, double& len) {
     double rs;
@@ -74,9 +80,13 @@ __device__ __forceinline__ bool is_valid_angle(double angle, double i0, double i
 // Goal rotation R = Rz(yaw) Ry(pitch) Rx(roll)  (scipy from_euler("xyz"), extrinsic; S:420).
 struct Rot {
     double m[9];  // row-major
-    __device__ __forceinline__ V3 apply(V3 v) const {
-        return {m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z,
-                m[6] * v.x + m[7] * v.y + m[8] * v.z};
+    __device__ __forceinline__ V3 apply_add(V3 v, V3 t) const {  // R.v + t
+        return {fma(m[0], v.x, fma(m[1], v.y, fma(m[2], v.z, t.x))), fma(m[3], v.x, fma(m[4], v.y, fma(m[5], v.z, t.y))),
+                fma(m[6], v.x, fma(m[7], v.y, fma(m[8], v.z, t.z)))};
+    }
+    __device__ __forceinline__ V3 apply_d(V3 v, V3 t) const {  // R.v + t with unfused rounding
+        return {m[0] * v.x + m[1] * v.y + m[2] * v.z + t.x, m[3] * v.x + m[4] * v.y + m[5] * v.z + t.y,
+                m[6] * v.x + m[7] * v.y + m[8] * v.z + t.z};
     }
     __device__ __forceinline__ V3 col0() const { return {m[0], m[3], m[6]}; }
 };
@@ -86,19 +96,26 @@ __device__ __forceinline__ Rot rot_from_euler(double roll, double pitch, double 
     fast_sincos(pitch, &sb, &cb);
     fast_sincos(yaw, &sc, &cc);
     Rot r;
-    r.m[0] = cc * cb; r.m[1] = cc * sb * sa - sc * ca; r.m[2] = cc * sb * ca + sc * sa;
-    r.m[3] = sc * cb; r.m[4] = sc * sb * sa + cc * ca; r.m[5] = sc * sb * ca - cc * sa;
+    const double ccsb = cc * sb, scsb = sc * sb;
+    r.m[0] = cc * cb; r.m[1] = fma(ccsb, sa, -(sc * ca)); r.m[2] = fma(ccsb, ca, sc * sa);
+    r.m[3] = sc * cb; r.m[4] = fma(scsb, sa, cc * ca);    r.m[5] = fma(scsb, ca, -(cc * sa));
     r.m[6] = -sb;     r.m[7] = cb * sa;                r.m[8] = cb * ca;
     return r;
 }
 
-// Columns of utils.rotation_matrix_from_vector(n) (U:59-81): the rotation taking e_x to n/|n|.
-// c0 is only needed for the "which side of the wrist-limit plane" tests.
+// Columns of utils.rotation_matrix_from_vector(n) (U:59-81): the rotation taking e_x to u = n/|n|.
+// c0 is only needed for the "which side of the wrist-limit plane" tests (frame_c0).
 struct Frame {
     V3 c0, c1, c2;
 };
-__device__ __forceinline__ Frame frame_from_normal(V3 n) {
-    V3 u = normalized(n);
+// u must already be normalised (the reference divides by the norm first, U:66).
+__device__ __forceinline__ V3 frame_c0(V3 u) {
+    bool yz = np_isclose(0.0, u.y) && np_isclose(0.0, u.z);
+    if (yz && np_isclose(1.0, u.x)) return {1, 0, 0};
+    if (yz && np_isclose(1.0, -u.x)) return {-1, 0, 0};
+    return u;  // R00 = 1 - s^2 (1-c)/s^2 = c to rounding
+}
+__device__ __forceinline__ Frame frame_from_unit(V3 u) {
     Frame F;
     // [D] colinear special cases, numpy.isclose semantics with the tolerance scaled by the 2nd argument
     bool yz = np_isclose(0.0, u.y) && np_isclose(0.0, u.z);
@@ -111,12 +128,13 @@ __device__ __forceinline__ Frame frame_from_normal(V3 n) {
         return F;
     }
     // Rodrigues I + K + K^2 (1-c)/s^2 with v = e_x x u = (0, -u_z, u_y)
-    double s2 = u.z * u.z + u.y * u.y;
+    double s2 = fma(u.z, u.z, u.y * u.y);
     double h = (1 - u.x) * fast_rcp(s2);
-    double yzh = (u.y * u.z) * h;
-    F.c0 = {1 - s2 * h, u.y, u.z};
-    F.c1 = {-u.y, 1 - (u.y * u.y) * h, -yzh};
-    F.c2 = {-u.z, -yzh, 1 - (u.z * u.z) * h};
+    double yh = u.y * h, zh = u.z * h;
+    double yzh = u.y * zh;
+    F.c0 = {fma(-s2, h, 1.0), u.y, u.z};
+    F.c1 = {-u.y, fma(-u.y, yh, 1.0), -yzh};
+    F.c2 = {-u.z, -yzh, fma(-u.z, zh, 1.0)};
     return F;
 }
 
@@ -125,6 +143,7 @@ struct Reach {
     int state;     // RSIK_STATE_*
     bool ok;
     double i0, i1; // theta interval
+    double ct0, st0; // cos / sin of i0 (from the intersection point itself, no trigonometric call)
     V3 pos;        // self.goal_pose[0]
     V3 w;          // self.wrist_position
     V3 c2;         // intersection circle centre
@@ -143,7 +162,7 @@ __device__ __forceinline__ V3 cvec(const Acc& A, int off) {
 template <class Acc>
 __device__ __forceinline__ V3 wrist_position(const Acc& A, const Rot& Rg, V3 pos) {
     V3 tl = cvec(A, RSIK_C_TIPL);
-    return Rg.apply(tl) + pos;
+    return Rg.apply_d(tl, pos);
 }
 
 // SymbolicIK.is_reachable (S:121-282) including is_pose_in_robot_reach (S:284-307),
@@ -162,11 +181,11 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
     // [D] S:284-307
     V3 gp = pos_in;
     V3 dv = gp - s;
-    double d = norm(dv);
+    const double d0 = norm(dv);
     int st = RSIK_STATE_REACHABLE;
-    if (d > A(RSIK_C_MAX_LEN)) {
-        double nd = d + pm;
-        gp = s + (dv * fast_rcp(nd)) * A(RSIK_C_MAX_LEN);
+    if (d0 > A(RSIK_C_MAX_LEN)) {
+        double nd = d0 + pm;
+        gp = madd(dv * fast_rcp(nd), A(RSIK_C_MAX_LEN), s);
         st = RSIK_STATE_POSE_OUT_OF_REACH;
     }
     if (gp.x < bl) {
@@ -175,7 +194,7 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
     }
     r.state = st;
     r.stage = 0;
-    r.pos = gp; r.w = gp; r.c2 = gp; r.n2 = gp; r.a1 = gp; r.a2 = gp; r.r2 = 0.0;
+    r.pos = gp; r.w = gp; r.c2 = gp; r.n2 = gp; r.a1 = gp; r.a2 = gp; r.r2 = 0.0; r.ct0 = 1.0; r.st0 = 0.0;
     if (!NO_LIMITS && st != RSIK_STATE_REACHABLE) return r;
     r.stage = 1;
 
@@ -189,13 +208,16 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
     }
     V3 P = w - s;
     double dsw = norm(P);
+    double d = dsw;  // get_intersection_circle recomputes the same norm (S:373); only the min-distance branch changes it
     V3 self_pos = gp;  // what ends up in self.goal_pose (differs from the local only in the NO_LIMITS far case, Q4)
     if (NO_LIMITS) {
         if (dsw > upf) {  // S:102-105: self.wrist_position moved onto the sphere, self.goal_pose shifted
             double nd = fabs(dsw) + pm;
-            V3 nw = s + ((w - s) * fast_rcp(nd)) * upf;
+            V3 nw = madd((w - s) * fast_rcp(nd), upf, s);
             self_pos = gp + (nw - w);
             w = nw;
+            P = w - s;
+            d = norm(P);
         }
     } else {
         if (dsw > upf) {  // [D] S:157-161
@@ -206,15 +228,15 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
     }
     if (dsw < A(RSIK_C_MIN_DIST)) {  // [D] S:166-171 / S:107-112
         double nd = fabs(dsw) + pm;
-        V3 nw = s + ((w - s) * fast_rcp(nd)) * A(RSIK_C_MIN_DIST);
+        V3 nw = madd((w - s) * fast_rcp(nd), A(RSIK_C_MIN_DIST), s);
         gp = gp + (nw - w);
         w = wrist_position(A, Rg, gp);
         self_pos = gp;
+        P = w - s;
+        d = norm(P);
     }
 
     // S:366-399 intersection circle of the shoulder sphere (radius u) and the wrist sphere (radius f)
-    P = w - s;
-    d = sqrt_cr(P.x * P.x + P.y * P.y + P.z * P.z);
     r.pos = self_pos;
     r.w = w;
     if (d > upf) {  // [D] S:374
@@ -223,36 +245,43 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
     }
     const double inv_d = fast_rcp(d);
     V3 n2 = P * inv_d;
-    double d2 = d * d, k = d2 - f * f + u * u;
-    // the radicand is exactly 0 for a fully extended arm (Q23): keep the library sqrt (handles +0) there
-    double r2 = (0.5 * inv_d) * sqrt(4 * d2 * (u * u) - k * k);
-    V3 c2 = s + n2 * (k * (0.5 * inv_d));
-    Frame F2 = frame_from_normal(n2);
+    double r2;
+    V3 c2;
+    {
+        double d2 = d * d, k = d2 - f * f + u * u;
+        // [D] the radicand is exactly 0 for a fully extended arm (Q23) and must not become -1e-18 through an fma
+        double rad = 4 * d2 * (u * u) - k * k;
+        r2 = (0.5 * inv_d) * ((rad == 0.0) ? 0.0 : sqrt_cr(rad));
+        c2 = s + n2 * (k * (0.5 * inv_d));
+    }
+    Frame F2 = frame_from_unit(n2);
     r.c2 = c2; r.r2 = r2; r.n2 = n2; r.a1 = F2.c1; r.a2 = F2.c2;
     r.stage = 2;
+    r.ct0 = -1.0; r.st0 = -1.2246467991473532e-16;  // cos(-pi), sin(-pi) as the reference's np.cos/np.sin return them
     if (NO_LIMITS) {
         r.ok = true; r.state = RSIK_STATE_REACHABLE; r.i0 = -kPi; r.i1 = kPi;
         return r;
     }
 
-    // S:401-416 wrist-limit circle (cone of half-angle wrist_limit around the hand axis)
+    // S:401-416 wrist-limit circle (cone of half-angle wrist_limit around the hand axis).
+    // |w - goal| = |tip| by construction, so the unit normal costs one multiply by a constant.
     V3 n1 = w - gp;
-    V3 N1 = normalized(n1);
-    V3 c1 = w + N1 * A(RSIK_C_WRIST_AX);
+    V3 N1 = n1 * A(RSIK_C_INV_GRIP);
+    V3 c1 = madd(N1, A(RSIK_C_WRIST_AX), w);
     double r1 = A(RSIK_C_WRIST_R);
 
     // S:427-509 are_circles_linked, wrist-centred coordinates
     V3 p1 = c1 - w, p2 = c2 - w;
-    Frame F1 = frame_from_normal(n1);
+    const V3 f1 = frame_c0(N1);
     // [D] x of T_limitation_torso . p = c0.p + (-c0).p1
-    double tlx = (-F1.c0.x) * p1.x + (-F1.c0.y) * p1.y + (-F1.c0.z) * p1.z;
-    bool side_ok = (F1.c0.x * p2.x + F1.c0.y * p2.y + F1.c0.z * p2.z + tlx) > 0;
+    const double tlx = -dot_d(f1, p1);
+    bool side_ok = (dot_d(f1, p2) + tlx) > 0;
     r.state = side_ok ? RSIK_STATE_REACHABLE : RSIK_STATE_LIMITED_BY_WRIST;
     r.ok = side_ok;
     r.i0 = side_ok ? -kPi : __builtin_nan("");
     r.i1 = side_ok ? kPi : __builtin_nan("");
 
-    V3 N2 = normalized(n2);
+    const V3 N2 = n2;  // already unit (the reference renormalises: a 1-ulp no-op)
     const double mg = A(RSIK_C_NORMAL_MARGIN);
     // [D] S:475-483 parallel planes
     bool par = (fabs(N2.x - N1.x) < mg && fabs(N2.y - N1.y) < mg && fabs(N2.z - N1.z) < mg) ||
@@ -270,14 +299,17 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
     double t0 = dot(N2, b) * inv_nv;
     double t1 = dot(N1, b) * inv_nv;
     if (np_isclose(t1, t0)) return r;  // [D] S:582-583 (Q7)
-    V3 q = v1 * t0 + p1;
+    V3 q = madd(v1, t0, p1);
 
     // S:608-645 circle 1 (centre p1, radius r1) with the line (q, v)
     V3 wv = q - p1;
-    double qa = dot(v, v);
-    double qb = 2 * dot(v, wv);
-    double qc = dot(wv, wv) - r1 * r1;
-    double disc = qb * qb - 4 * qa * qc;
+    double qa, qb, disc;
+    {
+        qa = v.x * v.x + v.y * v.y + v.z * v.z;
+        qb = 2 * (v.x * wv.x + v.y * wv.y + v.z * wv.z);
+        double qc = (wv.x * wv.x + wv.y * wv.y + wv.z * wv.z) - r1 * r1;
+        disc = qb * qb - 4 * qa * qc;
+    }
     if (disc < 0) return r;  // [D]
 
     // S:511-568 angles of the intersection points in the circle-2 frame
@@ -288,32 +320,43 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
     const double inv_2qa = fast_rcp(2 * qa);
     if (disc == 0) {  // [D] tangent: interval [a, a] (Q8)
         double t = -qb * inv_2qa;
-        V3 p = q + v * t;
-        double ang = fast_atan2(dot(a2, p) + oz, dot(a1, p) + oy);
-        r.i0 = ang; r.i1 = ang;
+        V3 p = madd(v, t, q);
+        double ly = dot(a1, p) + oy, lz = dot(a2, p) + oz;
+        double ang = fast_atan2(lz, ly);
+        double il = rsqrt_fast(ly * ly + lz * lz);
+        r.i0 = ang; r.i1 = ang; r.ct0 = ly * il; r.st0 = lz * il;
         return r;
     }
     double sq = sqrt_cr(disc);
     double ta = (-qb + sq) * inv_2qa, tb = (-qb - sq) * inv_2qa;
-    V3 pa = q + v * ta, pb = q + v * tb;
-    double ang1 = fast_atan2(dot(a2, pa) + oz, dot(a1, pa) + oy);
-    double ang2 = fast_atan2(dot(a2, pb) + oz, dot(a1, pb) + oy);
-    if (ang2 < ang1) { double t = ang1; ang1 = ang2; ang2 = t; }
+    V3 pa = madd(v, ta, q), pb = madd(v, tb, q);
+    double ly1 = dot(a1, pa) + oy, lz1 = dot(a2, pa) + oz;
+    double ly2 = dot(a1, pb) + oy, lz2 = dot(a2, pb) + oz;
+    double ang1 = fast_atan2(lz1, ly1);
+    double ang2 = fast_atan2(lz2, ly2);
+    if (ang2 < ang1) {
+        double t = ang1; ang1 = ang2; ang2 = t;
+        t = ly1; ly1 = ly2; ly2 = t;
+        t = lz1; lz1 = lz2; lz2 = t;
+    }
     double am = (ang1 + ang2) / 2;
     double sm, cm;
     fast_sincos(am, &sm, &cm);
     double ty = cm * r2, tz = sm * r2;
-    V3 tp = {a1.x * ty + a2.x * tz + p2.x, a1.y * ty + a2.y * tz + p2.y, a1.z * ty + a2.z * tz + p2.z};
-    bool inside = (F1.c0.x * tp.x + F1.c0.y * tp.y + F1.c0.z * tp.z + tlx) > 0;  // [D] S:564
+    V3 tp = madd(a1, ty, madd(a2, tz, p2));
+    bool inside = (dot_d(f1, tp) + tlx) > 0;  // [D] S:564
     r.i0 = inside ? ang1 : ang2;
     r.i1 = inside ? ang2 : ang1;
+    double ly = inside ? ly1 : ly2, lz = inside ? lz1 : lz2;
+    double il = rsqrt_fast(ly * ly + lz * lz);
+    r.ct0 = ly * il; r.st0 = lz * il;
     return r;
 }
 
 // S:684-695
 __device__ __forceinline__ V3 elbow_on_circle(const Reach& r, double ct, double st) {
     double y = r.r2 * ct, z = r.r2 * st;
-    return {r.a1.x * y + r.a2.x * z + r.c2.x, r.a1.y * y + r.a2.y * z + r.c2.y, r.a1.z * y + r.a2.z * z + r.c2.z};
+    return madd(r.a1, y, madd(r.a2, z, r.c2));
 }
 
 // [D] S:708-713 / U:459-464: elbow above the singularity plane
@@ -342,19 +385,20 @@ struct JointsOut {
 //   G = Rz(-sr) Ry(-sp) has rows  q/|q|, (-q_y c, rho/|q|, -q_y s)/... , (-s, 0, c)   with (c, s) = (q_x, q_z)/rho
 // so no trigonometric function of a computed joint angle is ever evaluated; the same holds for the
 // elbow (H) and wrist (K) frames.  Exact-zero singularities fall back to previous_joints (S:751-753, 782-784).
-template <class Acc>
-__device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, double theta, const double* prev) {
+// FRESH = true: the state comes straight from reach() on the same pose (the fused kernels), so |wrist - elbow| is
+// the forearm length by construction; FRESH = false (stored solver state, possibly moved by an earlier projection,
+// Q1) measures it.
+template <bool FRESH, class Acc>
+__device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, double ct, double st, const double* prev) {
     JointsOut o;
-    double st, ct;
-    fast_sincos(theta, &st, &ct);
     V3 e = elbow_on_circle(r, ct, st);
     o.projected = false;
     if (above_singularity_plane(A, e)) {  // S:708-718 -> make_elbow_projection S:647-682
         V3 Pl = cvec(A, RSIK_C_PLANE_P), v3 = cvec(A, RSIK_C_PLANE_N), pc = cvec(A, RSIK_C_PROJ_CENTER);
         double dist = dot(e - Pl, v3);
-        V3 pe = e - v3 * dist;
+        V3 pe = madd(v3, -dist, e);
         V3 V = pe - pc;
-        V3 ne = pc + normalized(V) * A(RSIK_C_PROJ_RADIUS);
+        V3 ne = madd(normalized(V), A(RSIK_C_PROJ_RADIUS), pc);
         r.pos = r.pos + (ne - e);
         e = ne;
         r.w = wrist_position(A, Rg, r.pos);
@@ -364,9 +408,9 @@ __device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, do
     const double u = A(RSIK_C_UPPER_ARM), f = A(RSIK_C_FOREARM);
     // shoulder frame: x = M_shoulder_torso . p + P_shoulder_torso (S:728-741)
     auto to_shoulder = [&](V3 p) -> V3 {
-        return {A(RSIK_C_MST + 0) * p.x + A(RSIK_C_MST + 1) * p.y + A(RSIK_C_MST + 2) * p.z + A(RSIK_C_TSH + 0),
-                A(RSIK_C_MST + 3) * p.x + A(RSIK_C_MST + 4) * p.y + A(RSIK_C_MST + 5) * p.z + A(RSIK_C_TSH + 1),
-                A(RSIK_C_MST + 6) * p.x + A(RSIK_C_MST + 7) * p.y + A(RSIK_C_MST + 8) * p.z + A(RSIK_C_TSH + 2)};
+        return {fma(A(RSIK_C_MST + 0), p.x, fma(A(RSIK_C_MST + 1), p.y, fma(A(RSIK_C_MST + 2), p.z, A(RSIK_C_TSH + 0)))),
+                fma(A(RSIK_C_MST + 3), p.x, fma(A(RSIK_C_MST + 4), p.y, fma(A(RSIK_C_MST + 5), p.z, A(RSIK_C_TSH + 1)))),
+                fma(A(RSIK_C_MST + 6), p.x, fma(A(RSIK_C_MST + 7), p.y, fma(A(RSIK_C_MST + 8), p.z, A(RSIK_C_TSH + 2))))};
     };
     V3 q = to_shoulder(e);
     // shoulder pitch / roll (S:751-766)
@@ -383,7 +427,7 @@ __device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, do
         cphi = q.x * irho; sphi = q.z * irho;
     }
     double sr = fast_atan2(q.y, rho);
-    const double iL = rsqrt_fast(rho * rho + q.y * q.y);
+    const double iL = A(RSIK_C_INV_U);  // |e - shoulder| = upper arm length by construction
     double cr = rho * iL, srs = q.y * iL;
     // G = Rz(-sr) Ry(-sp): rows g0, g1, g2
     V3 g0 = {cr * cphi, srs, cr * sphi};
@@ -407,7 +451,7 @@ __device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, do
         ca = pw.z * isig; sa = pw.y * isig;
     }
     double ep = -fast_atan2(sigma, pw.x);
-    const double ilam = rsqrt_fast(sigma * sigma + pw.x * pw.x);
+    const double ilam = FRESH ? A(RSIK_C_INV_F) : rsqrt_fast(fma(sigma, sigma, pw.x * pw.x));
     double cchi = pw.x * ilam, schi = sigma * ilam;
     // H = Ry(-ep) Rx(ey)
     V3 h0 = {cchi, schi * sa, schi * ca};
@@ -419,7 +463,7 @@ __device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, do
     };
     // wrist roll / pitch (S:808-826)
     V3 tl = cvec(A, RSIK_C_TIPL);
-    V3 ptip = Rg.apply(V3{tl.x, tl.y, 0.0}) + r.pos;
+    V3 ptip = Rg.apply_add(V3{tl.x, tl.y, 0.0}, r.pos);
     V3 t = to_wrist(ptip);
     double tau, wr, cw, sw;
     wr = kPi - fast_atan2(t.y, -t.x);
@@ -433,16 +477,14 @@ __device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, do
         cw = t.x * itau; sw = t.y * itau;
     }
     double wp = fast_atan2(t.z, tau);
-    const double imu = rsqrt_fast(tau * tau + t.z * t.z);
+    const double imu = FRESH ? A(RSIK_C_INV_TIPZ) : rsqrt_fast(fma(tau, tau, t.z * t.z));  // |tip' - wrist| = |tip_z|
     double cp = tau * imu, spp = t.z * imu;
     // K = Ry(wp) Rz(-wr); only rows 1, 2 are needed for the yaw
     V3 k1 = {-sw, cw, 0.0};
     V3 k2 = {-spp * cw, -spp * sw, cp};
     // wrist yaw (S:839-848): direction of the goal frame's x axis seen from the tip frame
     V3 xg = Rg.col0();
-    V3 xs = {A(RSIK_C_MST + 0) * xg.x + A(RSIK_C_MST + 1) * xg.y + A(RSIK_C_MST + 2) * xg.z,
-             A(RSIK_C_MST + 3) * xg.x + A(RSIK_C_MST + 4) * xg.y + A(RSIK_C_MST + 5) * xg.z,
-             A(RSIK_C_MST + 6) * xg.x + A(RSIK_C_MST + 7) * xg.y + A(RSIK_C_MST + 8) * xg.z};
+    V3 xs = {dot(cvec(A, RSIK_C_MST + 0), xg), dot(cvec(A, RSIK_C_MST + 3), xg), dot(cvec(A, RSIK_C_MST + 6), xg)};
     V3 xe = {dot(g0, xs), dot(g1, xs), dot(g2, xs)};
     V3 xw = {dot(h0, xe), dot(h1, xe), dot(h2, xe)};
     double gy = dot(k1, xw), gz = dot(k2, xw);

@@ -86,14 +86,18 @@ __global__ __launch_bounds__(kBlock) void solve_kernel(const SolveArgs K) {
     double jv[7] = {nan, nan, nan, nan, nan, nan, nan};
     double ev[3] = {nan, nan, nan};
     if (K.theta_policy != RSIK_THETA_NONE && r.ok) {
-        double theta = r.i0;
-        if (K.theta_policy == RSIK_THETA_EXPLICIT) theta = K.theta_in[ii];
-        else if (K.theta_policy == RSIK_THETA_FRACTION) {
-            double a = r.i0, b = r.i1;
-            if (a > b) b += kTwoPi;
-            theta = a + K.theta_in[ii] * (b - a);
+        double ct = r.ct0, st = r.st0;  // theta = interval[0]: cos/sin come straight from the intersection point
+        if (K.theta_policy != RSIK_THETA_INTERVAL0) {
+            double theta;
+            if (K.theta_policy == RSIK_THETA_EXPLICIT) theta = K.theta_in[ii];
+            else {
+                double a = r.i0, b = r.i1;
+                if (a > b) b += kTwoPi;
+                theta = a + K.theta_in[ii] * (b - a);
+            }
+            fast_sincos(theta, &st, &ct);
         }
-        JointsOut o = joints_from_theta(A, r, Rg, theta, K.prev);
+        JointsOut o = joints_from_theta<true>(A, r, Rg, ct, st, K.prev);
 #pragma unroll
         for (int k = 0; k < 7; k++) jv[k] = o.j[k];
         ev[0] = o.elbow.x; ev[1] = o.elbow.y; ev[2] = o.elbow.z;
@@ -187,7 +191,7 @@ __device__ __forceinline__ void sweep_theta_grid(const DiscreteArgs& K, uint64_t
                 if (k < K.nb) {
                     double th = (k == K.nb - 1) ? gb : ((double)k * gstep + ga);  // np.linspace (Q11)
                     double st, ct;
-                    sincos(th, &st, &ct);
+                    fast_sincos(th, &st, &ct);
                     double y = r2 * ct, z = r2 * st;
                     V3 e = {a1.x * y + a2.x * z + c2.x, a1.y * y + a2.y * z + c2.y, a1.z * y + a2.z * z + c2.z};
                     if (is_elbow_ok(A, e)) {
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(kBlock) void control_discrete_kernel(const Discrete
     if (r.ok) {  // U:357-364 preferred-theta shortcut
         if (is_valid_angle(pref, r.i0, r.i1)) {
             double st, ct;
-            sincos(pref, &st, &ct);
+            fast_sincos(pref, &st, &ct);
             if (is_elbow_ok(A, elbow_on_circle(r, ct, st))) { found = true; theta = pref; }
         }
         need = !found;
@@ -283,16 +287,18 @@ __global__ __launch_bounds__(kBlock) void control_discrete_kernel(const Discrete
     double c4, s4, c5, s5, c6, s6;
     if (found) {  // C:454-456
         theta = limit_theta_to_interval(theta, K.lim[slot][0], K.lim[slot][1]);
-        JointsOut o = joints_from_theta(A, r, Rg, theta, prev);
+        double st, ct;
+        fast_sincos(theta, &st, &ct);
+        JointsOut o = joints_from_theta<true>(A, r, Rg, ct, st, prev);
 #pragma unroll
         for (int k = 0; k < 7; k++) jv[k] = o.j[k];
         c4 = o.c4; s4 = o.s4; c5 = o.c5; s5 = o.s5; c6 = o.c6; s6 = o.s6;
     } else {  // C:457-458
 #pragma unroll
         for (int k = 0; k < 7; k++) jv[k] = K.current_joints ? K.current_joints[ii * 7 + k] : prev[k];
-        sincos(jv[4], &s4, &c4);
-        sincos(jv[5], &s5, &c5);
-        sincos(jv[6], &s6, &c6);
+        fast_sincos(jv[4], &s4, &c4);
+        fast_sincos(jv[5], &s5, &c5);
+        fast_sincos(jv[6], &s6, &c6);
     }
     bool em = safety_checks(jv, c4, s4, c5, s5, c6, s6, prev, K.max_angle, K.cos_max, K.sin_max);
     store_rows<7>(K.joints, wave_base, K.n, lane, lds_out[wave], jv);
@@ -358,7 +364,7 @@ __device__ __forceinline__ Reach reach_from_state(const double* S) {
     r.c2 = {S[9], S[10], S[11]};
     r.r2 = S[12];
     r.n2 = {S[13], S[14], S[15]};
-    Frame F = frame_from_normal(r.n2);  // S:686: get_elbow_position rebuilds the frame from the stored normal
+    Frame F = frame_from_unit(normalized(r.n2));  // S:686: get_elbow_position rebuilds the frame from the stored normal
     r.a1 = F.c1; r.a2 = F.c2;
     return r;
 }
@@ -375,7 +381,9 @@ __global__ __launch_bounds__(kBlock) void joints_state_kernel(const StateArgs K)
     double prev[7];
 #pragma unroll
     for (int k = 0; k < 7; k++) prev[k] = K.prev ? K.prev[i * 7 + k] : 0.0;
-    JointsOut o = joints_from_theta(A, r, Rg, K.theta[i], prev);
+    double st, ct;
+    fast_sincos(K.theta[i], &st, &ct);
+    JointsOut o = joints_from_theta<false>(A, r, Rg, ct, st, prev);
 #pragma unroll
     for (int k = 0; k < 7; k++) K.joints[i * 7 + k] = o.j[k];
     S[0] = r.pos.x; S[1] = r.pos.y; S[2] = r.pos.z;
@@ -391,7 +399,7 @@ __global__ __launch_bounds__(kBlock) void elbow_state_kernel(const StateArgs K) 
     const double* S = K.solver_state + i * RSIK_SOLVER_STATE_STRIDE;
     Reach r = reach_from_state(S);
     double st, ct;
-    sincos(K.theta[i], &st, &ct);
+    fast_sincos(K.theta[i], &st, &ct);
     V3 e = elbow_on_circle(r, ct, st);
     K.elbow[3 * i] = e.x; K.elbow[3 * i + 1] = e.y; K.elbow[3 * i + 2] = e.z;
 }
