@@ -174,6 +174,33 @@ int rsik_control_discrete(rsik_ctx *ctx, int64_t n, const double *const m12_soa[
                           double *joints, uint8_t *reachable, uint8_t *state, uint8_t *emergency);
 
 /*
+ * rsik_control_continuous_step — ControlIK.symbolic_inverse_kinematics(name, M, "continuous", ...)
+ * (control_ik.py:162-274 -> symbolic_inverse_kinematics_continuous :276-407) for n independent trajectories,
+ * one control step per call.  The reference keeps previous_theta / previous_sol / init / emergency_stop on the
+ * ControlIK object (control_ik.py:60-83); here they live in a caller-owned device array
+ * cont_state[RSIK_CONT_STATE_ROWS][n] (SoA): row 0 previous_theta, rows 1-7 previous_sol, row 8 init (0/1),
+ * row 9 emergency_stop (0/1), row 10 has_previous_sol (0/1).
+ *
+ *   m12_soa               goal matrices of this step (layout as rsik_control_discrete)
+ *   current_pose_m12_soa  current_pose of trajectories that (re)initialise this step, or NULL (=> the goal matrix)
+ *   timed_out             [n] uint8 or NULL: 1 replaces the reference's wall-clock test
+ *                         abs(t - last_call_t) > call_timeout (control_ik.py:296-304)
+ *   preferred_theta       the preferred_theta argument (r convention; used by the init search and the unreachable branch)
+ *   preferred_theta_self_host  2 doubles: ControlIK.preferred_theta["r_arm"], ["l_arm"] (control_ik.py:133-139),
+ *                         used by the reachable branch (Q14)
+ *   current_joints        [n,7] device or NULL (=> previous_sol)
+ *   state codes           RSIK_STATE_EMPTY when reachable, RSIK_STATE_LIMITED_BY_SHOULDER, the is_reachable state when
+ *                         unreachable, RSIK_STATE_EMERGENCY while the emergency stop is latched.
+ */
+#define RSIK_CONT_STATE_ROWS 11
+int rsik_control_continuous_step(rsik_ctx *ctx, int64_t n, const double *const m12_soa[12],
+                                 const double *const current_pose_m12_soa[12], const uint8_t *arm, int arm_uniform,
+                                 const uint8_t *timed_out, double preferred_theta, const double *preferred_theta_self_host,
+                                 int constrained_mode, double d_theta_max, const double *current_joints,
+                                 double orbita3d_max_angle, double *cont_state, double *joints, uint8_t *reachable,
+                                 uint8_t *state);
+
+/*
  * Solver-state entry points: the scalar drop-in API.  A SymbolicIK object keeps self.goal_pose,
  * self.wrist_position and self.intersection_circle between is_reachable() and the closure it returns
  * (symbolic_ik.py:143-144,185,235), and get_joints() mutates them when the elbow projection fires

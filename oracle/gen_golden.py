@@ -483,6 +483,56 @@ def gen_continuous(out, n_traj=6, n_steps=400):
     np.savez_compressed(os.path.join(out, "g6_control_continuous.npz"), **data)
 
 
+def gen_continuous_start(out, n_traj=8, n_steps=150):
+    """G7: like G6 but every trajectory starts from an explicit, generic (current_joints, current_pose) pair, so the
+    start-up ternary search (utils.py:267-331) is not sitting on the exact tie it hits for the constructor's default
+    arms-along-the-body configuration."""
+    rng = np.random.default_rng(6)
+    data = {}
+    real_time = ref_control_mod.time
+    for arm in ARMS:
+        phases = rng.uniform(0.0, 40.0, size=n_traj)
+        cur_j = rng.uniform(-0.6, 0.6, size=(n_traj, 7))
+        Ms = np.zeros((n_traj, n_steps, 4, 4))
+        P0 = np.zeros((n_traj, 4, 4))
+        J = np.zeros((n_traj, n_steps, 7))
+        F = np.zeros((n_traj, n_steps), dtype=np.uint8)
+        S = np.zeros((n_traj, n_steps), dtype=np.uint8)
+        TH = np.zeros((n_traj, n_steps))
+        for k in range(n_traj):
+            clock = FakeClock()
+            ref_control_mod.time = clock
+            try:
+                ctrl = quiet(ControlIK, urdf_path="../config_files/reachy2.urdf", is_dvt=(k % 2 == 1))
+                p0, e0 = trajectory_pose(11.0 + phases[k] - 0.3, arm)
+                P0[k] = pose_to_matrix(p0 * np.array([0.8, 1.0, 1.0]) + rng.uniform(-0.02, 0.02, 3), e0 + rng.uniform(-0.1, 0.1, 3))
+                for i in range(n_steps):
+                    t = i / 120.0 + 11.0 + phases[k]
+                    pos, eul = trajectory_pose(t, arm)
+                    M = pose_to_matrix(pos, eul)
+                    Ms[k, i] = M
+                    clock.t += 1.0 / 120.0
+                    kw = {}
+                    if i == 0:
+                        kw = dict(current_joints=list(cur_j[k]), current_pose=P0[k])
+                    j, ok, st = quiet(ctrl.symbolic_inverse_kinematics, arm, M, "continuous", d_theta_max=0.01, **kw)
+                    J[k, i] = np.array(j, dtype=float)
+                    F[k, i] = bool(ok)
+                    S[k, i] = STATE_CODES.get(st, 8)
+                    TH[k, i] = ctrl.previous_theta[arm]
+            finally:
+                ref_control_mod.time = real_time
+        data[f"{arm}_M"] = Ms
+        data[f"{arm}_start_pose"] = P0
+        data[f"{arm}_start_joints"] = cur_j
+        data[f"{arm}_is_dvt"] = (np.arange(n_traj) % 2 == 1).astype(np.uint8)
+        data[f"{arm}_joints"] = J
+        data[f"{arm}_reachable"] = F
+        data[f"{arm}_state"] = S
+        data[f"{arm}_previous_theta"] = TH
+    np.savez_compressed(os.path.join(out, "g7_control_continuous_start.npz"), **data)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
@@ -491,7 +541,8 @@ def main():
     out = os.path.abspath(args.out)
     os.makedirs(out, exist_ok=True)
     steps = [("g0", gen_constants), ("g1", gen_catalogue), ("g2", gen_sweep), ("g3", gen_reachable),
-             ("g4", gen_control), ("g5", gen_helpers), ("g6", gen_continuous)]
+             ("g4", gen_control), ("g5", gen_helpers), ("g6", gen_continuous),
+             ("g7", gen_continuous_start)]
     for name, fn in steps:
         if args.only and name not in args.only.split(","):
             continue

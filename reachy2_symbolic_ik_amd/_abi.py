@@ -39,6 +39,8 @@ PROTOTYPES = {
     "rsik_solve": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp), _vp, C.c_int, C.c_int, _vp, _dp, _vp, _vp, _vp, _vp, _vp]),
     "rsik_control_discrete": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp), _vp, C.c_int, C.c_int, C.c_double, C.c_int, _dp,
                                         _vp, C.c_double, _vp, _vp, _vp, _vp]),
+    "rsik_control_continuous_step": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp), C.POINTER(_vp), _vp, C.c_int, _vp, C.c_double, _dp,
+                                               C.c_int, C.c_double, _vp, C.c_double, _vp, _vp, _vp, _vp]),
     "rsik_reach_state": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp), _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "rsik_joints_from_state": (C.c_int, [_vp, C.c_int64, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     "rsik_elbow_from_state": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp]),
@@ -46,6 +48,7 @@ PROTOTYPES = {
 }
 
 SOLVER_STATE_STRIDE = 24
+CONT_STATE_ROWS = 11
 
 
 class RsikError(RuntimeError):

@@ -235,6 +235,67 @@ class HipSolver:
                 self._check(self.lib.rsik_control_discrete(self._h, *cargs))
         return res
 
+    # ------------------------------------------------------------------ rsik_control_continuous_step
+    def new_continuous_state(self, n: int) -> torch.Tensor:
+        return torch.zeros((_abi.CONT_STATE_ROWS, n), dtype=_F64, device=self.device)
+
+    def control_continuous_step(
+        self,
+        m12_soa: torch.Tensor,
+        cont_state: torch.Tensor,
+        preferred_theta_self: Sequence[float],
+        arm: Optional[torch.Tensor] = None,
+        arm_uniform: int = 0,
+        timed_out: Optional[torch.Tensor] = None,
+        preferred_theta: float = -4 * np.pi / 6,
+        constrained_mode: int = _abi.MODE_UNCONSTRAINED,
+        d_theta_max: float = 0.01,
+        current_joints: Optional[torch.Tensor] = None,
+        current_pose_m12: Optional[torch.Tensor] = None,
+        orbita3d_max_angle: float = float(np.deg2rad(42.5)),
+        out: Optional[Dict[str, torch.Tensor]] = None,
+    ) -> Dict[str, torch.Tensor]:
+        """One control step for n trajectories; `cont_state` ([11, n], see include/rsik.h) is updated in place."""
+        if m12_soa.dim() != 2 or m12_soa.shape[0] != 12:
+            raise ValueError("m12_soa must have shape [12, n]")
+        n = int(m12_soa.shape[1])
+        m12_soa = self._dev_f64(m12_soa, (12, n), "m12_soa")
+        if (not isinstance(cont_state, torch.Tensor) or cont_state.dtype != _F64 or cont_state.device != self.device
+                or tuple(cont_state.shape) != (_abi.CONT_STATE_ROWS, n) or not cont_state.is_contiguous()):
+            raise ValueError(f"cont_state must be a contiguous float64 [{_abi.CONT_STATE_ROWS}, {n}] tensor on {self.device}")
+        if arm is not None:
+            arm = self._dev_u8(arm, n, "arm")
+        if timed_out is not None:
+            timed_out = self._dev_u8(timed_out, n, "timed_out")
+        if current_joints is not None:
+            current_joints = self._dev_f64(current_joints, (n, 7), "current_joints")
+        cp = None
+        if current_pose_m12 is not None:
+            current_pose_m12 = self._dev_f64(current_pose_m12, (12, n), "current_pose_m12")
+            cp = (C.c_void_p * 12)(*[current_pose_m12[k].data_ptr() for k in range(12)])
+        pts = np.ascontiguousarray(preferred_theta_self, dtype=np.float64)
+        if pts.shape != (2,):
+            raise ValueError("preferred_theta_self must have 2 entries (r, l)")
+        if out is None:
+            out = {}
+        joints = out.get("joints", None)
+        if joints is None:
+            joints = torch.empty((n, 7), dtype=_F64, device=self.device)
+        reachable = out.get("reachable", None)
+        if reachable is None:
+            reachable = torch.empty((n,), dtype=_U8, device=self.device)
+        state = out.get("state", None)
+        if state is None:
+            state = torch.empty((n,), dtype=_U8, device=self.device)
+        cols = (C.c_void_p * 12)(*[m12_soa[k].data_ptr() for k in range(12)])
+        with torch.cuda.device(self.device):
+            self._bind_stream()
+            self._check(self.lib.rsik_control_continuous_step(
+                self._h, n, cols, cp, _ptr(arm), int(arm_uniform), _ptr(timed_out), float(preferred_theta),
+                pts.ctypes.data_as(C.POINTER(C.c_double)), int(constrained_mode), float(d_theta_max), _ptr(current_joints),
+                float(orbita3d_max_angle), _ptr(cont_state), _ptr(joints), _ptr(reachable), _ptr(state)))
+        return {"joints": joints, "reachable": reachable, "state": state}
+
     # ------------------------------------------------------------------ solver-state entry points
     def new_solver_state(self, n: int) -> torch.Tensor:
         return torch.zeros((n, _abi.SOLVER_STATE_STRIDE), dtype=_F64, device=self.device)

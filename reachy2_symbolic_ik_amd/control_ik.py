@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import copy
 import os
+import time
 from typing import Any, Dict, Optional, Tuple
 
 import numpy as np
@@ -217,8 +218,12 @@ class ControlIK:
             raise UnboundLocalError("local variable 'interval_limit' referenced before assignment")
         if current_joints == []:
             current_joints = self.previous_sol[name].tolist()
+        if len(current_pose) == 0:
+            current_pose = self.previous_pose[name]
         if control_type == "continuous" or control_type == "unfreeze":
-            raise NotImplementedError("continuous mode: use symbolic_inverse_kinematics_continuous_batch (state-carrying kernel)")
+            ik_joints, is_reachable, state = self._continuous_scalar(
+                name, np.asarray(M, dtype=np.float64), current_joints, np.asarray(current_pose, dtype=np.float64),
+                constrained_mode, d_theta_max, preferred_theta)
         elif control_type == "discrete":
             M = np.asarray(M, dtype=np.float64)
             res = self.symbolic_inverse_kinematics_batch(
@@ -235,7 +240,98 @@ class ControlIK:
         self.previous_pose[name] = M
         return ik_joints, is_reachable, state
 
+    def _continuous_scalar(self, name: str, M: np.ndarray, current_joints: list, current_pose: np.ndarray,
+                           constrained_mode: str, d_theta_max: float, preferred_theta: float):
+        """control_ik.py:276-407 for one call: the object's previous_theta / previous_sol / init / emergency_stop are
+        mirrored into a one-trajectory device state, the step kernel runs, and the attributes are read back."""
+        t = time.time()
+        timed_out = abs(t - self.last_call_t[name]) > self.call_timeout
+        self.last_call_t[name] = t
+        st = self._solver.new_continuous_state(1)
+        host = np.zeros(_abi.CONT_STATE_ROWS)
+        host[0] = self.previous_theta[name]
+        has_prev = len(self.previous_sol[name]) == 7
+        if has_prev:
+            host[1:8] = self.previous_sol[name]
+        host[8] = 1.0 if self.init else 0.0
+        host[9] = 0.0
+        host[10] = 1.0 if has_prev else 0.0
+        st.copy_(torch.as_tensor(host.reshape(-1, 1)))
+        cj = np.asarray(current_joints, dtype=np.float64)
+        cj_t = torch.as_tensor(cj.reshape(1, 7)) if cj.size == 7 else None
+        res = self.symbolic_inverse_kinematics_continuous_batch(
+            name, M.reshape(1, 4, 4), st, timed_out=np.array([1 if timed_out else 0], dtype=np.uint8),
+            current_joints=cj_t, current_pose=current_pose.reshape(1, 4, 4), constrained_mode=constrained_mode,
+            d_theta_max=d_theta_max, preferred_theta=preferred_theta)
+        back = st[:, 0].cpu().numpy()
+        ik_joints = res["joints"][0].cpu().numpy()
+        self.previous_theta[name] = float(back[0])
+        self.init = bool(back[8])
+        if back[9] != 0.0:
+            self.emergency_stop = True
+            self.emergency_state += f"\n EMERGENCY STOP: joints are not continuous or multiturn limit reached ({name})"
+        if not self.emergency_stop:
+            self.previous_sol[name] = copy.deepcopy(ik_joints)
+        else:
+            self.previous_sol[name] = back[1:8].copy()
+        return ik_joints, bool(res["reachable"].item()), STATE_STRINGS[int(res["state"].item())]
+
     # ------------------------------------------------------------------ MI355X-native batch API
+    def new_continuous_state(self, name: Any, n: int) -> torch.Tensor:
+        """Per-trajectory state [11, n] initialised like a freshly constructed ControlIK (control_ik.py:133-160):
+        previous_theta / previous_sol of the arm(s), init = True, no emergency stop."""
+        st = self._solver.new_continuous_state(n)
+        if isinstance(name, str):
+            arm_ids = np.full(n, ARM_IDS[name], dtype=np.int64)
+        else:
+            arm_ids = (name.cpu().numpy() if isinstance(name, torch.Tensor) else np.asarray(name)).astype(np.int64)
+        names = ["r_arm", "l_arm"]
+        host = np.zeros((_abi.CONT_STATE_ROWS, n))
+        for k in (0, 1):
+            m = arm_ids == k
+            if m.any():
+                host[0, m] = self.previous_theta[names[k]]
+                host[1:8, m] = np.asarray(self.previous_sol[names[k]], dtype=np.float64).reshape(7, 1)
+        host[8] = 1.0
+        host[10] = 1.0
+        st.copy_(torch.as_tensor(host))
+        return st
+
+    def symbolic_inverse_kinematics_continuous_batch(
+        self,
+        name: Any,
+        M: Any,
+        cont_state: torch.Tensor,
+        timed_out: Any = None,
+        current_joints: Any = None,
+        current_pose: Any = None,
+        constrained_mode: str = "unconstrained",
+        d_theta_max: float = 0.01,
+        preferred_theta: float = -4 * np.pi / 6,
+        out: Optional[Dict[str, torch.Tensor]] = None,
+    ) -> Dict[str, torch.Tensor]:
+        """Continuous-mode IK, one control step for n independent trajectories (state carried in `cont_state`,
+        updated in place).  `timed_out` [n] uint8 replaces the reference's 0.2 s wall-clock test; pass 1 on the first
+        step of a trajectory to reproduce the reference's start-up (re-initialisation from current_joints /
+        current_pose, control_ik.py:296-325)."""
+        if constrained_mode not in _abi.MODES:
+            raise UnboundLocalError("local variable 'interval_limit' referenced before assignment")
+        dev = self._solver.device
+        m12 = matrices_to_m12_soa(M, dev)
+        cp = None if current_pose is None else matrices_to_m12_soa(current_pose, dev)
+        arm_t, arm_uniform = None, 0
+        if isinstance(name, str):
+            arm_uniform = ARM_IDS[name]
+        else:
+            arm_t = name
+        pts = [self.preferred_theta.get("r_arm", -4 * np.pi / 6), self.preferred_theta.get("l_arm", -np.pi + 4 * np.pi / 6)]
+        self._upload_arms()
+        return self._solver.control_continuous_step(
+            m12, cont_state, pts, arm=arm_t, arm_uniform=arm_uniform, timed_out=timed_out,
+            preferred_theta=float(preferred_theta), constrained_mode=_abi.MODES[constrained_mode],
+            d_theta_max=float(d_theta_max), current_joints=current_joints, current_pose_m12=cp,
+            orbita3d_max_angle=float(self.orbita3D_max_angle), out=out)
+
     def symbolic_inverse_kinematics_batch(
         self,
         name: Any,

@@ -561,4 +561,63 @@ __device__ __forceinline__ bool safety_checks(double (&j)[7], double ca, double 
     return emergency;
 }
 
+// utils.get_best_discrete_theta (U:334-396), one pose per lane (serial grid walk): used by the continuous mode with
+// its fixed 10-point grid (C:350-361); the discrete mode uses the wave-cooperative sweep in rsik_lib.hip.
+template <class Acc>
+__device__ bool best_discrete_theta_serial(const Acc& A, const Reach& r, int nb, double pref, double& theta_out) {
+    if (is_valid_angle(pref, r.i0, r.i1)) {
+        double st, ct;
+        fast_sincos(pref, &st, &ct);
+        if (is_elbow_ok(A, elbow_on_circle(r, ct, st))) { theta_out = pref; return true; }
+    }
+    double a, b;
+    if (fabs(fabs(r.i0) + fabs(r.i1) - kTwoPi) < 0.00001) { a = kPi / 2; b = kPi / 2 + kTwoPi; }
+    else if (r.i0 < r.i1) { a = r.i0; b = r.i1; }
+    else { a = r.i0; b = r.i1 + kTwoPi; }
+    const double step = (b - a) / (double)(nb - 1);
+    bool found = false;
+    double best = 0.0, best_d = __builtin_inf();
+    for (int k = 0; k < nb; k++) {
+        double th = (k == nb - 1) ? b : ((double)k * step + a);
+        double st, ct;
+        fast_sincos(th, &st, &ct);
+        if (is_elbow_ok(A, elbow_on_circle(r, ct, st))) {
+            double dist = fabs(angle_diff(th, pref));
+            if (dist < best_d) { best_d = dist; best = th; found = true; }
+        }
+    }
+    theta_out = best;
+    return found;
+}
+
+// utils.get_best_theta_to_current_joints (U:267-331) with a flat 7-joint target (C:322-324): ternary search over the
+// circle; every evaluation is a state-mutating get_joints call exactly like the reference (Q1).
+template <class Acc>
+__device__ double best_theta_to_current_joints(const Acc& A, Reach& r, const Rot& Rg, const double* cur, double pref) {
+    const double zeros[7] = {0, 0, 0, 0, 0, 0, 0};
+    auto dist_at = [&](double th) -> double {
+        double st, ct;
+        fast_sincos(th, &st, &ct);
+        JointsOut o = joints_from_theta<false>(A, r, Rg, ct, st, zeros);
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) { double d = angle_diff(o.j[k], cur[k]); acc += d * d; }
+        return sqrt(acc);
+    };
+    double low = -kPi, high = kPi;
+    if (A(RSIK_C_SIDE) < 0) { low = 0; high = kTwoPi; }
+    const double tolerance = 0.01;
+    if (dist_at(pref) < tolerance) return pref;
+    while ((high - low) > tolerance) {
+        double mid1 = low + (high - low) / 3;
+        double mid2 = high - (high - low) / 3;
+        double f1 = dist_at(mid1);
+        double f2 = dist_at(mid2);
+        if (f1 < f2) high = mid2; else low = mid1;
+    }
+    double best = (low + high) / 2;
+    (void)dist_at(best);  // U:324
+    return best;
+}
+
 }  // namespace rsik

@@ -310,6 +310,149 @@ __global__ __launch_bounds__(kBlock) void control_discrete_kernel(const Discrete
 }
 
 // ------------------------------------------------------------------------------------------
+// ControlIK continuous mode (C:276-407), one launch = one control step of n independent trajectories.
+// Per-trajectory state lives in a caller-owned SoA array state[RSIK_CONT_STATE_ROWS][n]:
+//   row 0 previous_theta, rows 1-7 previous_sol, row 8 init, row 9 emergency_stop, row 10 has_previous_sol.
+// The reference's wall-clock timeout (C:296-304) becomes the per-trajectory `timed_out` byte.
+// ------------------------------------------------------------------------------------------
+struct ContinuousArgs {
+    int64_t n;
+    const double* in[12];
+    const double* cur_pose[12];   // current_pose of a (re)initialising trajectory, NULL columns => goal matrix itself
+    const uint8_t* arm;
+    const uint8_t* timed_out;     // NULL => nobody timed out
+    double pref_arg[2];           // preferred_theta argument per arm slot (mirrored for l)
+    double pref_self[2];          // ControlIK.preferred_theta[name] per arm slot
+    double lim[2][2];
+    double d_theta_max;
+    const double* current_joints; // [n,7] or NULL => previous_sol
+    double max_angle, cos_max, sin_max;
+    double* st;                   // state SoA
+    double* joints;
+    uint8_t* reachable;
+    uint8_t* state;
+    ArmC arms[2];
+};
+
+__device__ __forceinline__ void load_m12(const double* const* in, int64_t i, Rot& Rg, V3& pos) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rg.m[k] = in[k][i];
+    bool eye = true;
+#pragma unroll
+    for (int k = 0; k < 9; k++) eye = eye && np_isclose(Rg.m[k], (k % 4 == 0) ? 1.0 : 0.0);
+    if (eye) {  // C:212-214 np.allclose(R, I)
+#pragma unroll
+        for (int k = 0; k < 9; k++) Rg.m[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    }
+    pos = {in[9][i], in[10][i], in[11][i]};
+}
+
+template <bool MIXED>
+__global__ __launch_bounds__(kBlock) void control_continuous_kernel(const ContinuousArgs K) {
+    __shared__ double lds_out[kBlock / 64][64 * 7];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t wave_base = (int64_t)blockIdx.x * kBlock + wave * 64;
+    const bool live = i < K.n;
+    const int64_t ii = live ? i : (K.n - 1);
+    const int64_t n = K.n;
+
+    Acc<MIXED> A{K.arms, false};
+    if constexpr (MIXED) A.isl = K.arm[ii] != 0;
+    const int slot = MIXED ? (A.isl ? 1 : 0) : 0;
+
+    double prev_theta = K.st[0 * n + ii];
+    double prev_sol[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) prev_sol[k] = K.st[(1 + k) * n + ii];
+    bool init = K.st[8 * n + ii] != 0.0;
+    bool emergency = K.st[9 * n + ii] != 0.0;
+    bool has_prev = K.st[10 * n + ii] != 0.0;
+
+    double jv[7];
+    int st_code = RSIK_STATE_EMPTY;
+    bool ok = false;
+    if (emergency) {  // C:205-210
+#pragma unroll
+        for (int k = 0; k < 7; k++) jv[k] = prev_sol[k];
+        st_code = RSIK_STATE_EMERGENCY;
+    } else {
+        Rot Rg;
+        V3 pos;
+        load_m12(K.in, ii, Rg, pos);
+        const double pref = K.pref_arg[slot];
+        if (K.timed_out && K.timed_out[ii]) { has_prev = false; init = true; }  // C:298-304
+        if (!has_prev) {  // C:306-325
+            if (K.current_joints) {
+#pragma unroll
+                for (int k = 0; k < 7; k++) prev_sol[k] = K.current_joints[ii * 7 + k];
+            }
+            has_prev = true;
+            Rot Rc;
+            V3 cpos;
+            load_m12(K.cur_pose[0] ? K.cur_pose : K.in, ii, Rc, cpos);
+            Reach rc = reach<true>(A, cpos, Rc);
+            prev_theta = best_theta_to_current_joints(A, rc, Rc, prev_sol, pref);
+        }
+        Reach r = reach<false>(A, pos, Rg);
+        double theta;
+        ok = r.ok;
+        if (r.ok) {  // C:338-366
+            ok = best_discrete_theta_serial(A, r, 10, K.pref_self[slot], theta);  // U:220-264 get_best_continuous_theta2
+            if (!ok) {
+                theta = prev_theta;
+                st_code = RSIK_STATE_LIMITED_BY_SHOULDER;
+            } else if (!(fabs(angle_diff(theta, prev_theta)) < K.d_theta_max)) {
+                double ad = angle_diff(theta, prev_theta);
+                theta = prev_theta + (ad / fabs(ad)) * K.d_theta_max;
+            }
+        } else {  // C:368-388
+            const int st_reach = r.state;
+            r = reach<true>(A, pos, Rg);
+            double ad = angle_diff(pref, prev_theta);  // U:115-127 tend_to_preferred_theta
+            theta = (fabs(ad) < K.d_theta_max) ? pref : (prev_theta + (ad / fabs(ad)) * K.d_theta_max);
+            st_code = st_reach;
+        }
+        theta = limit_theta_to_interval(theta, K.lim[slot][0], K.lim[slot][1]);
+        prev_theta = theta;
+        double sn, cs;
+        fast_sincos(theta, &sn, &cs);
+        JointsOut o = joints_from_theta<true>(A, r, Rg, cs, sn, prev_sol);
+#pragma unroll
+        for (int k = 0; k < 7; k++) jv[k] = o.j[k];
+        bool em = safety_checks(jv, o.c4, o.s4, o.c5, o.s5, o.c6, o.s6, prev_sol, K.max_angle, K.cos_max, K.sin_max);
+        emergency = emergency || em;
+        if (!init) {  // U:571-589 continuity_check, thresholds C:398
+            bool disc = false;
+#pragma unroll
+            for (int k = 0; k < 7; k++) disc = disc || (fabs(angle_diff(jv[k], prev_sol[k])) > (k < 4 ? 0.5 : 1.0));
+            if (disc) {
+                emergency = true;
+#pragma unroll
+                for (int k = 0; k < 7; k++) jv[k] = prev_sol[k];
+            }
+        }
+        init = false;
+        if (!emergency) {
+#pragma unroll
+            for (int k = 0; k < 7; k++) prev_sol[k] = jv[k];
+        }
+    }
+    store_rows<7>(K.joints, wave_base, K.n, lane, lds_out[wave], jv);
+    if (live) {
+        K.st[0 * n + i] = prev_theta;
+#pragma unroll
+        for (int k = 0; k < 7; k++) K.st[(1 + k) * n + i] = prev_sol[k];
+        K.st[8 * n + i] = init ? 1.0 : 0.0;
+        K.st[9 * n + i] = emergency ? 1.0 : 0.0;
+        K.st[10 * n + i] = has_prev ? 1.0 : 0.0;
+        if (K.reachable) K.reachable[i] = ok ? 1 : 0;
+        if (K.state) K.state[i] = (uint8_t)st_code;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Solver-state kernels: the scalar drop-in API (SymbolicIK objects keep `self.goal_pose`,
 // `self.wrist_position`, `self.intersection_circle` between is_reachable() and the returned closure, Q1).
 // State row layout (RSIK_SOLVER_STATE_STRIDE doubles):
@@ -661,6 +804,57 @@ int rsik_control_discrete(rsik_ctx* ctx, int64_t n, const double* const m12_soa[
     if (rc != RSIK_OK) return rc;
     if (arm) hipLaunchKernelGGL(rsik::control_discrete_kernel<true>, grid, block, 0, ctx->stream, K);
     else hipLaunchKernelGGL(rsik::control_discrete_kernel<false>, grid, block, 0, ctx->stream, K);
+    RSIK_HIP(ctx, hipGetLastError());
+    return RSIK_OK;
+}
+
+int rsik_control_continuous_step(rsik_ctx* ctx, int64_t n, const double* const m12_soa[12],
+                                 const double* const current_pose_m12_soa[12], const uint8_t* arm, int arm_uniform,
+                                 const uint8_t* timed_out, double preferred_theta, const double* preferred_theta_self_host,
+                                 int constrained_mode, double d_theta_max, const double* current_joints,
+                                 double orbita3d_max_angle, double* cont_state, double* joints, uint8_t* reachable,
+                                 uint8_t* state) {
+    if (!ctx) return RSIK_E_INVALID;
+    if (n < 0) return fail(ctx, RSIK_E_INVALID, "rsik_control_continuous_step: n < 0");
+    if (constrained_mode != RSIK_MODE_UNCONSTRAINED && constrained_mode != RSIK_MODE_LOW_ELBOW)
+        return fail(ctx, RSIK_E_INVALID, "rsik_control_continuous_step: unknown constrained_mode");
+    if (!preferred_theta_self_host)
+        return fail(ctx, RSIK_E_INVALID, "rsik_control_continuous_step: preferred_theta_self_host is NULL");
+    int rc = check_arms(ctx, arm, arm_uniform, "rsik_control_continuous_step");
+    if (rc != RSIK_OK) return rc;
+    if (n == 0) return RSIK_OK;
+    if (!m12_soa || !cont_state || !joints)
+        return fail(ctx, RSIK_E_INVALID, "rsik_control_continuous_step: m12_soa / cont_state / joints is NULL");
+    rsik::ContinuousArgs K;
+    std::memset(&K, 0, sizeof K);
+    K.n = n;
+    for (int k = 0; k < 12; k++) {
+        if (!m12_soa[k]) return fail(ctx, RSIK_E_INVALID, "rsik_control_continuous_step: an m12_soa column is NULL");
+        K.in[k] = m12_soa[k];
+        K.cur_pose[k] = current_pose_m12_soa ? current_pose_m12_soa[k] : nullptr;
+        if (current_pose_m12_soa && !current_pose_m12_soa[k])
+            return fail(ctx, RSIK_E_INVALID, "rsik_control_continuous_step: a current_pose column is NULL");
+    }
+    K.arm = arm;
+    K.timed_out = timed_out;
+    for (int slot = 0; slot < 2; slot++) {
+        const int a = arm ? slot : arm_uniform;
+        control_limits(a, constrained_mode, preferred_theta, K.lim[slot], &K.pref_arg[slot]);
+        K.pref_self[slot] = preferred_theta_self_host[a];
+        K.arms[slot] = ctx->arms[a];
+    }
+    K.d_theta_max = d_theta_max;
+    K.current_joints = current_joints;
+    K.max_angle = orbita3d_max_angle;
+    K.cos_max = std::cos(orbita3d_max_angle);
+    K.sin_max = std::sin(orbita3d_max_angle);
+    K.st = cont_state; K.joints = joints; K.reachable = reachable; K.state = state;
+    RSIK_HIP(ctx, hipSetDevice(ctx->device));
+    dim3 grid, block(rsik::kBlock);
+    rc = launch_dims(ctx, n, &grid, "rsik_control_continuous_step");
+    if (rc != RSIK_OK) return rc;
+    if (arm) hipLaunchKernelGGL(rsik::control_continuous_kernel<true>, grid, block, 0, ctx->stream, K);
+    else hipLaunchKernelGGL(rsik::control_continuous_kernel<false>, grid, block, 0, ctx->stream, K);
     RSIK_HIP(ctx, hipGetLastError());
     return RSIK_OK;
 }

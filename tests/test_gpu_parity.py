@@ -398,3 +398,144 @@ def test_device_math_accuracy(torch_mod):
     m, ad = hs.debug_math(5, t(aa), t(bb))
     np.testing.assert_array_equal(m.cpu().numpy(), aa % (2 * np.pi))   # Python float modulo, bit for bit
     np.testing.assert_array_equal(ad.cpu().numpy(), ((aa - bb + np.pi) % (2 * np.pi)) - np.pi)
+
+
+# ------------------------------------------------------------------------------------------ rsik_control_continuous_step
+def _run_continuous(c, arm, Ms, start_joints=None, start_pose=None):
+    ntraj, nsteps = Ms.shape[:2]
+    st = c.new_continuous_state(arm, ntraj)
+    prev = np.tile(np.asarray(c.previous_pose[arm], dtype=np.float64), (ntraj, 1, 1)) if start_pose is None else start_pose
+    out = []
+    for i in range(nsteps):
+        res = to_np(c.symbolic_inverse_kinematics_continuous_batch(
+            arm, Ms[:, i], st, timed_out=np.full(ntraj, 1 if i == 0 else 0, dtype=np.uint8), current_pose=prev,
+            current_joints=(start_joints if i == 0 else None)))
+        prev = Ms[:, i]
+        res["theta"] = st[0].cpu().numpy().copy()
+        out.append(res)
+    return out, st
+
+
+def test_control_continuous_golden_default_start(golden_dir, torch_mod):
+    """G6: 6 trajectories x 400 steps per arm recorded from the reference with a fake clock, started from the
+    constructor's default arms-along-the-body configuration; all trajectories of an arm advance together, one kernel
+    launch per control step, state carried in HBM between launches.
+
+    For that default configuration the reference's start-up ternary search (utils.py:302-319) compares two distances
+    that are equal up to rounding (the optimum -pi/2 is centred between mid1 and mid2 at one iteration), so which
+    half it keeps is decided by the last bit of NumPy's arithmetic; any theta within the search tolerance (0.01) is
+    an equally valid outcome.  Flags and states must match exactly; theta and joints must agree exactly from the
+    step at which the rate-limited theta has re-converged (it moves d_theta_max per step), and stay within the
+    tolerance before."""
+    g = load(golden_dir, "g6_control_continuous.npz")
+    c = make_control()
+    frac = {}
+    for arm in ("r_arm", "l_arm"):
+        Ms, J, F, S, TH = g[f"{arm}_M"], g[f"{arm}_joints"], g[f"{arm}_reachable"], g[f"{arm}_state"], g[f"{arm}_previous_theta"]
+        out, st = _run_continuous(c, arm, Ms)
+        n_conv = 0
+        for i, res in enumerate(out):
+            np.testing.assert_array_equal(res["reachable"], F[:, i], err_msg=f"{arm} step {i}")
+            np.testing.assert_array_equal(res["state"], S[:, i], err_msg=f"{arm} step {i}")
+            dth = res["theta"] - TH[:, i]
+            dth = np.abs(dth - 2 * np.pi * np.round(dth / (2 * np.pi)))  # theta is re-wrapped to (-pi, pi] every step
+            assert np.max(dth) < 0.01 + 1e-12, (arm, i)
+            conv = dth < 1e-9
+            assert np.max(np.abs(res["joints"][conv] - J[:, i][conv]), initial=0.0) < 1e-7, (arm, i)
+            assert np.max(np.abs(res["joints"] - J[:, i])) < 0.05
+            n_conv += int(conv.sum())
+        frac[arm] = n_conv / (len(out) * Ms.shape[0])
+        assert st[9].sum().item() == 0  # no emergency stop on these trajectories
+    # a trajectory re-converges when its theta reaches a target both runs share (interval end, preferred theta ...)
+    assert max(frac.values()) > 0.5 and min(frac.values()) > 0.05, frac
+
+
+def test_control_continuous_golden_explicit_start(golden_dir, torch_mod):
+    """G7: explicit generic (current_joints, current_pose) start, DVT offset on odd trajectories: exact parity from
+    the first step on (flags, states, joints, carried theta)."""
+    g = load(golden_dir, "g7_control_continuous_start.npz")
+    for is_dvt in (False, True):
+        c = make_control(is_dvt)
+        for arm in ("r_arm", "l_arm"):
+            sel = g[f"{arm}_is_dvt"].astype(bool) == is_dvt
+            Ms, J, F, S, TH = (g[f"{arm}_{k}"][sel] for k in ("M", "joints", "reachable", "state", "previous_theta"))
+            out, st = _run_continuous(c, arm, Ms, start_joints=g[f"{arm}_start_joints"][sel], start_pose=g[f"{arm}_start_pose"][sel])
+            for i, res in enumerate(out):
+                np.testing.assert_array_equal(res["reachable"], F[:, i], err_msg=f"{arm} step {i}")
+                np.testing.assert_array_equal(res["state"], S[:, i], err_msg=f"{arm} step {i}")
+                assert np.max(np.abs(res["theta"] - TH[:, i])) < 1e-9, (arm, i)
+                assert np.max(np.abs(res["joints"] - J[:, i])) < 1e-7, (arm, i)
+
+
+def test_control_continuous_scalar_api(golden_dir, torch_mod, monkeypatch):
+    """The reference call shape `symbolic_inverse_kinematics(name, M, "continuous")`, with the clock patched like the
+    golden generator patched the reference's."""
+    import reachy2_symbolic_ik_amd.control_ik as cik
+
+    g = load(golden_dir, "g6_control_continuous.npz")
+
+    class Clock:
+        t = 1000.0
+
+        @staticmethod
+        def time():
+            return Clock.t
+
+    monkeypatch.setattr(cik, "time", Clock)
+    for arm in ("r_arm", "l_arm"):
+        c = make_control()
+        Ms, J, F, S = g[f"{arm}_M"][0], g[f"{arm}_joints"][0], g[f"{arm}_reachable"][0], g[f"{arm}_state"][0]
+        from reachy2_symbolic_ik_amd import STATE_STRINGS
+        for i in range(60):
+            Clock.t += 1.0 / 120.0
+            j, ok, st = c.symbolic_inverse_kinematics(arm, Ms[i], "continuous", d_theta_max=0.01)
+            assert ok == bool(F[i]) and st == STATE_STRINGS[S[i]], (arm, i)
+            dth = abs(c.previous_theta[arm] - g[f"{arm}_previous_theta"][0, i])
+            assert dth < 0.01 + 1e-12  # default start: see test_control_continuous_golden_default_start
+            assert np.max(np.abs(np.asarray(j) - J[i])) < (1e-7 if dth < 1e-9 else 0.05), (arm, i)
+        assert not c.emergency_stop and not c.init
+
+
+def test_control_continuous_against_checker_dvt_and_emergency(torch_mod, orc):
+    """Random jumpy goal sequences (DVT singularity offset, so the elbow projection and the emergency stop both fire),
+    step by step against the CPU checker's state machine."""
+    c = make_control(is_dvt=True)
+    rng = np.random.default_rng(77)
+    ntraj, nsteps = 96, 25
+    for ai, arm in enumerate(("r_arm", "l_arm")):
+        a = orc.Arm(arm, 0.03)
+        y = -0.2 if arm == "r_arm" else 0.2
+        base = np.array([0.35, y, -0.25])
+        from scipy.spatial.transform import Rotation as R
+        Ms = np.zeros((ntraj, nsteps, 4, 4))
+        for k in range(ntraj):
+            p = base + rng.uniform(-0.15, 0.15, 3)
+            e = np.array([0.0, -np.pi / 2, 0.0]) + rng.uniform(-0.5, 0.5, 3)
+            for i in range(nsteps):
+                jump = 0.2 if (k % 4 == 0 and i == 12) else 0.004   # a few trajectories jump -> continuity emergency stop
+                p = p + rng.uniform(-jump, jump, 3)
+                e = e + rng.uniform(-jump, jump, 3)
+                Ms[k, i] = np.eye(4)
+                Ms[k, i, :3, :3] = R.from_euler("xyz", e).as_matrix()
+                Ms[k, i, :3, 3] = p
+        st = c.new_continuous_state(arm, ntraj)
+        states = [orc.ContinuousState(c.previous_theta[arm], c.previous_sol[arm]) for _ in range(ntraj)]
+        start_j = rng.uniform(-0.6, 0.6, size=(ntraj, 7))   # generic start: no tie in the start-up search
+        prev = Ms[:, 0].copy()
+        prev[:, :3, 3] += rng.uniform(-0.02, 0.02, size=(ntraj, 3))
+        n_em = 0
+        for i in range(nsteps):
+            res = to_np(c.symbolic_inverse_kinematics_continuous_batch(
+                arm, Ms[:, i], st, timed_out=np.full(ntraj, 1 if i == 0 else 0, dtype=np.uint8), current_pose=prev,
+                current_joints=(start_j if i == 0 else None)))
+            for k in range(ntraj):
+                cs = states[k]
+                j, ok, code = orc.control_continuous_step(a, cs, Ms[k, i], timed_out=(i == 0), preferred_theta_arg=-4 * np.pi / 6,
+                                                          preferred_theta_self=c.preferred_theta[arm], constrained_mode=0,
+                                                          current_joints=(start_j[k] if i == 0 else cs.previous_sol),
+                                                          current_pose=prev[k])
+                assert ok == bool(res["reachable"][k]) and code == res["state"][k], (arm, k, i)
+                assert np.max(np.abs(j - res["joints"][k])) < 1e-7, (arm, k, i)
+            prev = Ms[:, i]
+        n_em = int(st[9].sum().item())
+        assert n_em == sum(s.emergency_stop for s in states) and n_em > 0

@@ -236,6 +236,29 @@ def test_control_continuous(golden_dir):
             assert not cs.emergency_stop
 
 
+def test_control_continuous_explicit_start(golden_dir):
+    """G7: trajectories that start from an explicit (current_joints, current_pose) pair; odd trajectories run with the
+    DVT singularity offset (elbow projection active)."""
+    g = load(golden_dir, "g7_control_continuous_start.npz")
+    g0 = load(golden_dir, "g0_constants.npz")
+    pref_arg = -4 * np.pi / 6
+    for arm in ("r_arm", "l_arm"):
+        Ms, J, F, S, TH = g[f"{arm}_M"], g[f"{arm}_joints"], g[f"{arm}_reachable"], g[f"{arm}_state"], g[f"{arm}_previous_theta"]
+        for k in range(Ms.shape[0]):
+            a = orc.Arm(arm, 0.03 if g[f"{arm}_is_dvt"][k] else -1.01)
+            cs = orc.ContinuousState(g0[f"{arm}_urdf_previous_theta_init"], g0[f"{arm}_urdf_previous_sol"])
+            prev_pose = g[f"{arm}_start_pose"][k]
+            for i in range(Ms.shape[1]):
+                cur = g[f"{arm}_start_joints"][k] if i == 0 else cs.previous_sol
+                j, ok, st = orc.control_continuous_step(a, cs, Ms[k, i], timed_out=(i == 0), preferred_theta_arg=pref_arg,
+                                                        preferred_theta_self=g0[f"{arm}_urdf_preferred_theta"],
+                                                        constrained_mode=0, current_joints=cur, current_pose=prev_pose)
+                prev_pose = Ms[k, i]
+                assert ok == bool(F[k, i]) and st == S[k, i], (arm, k, i)
+                assert np.max(np.abs(j - J[k, i])) < 1e-7, (arm, k, i)
+                assert abs(cs.previous_theta - TH[k, i]) < 1e-9
+
+
 def test_python_float_mod_semantics():
     L = orc.lib()
     rng = np.random.default_rng(7)
