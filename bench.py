@@ -27,7 +27,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
-BYTES_PER_POSE = {2: 48 + 56 + 16 + 1 + 1, 3: 96 + 56 + 1 + 1}
+BYTES_PER_POSE = {2: 48 + 56 + 16 + 1 + 1, 3: 96 + 56 + 1 + 1, 4: 49 + 56 + 16 + 1 + 1, 5: 96 + 58 + 2 * 88}
 URDF = "config_files/reachy2_ik_minimal.urdf"
 SHOULDER_R = np.array([0.0, -0.2, 0.0])
 
@@ -95,6 +95,27 @@ def make_config3_matrices(n, seed=20250204, device=0):
     return M
 
 
+def make_config5_trajectories(n_traj, n_steps, seed=20250204, device=0):
+    """task-space generator shaped like the reference's tests/test_sdk.py:38-63 (x0,y0,z0 =
+    0.65,-0.2,0; rpy0 = 0,-pi/2,0; amp 0.35 m / pi/6 rad; freqs 0.6,0.34,0.78,0.18,0.31,0.47; t = k/120 + 11 + phase).
+    Returns the goal matrices of every step packed [n_steps, 12, n_traj] on the device."""
+    import torch
+
+    dev = torch.device("cuda", device)
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    phase = (torch.rand(n_traj, generator=g, dtype=torch.float64) * 40.0).to(dev)
+    k = torch.arange(n_steps, dtype=torch.float64, device=dev)
+    t = (k / 120.0 + 11.0)[:, None] + phase[None, :]
+    c0 = [0.65, -0.2, 0.0, 0.0, -np.pi / 2, 0.0]
+    amp = [0.35, 0.35, 0.35, np.pi / 6, np.pi / 6, np.pi / 6]
+    freq = [0.6, 0.34, 0.78, 0.18, 0.31, 0.47]
+    v = [c + a * torch.sin(f * t) for c, a, f in zip(c0, amp, freq)]
+    ca, sa, cb, sb, cc, sc = torch.cos(v[3]), torch.sin(v[3]), torch.cos(v[4]), torch.sin(v[4]), torch.cos(v[5]), torch.sin(v[5])
+    rows = [cc * cb, cc * sb * sa - sc * ca, cc * sb * ca + sc * sa, sc * cb, sc * sb * sa + cc * ca, sc * sb * ca - cc * sa,
+            -sb, cb * sa, cb * ca, v[0], v[1], v[2]]
+    return torch.stack(rows, dim=1).contiguous()
+
+
 def cpu_baseline(config, inputs, seconds):
     """Times the CPU checker (oracle/, a C restatement of the reference path = kind "port") on the host cores,
     on a bounded sample of the SAME workload.  Reported baseline, not the target."""
@@ -105,12 +126,15 @@ def cpu_baseline(config, inputs, seconds):
     except AttributeError:
         avail = os.cpu_count() or 1
     avail = max(1, min(avail, orc.lib().orc_max_threads()))
-    if config == 2:
-        pos, eul = inputs
+    if config in (2, 4):
+        pos, eul = inputs[0], inputs[1]
         m = min(len(pos), 1 << 18)
         pos, eul = np.ascontiguousarray(pos[:m]), np.ascontiguousarray(eul[:m])
+        arm_id = None if config == 2 else np.ascontiguousarray(inputs[2][:m])
         ar, al = orc.Arm("r_arm", 0.03), orc.Arm("l_arm", 0.03)
-        run = lambda nt: orc.solve_batch(ar, al, pos, eul, nthreads=nt)  # noqa: E731
+        run = lambda nt: orc.solve_batch(ar, al, pos, eul, arm_id=arm_id, nthreads=nt)  # noqa: E731
+    elif config == 5:
+        return None  # the checker's continuous step is a per-trajectory state machine driven from Python: not timed
     else:
         M = np.ascontiguousarray(inputs[: min(len(inputs), 1 << 17)])
         m = len(M)
@@ -150,7 +174,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", type=int, default=2, choices=[2, 3])
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5])
     ap.add_argument("--poses", type=int, default=0, help="poses per GPU (default: the BASELINE size)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -174,7 +198,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)
     n_gpus = world
     cfg = args.config
-    n = args.poses or ((1 << 20) if cfg == 2 else (1 << 18))
+    n = args.poses or {2: 1 << 20, 3: 1 << 18, 4: 1 << 20, 5: 4096}[cfg]
 
     # ---- synthetic inputs, resident in HBM before the timed region
     if cfg == 2:
@@ -193,6 +217,53 @@ def main():
         step_kernel = plan["launch"]  # one rsik_solve call with pre-bound arguments
         workload = f"config2: r_arm is_reachable + theta_to_joints_func(interval[0]), {n} random reachable poses per GPU"
         kernel_name = "solve_kernel"
+    elif cfg == 4:
+        from reachy2_symbolic_ik_amd import DualArmIK
+
+        pos, eul = make_config2_poses(n, seed=20250204 + rank, device=local_rank)
+        arm_id = (np.random.default_rng(99 + rank).uniform(size=n) < 0.5).astype(np.uint8)
+        sgn = np.where(arm_id == 1, -1.0, 1.0)
+        pos = pos * np.stack([np.ones(n), sgn, np.ones(n)], axis=1)      # l poses = mirror of r poses (G5 rule)
+        eul = eul * np.stack([sgn, np.ones(n), sgn], axis=1)
+        inputs = (pos, eul, arm_id)
+        dual = _quiet(DualArmIK, device=local_rank)
+        soa = torch.as_tensor(np.ascontiguousarray(np.concatenate([pos.T, eul.T], axis=0))).to(dev)
+        arm_t = torch.as_tensor(arm_id).to(dev)
+        out = {
+            "joints": torch.empty((n, 7), dtype=torch.float64, device=dev),
+            "interval": torch.empty((n, 2), dtype=torch.float64, device=dev),
+            "reachable": torch.empty((n,), dtype=torch.uint8, device=dev),
+            "state": torch.empty((n,), dtype=torch.uint8, device=dev),
+        }
+        plan = dual.solve_batch(arm_t, soa, want_elbow=False, out=out, plan_only=True)
+        step_kernel = plan["launch"]
+        workload = f"config4: r_arm + l_arm mixed (per-pose arm byte), {n} reachable poses per GPU, theta = interval[0]"
+        kernel_name = "solve_kernel<mixed>"
+    elif cfg == 5:
+        n_steps = 1000
+        n_traj = n
+        traj = make_config5_trajectories(n_traj, n_steps, seed=20250204 + rank, device=local_rank)
+        inputs = None
+        ctrl = _quiet(ControlIK, urdf_path=URDF, device=local_rank)
+        cont = ctrl.new_continuous_state("r_arm", n_traj)
+        cont0 = cont.clone()
+        out = {
+            "joints": torch.empty((n_traj, 7), dtype=torch.float64, device=dev),
+            "reachable": torch.empty((n_traj,), dtype=torch.uint8, device=dev),
+            "state": torch.empty((n_traj,), dtype=torch.uint8, device=dev),
+        }
+        first = torch.ones((n_traj,), dtype=torch.uint8, device=dev)
+        none = torch.zeros((n_traj,), dtype=torch.uint8, device=dev)
+
+        def step_kernel():  # one "step" of the bench = one 1000-step pass over all trajectories (1000 launches)
+            cont.copy_(cont0)
+            for k in range(n_steps):
+                ctrl.symbolic_inverse_kinematics_continuous_batch("r_arm", traj[k], cont, timed_out=(first if k == 0 else none),
+                                                                  current_pose=(traj[0] if k == 0 else None), out=out)
+
+        workload = f"config5: ControlIK continuous, {n_traj} trajectories x {n_steps} steps, state carried across launches"
+        kernel_name = "control_continuous_kernel"
+        n = n * n_steps  # units per bench step = trajectory-steps
     else:
         M = make_config3_matrices(n, seed=20250204 + rank, device=local_rank)
         inputs = M
@@ -214,16 +285,22 @@ def main():
 
     gathered = None
     if world > 1:
+        from reachy2_symbolic_ik_amd.distributed import all_gather_rows
+
+        rows = out["joints"].shape[0]
         gathered = {
-            "joints": torch.empty((world * n, 7), dtype=torch.float64, device=dev),
-            "reachable": torch.empty((world * n,), dtype=torch.uint8, device=dev),
+            "joints": torch.empty((world * rows, 7), dtype=torch.float64, device=dev),
+            "reachable": torch.empty((world * rows,), dtype=torch.uint8, device=dev),
         }
+
+    def gather():  # the final joint array (+ flags) is all-gathered over xGMI (RCCL)
+        all_gather_rows(out["joints"], world * out["joints"].shape[0], out=gathered["joints"])
+        all_gather_rows(out["reachable"], world * out["reachable"].shape[0], out=gathered["reachable"])
 
     def step():
         step_kernel()
-        if world > 1:  # the final joint array (+ flags) is all-gathered over xGMI
-            dist.all_gather_into_tensor(gathered["joints"], out["joints"])
-            dist.all_gather_into_tensor(gathered["reachable"], out["reachable"])
+        if world > 1:
+            gather()
 
     def fence():
         torch.cuda.synchronize()
@@ -235,18 +312,25 @@ def main():
         step()
     fence()
     # ---- timed region: exactly K steps; per-launch kernel time from events on the launch stream
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # N = 1: one event pair over the whole region (back-to-back launches, includes the ~1.5 us boundaries);
+    # N > 1: one pair per launch so the all-gather is excluded from the kernel time.
+    per_launch = world > 1
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps if per_launch else 1)]
     t0 = time.perf_counter()
+    if not per_launch:
+        ev[0][0].record()
     for k in range(args.steps):
-        ev[k][0].record()
+        if per_launch:
+            ev[k][0].record()
         step_kernel()
-        ev[k][1].record()
-        if world > 1:
-            dist.all_gather_into_tensor(gathered["joints"], out["joints"])
-            dist.all_gather_into_tensor(gathered["reachable"], out["reachable"])
+        if per_launch:
+            ev[k][1].record()
+            gather()
+    if not per_launch:
+        ev[0][1].record()
     fence()
     elapsed = time.perf_counter() - t0
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) / (1 if per_launch else args.steps)
     if world > 1:
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -254,7 +338,7 @@ def main():
 
     # sanity: the timed outputs are real results (flags all "reachable" for config 2)
     n_ok = int(out["reachable"].sum().item())
-    if cfg == 2:
+    if cfg in (2, 4):
         assert n_ok == n, f"{n - n_ok} poses of the reachable workload came back unreachable"
         assert bool(torch.isfinite(out["joints"]).all()), "non-finite joints"
 
@@ -276,7 +360,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": workload, "poses_per_gpu": n, "theta_policy": "interval[0]" if cfg == 2 else "discrete sweep nb=64",
+            "config": {"workload": workload, "poses_per_gpu": n, "theta_policy": {2: "interval[0]", 3: "discrete sweep nb=64", 4: "interval[0]", 5: "continuous, d_theta_max=0.01"}[cfg],
                        "collective": "none" if world == 1 else "RCCL all-gather of joints [n,7] f64 + reachable u8 per step"},
             "roofline": {
                 "bound": "hbm",
@@ -292,8 +376,15 @@ def main():
                 "note": "fp64 VALU-bound path (see DESIGN.md): HBM fraction is reported as the contract asks, VALU issue is the binding limit",
             },
         }
+        if cfg == 5:
+            line["metric"] = "IK control steps/sec (ControlIK continuous, r_arm trajectories)"
+            line["unit"] = "steps/s"
+            line["roofline"]["kernel_ms"] = kernel_ms / 1000  # per launch (1000 launches per bench step)
+            line["roofline"]["kernel_only_solves_per_s_per_gpu"] = n / (kernel_ms * 1e-3)
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg, inputs, args.cpu_seconds)
+            base = cpu_baseline(cfg, inputs, args.cpu_seconds)
+            if base is not None:
+                line["cpu_baseline"] = base
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -6,7 +6,7 @@ hand-written HIP kernels for gfx950 behind the C ABI of include/rsik.h.
 """
 from .constants import STATE_STRINGS, ArmGeometry, default_ik_parameters  # noqa: F401
 
-__all__ = ["SymbolicIK", "ControlIK", "HipSolver", "ArmGeometry", "STATE_STRINGS", "default_ik_parameters"]
+__all__ = ["SymbolicIK", "DualArmIK", "ControlIK", "HipSolver", "ArmGeometry", "STATE_STRINGS", "default_ik_parameters"]
 
 
 def __getattr__(name):
@@ -15,6 +15,10 @@ def __getattr__(name):
         from .symbolic_ik import SymbolicIK
 
         return SymbolicIK
+    if name == "DualArmIK":
+        from .symbolic_ik import DualArmIK
+
+        return DualArmIK
     if name == "ControlIK":
         from .control_ik import ControlIK
 

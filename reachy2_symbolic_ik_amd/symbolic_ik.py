@@ -187,3 +187,32 @@ class SymbolicIK:
     def state_strings(codes: Any) -> list:
         c = codes.cpu().numpy() if isinstance(codes, torch.Tensor) else np.asarray(codes)
         return [STATE_STRINGS[int(k)] for k in c]
+
+
+class DualArmIK:
+    """Mixed r/l batches in one launch (BASELINE config 4): two SymbolicIK objects sharing one device context, the arm
+    of every pose given by a uint8 array (0 = r_arm, 1 = l_arm)."""
+
+    def __init__(self, device: Any = None, solver: Optional[HipSolver] = None, **symbolic_ik_kwargs: Any) -> None:
+        self._solver = solver if solver is not None else HipSolver(device)
+        self.r_arm = SymbolicIK("r_arm", solver=self._solver, **symbolic_ik_kwargs)
+        self.l_arm = SymbolicIK("l_arm", solver=self._solver, **symbolic_ik_kwargs)
+
+    @property
+    def solver(self) -> HipSolver:
+        return self._solver
+
+    def solve_batch(self, arm_ids: Any, poses: Any, theta: Any = "interval0", previous_joints: Optional[Sequence[float]] = None,
+                    want_elbow: bool = True, out: Optional[Dict[str, torch.Tensor]] = None,
+                    plan_only: bool = False) -> Dict[str, torch.Tensor]:
+        soa = poses_to_soa(poses, self._solver.device)
+        theta_in = None
+        if isinstance(theta, str):
+            policy = _THETA_POLICIES[theta]
+        else:
+            policy = _THETA_POLICIES[theta[0]]
+            theta_in = theta[1]
+        self.r_arm._upload()
+        self.l_arm._upload()
+        return self._solver.solve(soa, arm=arm_ids, theta_policy=policy, theta_in=theta_in, previous_joints=previous_joints,
+                                  want_elbow=want_elbow, out=out, plan_only=plan_only)
