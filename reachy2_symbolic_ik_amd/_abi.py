@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librsik_hip.so")
+# RSIK_LIB_PATH: alternative build of the same ABI (A/B timing of kernel variants); default = the in-tree library
+LIB_PATH = os.environ.get("RSIK_LIB_PATH") or os.path.join(_HERE, "csrc", "librsik_hip.so")
 
 RSIK_OK = 0
 RSIK_E_INVALID, RSIK_E_NO_DEVICE, RSIK_E_HIP, RSIK_E_NOT_SET = -1, -2, -3, -4

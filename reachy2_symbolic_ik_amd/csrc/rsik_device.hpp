@@ -91,10 +91,10 @@ struct Rot {
     __device__ __forceinline__ V3 col0() const { return {m[0], m[3], m[6]}; }
 };
 __device__ __forceinline__ Rot rot_from_euler(double roll, double pitch, double yaw) {
-    double sa, ca, sb, cb, sc, cc;
-    fast_sincos(roll, &sa, &ca);
-    fast_sincos(pitch, &sb, &cb);
-    fast_sincos(yaw, &sc, &cc);
+    const double ang[3] = {roll, pitch, yaw};
+    double sn[3], cs[3];
+    fast_sincos_n<3>(ang, sn, cs);  // three angles in lock step
+    const double sa = sn[0], ca = cs[0], sb = sn[1], cb = cs[1], sc = sn[2], cc = cs[2];
     Rot r;
     const double ccsb = cc * sb, scsb = sc * sb;
     r.m[0] = cc * cb; r.m[1] = fma(ccsb, sa, -(sc * ca)); r.m[2] = fma(ccsb, ca, sc * sa);
@@ -108,25 +108,19 @@ __device__ __forceinline__ Rot rot_from_euler(double roll, double pitch, double 
 struct Frame {
     V3 c0, c1, c2;
 };
-// u must already be normalised (the reference divides by the norm first, U:66).
+// u must already be normalised (the reference divides by the norm first, U:66).  The two colinear special cases
+// need |u_y|, |u_z| <~ 1e-8: one rarely-taken branch, kept out of the straight-line code.
+__device__ __forceinline__ bool frame_is_special(V3 u) { return np_isclose(0.0, u.y) && np_isclose(0.0, u.z); }
 __device__ __forceinline__ V3 frame_c0(V3 u) {
-    bool yz = np_isclose(0.0, u.y) && np_isclose(0.0, u.z);
-    if (yz && np_isclose(1.0, u.x)) return {1, 0, 0};
-    if (yz && np_isclose(1.0, -u.x)) return {-1, 0, 0};
-    return u;  // R00 = 1 - s^2 (1-c)/s^2 = c to rounding
+    V3 c0 = u;  // R00 = 1 - s^2 (1-c)/s^2 = c to rounding
+    if (__builtin_expect(frame_is_special(u), 0)) {
+        if (np_isclose(1.0, u.x)) c0 = {1, 0, 0};
+        else if (np_isclose(1.0, -u.x)) c0 = {-1, 0, 0};
+    }
+    return c0;
 }
 __device__ __forceinline__ Frame frame_from_unit(V3 u) {
     Frame F;
-    // [D] colinear special cases, numpy.isclose semantics with the tolerance scaled by the 2nd argument
-    bool yz = np_isclose(0.0, u.y) && np_isclose(0.0, u.z);
-    if (yz && np_isclose(1.0, u.x)) {
-        F.c0 = {1, 0, 0}; F.c1 = {0, 1, 0}; F.c2 = {0, 0, 1};
-        return F;
-    }
-    if (yz && np_isclose(1.0, -u.x)) {
-        F.c0 = {-1, 0, 0}; F.c1 = {0, 1, 0}; F.c2 = {0, 0, -1};
-        return F;
-    }
     // Rodrigues I + K + K^2 (1-c)/s^2 with v = e_x x u = (0, -u_z, u_y)
     double s2 = fma(u.z, u.z, u.y * u.y);
     double h = (1 - u.x) * fast_rcp(s2);
@@ -135,6 +129,11 @@ __device__ __forceinline__ Frame frame_from_unit(V3 u) {
     F.c0 = {fma(-s2, h, 1.0), u.y, u.z};
     F.c1 = {-u.y, fma(-u.y, yh, 1.0), -yzh};
     F.c2 = {-u.z, -yzh, fma(-u.z, zh, 1.0)};
+    // [D] colinear special cases, numpy.isclose semantics with the tolerance scaled by the 2nd argument
+    if (__builtin_expect(frame_is_special(u), 0)) {
+        if (np_isclose(1.0, u.x)) { F.c0 = {1, 0, 0}; F.c1 = {0, 1, 0}; F.c2 = {0, 0, 1}; }
+        else if (np_isclose(1.0, -u.x)) { F.c0 = {-1, 0, 0}; F.c1 = {0, 1, 0}; F.c2 = {0, 0, -1}; }
+    }
     return F;
 }
 
@@ -332,8 +331,13 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
     V3 pa = madd(v, ta, q), pb = madd(v, tb, q);
     double ly1 = dot(a1, pa) + oy, lz1 = dot(a2, pa) + oz;
     double ly2 = dot(a1, pb) + oy, lz2 = dot(a2, pb) + oz;
-    double ang1 = fast_atan2(lz1, ly1);
-    double ang2 = fast_atan2(lz2, ly2);
+    double ang1, ang2;
+    {
+        const double yy[2] = {lz1, lz2}, xx[2] = {ly1, ly2};
+        double aa[2];
+        fast_atan2_n<2>(yy, xx, aa);
+        ang1 = aa[0]; ang2 = aa[1];
+    }
     if (ang2 < ang1) {
         double t = ang1; ang1 = ang2; ang2 = t;
         t = ly1; ly1 = ly2; ly2 = t;
@@ -414,19 +418,22 @@ __device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, do
     };
     V3 q = to_shoulder(e);
     // shoulder pitch / roll (S:751-766)
-    double cphi, sphi, sp, rho;
-    if (q.x == 0 && q.z == 0) {  // [D] exact singularity: keep the previous pitch
-        sp = prev[0];
+    // The seven joint angles are pure outputs (no rotation below is built from an angle), so their atan2 are
+    // collected in (ay, ax) and evaluated together at the end, seven polynomials in lock step.
+    double ay[7], ax[7];
+    double cphi, sphi, rho;
+    const bool sing_sp = (q.x == 0 && q.z == 0);
+    if (sing_sp) {  // [D] exact singularity: keep the previous pitch
         double s_, c_;
-        sincos(sp, &s_, &c_);
+        fast_sincos(prev[0], &s_, &c_);
         cphi = c_; sphi = -s_; rho = 0.0;
     } else {
         double irho;
         sqrt_rsqrt(q.x * q.x + q.z * q.z, rho, irho);
-        sp = -fast_atan2(q.z, q.x);
         cphi = q.x * irho; sphi = q.z * irho;
     }
-    double sr = fast_atan2(q.y, rho);
+    ay[0] = q.z; ax[0] = q.x;   // shoulder_pitch = -atan2
+    ay[1] = q.y; ax[1] = rho;   // shoulder_roll
     const double iL = A(RSIK_C_INV_U);  // |e - shoulder| = upper arm length by construction
     double cr = rho * iL, srs = q.y * iL;
     // G = Rz(-sr) Ry(-sp): rows g0, g1, g2
@@ -439,18 +446,18 @@ __device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, do
     };
     // elbow yaw / pitch (S:780-797)
     V3 pw = to_elbow(r.w);
-    double sigma, ey, ca, sa;
-    if (pw.y == 0 && pw.z == 0) {  // [D] exact singularity
-        ey = prev[2];
-        sincos(ey, &sa, &ca);
+    double sigma, ca, sa;
+    const bool sing_ey = (pw.y == 0 && pw.z == 0);
+    if (sing_ey) {  // [D] exact singularity
+        fast_sincos(prev[2], &sa, &ca);
         sigma = 0.0;
     } else {
         double isig;
         sqrt_rsqrt(pw.y * pw.y + pw.z * pw.z, sigma, isig);
-        ey = -kPi / 2 + fast_atan2(pw.z, -pw.y);
         ca = pw.z * isig; sa = pw.y * isig;
     }
-    double ep = -fast_atan2(sigma, pw.x);
+    ay[2] = pw.z; ax[2] = -pw.y;  // elbow_yaw = -pi/2 + atan2
+    ay[3] = sigma; ax[3] = pw.x;  // elbow_pitch = -atan2
     const double ilam = FRESH ? A(RSIK_C_INV_F) : rsqrt_fast(fma(sigma, sigma, pw.x * pw.x));
     double cchi = pw.x * ilam, schi = sigma * ilam;
     // H = Ry(-ep) Rx(ey)
@@ -465,18 +472,19 @@ __device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, do
     V3 tl = cvec(A, RSIK_C_TIPL);
     V3 ptip = Rg.apply_add(V3{tl.x, tl.y, 0.0}, r.pos);
     V3 t = to_wrist(ptip);
-    double tau, wr, cw, sw;
-    wr = kPi - fast_atan2(t.y, -t.x);
-    if (wr > kPi) wr = wr - kTwoPi;
+    double tau, cw, sw;
     if (t.x == 0 && t.y == 0) {
-        sincos(wr, &sw, &cw);
+        double w0 = kPi - fast_atan2(t.y, -t.x);
+        if (w0 > kPi) w0 = w0 - kTwoPi;
+        fast_sincos(w0, &sw, &cw);
         tau = 0.0;
     } else {
         double itau;
         sqrt_rsqrt(t.x * t.x + t.y * t.y, tau, itau);
         cw = t.x * itau; sw = t.y * itau;
     }
-    double wp = fast_atan2(t.z, tau);
+    ay[4] = t.y; ax[4] = -t.x;  // wrist_roll = pi - atan2, wrapped
+    ay[5] = t.z; ax[5] = tau;   // wrist_pitch
     const double imu = FRESH ? A(RSIK_C_INV_TIPZ) : rsqrt_fast(fma(tau, tau, t.z * t.z));  // |tip' - wrist| = |tip_z|
     double cp = tau * imu, spp = t.z * imu;
     // K = Ry(wp) Rz(-wr); only rows 1, 2 are needed for the yaw
@@ -488,9 +496,18 @@ __device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, do
     V3 xe = {dot(g0, xs), dot(g1, xs), dot(g2, xs)};
     V3 xw = {dot(h0, xe), dot(h1, xe), dot(h2, xe)};
     double gy = dot(k1, xw), gz = dot(k2, xw);
-    double wy = -fast_atan2(gy, gz);
-
-    o.j[0] = sp; o.j[1] = sr; o.j[2] = ey; o.j[3] = ep; o.j[4] = wr; o.j[5] = -wp; o.j[6] = -wy;
+    ay[6] = gy; ax[6] = gz;     // wrist_yaw = -atan2
+    double at[7];
+    fast_atan2_n<7>(ay, ax, at);
+    double wr = kPi - at[4];
+    if (wr > kPi) wr = wr - kTwoPi;
+    o.j[0] = sing_sp ? prev[0] : -at[0];
+    o.j[1] = at[1];
+    o.j[2] = sing_ey ? prev[2] : (-kPi / 2 + at[2]);
+    o.j[3] = -at[3];
+    o.j[4] = wr;
+    o.j[5] = -at[5];
+    o.j[6] = at[6];
     const double el = A(RSIK_C_ELBOW_LIMIT);  // S:853-861
     if (o.j[3] > el) o.j[3] = el;
     if (o.j[3] < -el) o.j[3] = -el;
@@ -544,9 +561,13 @@ __device__ __forceinline__ bool safety_checks(double (&j)[7], double ca, double 
     // W' = Rz(alpha) Ry(beta') Rz(gamma); intrinsic XYZ angles of W'
     double V02 = cal * sbe, V12 = sal * sbe, V22 = cbe;
     double V01 = -cal * cbe * sga - sal * cga, V00 = cal * cbe * cga - sal * sga;
-    j[4] = fast_atan2(-V12, V22);
-    j[5] = fast_atan2(V02, sqrt(fma(-V02, V02, 1.0)));  // asin(V02); |V02| <= sin(max_angle) after the clamp
-    j[6] = fast_atan2(-V01, V00);
+    {
+        const double yy[3] = {-V12, V02, -V01};
+        const double xx[3] = {V22, sqrt(fma(-V02, V02, 1.0)), V00};  // middle: asin(V02); |V02| <= sin(max_angle) after the clamp
+        double aa[3];
+        fast_atan2_n<3>(yy, xx, aa);
+        j[4] = aa[0]; j[5] = aa[1]; j[6] = aa[2];
+    }
     bool emergency = false;
 #pragma unroll
     for (int k = 0; k < 7; k++) j[k] = prev[k] + angle_diff(j[k], prev[k]);

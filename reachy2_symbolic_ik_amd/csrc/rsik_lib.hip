@@ -64,8 +64,11 @@ __device__ __forceinline__ void store_rows(double* __restrict__ out, int64_t wav
     __builtin_amdgcn_wave_barrier();
 }
 
+#ifndef RSIK_SOLVE_MIN_WAVES
+#define RSIK_SOLVE_MIN_WAVES 1
+#endif
 template <bool MIXED>
-__global__ __launch_bounds__(kBlock) void solve_kernel(const SolveArgs K) {
+__global__ __launch_bounds__(kBlock, RSIK_SOLVE_MIN_WAVES) void solve_kernel(const SolveArgs K) {
     __shared__ double lds[kBlock / 64][64 * 7];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
