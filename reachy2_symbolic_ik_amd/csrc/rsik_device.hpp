@@ -582,20 +582,10 @@ __device__ __forceinline__ bool safety_checks(double (&j)[7], double ca, double 
     return emergency;
 }
 
-// utils.get_best_discrete_theta (U:334-396), one pose per lane (serial grid walk): used by the continuous mode with
-// its fixed 10-point grid (C:350-361); the discrete mode uses the wave-cooperative sweep in rsik_lib.hip.
+// The grid part of utils.get_best_discrete_theta (U:372-396), one pose per lane, walking every grid point.
 template <class Acc>
-__device__ bool best_discrete_theta_serial(const Acc& A, const Reach& r, int nb, double pref, double& theta_out) {
-    if (is_valid_angle(pref, r.i0, r.i1)) {
-        double st, ct;
-        fast_sincos(pref, &st, &ct);
-        if (is_elbow_ok(A, elbow_on_circle(r, ct, st))) { theta_out = pref; return true; }
-    }
-    double a, b;
-    if (fabs(fabs(r.i0) + fabs(r.i1) - kTwoPi) < 0.00001) { a = kPi / 2; b = kPi / 2 + kTwoPi; }
-    else if (r.i0 < r.i1) { a = r.i0; b = r.i1; }
-    else { a = r.i0; b = r.i1 + kTwoPi; }
-    const double step = (b - a) / (double)(nb - 1);
+__device__ bool best_discrete_theta_grid(const Acc& A, const Reach& r, double a, double step, double b, int nb, double pref,
+                                         double& theta_out) {
     bool found = false;
     double best = 0.0, best_d = __builtin_inf();
     for (int k = 0; k < nb; k++) {
@@ -609,6 +599,23 @@ __device__ bool best_discrete_theta_serial(const Acc& A, const Reach& r, int nb,
     }
     theta_out = best;
     return found;
+}
+
+// utils.get_best_discrete_theta (U:334-396), one pose per lane: used by the continuous mode with its fixed 10-point
+// grid (C:350-361); the discrete mode picks between this, the arc-end candidates and the wave-cooperative sweep.
+template <class Acc>
+__device__ bool best_discrete_theta_serial(const Acc& A, const Reach& r, int nb, double pref, double& theta_out) {
+    if (is_valid_angle(pref, r.i0, r.i1)) {
+        double st, ct;
+        fast_sincos(pref, &st, &ct);
+        if (is_elbow_ok(A, elbow_on_circle(r, ct, st))) { theta_out = pref; return true; }
+    }
+    double a, b;
+    if (fabs(fabs(r.i0) + fabs(r.i1) - kTwoPi) < 0.00001) { a = kPi / 2; b = kPi / 2 + kTwoPi; }
+    else if (r.i0 < r.i1) { a = r.i0; b = r.i1; }
+    else { a = r.i0; b = r.i1 + kTwoPi; }
+    const double step = (b - a) / (double)(nb - 1);
+    return best_discrete_theta_grid(A, r, a, step, b, nb, pref, theta_out);
 }
 
 // utils.get_best_theta_to_current_joints (U:267-331) with a flat 7-joint target (C:322-324): ternary search over the
@@ -639,6 +646,81 @@ __device__ double best_theta_to_current_joints(const Acc& A, Reach& r, const Rot
     double best = (low + high) / 2;
     (void)dist_at(best);  // U:324
     return best;
+}
+
+// utils.get_best_discrete_theta's grid search (U:366-396) without walking the whole grid.
+//
+// Both halves of is_elbow_ok (U:443-465) are of the form  A cos(theta) + B sin(theta) < D  on the elbow circle, i.e.
+// each is satisfied on one open arc whose two end angles are phi +- acos(D / R) (R = |(A, B)|, phi = atan2(B, A)).
+// The grid points that pass are therefore at most a few index runs delimited by those four angles and the grid ends,
+// and inside a run |angle_diff(theta_k, preferred)| is smallest either next to the preferred angle or at a run end.
+// So the first-strict-minimum of the reference is among: the two grid ends, the 4 grid points around the preferred
+// angle and the 4 grid points around each arc end (22 evaluations, independent of nb_search_points).  Each candidate is
+// then judged with the reference's own predicate and distance (same theta_k = linspace value, same is_elbow_ok), so the
+// analytic arcs only propose candidates, they never decide.  `fast_ok` = false (degenerate step) asks the caller to
+// fall back to the exhaustive wave-cooperative sweep.
+template <class Acc>
+__device__ bool grid_theta_candidates(const Acc& A, const Reach& r, double a, double step, double b, int nb, double pref,
+                                      double& theta_out, bool& fast_ok) {
+    fast_ok = step > 1e-9;
+    const double side = A(RSIK_C_SIDE), sc = A(RSIK_C_SING_COEFF);
+    // constraint 1: side * e_y < -0.2;  constraint 2: e_z - sc * e_x < es_z - so - sc * es_x
+    const double A1 = side * r.r2 * r.a1.y, B1 = side * r.r2 * r.a2.y, D1 = -0.2 - side * r.c2.y;
+    const double A2 = r.r2 * fma(-sc, r.a1.x, r.a1.z), B2 = r.r2 * fma(-sc, r.a2.x, r.a2.z);
+    const double D2 = (A(RSIK_C_ES + 2) - A(RSIK_C_SING_OFFSET) - sc * A(RSIK_C_ES)) - fma(-sc, r.c2.x, r.c2.z);
+    const double R1s = fma(A1, A1, B1 * B1), R2s = fma(A2, A2, B2 * B2);
+    const bool v1 = R1s > D1 * D1, v2 = R2s > D2 * D2;  // the constraint really changes sign on the circle
+    double ang[5];
+    {
+        const double yy[4] = {B1, sqrt(fmax(R1s - D1 * D1, 0.0)), B2, sqrt(fmax(R2s - D2 * D2, 0.0))};
+        const double xx[4] = {A1, D1, A2, D2};
+        double at[4];
+        fast_atan2_n<4>(yy, xx, at);  // phi_1, alpha_1 = acos(D1/R1), phi_2, alpha_2
+        ang[0] = pref;
+        ang[1] = v1 ? at[0] + at[1] : a;
+        ang[2] = v1 ? at[0] - at[1] : a;
+        ang[3] = v2 ? at[2] + at[3] : a;
+        ang[4] = v2 ? at[2] - at[3] : a;
+    }
+    const double inv_step = fast_rcp(step);
+    const int last = nb - 1;
+    double best_d = __builtin_inf();
+    int best_k = 0x7fffffff;
+    double best_th = 0.0;
+    auto judge = [&](int k, double th, double sn, double cs) {
+        if (is_elbow_ok(A, elbow_on_circle(r, cs, sn))) {
+            double dist = fabs(angle_diff(th, pref));
+            if (dist < best_d || (dist == best_d && k < best_k)) { best_d = dist; best_k = k; best_th = th; }
+        }
+    };
+    auto theta_of = [&](int k) -> double { return (k == last) ? b : ((double)k * step + a); };  // np.linspace (Q11)
+    {   // the two grid ends
+        const double th[2] = {theta_of(0), theta_of(last)};
+        double sn[2], cs[2];
+        fast_sincos_n<2>(th, sn, cs);
+        judge(0, th[0], sn[0], cs[0]);
+        judge(last, th[1], sn[1], cs[1]);
+    }
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        double pos = pymod_2pi(ang[j] - a) * inv_step;   // real-valued grid index of the anchor angle
+        pos = (pos < 2.0e9) ? pos : 0.0;                 // also catches NaN
+        const int k0 = (int)pos - 1;
+        int kk[4];
+        double th[4], sn[4], cs[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            int k = k0 + t;
+            k = k < 0 ? 0 : (k > last ? last : k);
+            kk[t] = k;
+            th[t] = theta_of(k);
+        }
+        fast_sincos_n<4>(th, sn, cs);
+#pragma unroll
+        for (int t = 0; t < 4; t++) judge(kk[t], th[t], sn[t], cs[t]);
+    }
+    theta_out = best_th;
+    return best_k != 0x7fffffff;
 }
 
 }  // namespace rsik

@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -128,6 +129,7 @@ struct DiscreteArgs {
     const uint8_t* arm;
     int nb;
     int log2p;            // sweep sub-group width P = 1 << log2p  (P = pow2ceil(min(nb, 64)))
+    int sweep_mode;       // 0 auto, 1 always the exhaustive wave-cooperative sweep, 2 always the per-lane search
     double pref[2];       // preferred theta per arm slot (already mirrored for l, C:252)
     double lim[2][2];     // interval_limit per arm slot (C:225-250)
     double prev_sol[2][7];
@@ -274,13 +276,37 @@ __global__ __launch_bounds__(kBlock) void control_discrete_kernel(const Discrete
         g[6][lane] = r.a2.x; g[7][lane] = r.a2.y; g[8][lane] = r.a2.z;
         g[9][lane] = r.r2; g[10][lane] = a; g[11][lane] = step; g[12][lane] = b;
     }
+    // Two ways to search the grid, chosen per wave (wave-uniform): when only a few lanes need it, the exhaustive
+    // wave-cooperative sweep (cost ~ number of such poses); when most lanes need it, every lane searches its own
+    // pose serially — the whole grid if it is short, else the 22 arc-end candidates (grid_theta_candidates).
+    const uint64_t need_mask = __ballot(need);
+    const int cnt = __popcll(need_mask);
+    const int serial_evals = (K.nb <= 24) ? K.nb : 22;
+    const int coop_rounds = ((cnt + (64 >> K.log2p) - 1) >> (6 - K.log2p)) * ((K.nb + 63) >> 6);
+    bool dense = serial_evals * 70 + (K.nb <= 24 ? 0 : 350) < coop_rounds * 150;
+    if (K.sweep_mode == 1) dense = false;
+    if (K.sweep_mode == 2) dense = true;
+    bool coop = need;
+    double th_serial = 0.0;
+    bool found_serial = false;
+    if (dense && need) {
+        const double ga = lds_geo[wave][10][lane], gstep = lds_geo[wave][11][lane], gb = lds_geo[wave][12][lane];
+        if (K.nb <= 24) {
+            found_serial = best_discrete_theta_grid(A, r, ga, gstep, gb, K.nb, pref, th_serial);
+            coop = false;
+        } else {
+            bool fast_ok;
+            found_serial = grid_theta_candidates(A, r, ga, gstep, gb, K.nb, pref, th_serial, fast_ok);
+            coop = !fast_ok;
+        }
+    }
     wave_lds_sync();
-    const uint64_t mask = __ballot(need);
+    const uint64_t mask = __ballot(coop);
     sweep_theta_grid<MIXED>(K, mask, lane, A.isl, lds_geo[wave], lds_res[wave]);
     wave_lds_sync();
     int st_code = r.state;
     if (need) {
-        double th = lds_res[wave][lane];
+        double th = coop ? lds_res[wave][lane] : (found_serial ? th_serial : __builtin_nan(""));
         if (th == th) { found = true; theta = th; }
         else st_code = RSIK_STATE_LIMITED_BY_SHOULDER;  // C:451-452
     }
@@ -790,6 +816,8 @@ int rsik_control_discrete(rsik_ctx* ctx, int64_t n, const double* const m12_soa[
     int lg = 0;
     while ((1 << lg) < nb_search_points && lg < 6) lg++;
     K.log2p = lg;
+    const char* sm = std::getenv("RSIK_SWEEP_MODE");  // test hook: force one of the two grid-search strategies
+    K.sweep_mode = sm ? std::atoi(sm) : 0;
     for (int slot = 0; slot < 2; slot++) {
         const int a = arm ? slot : arm_uniform;
         control_limits(a, constrained_mode, preferred_theta, K.lim[slot], &K.pref[slot]);

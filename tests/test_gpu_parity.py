@@ -333,9 +333,13 @@ def test_control_random(golden_dir, torch_mod, dvt_tag, is_dvt):
                 assert np.max(np.abs(np.array(j) - g[pre + "var_joints"][k])) < TOL
 
 
-@pytest.mark.parametrize("nb", [2, 3, 10, 20, 33, 64, 65, 100, 200])
-def test_control_grid_sizes_match_checker(golden_dir, torch_mod, orc, nb):
-    """The wave-cooperative sweep packs 64/pow2ceil(nb) poses per round and needs extra rounds above 64 points."""
+@pytest.mark.parametrize("mode", ["0", "1", "2"])
+@pytest.mark.parametrize("nb", [2, 3, 10, 20, 25, 33, 64, 65, 100, 200, 1000])
+def test_control_grid_sizes_match_checker(golden_dir, torch_mod, orc, nb, mode, monkeypatch):
+    """Grid search strategies (RSIK_SWEEP_MODE: 0 = per-wave choice, 1 = exhaustive wave-cooperative sweep, which packs
+    64/pow2ceil(nb) poses per round and needs extra rounds above 64 points, 2 = per-lane search: whole grid up to 24
+    points, the 22 arc-end candidates above) must all reproduce the reference's first strict minimum."""
+    monkeypatch.setenv("RSIK_SWEEP_MODE", mode)
     g = load(golden_dir, "g4_control_discrete.npz")
     c = make_control()
     c.nb_search_points = nb
@@ -349,9 +353,13 @@ def test_control_grid_sizes_match_checker(golden_dir, torch_mod, orc, nb):
     assert np.max(np.abs(res["joints"] - ref["joints"])) < TOL
 
 
-def test_config3_full_size_against_checker(torch_mod, orc):
-    """BASELINE config 3 at full size: 262 144 wrist-reachable goal matrices, 64-point sweep."""
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_config3_full_size_against_checker(torch_mod, orc, mode, monkeypatch):
+    """BASELINE config 3 at full size: 262 144 wrist-reachable goal matrices, 64-point sweep, with either grid-search
+    strategy forced."""
     from bench import make_config3_matrices
+
+    monkeypatch.setenv("RSIK_SWEEP_MODE", mode)
 
     M = make_config3_matrices(1 << 18, seed=20250204)
     c = make_control()
