@@ -17,7 +17,10 @@
 
 namespace rsik {
 
-constexpr int kBlock = 256;
+#ifndef RSIK_BLOCK
+#define RSIK_BLOCK 256
+#endif
+constexpr int kBlock = RSIK_BLOCK;
 
 struct SolveArgs {
     int64_t n;
