@@ -259,11 +259,15 @@ def main():
         first = torch.ones((n_traj,), dtype=torch.uint8, device=dev)
         none = torch.zeros((n_traj,), dtype=torch.uint8, device=dev)
 
-        def step_kernel():  # one "step" of the bench = one 1000-step pass over all trajectories (1000 launches)
+        out = {
+            "joints": torch.empty((n_steps, n_traj, 7), dtype=torch.float64, device=dev),
+            "reachable": torch.empty((n_steps, n_traj), dtype=torch.uint8, device=dev),
+            "state": torch.empty((n_steps, n_traj), dtype=torch.uint8, device=dev),
+        }
+
+        def step_kernel():  # one "step" of the bench = one 1000-step pass over all trajectories (1000 launches from C)
             cont.copy_(cont0)
-            for k in range(n_steps):
-                ctrl.symbolic_inverse_kinematics_continuous_batch("r_arm", traj[k], cont, timed_out=(first if k == 0 else none),
-                                                                  current_pose=(traj[0] if k == 0 else None), out=out)
+            ctrl.run_continuous_trajectories("r_arm", traj, cont, first_step_timed_out=True, current_pose=traj[0], out=out)
 
         workload = f"config5: ControlIK continuous, {n_traj} trajectories x {n_steps} steps, state carried across launches"
         kernel_name = "control_continuous_kernel"

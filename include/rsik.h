@@ -201,6 +201,22 @@ int rsik_control_continuous_step(rsik_ctx *ctx, int64_t n, const double *const m
                                  uint8_t *state);
 
 /*
+ * rsik_control_continuous_run — n_steps consecutive rsik_control_continuous_step launches issued from one host call
+ * (the whole trajectory batch resident in HBM; the per-trajectory state is carried from launch to launch).
+ *   m12_steps        device [n_steps][12][n]: the goal matrices of every step
+ *   current_pose_m12_soa / current_joints   used by the first step only (see rsik_control_continuous_step)
+ *   first_step_timed_out  non-zero: every trajectory (re)initialises on the first step (the reference's behaviour for
+ *                    the first call after construction, control_ik.py:160,298)
+ *   joints_steps     device [n_steps][n][7]; reachable_steps / state_steps device [n_steps][n] or NULL
+ */
+int rsik_control_continuous_run(rsik_ctx *ctx, int64_t n, int64_t n_steps, const double *m12_steps,
+                                const double *const current_pose_m12_soa[12], const uint8_t *arm, int arm_uniform,
+                                int first_step_timed_out, double preferred_theta, const double *preferred_theta_self_host,
+                                int constrained_mode, double d_theta_max, const double *current_joints,
+                                double orbita3d_max_angle, double *cont_state, double *joints_steps,
+                                uint8_t *reachable_steps, uint8_t *state_steps);
+
+/*
  * Solver-state entry points: the scalar drop-in API.  A SymbolicIK object keeps self.goal_pose,
  * self.wrist_position and self.intersection_circle between is_reachable() and the closure it returns
  * (symbolic_ik.py:143-144,185,235), and get_joints() mutates them when the elbow projection fires

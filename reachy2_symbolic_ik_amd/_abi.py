@@ -42,6 +42,8 @@ PROTOTYPES = {
                                         _vp, C.c_double, _vp, _vp, _vp, _vp]),
     "rsik_control_continuous_step": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp), C.POINTER(_vp), _vp, C.c_int, _vp, C.c_double, _dp,
                                                C.c_int, C.c_double, _vp, C.c_double, _vp, _vp, _vp, _vp]),
+    "rsik_control_continuous_run": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp, C.POINTER(_vp), _vp, C.c_int, C.c_int, C.c_double, _dp,
+                                              C.c_int, C.c_double, _vp, C.c_double, _vp, _vp, _vp, _vp]),
     "rsik_reach_state": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp), _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "rsik_joints_from_state": (C.c_int, [_vp, C.c_int64, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     "rsik_elbow_from_state": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp]),

@@ -296,6 +296,60 @@ class HipSolver:
                 float(orbita3d_max_angle), _ptr(cont_state), _ptr(joints), _ptr(reachable), _ptr(state)))
         return {"joints": joints, "reachable": reachable, "state": state}
 
+    def control_continuous_run(
+        self,
+        m12_steps: torch.Tensor,
+        cont_state: torch.Tensor,
+        preferred_theta_self: Sequence[float],
+        arm: Optional[torch.Tensor] = None,
+        arm_uniform: int = 0,
+        first_step_timed_out: bool = True,
+        preferred_theta: float = -4 * np.pi / 6,
+        constrained_mode: int = _abi.MODE_UNCONSTRAINED,
+        d_theta_max: float = 0.01,
+        current_joints: Optional[torch.Tensor] = None,
+        current_pose_m12: Optional[torch.Tensor] = None,
+        orbita3d_max_angle: float = float(np.deg2rad(42.5)),
+        out: Optional[Dict[str, torch.Tensor]] = None,
+    ) -> Dict[str, torch.Tensor]:
+        """m12_steps: [n_steps, 12, n] float64 on the device.  Runs every step (one launch each, issued from C) and
+        returns joints [n_steps, n, 7], reachable / state [n_steps, n]; `cont_state` is updated in place."""
+        if m12_steps.dim() != 3 or m12_steps.shape[1] != 12:
+            raise ValueError("m12_steps must have shape [n_steps, 12, n]")
+        n_steps, _, n = (int(v) for v in m12_steps.shape)
+        if m12_steps.dtype != _F64 or m12_steps.device != self.device or not m12_steps.is_contiguous():
+            m12_steps = m12_steps.to(device=self.device, dtype=_F64).contiguous()
+        if (cont_state.dtype != _F64 or cont_state.device != self.device or tuple(cont_state.shape) != (_abi.CONT_STATE_ROWS, n)
+                or not cont_state.is_contiguous()):
+            raise ValueError(f"cont_state must be a contiguous float64 [{_abi.CONT_STATE_ROWS}, {n}] tensor on {self.device}")
+        if arm is not None:
+            arm = self._dev_u8(arm, n, "arm")
+        if current_joints is not None:
+            current_joints = self._dev_f64(current_joints, (n, 7), "current_joints")
+        cp = None
+        if current_pose_m12 is not None:
+            current_pose_m12 = self._dev_f64(current_pose_m12, (12, n), "current_pose_m12")
+            cp = (C.c_void_p * 12)(*[current_pose_m12[k].data_ptr() for k in range(12)])
+        pts = np.ascontiguousarray(preferred_theta_self, dtype=np.float64)
+        if out is None:
+            out = {}
+        joints = out.get("joints", None)
+        if joints is None:
+            joints = torch.empty((n_steps, n, 7), dtype=_F64, device=self.device)
+        reachable = out.get("reachable", None)
+        if reachable is None:
+            reachable = torch.empty((n_steps, n), dtype=_U8, device=self.device)
+        state = out.get("state", None)
+        if state is None:
+            state = torch.empty((n_steps, n), dtype=_U8, device=self.device)
+        with torch.cuda.device(self.device):
+            self._bind_stream()
+            self._check(self.lib.rsik_control_continuous_run(
+                self._h, n, n_steps, _ptr(m12_steps), cp, _ptr(arm), int(arm_uniform), int(bool(first_step_timed_out)),
+                float(preferred_theta), pts.ctypes.data_as(C.POINTER(C.c_double)), int(constrained_mode), float(d_theta_max),
+                _ptr(current_joints), float(orbita3d_max_angle), _ptr(cont_state), _ptr(joints), _ptr(reachable), _ptr(state)))
+        return {"joints": joints, "reachable": reachable, "state": state}
+
     # ------------------------------------------------------------------ solver-state entry points
     def new_solver_state(self, n: int) -> torch.Tensor:
         return torch.zeros((n, _abi.SOLVER_STATE_STRIDE), dtype=_F64, device=self.device)

@@ -364,3 +364,37 @@ class ControlIK:
             preferred_theta=float(preferred_theta), constrained_mode=_abi.MODES[constrained_mode],
             previous_sol=self._previous_sol_2x7(), current_joints=current_joints,
             orbita3d_max_angle=float(self.orbita3D_max_angle), out=out, plan_only=plan_only)
+
+    def run_continuous_trajectories(
+        self,
+        name: Any,
+        M_steps: Any,
+        cont_state: torch.Tensor,
+        first_step_timed_out: bool = True,
+        current_joints: Any = None,
+        current_pose: Any = None,
+        constrained_mode: str = "unconstrained",
+        d_theta_max: float = 0.01,
+        preferred_theta: float = -4 * np.pi / 6,
+        out: Optional[Dict[str, torch.Tensor]] = None,
+    ) -> Dict[str, torch.Tensor]:
+        """All steps of n parallel trajectories with one host call.  M_steps: [n_steps, n, 4, 4] or packed
+        [n_steps, 12, n].  Returns joints [n_steps, n, 7], reachable / state [n_steps, n]."""
+        if constrained_mode not in _abi.MODES:
+            raise UnboundLocalError("local variable 'interval_limit' referenced before assignment")
+        dev = self._solver.device
+        t = M_steps if isinstance(M_steps, torch.Tensor) else torch.as_tensor(np.asarray(M_steps, dtype=np.float64))
+        t = t.to(device=dev, dtype=torch.float64)
+        if t.dim() == 4 and tuple(t.shape[2:]) == (4, 4):
+            rot = t[:, :, :3, :3].reshape(t.shape[0], t.shape[1], 9)
+            t = torch.cat([rot, t[:, :, :3, 3]], dim=2).permute(0, 2, 1)
+        m12_steps = t.contiguous()
+        cp = None if current_pose is None else matrices_to_m12_soa(current_pose, dev)
+        arm_t, arm_uniform = (None, ARM_IDS[name]) if isinstance(name, str) else (name, 0)
+        pts = [self.preferred_theta.get("r_arm", -4 * np.pi / 6), self.preferred_theta.get("l_arm", -np.pi + 4 * np.pi / 6)]
+        self._upload_arms()
+        return self._solver.control_continuous_run(
+            m12_steps, cont_state, pts, arm=arm_t, arm_uniform=arm_uniform, first_step_timed_out=first_step_timed_out,
+            preferred_theta=float(preferred_theta), constrained_mode=_abi.MODES[constrained_mode],
+            d_theta_max=float(d_theta_max), current_joints=current_joints, current_pose_m12=cp,
+            orbita3d_max_angle=float(self.orbita3D_max_angle), out=out)

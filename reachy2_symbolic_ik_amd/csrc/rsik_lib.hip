@@ -917,6 +917,40 @@ int rsik_control_continuous_step(rsik_ctx* ctx, int64_t n, const double* const m
     return RSIK_OK;
 }
 
+int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const double* m12_steps,
+                                const double* const current_pose_m12_soa[12], const uint8_t* arm, int arm_uniform,
+                                int first_step_timed_out, double preferred_theta, const double* preferred_theta_self_host,
+                                int constrained_mode, double d_theta_max, const double* current_joints,
+                                double orbita3d_max_angle, double* cont_state, double* joints_steps,
+                                uint8_t* reachable_steps, uint8_t* state_steps) {
+    if (!ctx) return RSIK_E_INVALID;
+    if (n < 0 || n_steps < 0) return fail(ctx, RSIK_E_INVALID, "rsik_control_continuous_run: negative size");
+    if (n == 0 || n_steps == 0) return RSIK_OK;
+    if (!m12_steps || !joints_steps) return fail(ctx, RSIK_E_INVALID, "rsik_control_continuous_run: NULL buffer");
+    uint8_t* flags = nullptr;
+    if (first_step_timed_out) {  // one-off [n] array of ones for the first launch
+        RSIK_HIP(ctx, hipSetDevice(ctx->device));
+        RSIK_HIP(ctx, hipMallocAsync(reinterpret_cast<void**>(&flags), (size_t)n, ctx->stream));
+        RSIK_HIP(ctx, hipMemsetAsync(flags, 1, (size_t)n, ctx->stream));
+    }
+    int rc = RSIK_OK;
+    for (int64_t k = 0; k < n_steps && rc == RSIK_OK; k++) {
+        const double* cols[12];
+        for (int c = 0; c < 12; c++) cols[c] = m12_steps + ((size_t)k * 12 + c) * (size_t)n;
+        rc = rsik_control_continuous_step(ctx, n, cols, k == 0 ? current_pose_m12_soa : nullptr, arm, arm_uniform,
+                                          k == 0 ? flags : nullptr, preferred_theta, preferred_theta_self_host,
+                                          constrained_mode, d_theta_max, k == 0 ? current_joints : nullptr,
+                                          orbita3d_max_angle, cont_state, joints_steps + (size_t)k * n * 7,
+                                          reachable_steps ? reachable_steps + (size_t)k * n : nullptr,
+                                          state_steps ? state_steps + (size_t)k * n : nullptr);
+    }
+    if (flags) {
+        hipError_t e = hipFreeAsync(flags, ctx->stream);
+        if (e != hipSuccess && rc == RSIK_OK) return hip_fail(ctx, e, "hipFreeAsync");
+    }
+    return rc;
+}
+
 static int fill_state_args(rsik_ctx* ctx, rsik::StateArgs* K, int64_t n, const uint8_t* arm, int arm_uniform,
                            const char* who) {
     if (n < 0) return fail(ctx, RSIK_E_INVALID, std::string(who) + ": n < 0");

@@ -547,3 +547,21 @@ def test_control_continuous_against_checker_dvt_and_emergency(torch_mod, orc):
             prev = Ms[:, i]
         n_em = int(st[9].sum().item())
         assert n_em == sum(s.emergency_stop for s in states) and n_em > 0
+
+
+def test_continuous_run_equals_stepwise(golden_dir, torch_mod):
+    """rsik_control_continuous_run (all steps from one host call) against G7 and against the step-by-step API."""
+    g = load(golden_dir, "g7_control_continuous_start.npz")
+    c = make_control()
+    for arm in ("r_arm", "l_arm"):
+        sel = ~g[f"{arm}_is_dvt"].astype(bool)
+        Ms, J, F, S = (g[f"{arm}_{k}"][sel] for k in ("M", "joints", "reachable", "state"))
+        st = c.new_continuous_state(arm, Ms.shape[0])
+        res = to_np(c.run_continuous_trajectories(arm, np.swapaxes(Ms, 0, 1), st, first_step_timed_out=True,
+                                                  current_joints=g[f"{arm}_start_joints"][sel],
+                                                  current_pose=g[f"{arm}_start_pose"][sel]))
+        np.testing.assert_array_equal(res["reachable"], F.T)
+        np.testing.assert_array_equal(res["state"], S.T)
+        assert np.max(np.abs(res["joints"] - np.swapaxes(J, 0, 1))) < 1e-7
+        out, st2 = _run_continuous(c, arm, Ms, start_joints=g[f"{arm}_start_joints"][sel], start_pose=g[f"{arm}_start_pose"][sel])
+        assert torch_mod.equal(st, st2)
