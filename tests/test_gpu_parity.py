@@ -565,3 +565,34 @@ def test_continuous_run_equals_stepwise(golden_dir, torch_mod):
         assert np.max(np.abs(res["joints"] - np.swapaxes(J, 0, 1))) < 1e-7
         out, st2 = _run_continuous(c, arm, Ms, start_joints=g[f"{arm}_start_joints"][sel], start_pose=g[f"{arm}_start_pose"][sel])
         assert torch_mod.equal(st, st2)
+
+
+# ------------------------------------------------------------------------------------------ oracle-free properties
+def test_fk_of_ik_is_identity_full_size(torch_mod):
+    """Size-independent, checker-free property at the BASELINE size: forward kinematics of the solved joints gives the
+    goal pose back (1 M poses, any theta inside the interval), wherever the solver does not move the goal (no backward
+    wrist shift, no min-distance reduce; singularity_offset = -1.01 so no elbow projection)."""
+    from bench import make_config2_poses
+    from tests.fk_numpy import forward_kinematics
+
+    pos, eul = make_config2_poses(1 << 20, seed=4242)
+    solver, r, l = make_symbolic(-1.01)
+    rng = np.random.default_rng(9)
+    frac = torch_mod.as_tensor(rng.uniform(0.02, 0.98, size=len(pos))).cuda()
+    res = to_np(r.solve_batch(soa(pos, eul, torch_mod), theta=("fraction", frac)))
+    assert res["reachable"].all()
+    from reachy2_symbolic_ik_amd.constants import euler_xyz_extrinsic
+    ca, sa, cb, sb, cc, sc = (f(eul[:, k]) for k in (0, 1, 2) for f in (np.cos, np.sin))
+    Rg = np.empty((len(pos), 3, 3))
+    Rg[:, 0, 0] = cc * cb; Rg[:, 0, 1] = cc * sb * sa - sc * ca; Rg[:, 0, 2] = cc * sb * ca + sc * sa
+    Rg[:, 1, 0] = sc * cb; Rg[:, 1, 1] = sc * sb * sa + cc * ca; Rg[:, 1, 2] = sc * sb * ca - cc * sa
+    Rg[:, 2, 0] = -sb; Rg[:, 2, 1] = cb * sa; Rg[:, 2, 2] = cb * ca
+    assert np.allclose(Rg[0], euler_xyz_extrinsic(eul[0]))
+    s = np.array([0.0, -0.2, 0.0])
+    w = pos + 0.1 * Rg[:, :, 2]
+    dsw = np.linalg.norm(w - s, axis=1)
+    untouched = (w[:, 0] >= 0.02 + 1e-9) & (dsw >= r.shoulder_wrist_min_distance + 1e-9)
+    assert untouched.mean() > 0.8
+    p_fk, R_fk = forward_kinematics(res["joints"][untouched], s, [-15, 0, 10], 0.28, 0.28, 0.10)
+    assert np.max(np.abs(p_fk - pos[untouched])) < 1e-9
+    assert np.max(np.abs(R_fk - Rg[untouched])) < 1e-8
