@@ -384,6 +384,14 @@ def main():
                 "note": "fp64 VALU-bound path (see DESIGN.md): HBM fraction is reported as the contract asks, VALU issue is the binding limit",
             },
         }
+        try:  # HBM traffic per launch as measured by the committed rocprofv3 PMC passes (same workload size only)
+            with open(os.path.join(ROOT, "profiles", "r01", "traffic.json")) as fh:
+                t = json.load(fh).get(str(cfg))
+            if t and t["poses_per_gpu"] == n:
+                line["roofline"]["traffic"] = t["bytes"]
+                line["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (profiles/r01/traffic.json)"
+        except (OSError, ValueError, KeyError):
+            pass
         if cfg == 5:
             line["metric"] = "IK control steps/sec (ControlIK continuous, r_arm trajectories)"
             line["unit"] = "steps/s"

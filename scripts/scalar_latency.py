@@ -1,0 +1,22 @@
+"""Per-call latency of the scalar drop-in API (harness shaped like the reference's src/benchmark/ik_benchmarks.py:12-33)."""
+import contextlib, io, sys, time
+import numpy as np
+sys.path.insert(0, ".")
+from reachy2_symbolic_ik_amd import SymbolicIK, ControlIK
+with contextlib.redirect_stdout(io.StringIO()):
+    ik = SymbolicIK()
+    c = ControlIK(urdf_path="config_files/reachy2_ik_minimal.urdf")
+pose = np.array([[0.3, -0.1, 0.1], [np.radians(20), np.radians(-50), np.radians(20)]])
+pose2 = np.array([[0.55, -0.3, -0.15], [0, -np.pi / 2, 0]])
+def timeit(fn, n=500):
+    fn(); t = time.perf_counter()
+    for _ in range(n): fn()
+    return (time.perf_counter() - t) / n * 1e6
+print("is_reachable            %.1f us" % timeit(lambda: ik.is_reachable(pose2)))
+ok, itv, fn, st = ik.is_reachable(pose2)
+print("get_joints              %.1f us" % timeit(lambda: fn(itv[0])))
+print("get_elbow_position      %.1f us" % timeit(lambda: ik.get_elbow_position(0.3)))
+from scipy.spatial.transform import Rotation as R
+M = np.eye(4); M[:3, :3] = R.from_euler("xyz", pose2[1]).as_matrix(); M[:3, 3] = pose2[0]
+print("ControlIK discrete      %.1f us" % timeit(lambda: c.symbolic_inverse_kinematics("r_arm", M, "discrete")))
+print("ControlIK continuous    %.1f us" % timeit(lambda: c.symbolic_inverse_kinematics("r_arm", M, "continuous")))
