@@ -178,6 +178,9 @@ def main():
     ap.add_argument("--poses", type=int, default=0, help="poses per GPU (default: the BASELINE size)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="N = 1: replay a captured hipGraph of the K launches (measured slower than eager pre-bound launches: "
+                         "63 vs 58 us per 1 M-pose kernel, so eager is the default)")
     args = ap.parse_args()
 
     import torch
@@ -187,6 +190,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("RSIK_BENCH_SINGLE_DEVICE"):
+        local_rank = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -195,7 +200,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group(backend="nccl", device_id=dev)
+        # RSIK_BENCH_BACKEND=gloo + RSIK_BENCH_SINGLE_DEVICE=1: exercise the multi-process path on a 1-GPU box (tests only)
+        backend = os.environ.get("RSIK_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
     n_gpus = world
     cfg = args.config
     n = args.poses or {2: 1 << 20, 3: 1 << 18, 4: 1 << 20, 5: 4096}[cfg]
@@ -320,20 +330,35 @@ def main():
         step()
     fence()
     # ---- timed region: exactly K steps; per-launch kernel time from events on the launch stream
-    # N = 1: one event pair over the whole region (back-to-back launches, includes the ~1.5 us boundaries);
-    # N > 1: one pair per launch so the all-gather is excluded from the kernel time.
+    # N = 1: K back-to-back pre-bound launches (or, with --graph, one replay of a captured hipGraph) bracketed by ONE
+    # event pair: kernel time = elapsed / K, including the ~1.5 us kernel boundaries;
+    # N > 1: one event pair per launch so the all-gather is excluded from the kernel time.
     per_launch = world > 1
+    graph = None
+    if not per_launch and args.graph and cfg != 5:
+        hs = {2: lambda: ik.solver, 3: lambda: ctrl._solver, 4: lambda: dual.solver}[cfg]()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            hs._bind_stream()  # the pre-bound launches go to the capture stream
+            for _ in range(args.steps):
+                step_kernel()
+        hs._bind_stream()
+        graph.replay()  # untimed
+        fence()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps if per_launch else 1)]
     t0 = time.perf_counter()
     if not per_launch:
         ev[0][0].record()
-    for k in range(args.steps):
-        if per_launch:
-            ev[k][0].record()
-        step_kernel()
-        if per_launch:
-            ev[k][1].record()
-            gather()
+    if graph is not None:
+        graph.replay()  # exactly K launches of the hot path
+    else:
+        for k in range(args.steps):
+            if per_launch:
+                ev[k][0].record()
+            step_kernel()
+            if per_launch:
+                ev[k][1].record()
+                gather()
     if not per_launch:
         ev[0][1].record()
     fence()
@@ -368,6 +393,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            "launch": "hipGraph replay of K captured launches" if graph is not None else "eager",
             "config": {"workload": workload, "poses_per_gpu": n, "theta_policy": {2: "interval[0]", 3: "discrete sweep nb=64", 4: "interval[0]", 5: "continuous, d_theta_max=0.01"}[cfg],
                        "collective": "none" if world == 1 else "RCCL all-gather of joints [n,7] f64 + reachable u8 per step"},
             "roofline": {

@@ -703,6 +703,10 @@ __device__ bool grid_theta_candidates(const Acc& A, const Reach& r, double a, do
     }
 #pragma unroll
     for (int j = 0; j < 5; j++) {
+        // an arc that never ends on the circle has no end points to look around: skip the pair when that holds for the
+        // whole wave (wave-uniform branch; e.g. the singularity-plane half never binds with the non-DVT offset, Q18)
+        const bool anchor_valid = (j == 0) ? true : ((j <= 2) ? v1 : v2);
+        if (!__any(anchor_valid)) continue;
         double pos = pymod_2pi(ang[j] - a) * inv_step;   // real-valued grid index of the anchor angle
         pos = (pos < 2.0e9) ? pos : 0.0;                 // also catches NaN
         const int k0 = (int)pos - 1;

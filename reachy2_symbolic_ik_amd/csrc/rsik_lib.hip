@@ -242,8 +242,11 @@ __device__ __forceinline__ void sweep_theta_grid(const DiscreteArgs& K, uint64_t
     }
 }
 
+#ifndef RSIK_DISC_MIN_WAVES
+#define RSIK_DISC_MIN_WAVES 3  // 168 VGPR (28 B scratch) beats 182 VGPR at 2 waves/SIMD: 37.6 vs 39.0 us on config 3
+#endif
 template <bool MIXED>
-__global__ __launch_bounds__(kBlock) void control_discrete_kernel(const DiscreteArgs K) {
+__global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) void control_discrete_kernel(const DiscreteArgs K) {
     __shared__ double lds_out[kBlock / 64][64 * 7];
     __shared__ double lds_geo[kBlock / 64][kGeo][64];
     __shared__ double lds_res[kBlock / 64][64];

@@ -169,3 +169,18 @@ def test_packing_helpers():
     np.testing.assert_array_equal(s.numpy()[3:].T, poses[:, 1])
     with pytest.raises(ValueError):
         poses_to_soa(np.zeros((3, 5)), torch.device("cpu"))
+
+
+def test_utils_format_helpers():
+    """README.md:96-110 builds its goal matrix with these two helpers."""
+    from scipy.spatial.transform import Rotation as R
+
+    from reachy2_symbolic_ik_amd.utils import get_euler_from_homogeneous_matrix, make_homogenous_matrix_from_rotation_matrix
+
+    rot = R.from_euler("xyz", [0.3, -0.7, 1.1]).as_matrix()
+    M = make_homogenous_matrix_from_rotation_matrix([0.55, -0.3, -0.15], rot)
+    assert M.shape == (4, 4) and np.array_equal(M[3], [0, 0, 0, 1]) and np.array_equal(M[:3, :3], rot)
+    pos, eul = get_euler_from_homogeneous_matrix(M)
+    np.testing.assert_allclose(pos, [0.55, -0.3, -0.15])
+    np.testing.assert_allclose(eul, [0.3, -0.7, 1.1], atol=1e-14)
+    assert np.allclose(get_euler_from_homogeneous_matrix(M, degrees=True)[1], np.degrees([0.3, -0.7, 1.1]))
