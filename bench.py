@@ -346,6 +346,7 @@ def main():
         graph.replay()  # untimed
         fence()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps if per_launch else 1)]
+    ev_g = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps if per_launch else 0)]
     t0 = time.perf_counter()
     if not per_launch:
         ev[0][0].record()
@@ -359,15 +360,17 @@ def main():
             if per_launch:
                 ev[k][1].record()
                 gather()
+                ev_g[k].record()
     if not per_launch:
         ev[0][1].record()
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) / (1 if per_launch else args.steps)
+    gather_ms = float(np.mean([ev[k][1].elapsed_time(ev_g[k]) for k in range(len(ev_g))])) if ev_g else 0.0
     if world > 1:
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, kernel_ms, gather_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms = float(t[0]), float(t[1])
+        elapsed, kernel_ms, gather_ms = float(t[0]), float(t[1]), float(t[2])
 
     # sanity: the timed outputs are real results (flags all "reachable" for config 2)
     n_ok = int(out["reachable"].sum().item())
@@ -407,6 +410,8 @@ def main():
                 "algorithmic_bytes_per_pose": bpp,
                 "kernel_ms": kernel_ms,
                 "kernel_only_solves_per_s_per_gpu": n / (kernel_ms * 1e-3),
+                "gather_ms": gather_ms if world > 1 else None,
+                "gather_only_solves_per_s": (n * n_gpus / (gather_ms * 1e-3)) if (world > 1 and gather_ms > 0) else None,
                 "note": "fp64 VALU-bound path (see DESIGN.md): HBM fraction is reported as the contract asks, VALU issue is the binding limit",
             },
         }
