@@ -94,75 +94,79 @@ class ControlIK:
         device: Any = None,
         solver: Optional[HipSolver] = None,
     ) -> None:
+        # public attributes of the reference object (control_ik.py:60-84)
         self.symbolic_ik_solver: Dict[str, SymbolicIK] = {}
-        self.last_call_t: Dict[str, float] = {}
-        self.call_timeout = 0.2
-        self.nb_search_points = 20
-        self.emergency_state = ""
-        self.emergency_stop = False
-        self.init = True
-        self.logger = logger
-        if is_dvt:
-            self.singularity_offset = 0.03
-            if self.logger is not None:
-                self.logger.info("DVT mode activated", throttle_duration_sec=0.1)
-            else:
-                print("DVT mode activated")
-        else:
-            self.singularity_offset = -1.01
-        self.singularity_limit_coeff = 1.0
         self.preferred_theta: Dict[str, float] = {}
         self.previous_theta: Dict[str, float] = {}
         self.previous_sol: Dict[str, npt.NDArray[np.float64]] = {}
         self.previous_pose: Dict[str, npt.NDArray[np.float64]] = {}
+        self.last_call_t: Dict[str, float] = {}
+        self.logger = logger
+        self.call_timeout, self.nb_search_points = 0.2, 20
+        self.emergency_state, self.emergency_stop, self.init = "", False, True
+        self.singularity_offset, self.singularity_limit_coeff = (0.03 if is_dvt else -1.01), 1.0
         self.orbita3D_max_angle = np.deg2rad(42.5)
+        if is_dvt:
+            self._say("DVT mode activated", 0.1)
 
-        if urdf_path == "" and urdf == "":
-            raise ValueError("No URDF provided")
-        if urdf_path != "" and urdf == "":
-            urdf_path = os.path.join(os.path.dirname(__file__), urdf_path)
-            if os.path.isfile(urdf_path) and os.path.getsize(urdf_path) > 0:
-                with open(urdf_path, "r") as fh:
-                    urdf = fh.read()
-            if urdf == "":
-                raise ValueError("Empty URDF file")
-        if reachy_model in ("full_kit", "headless"):
-            arms = ["r", "l"]
-        elif reachy_model == "starter_kit_right":
-            arms = ["r"]
-        elif reachy_model == "starter_kit_left":
-            arms = ["l"]
-        elif reachy_model == "mini":
-            arms = []
+        arms = self._arm_prefixes(reachy_model, self._read_urdf(urdf, urdf_path))
+        self._solver = solver if solver is not None else (HipSolver(device) if arms[0] else None)
+        for prefix in arms[0]:
+            self._add_arm(prefix, arms[1], current_joints, current_pose)
+
+    _MODEL_ARMS = {"full_kit": ["r", "l"], "headless": ["r", "l"], "starter_kit_right": ["r"], "starter_kit_left": ["l"],
+                   "mini": []}
+
+    def _say(self, message: str, throttle: float) -> None:
+        """rclpy-style logger if one was injected, else stdout (control_ik.py:72-75, 200-209)."""
+        if self.logger is None:
+            print(message)
         else:
+            self.logger.info(message, throttle_duration_sec=throttle)
+
+    @staticmethod
+    def _read_urdf(urdf: str, urdf_path: str) -> str:
+        """control_ik.py:86-97: URDF text, or the file at `urdf_path` relative to this package."""
+        if not urdf and not urdf_path:
+            raise ValueError("No URDF provided")
+        if urdf:
+            return urdf
+        path = os.path.join(os.path.dirname(__file__), urdf_path)
+        text = ""
+        if os.path.isfile(path) and os.path.getsize(path) > 0:
+            with open(path, "r") as fh:
+                text = fh.read()
+        if not text:
+            raise ValueError("Empty URDF file")
+        return text
+
+    @classmethod
+    def _arm_prefixes(cls, reachy_model: str, urdf: str):
+        """control_ik.py:98-112: which arms the model has, and their IK parameters from the URDF."""
+        if reachy_model not in cls._MODEL_ARMS:
             raise ValueError(f"Unknown Reachy model {reachy_model}")
+        prefixes = cls._MODEL_ARMS[reachy_model]
         try:
-            ik_parameters = get_ik_parameters_from_urdf(urdf, arms)
+            return prefixes, get_ik_parameters_from_urdf(urdf, prefixes)
         except Exception as e:
             raise ValueError(f"Error while parsing URDF: {e}")
 
-        self._solver = solver if solver is not None else (HipSolver(device) if arms else None)
-        for prefix in arms:
-            arm = f"{prefix}_arm"
-            if ik_parameters != {}:
-                self.symbolic_ik_solver[arm] = SymbolicIK(
-                    arm=arm, ik_parameters=ik_parameters, singularity_offset=self.singularity_offset,
-                    singularity_limit_coeff=self.singularity_limit_coeff, solver=self._solver)
-            else:
-                self.symbolic_ik_solver[arm] = SymbolicIK(
-                    arm=arm, wrist_limit=np.rad2deg(self.orbita3D_max_angle), singularity_offset=self.singularity_offset,
-                    singularity_limit_coeff=self.singularity_limit_coeff, solver=self._solver)
-            preferred_theta = -4 * np.pi / 6
-            k = 0 if prefix == "r" else 1
-            self.preferred_theta[arm] = preferred_theta if prefix == "r" else -np.pi - preferred_theta
-            self.previous_sol[arm] = np.array(current_joints[k])
-            self.previous_pose[arm] = current_pose[k]
-            pose_tuple = self._matrix_to_pose(self.previous_pose[arm])
-            _, _, theta_to_joints_func = self.symbolic_ik_solver[arm].is_reachable_no_limits(pose_tuple)
-            best_prev_theta, _ = get_best_theta_to_current_joints(theta_to_joints_func, 20, current_joints, arm,
-                                                                  self.preferred_theta[arm])
-            self.previous_theta[arm] = best_prev_theta
-            self.last_call_t[arm] = 0.0
+    def _add_arm(self, prefix: str, ik_parameters: Dict[str, Any], current_joints: list, current_pose: list) -> None:
+        """control_ik.py:114-160: one SymbolicIK per arm and the start-up theta that best matches current_joints."""
+        arm, k = f"{prefix}_arm", "rl".index(prefix)
+        kwargs = dict(ik_parameters=ik_parameters) if ik_parameters else dict(wrist_limit=np.rad2deg(self.orbita3D_max_angle))
+        self.symbolic_ik_solver[arm] = SymbolicIK(arm=arm, singularity_offset=self.singularity_offset,
+                                                  singularity_limit_coeff=self.singularity_limit_coeff,
+                                                  solver=self._solver, **kwargs)
+        base = -4 * np.pi / 6
+        self.preferred_theta[arm] = base if k == 0 else -np.pi - base
+        self.previous_sol[arm] = np.array(current_joints[k])
+        self.previous_pose[arm] = current_pose[k]
+        self.last_call_t[arm] = 0.0
+        _, _, joints_of_theta = self.symbolic_ik_solver[arm].is_reachable_no_limits(self._matrix_to_pose(current_pose[k]))
+        # the reference hands over BOTH arms' joint lists here (Q15); kept, since it fixes previous_theta's start value
+        self.previous_theta[arm], _ = get_best_theta_to_current_joints(joints_of_theta, 20, current_joints, arm,
+                                                                       self.preferred_theta[arm])
 
     # ------------------------------------------------------------------ helpers
     @staticmethod
@@ -199,19 +203,11 @@ class ControlIK:
         preferred_theta: float = -4 * np.pi / 6,
     ) -> Tuple[npt.NDArray[np.float64], bool, str]:
         """control_ik.py:162-274."""
-        if control_type == "unfreeze":
-            self.emergency_stop = False
-            self.emergency_state = ""
-            self.init = True
-            if self.logger is not None:
-                self.logger.info(f"{name} Unfreeze", throttle_duration_sec=1.0)
-            else:
-                print(f"{name} Unfreeze")
-        if self.emergency_stop:
-            if self.logger is not None:
-                self.logger.info(f"{name} Emergency state: {self.emergency_state}", throttle_duration_sec=1.0)
-            else:
-                print(f"{name} Emergency state: {self.emergency_state}")
+        if control_type == "unfreeze":  # clears a latched emergency stop, then behaves like "continuous"
+            self.emergency_stop, self.emergency_state, self.init = False, "", True
+            self._say(f"{name} Unfreeze", 1.0)
+        if self.emergency_stop:  # latched: keep returning the last good solution
+            self._say(f"{name} Emergency state: {self.emergency_state}", 1.0)
             return self.previous_sol[name], False, self.emergency_state
         if constrained_mode not in _abi.MODES:
             # the reference leaves interval_limit unbound here (control_ik.py:225-232)
