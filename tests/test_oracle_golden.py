@@ -265,3 +265,24 @@ def test_python_float_mod_semantics():
     for a in np.concatenate([rng.uniform(-20, 20, 200), [0.0, -0.0, 2 * np.pi, -2 * np.pi, np.pi, -np.pi]]):
         for b in (2 * np.pi, -2 * np.pi):
             assert L.orc_pymod(float(a), b) == float(a) % b
+
+
+def test_forward_kinematics_of_reference_joints(golden_dir):
+    """tests/fk_numpy.py (the checker-free FK used by the GPU property test) against the reference's own joints:
+    FK(joints recorded from the reference) == goal pose wherever the reference does not move the goal."""
+    from tests.fk_numpy import forward_kinematics
+
+    g = load(golden_dir, "g3_reachable.npz")
+    for arm, s, off in (("r_arm", [0.0, -0.2, 0.0], [-15, 0, 10]), ("l_arm", [0.0, 0.2, 0.0], [15, 0, -10])):
+        pos, eul, J = g[f"{arm}_pos"], g[f"{arm}_eul"], g[f"{arm}_so101_in_joints"]
+        ca, sa, cb, sb, cc, sc = (f(eul[:, k]) for k in (0, 1, 2) for f in (np.cos, np.sin))
+        Rg = np.empty((len(pos), 3, 3))
+        Rg[:, 0, 0] = cc * cb; Rg[:, 0, 1] = cc * sb * sa - sc * ca; Rg[:, 0, 2] = cc * sb * ca + sc * sa
+        Rg[:, 1, 0] = sc * cb; Rg[:, 1, 1] = sc * sb * sa + cc * ca; Rg[:, 1, 2] = sc * sb * ca - cc * sa
+        Rg[:, 2, 0] = -sb; Rg[:, 2, 1] = cb * sa; Rg[:, 2, 2] = cb * ca
+        w = pos + 0.1 * Rg[:, :, 2]
+        ok = (w[:, 0] >= 0.02 + 1e-9) & (np.linalg.norm(w - np.array(s), axis=1) >= 0.2498725 + 1e-6)
+        assert ok.mean() > 0.7
+        p_fk, R_fk = forward_kinematics(J[ok], s, off, 0.28, 0.28, 0.10)
+        assert np.max(np.abs(p_fk - pos[ok])) < 1e-12
+        assert np.max(np.abs(R_fk - Rg[ok])) < 1e-11
