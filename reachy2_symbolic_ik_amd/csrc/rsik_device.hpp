@@ -180,7 +180,7 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
     // [D] S:284-307
     V3 gp = pos_in;
     V3 dv = gp - s;
-    const double d0 = norm(dv);
+    const double d0 = norm(dv);  // (the fused kernels exit right after this test, so the sqrt is only paid here)
     int st = RSIK_STATE_REACHABLE;
     if (d0 > A(RSIK_C_MAX_LEN)) {
         double nd = d0 + pm;
@@ -329,13 +329,15 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
     double sq = sqrt_cr(disc);
     double ta = (-qb + sq) * inv_2qa, tb = (-qb - sq) * inv_2qa;
     V3 pa = madd(v, ta, q), pb = madd(v, tb, q);
-    double ly1 = dot(a1, pa) + oy, lz1 = dot(a2, pa) + oz;
-    double ly2 = dot(a1, pb) + oy, lz2 = dot(a2, pb) + oz;
+    // Both points lie on circle 2 (the two circles share the wrist sphere), so (ly, lz) / r2 are unit vectors.
+    const double ir2 = (r2 > 0.0) ? fast_rcp(r2) : 0.0;
+    double ly1 = (dot(a1, pa) + oy) * ir2, lz1 = (dot(a2, pa) + oz) * ir2;
+    double ly2 = (dot(a1, pb) + oy) * ir2, lz2 = (dot(a2, pb) + oz) * ir2;
     double ang1, ang2;
     {
-        const double yy[2] = {lz1, lz2}, xx[2] = {ly1, ly2};
+        const double ss[2] = {lz1, lz2}, cc[2] = {ly1, ly2};
         double aa[2];
-        fast_atan2_n<2>(yy, xx, aa);
+        unit_atan2_n<2>(A.utab, ss, cc, aa);
         ang1 = aa[0]; ang2 = aa[1];
     }
     if (ang2 < ang1) {
@@ -351,9 +353,8 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
     bool inside = (dot_d(f1, tp) + tlx) > 0;  // [D] S:564
     r.i0 = inside ? ang1 : ang2;
     r.i1 = inside ? ang2 : ang1;
-    double ly = inside ? ly1 : ly2, lz = inside ? lz1 : lz2;
-    double il = rsqrt_fast(ly * ly + lz * lz);
-    r.ct0 = ly * il; r.st0 = lz * il;
+    r.ct0 = inside ? ly1 : ly2;
+    r.st0 = inside ? lz1 : lz2;
     return r;
 }
 
@@ -403,9 +404,11 @@ __device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, do
         V3 pe = madd(v3, -dist, e);
         V3 V = pe - pc;
         V3 ne = madd(normalized(V), A(RSIK_C_PROJ_RADIUS), pc);
-        r.pos = r.pos + (ne - e);
+        const V3 shift = ne - e;
+        r.pos = r.pos + shift;
         e = ne;
-        r.w = wrist_position(A, Rg, r.pos);
+        // S:718 recomputes the wrist from the moved goal; it is the old wrist moved by the same vector (to rounding)
+        r.w = FRESH ? (r.w + shift) : wrist_position(A, Rg, r.pos);
         o.projected = true;
     }
     o.elbow = e;
@@ -418,9 +421,8 @@ __device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, do
     };
     V3 q = to_shoulder(e);
     // shoulder pitch / roll (S:751-766)
-    // The seven joint angles are pure outputs (no rotation below is built from an angle), so their atan2 are
-    // collected in (ay, ax) and evaluated together at the end, seven polynomials in lock step.
-    double ay[7], ax[7];
+    // The seven joint angles are pure outputs (no rotation below is built from an angle): they are evaluated together
+    // at the end from the normalised direction vectors.
     double cphi, sphi, rho;
     const bool sing_sp = (q.x == 0 && q.z == 0);
     if (sing_sp) {  // [D] exact singularity: keep the previous pitch
@@ -432,8 +434,6 @@ __device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, do
         sqrt_rsqrt(q.x * q.x + q.z * q.z, rho, irho);
         cphi = q.x * irho; sphi = q.z * irho;
     }
-    ay[0] = q.z; ax[0] = q.x;   // shoulder_pitch = -atan2
-    ay[1] = q.y; ax[1] = rho;   // shoulder_roll
     const double iL = A(RSIK_C_INV_U);  // |e - shoulder| = upper arm length by construction
     double cr = rho * iL, srs = q.y * iL;
     // G = Rz(-sr) Ry(-sp): rows g0, g1, g2
@@ -456,8 +456,6 @@ __device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, do
         sqrt_rsqrt(pw.y * pw.y + pw.z * pw.z, sigma, isig);
         ca = pw.z * isig; sa = pw.y * isig;
     }
-    ay[2] = pw.z; ax[2] = -pw.y;  // elbow_yaw = -pi/2 + atan2
-    ay[3] = sigma; ax[3] = pw.x;  // elbow_pitch = -atan2
     const double ilam = FRESH ? A(RSIK_C_INV_F) : rsqrt_fast(fma(sigma, sigma, pw.x * pw.x));
     double cchi = pw.x * ilam, schi = sigma * ilam;
     // H = Ry(-ep) Rx(ey)
@@ -472,10 +470,11 @@ __device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, do
     V3 tl = cvec(A, RSIK_C_TIPL);
     V3 ptip = Rg.apply_add(V3{tl.x, tl.y, 0.0}, r.pos);
     V3 t = to_wrist(ptip);
-    double tau, cw, sw;
-    if (t.x == 0 && t.y == 0) {
-        double w0 = kPi - fast_atan2(t.y, -t.x);
-        if (w0 > kPi) w0 = w0 - kTwoPi;
+    double tau, cw, sw, wr_zero = 0.0;
+    const bool tau_zero = (t.x == 0 && t.y == 0);
+    if (tau_zero) {
+        wr_zero = kPi - fast_atan2(t.y, -t.x);  // +-0 arguments: 0 or pi like the C library
+        double w0 = wr_zero > kPi ? wr_zero - kTwoPi : wr_zero;
         fast_sincos(w0, &sw, &cw);
         tau = 0.0;
     } else {
@@ -483,8 +482,6 @@ __device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, do
         sqrt_rsqrt(t.x * t.x + t.y * t.y, tau, itau);
         cw = t.x * itau; sw = t.y * itau;
     }
-    ay[4] = t.y; ax[4] = -t.x;  // wrist_roll = pi - atan2, wrapped
-    ay[5] = t.z; ax[5] = tau;   // wrist_pitch
     const double imu = FRESH ? A(RSIK_C_INV_TIPZ) : rsqrt_fast(fma(tau, tau, t.z * t.z));  // |tip' - wrist| = |tip_z|
     double cp = tau * imu, spp = t.z * imu;
     // K = Ry(wp) Rz(-wr); only rows 1, 2 are needed for the yaw
@@ -496,10 +493,17 @@ __device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, do
     V3 xe = {dot(g0, xs), dot(g1, xs), dot(g2, xs)};
     V3 xw = {dot(h0, xe), dot(h1, xe), dot(h2, xe)};
     double gy = dot(k1, xw), gz = dot(k2, xw);
-    ay[6] = gy; ax[6] = gz;     // wrist_yaw = -atan2
+    // Six of the seven angles are the directions of vectors that were normalised above: unit_atan2_n (no division).
     double at[7];
-    fast_atan2_n<7>(ay, ax, at);
-    double wr = kPi - at[4];
+    {
+        const double us[6] = {sphi, srs, ca, schi, sw, spp};
+        const double uc[6] = {cphi, cr, -sa, cchi, -cw, cp};
+        double ua[6];
+        unit_atan2_n<6>(A.utab, us, uc, ua);
+        at[0] = ua[0]; at[1] = ua[1]; at[2] = ua[2]; at[3] = ua[3]; at[4] = ua[4]; at[5] = ua[5];
+    }
+    at[6] = fast_atan2(gy, gz);  // wrist_yaw = -atan2: (gy, gz) is a unit vector only for an on-axis tip, so the general form
+    double wr = tau_zero ? wr_zero : (kPi - at[4]);
     if (wr > kPi) wr = wr - kTwoPi;
     o.j[0] = sing_sp ? prev[0] : -at[0];
     o.j[1] = at[1];

@@ -46,22 +46,29 @@ struct Acc {
     const ArmC* a;
     bool isl;
     LdsConst lds;  // MIXED only: this lane's arm block in LDS
+    UnitAtanTab utab;  // LDS copy of the unit-vector atan2 table (rsik_math.hpp)
     __device__ __forceinline__ double operator()(int i) const {
         if constexpr (MIXED) return lds[i];
         else return a[0].v[i];
     }
 };
+// Workgroup-shared read-only data: the per-arm blocks (mixed launches) and the unit-vector atan2 table.
+struct SharedTables {
+    double arm[2][RSIK_ARM_CONSTS_COUNT];
+    double utab[kUnitAtanRows][4];
+};
 template <bool MIXED>
-__device__ __forceinline__ void stage_arm_consts(double (*lds_arm)[RSIK_ARM_CONSTS_COUNT], const ArmC* arms) {
+__device__ __forceinline__ void stage_tables(SharedTables& S, const ArmC* arms) {
     if constexpr (MIXED) {
         for (int k = threadIdx.x; k < 2 * RSIK_ARM_CONSTS_COUNT; k += blockDim.x)
-            lds_arm[k / RSIK_ARM_CONSTS_COUNT][k % RSIK_ARM_CONSTS_COUNT] = arms[k / RSIK_ARM_CONSTS_COUNT].v[k % RSIK_ARM_CONSTS_COUNT];
-        __syncthreads();
+            S.arm[k / RSIK_ARM_CONSTS_COUNT][k % RSIK_ARM_CONSTS_COUNT] = arms[k / RSIK_ARM_CONSTS_COUNT].v[k % RSIK_ARM_CONSTS_COUNT];
     }
+    stage_unit_atan_tab(S.utab);
+    __syncthreads();
 }
 template <bool MIXED>
-__device__ __forceinline__ Acc<MIXED> make_acc(const ArmC* arms, bool isl, double (*lds_arm)[RSIK_ARM_CONSTS_COUNT]) {
-    Acc<MIXED> A{arms, isl, (LdsConst)lds_arm[isl ? 1 : 0]};
+__device__ __forceinline__ Acc<MIXED> make_acc(const ArmC* arms, bool isl, SharedTables& S) {
+    Acc<MIXED> A{arms, isl, (LdsConst)S.arm[isl ? 1 : 0], (UnitAtanTab)&S.utab[0][0]};
     return A;
 }
 
@@ -99,9 +106,9 @@ __global__ __launch_bounds__(kBlock, RSIK_SOLVE_MIN_WAVES) void solve_kernel(con
     const bool live = i < K.n;
     const int64_t ii = live ? i : (K.n - 1);  // tail lanes recompute the last pose; stores are masked
 
-    __shared__ double lds_arm[MIXED ? 2 : 1][RSIK_ARM_CONSTS_COUNT];
-    stage_arm_consts<MIXED>(lds_arm, K.arms);
-    const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[ii] != 0) : false, lds_arm);
+    __shared__ SharedTables lds_tab;
+    stage_tables<MIXED>(lds_tab, K.arms);
+    const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[ii] != 0) : false, lds_tab);
 
     V3 pos = {K.in[0][ii], K.in[1][ii], K.in[2][ii]};
     Rot Rg = rot_from_euler(K.in[3][ii], K.in[4][ii], K.in[5][ii]);
@@ -181,8 +188,7 @@ constexpr int kGeo = 13;  // staged doubles per pose: c2(3) a1(3) a2(3) r2 a ste
 // posts the winner.  nb > 64 is handled by extra rounds of the same lanes.
 template <bool MIXED>
 __device__ __forceinline__ void sweep_theta_grid(const DiscreteArgs& K, uint64_t mask, int lane, bool my_isl,
-                                                 double (*lds_arm)[RSIK_ARM_CONSTS_COUNT], const double (*geo)[64],
-                                                 double* res) {
+                                                 SharedTables& lds_tab, const double (*geo)[64], double* res) {
     const int P = 1 << K.log2p;
     const int G = 64 >> K.log2p;
     const int sub = lane >> K.log2p;
@@ -205,7 +211,7 @@ __device__ __forceinline__ void sweep_theta_grid(const DiscreteArgs& K, uint64_t
         double ga = 0, gstep = 0, gb = 0;
         int src = p < 0 ? lane : p;
         bool isl = MIXED ? (__shfl((int)my_isl, src) != 0) : false;
-        const Acc<MIXED> A = make_acc<MIXED>(K.arms, isl, lds_arm);
+        const Acc<MIXED> A = make_acc<MIXED>(K.arms, isl, lds_tab);
         const int slot = MIXED ? (isl ? 1 : 0) : 0;
         if (p >= 0) {
             V3 c2 = {geo[0][p], geo[1][p], geo[2][p]};
@@ -257,9 +263,9 @@ __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) void control_discrete_
     const bool live = i < K.n;
     const int64_t ii = live ? i : (K.n - 1);
 
-    __shared__ double lds_arm[MIXED ? 2 : 1][RSIK_ARM_CONSTS_COUNT];
-    stage_arm_consts<MIXED>(lds_arm, K.arms);
-    const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[ii] != 0) : false, lds_arm);
+    __shared__ SharedTables lds_tab;
+    stage_tables<MIXED>(lds_tab, K.arms);
+    const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[ii] != 0) : false, lds_tab);
     const int slot = MIXED ? (A.isl ? 1 : 0) : 0;
 
     // C:212-217: M -> pose.  np.allclose(R, I) snaps to the identity; otherwise the reference's Euler
@@ -329,7 +335,7 @@ __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) void control_discrete_
     }
     wave_lds_sync();
     const uint64_t mask = __ballot(coop);
-    sweep_theta_grid<MIXED>(K, mask, lane, A.isl, lds_arm, lds_geo[wave], lds_res[wave]);
+    sweep_theta_grid<MIXED>(K, mask, lane, A.isl, lds_tab, lds_geo[wave], lds_res[wave]);
     wave_lds_sync();
     int st_code = r.state;
     if (need) {
@@ -414,9 +420,9 @@ __global__ __launch_bounds__(kBlock) void control_continuous_kernel(const Contin
     const int64_t ii = live ? i : (K.n - 1);
     const int64_t n = K.n;
 
-    __shared__ double lds_arm[MIXED ? 2 : 1][RSIK_ARM_CONSTS_COUNT];
-    stage_arm_consts<MIXED>(lds_arm, K.arms);
-    const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[ii] != 0) : false, lds_arm);
+    __shared__ SharedTables lds_tab;
+    stage_tables<MIXED>(lds_tab, K.arms);
+    const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[ii] != 0) : false, lds_tab);
     const int slot = MIXED ? (A.isl ? 1 : 0) : 0;
 
     double prev_theta = K.st[0 * n + ii];
@@ -535,10 +541,10 @@ struct StateArgs {
 template <bool MIXED>
 __global__ __launch_bounds__(kBlock) void reach_state_kernel(const StateArgs K) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    __shared__ double lds_arm[MIXED ? 2 : 1][RSIK_ARM_CONSTS_COUNT];
-    stage_arm_consts<MIXED>(lds_arm, K.arms);
+    __shared__ SharedTables lds_tab;
+    stage_tables<MIXED>(lds_tab, K.arms);
     if (i >= K.n) return;
-    const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[i] != 0) : false, lds_arm);
+    const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[i] != 0) : false, lds_tab);
     V3 pos = {K.in[0][i], K.in[1][i], K.in[2][i]};
     double e0 = K.in[3][i], e1 = K.in[4][i], e2 = K.in[5][i];
     Rot Rg = rot_from_euler(e0, e1, e2);
@@ -573,10 +579,10 @@ __device__ __forceinline__ Reach reach_from_state(const double* S) {
 template <bool MIXED>
 __global__ __launch_bounds__(kBlock) void joints_state_kernel(const StateArgs K) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    __shared__ double lds_arm[MIXED ? 2 : 1][RSIK_ARM_CONSTS_COUNT];
-    stage_arm_consts<MIXED>(lds_arm, K.arms);
+    __shared__ SharedTables lds_tab;
+    stage_tables<MIXED>(lds_tab, K.arms);
     if (i >= K.n) return;
-    const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[i] != 0) : false, lds_arm);
+    const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[i] != 0) : false, lds_tab);
     double* S = K.solver_state + i * RSIK_SOLVER_STATE_STRIDE;
     Reach r = reach_from_state(S);
     Rot Rg = rot_from_euler(S[3], S[4], S[5]);
