@@ -122,11 +122,12 @@ __device__ __forceinline__ V3 frame_c0(V3 u) {
 __device__ __forceinline__ Frame frame_from_unit(V3 u) {
     Frame F;
     // Rodrigues I + K + K^2 (1-c)/s^2 with v = e_x x u = (0, -u_z, u_y)
-    double s2 = fma(u.z, u.z, u.y * u.y);
-    double h = (1 - u.x) * fast_rcp(s2);
+    // (1 - c) / s^2 = 1 / (1 + c) for a unit vector; well conditioned for the half space u_x > -1 + 1e-8 left by the
+    // special cases below
+    double h = fast_rcp(1.0 + u.x);
     double yh = u.y * h, zh = u.z * h;
     double yzh = u.y * zh;
-    F.c0 = {fma(-s2, h, 1.0), u.y, u.z};
+    F.c0 = u;
     F.c1 = {-u.y, fma(-u.y, yh, 1.0), -yzh};
     F.c2 = {-u.z, -yzh, fma(-u.z, zh, 1.0)};
     // [D] colinear special cases, numpy.isclose semantics with the tolerance scaled by the 2nd argument
@@ -430,8 +431,9 @@ __device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, do
         fast_sincos(prev[0], &s_, &c_);
         cphi = c_; sphi = -s_; rho = 0.0;
     } else {
-        double irho;
-        sqrt_rsqrt(q.x * q.x + q.z * q.z, rho, irho);
+        const double rho2 = fma(q.x, q.x, q.z * q.z);
+        const double irho = rsqrt_fast(rho2);
+        rho = rho2 * irho;
         cphi = q.x * irho; sphi = q.z * irho;
     }
     const double iL = A(RSIK_C_INV_U);  // |e - shoulder| = upper arm length by construction
@@ -452,8 +454,9 @@ __device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, do
         fast_sincos(prev[2], &sa, &ca);
         sigma = 0.0;
     } else {
-        double isig;
-        sqrt_rsqrt(pw.y * pw.y + pw.z * pw.z, sigma, isig);
+        const double sig2 = fma(pw.y, pw.y, pw.z * pw.z);
+        const double isig = rsqrt_fast(sig2);
+        sigma = sig2 * isig;
         ca = pw.z * isig; sa = pw.y * isig;
     }
     const double ilam = FRESH ? A(RSIK_C_INV_F) : rsqrt_fast(fma(sigma, sigma, pw.x * pw.x));
@@ -478,8 +481,9 @@ __device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, do
         fast_sincos(w0, &sw, &cw);
         tau = 0.0;
     } else {
-        double itau;
-        sqrt_rsqrt(t.x * t.x + t.y * t.y, tau, itau);
+        const double tau2 = fma(t.x, t.x, t.y * t.y);
+        const double itau = rsqrt_fast(tau2);
+        tau = tau2 * itau;
         cw = t.x * itau; sw = t.y * itau;
     }
     const double imu = FRESH ? A(RSIK_C_INV_TIPZ) : rsqrt_fast(fma(tau, tau, t.z * t.z));  // |tip' - wrist| = |tip_z|
@@ -493,16 +497,15 @@ __device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, do
     V3 xe = {dot(g0, xs), dot(g1, xs), dot(g2, xs)};
     V3 xw = {dot(h0, xe), dot(h1, xe), dot(h2, xe)};
     double gy = dot(k1, xw), gz = dot(k2, xw);
-    // Six of the seven angles are the directions of vectors that were normalised above: unit_atan2_n (no division).
+    // All seven angles are directions of normalised vectors: unit_atan2_n (no division), seven in lock step.
+    const double ign = rsqrt_fast(fma(gy, gy, gz * gz));
+    const double c6 = gz * ign, s6 = gy * ign;
     double at[7];
     {
-        const double us[6] = {sphi, srs, ca, schi, sw, spp};
-        const double uc[6] = {cphi, cr, -sa, cchi, -cw, cp};
-        double ua[6];
-        unit_atan2_n<6>(A.utab, us, uc, ua);
-        at[0] = ua[0]; at[1] = ua[1]; at[2] = ua[2]; at[3] = ua[3]; at[4] = ua[4]; at[5] = ua[5];
+        const double us[7] = {sphi, srs, ca, schi, sw, spp, s6};
+        const double uc[7] = {cphi, cr, -sa, cchi, -cw, cp, c6};
+        unit_atan2_n<7>(A.utab, us, uc, at);
     }
-    at[6] = fast_atan2(gy, gz);  // wrist_yaw = -atan2: (gy, gz) is a unit vector only for an on-axis tip, so the general form
     double wr = tau_zero ? wr_zero : (kPi - at[4]);
     if (wr > kPi) wr = wr - kTwoPi;
     o.j[0] = sing_sp ? prev[0] : -at[0];
@@ -515,9 +518,8 @@ __device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, do
     const double el = A(RSIK_C_ELBOW_LIMIT);  // S:853-861
     if (o.j[3] > el) o.j[3] = el;
     if (o.j[3] < -el) o.j[3] = -el;
-    const double ign = rsqrt_fast(gy * gy + gz * gz);
     o.c4 = cw; o.s4 = sw; o.c5 = cp; o.s5 = -spp;
-    o.c6 = gz * ign; o.s6 = gy * ign;
+    o.c6 = c6; o.s6 = s6;
     return o;
 }
 
