@@ -169,7 +169,9 @@ __device__ __forceinline__ V3 wrist_position(const Acc& A, const Rot& Rg, V3 pos
 // reduce_goal_pose_no_limits (S:337-349), get_intersection_circle (S:366-399),
 // get_limitation_wrist_circle (S:401-416) and are_circles_linked (S:427-568).
 // NO_LIMITS = true gives SymbolicIK.is_reachable_no_limits (S:85-119): never fails on reach, interval [-pi, pi].
-template <bool NO_LIMITS, class Acc>
+// KEEP = false (fused kernels that only go on when r.ok): the geometry fields of a failed pose are left unwritten
+// instead of being filled with what the reference leaves on `self` (saves the register copies at every early exit).
+template <bool NO_LIMITS, bool KEEP = true, class Acc>
 __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
     Reach r;
     r.ok = false;
@@ -194,7 +196,7 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
     }
     r.state = st;
     r.stage = 0;
-    r.pos = gp; r.w = gp; r.c2 = gp; r.n2 = gp; r.a1 = gp; r.a2 = gp; r.r2 = 0.0; r.ct0 = 1.0; r.st0 = 0.0;
+    if (KEEP) { r.pos = gp; r.w = gp; r.c2 = gp; r.n2 = gp; r.a1 = gp; r.a2 = gp; r.r2 = 0.0; r.ct0 = 1.0; r.st0 = 0.0; }
     if (!NO_LIMITS && st != RSIK_STATE_REACHABLE) return r;
     r.stage = 1;
 
@@ -222,7 +224,7 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
     } else {
         if (dsw > upf) {  // [D] S:157-161
             r.state = RSIK_STATE_WRIST_OUT_OF_RANGE;
-            r.pos = gp; r.w = w;
+            if (KEEP) { r.pos = gp; r.w = w; }
             return r;
         }
     }
@@ -237,12 +239,13 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
     }
 
     // S:366-399 intersection circle of the shoulder sphere (radius u) and the wrist sphere (radius f)
-    r.pos = self_pos;
-    r.w = w;
     if (d > upf) {  // [D] S:374
         r.state = RSIK_STATE_SHOULD_NOT_HAPPEN;
+        if (KEEP) { r.pos = self_pos; r.w = w; }
         return r;
     }
+    r.pos = self_pos;
+    r.w = w;
     const double inv_d = fast_rcp(d);
     V3 n2 = P * inv_d;
     double r2;
@@ -257,9 +260,9 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
     Frame F2 = frame_from_unit(n2);
     r.c2 = c2; r.r2 = r2; r.n2 = n2; r.a1 = F2.c1; r.a2 = F2.c2;
     r.stage = 2;
-    r.ct0 = -1.0; r.st0 = -1.2246467991473532e-16;  // cos(-pi), sin(-pi) as the reference's np.cos/np.sin return them
     if (NO_LIMITS) {
         r.ok = true; r.state = RSIK_STATE_REACHABLE; r.i0 = -kPi; r.i1 = kPi;
+        r.ct0 = -1.0; r.st0 = -1.2246467991473532e-16;  // cos(-pi), sin(-pi) as np.cos/np.sin return them
         return r;
     }
 
@@ -278,15 +281,20 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
     bool side_ok = (dot_d(f1, p2) + tlx) > 0;
     r.state = side_ok ? RSIK_STATE_REACHABLE : RSIK_STATE_LIMITED_BY_WRIST;
     r.ok = side_ok;
-    r.i0 = side_ok ? -kPi : __builtin_nan("");
-    r.i1 = side_ok ? kPi : __builtin_nan("");
+    // the circles do not cross: whole circle [-pi, pi] or nothing, decided by the side (S:487-509).  Only the early
+    // exits pay for these values.
+    auto whole_or_nothing = [&]() {
+        r.i0 = side_ok ? -kPi : __builtin_nan("");
+        r.i1 = side_ok ? kPi : __builtin_nan("");
+        r.ct0 = -1.0; r.st0 = -1.2246467991473532e-16;  // cos(-pi), sin(-pi) as np.cos/np.sin return them
+    };
 
     const V3 N2 = n2;  // already unit (the reference renormalises: a 1-ulp no-op)
     const double mg = A(RSIK_C_NORMAL_MARGIN);
     // [D] S:475-483 parallel planes
     bool par = (fabs(N2.x - N1.x) < mg && fabs(N2.y - N1.y) < mg && fabs(N2.z - N1.z) < mg) ||
                (fabs(N2.x + N1.x) < mg && fabs(N2.y + N1.y) < mg && fabs(N2.z + N1.z) < mg);
-    if (par) return r;
+    if (par) { whole_or_nothing(); return r; }
 
     // S:588-606 + S:570-586: line of intersection of the two planes.  The reference solves
     // [v1, -v2] t = p2 - p1 by least squares; since v1, v2, (p2-p1 minus its v-part) are coplanar the
@@ -298,7 +306,7 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
     V3 b = p2 - p1;
     double t0 = dot(N2, b) * inv_nv;
     double t1 = dot(N1, b) * inv_nv;
-    if (np_isclose(t1, t0)) return r;  // [D] S:582-583 (Q7)
+    if (np_isclose(t1, t0)) { whole_or_nothing(); return r; }  // [D] S:582-583 (Q7)
     V3 q = madd(v1, t0, p1);
 
     // S:608-645 circle 1 (centre p1, radius r1) with the line (q, v)
@@ -310,7 +318,7 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
         double qc = (wv.x * wv.x + wv.y * wv.y + wv.z * wv.z) - r1 * r1;
         disc = qb * qb - 4 * qa * qc;
     }
-    if (disc < 0) return r;  // [D]
+    if (disc < 0) { whole_or_nothing(); return r; }  // [D]
 
     // S:511-568 angles of the intersection points in the circle-2 frame
     V3 a1 = F2.c1, a2 = F2.c2;
@@ -341,21 +349,20 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
         unit_atan2_n<2>(A.utab, ss, cc, aa);
         ang1 = aa[0]; ang2 = aa[1];
     }
-    if (ang2 < ang1) {
-        double t = ang1; ang1 = ang2; ang2 = t;
-        t = ly1; ly1 = ly2; ly2 = t;
-        t = lz1; lz1 = lz2; lz2 = t;
-    }
+    // S:548-566: the sorted pair [lo, hi] is the interval when the mid-angle point lies on the allowed side of the
+    // wrist-limit plane, [hi, lo] otherwise.  The mid angle is symmetric in the two points, so no sort is needed:
+    // interval[0] belongs to point 1 exactly when (inside != (ang2 < ang1)).
     double am = (ang1 + ang2) / 2;
     double sm, cm;
     fast_sincos(am, &sm, &cm);
     double ty = cm * r2, tz = sm * r2;
     V3 tp = madd(a1, ty, madd(a2, tz, p2));
-    bool inside = (dot_d(f1, tp) + tlx) > 0;  // [D] S:564
-    r.i0 = inside ? ang1 : ang2;
-    r.i1 = inside ? ang2 : ang1;
-    r.ct0 = inside ? ly1 : ly2;
-    r.st0 = inside ? lz1 : lz2;
+    const bool inside = (dot_d(f1, tp) + tlx) > 0;  // [D] S:564
+    const bool first = inside != (ang2 < ang1);
+    r.i0 = first ? ang1 : ang2;
+    r.i1 = first ? ang2 : ang1;
+    r.ct0 = first ? ly1 : ly2;
+    r.st0 = first ? lz1 : lz2;
     return r;
 }
 

@@ -52,6 +52,18 @@ struct Acc {
         else return a[0].v[i];
     }
 };
+// Same, with the uniform block addressed through an explicit kernarg-segment (constant address space) pointer.
+typedef const __attribute__((address_space(4))) double* KConst;
+template <bool MIXED>
+struct AccK {
+    KConst k;
+    LdsConst lds;
+    UnitAtanTab utab;
+    __device__ __forceinline__ double operator()(int i) const {
+        if constexpr (MIXED) return lds[i];
+        else return k[i];
+    }
+};
 // Workgroup-shared read-only data: the per-arm blocks (mixed launches) and the unit-vector atan2 table.
 struct SharedTables {
     double arm[2][RSIK_ARM_CONSTS_COUNT];
@@ -93,53 +105,76 @@ __device__ __forceinline__ void store_rows(double* __restrict__ out, int64_t wav
     __builtin_amdgcn_wave_barrier();
 }
 
+// Second half of store_rows for values the lanes have already put in LDS.
+template <int W>
+__device__ __forceinline__ void flush_rows(double* __restrict__ out, int64_t wave_base, int64_t n, int lane,
+                                           const double* __restrict__ lds_rows) {
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    int64_t rows = n - wave_base;
+    if (rows > 64) rows = 64;
+    const int64_t total = rows * W;
+    double* dst = out + wave_base * W;
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+        int idx = k * 64 + lane;
+        if (idx < total) dst[idx] = lds_rows[idx];
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 #ifndef RSIK_SOLVE_MIN_WAVES
 #define RSIK_SOLVE_MIN_WAVES 1
 #endif
+// Poses per thread: a workgroup walks RSIK_SOLVE_PPT consecutive tiles of kBlock poses; the six input columns of the
+// next tile are requested before the current tile is solved, so that only the first tile of a wave sees HBM latency.
+#ifndef RSIK_SOLVE_PPT
+#define RSIK_SOLVE_PPT 1
+#endif
+constexpr int kSolvePPT = RSIK_SOLVE_PPT;
+
+typedef const __attribute__((address_space(4))) SolveArgs& SolveArgsK;  // the kernarg segment itself
 template <bool MIXED>
-__global__ __launch_bounds__(kBlock, RSIK_SOLVE_MIN_WAVES) void solve_kernel(const SolveArgs K) {
-    __shared__ double lds[kBlock / 64][64 * 7];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const int64_t wave_base = (int64_t)blockIdx.x * kBlock + wave * 64;
-    const bool live = i < K.n;
-    const int64_t ii = live ? i : (K.n - 1);  // tail lanes recompute the last pose; stores are masked
+__device__ __forceinline__ void solve_one(SolveArgsK K, const AccK<MIXED>& A, double* lds_wave, int64_t i,
+                                          int64_t ii, int64_t wave_base, int lane, const double (&in)[6]) {
+    const V3 pos = {in[0], in[1], in[2]};
+    Rot Rg = rot_from_euler(in[3], in[4], in[5]);
 
-    __shared__ SharedTables lds_tab;
-    stage_tables<MIXED>(lds_tab, K.arms);
-    const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[ii] != 0) : false, lds_tab);
+    Reach r = reach<false, false>(A, pos, Rg);
 
-    V3 pos = {K.in[0][ii], K.in[1][ii], K.in[2][ii]};
-    Rot Rg = rot_from_euler(K.in[3][ii], K.in[4][ii], K.in[5][ii]);
-
-    Reach r = reach<false>(A, pos, Rg);
-
-    const double nan = __builtin_nan("");
-    double jv[7] = {nan, nan, nan, nan, nan, nan, nan};
-    double ev[3] = {nan, nan, nan};
-    if (K.theta_policy != RSIK_THETA_NONE && r.ok) {
-        double ct = r.ct0, st = r.st0;  // theta = interval[0]: cos/sin come straight from the intersection point
-        if (K.theta_policy != RSIK_THETA_INTERVAL0) {
-            double theta;
-            if (K.theta_policy == RSIK_THETA_EXPLICIT) theta = K.theta_in[ii];
-            else {
-                double a = r.i0, b = r.i1;
-                if (a > b) b += kTwoPi;
-                theta = a + K.theta_in[ii] * (b - a);
-            }
-            fast_sincos(theta, &st, &ct);
-        }
-        JointsOut o = joints_from_theta<true>(A, r, Rg, ct, st, K.prev);
-#pragma unroll
-        for (int k = 0; k < 7; k++) jv[k] = o.j[k];
-        ev[0] = o.elbow.x; ev[1] = o.elbow.y; ev[2] = o.elbow.z;
-    }
+    // joints [64,7] and elbow [64,3] of the wave are staged in LDS (row-major, as they go to HBM) by whichever branch
+    // the lane takes, then written out with coalesced rows: failed poses only cost their NaN fill when one exists
     if (K.theta_policy != RSIK_THETA_NONE) {
-        if (K.joints) store_rows<7>(K.joints, wave_base, K.n, lane, lds[wave], jv);
-        if (K.elbow) store_rows<3>(K.elbow, wave_base, K.n, lane, lds[wave], ev);
+        double* jrow = lds_wave + lane * 7;
+        double* erow = lds_wave + 64 * 7 + lane * 3;
+        if (r.ok) {
+            double ct = r.ct0, st = r.st0;  // theta = interval[0]: cos/sin come straight from the intersection point
+            if (K.theta_policy != RSIK_THETA_INTERVAL0) {
+                double theta;
+                if (K.theta_policy == RSIK_THETA_EXPLICIT) theta = K.theta_in[ii];
+                else {
+                    double a = r.i0, b = r.i1;
+                    if (a > b) b += kTwoPi;
+                    theta = a + K.theta_in[ii] * (b - a);
+                }
+                fast_sincos(theta, &st, &ct);
+            }
+            JointsOut o = joints_from_theta<true>(A, r, Rg, ct, st, (const double*)K.prev);
+#pragma unroll
+            for (int k = 0; k < 7; k++) jrow[k] = o.j[k];
+            erow[0] = o.elbow.x; erow[1] = o.elbow.y; erow[2] = o.elbow.z;
+        } else {
+            const double nan = __builtin_nan("");
+#pragma unroll
+            for (int k = 0; k < 7; k++) jrow[k] = nan;
+            erow[0] = nan; erow[1] = nan; erow[2] = nan;
+        }
+        if (wave_base < K.n) {
+            if (K.joints) flush_rows<7>(K.joints, wave_base, K.n, lane, lds_wave);
+            if (K.elbow) flush_rows<3>(K.elbow, wave_base, K.n, lane, lds_wave + 64 * 7);
+        }
     }
-    if (live) {
+    if (i < K.n) {
         if (K.interval) {
             double2 iv = {r.i0, r.i1};
             reinterpret_cast<double2*>(K.interval)[i] = iv;
@@ -147,6 +182,64 @@ __global__ __launch_bounds__(kBlock, RSIK_SOLVE_MIN_WAVES) void solve_kernel(con
         if (K.reachable) K.reachable[i] = r.ok ? 1 : 0;
         if (K.state) K.state[i] = (uint8_t)r.state;
     }
+}
+
+template <bool MIXED>
+__global__ __launch_bounds__(kBlock, RSIK_SOLVE_MIN_WAVES) void solve_kernel(const SolveArgs K) {
+    __shared__ double lds[kBlock / 64][64 * 10];
+    __shared__ SharedTables lds_tab;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t tile0 = (int64_t)blockIdx.x * (kBlock * kSolvePPT);
+    const int64_t last = K.n - 1;
+
+#ifdef RSIK_CLOCK_PROBE
+    const uint64_t probe_c0 = __builtin_readcyclecounter(), probe_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // the six pose loads are issued before the table staging barrier so that their latency overlaps it
+    double cur[6];
+    {
+        const int64_t i0 = tile0 + threadIdx.x;
+        const int64_t ii0 = i0 < K.n ? i0 : last;  // tail lanes recompute the last pose; stores are masked
+#pragma unroll
+        for (int k = 0; k < 6; k++) cur[k] = K.in[k][ii0];
+    }
+    stage_tables<MIXED>(lds_tab, K.arms);
+#pragma unroll 1
+    for (int it = 0; it < kSolvePPT; ++it) {
+        const int64_t i = tile0 + (int64_t)it * kBlock + threadIdx.x;
+        const int64_t ii = i < K.n ? i : last;
+        double nxt[6];
+        if (it + 1 < kSolvePPT) {
+            const int64_t in_ = i + kBlock;
+            const int64_t iin = in_ < K.n ? in_ : last;
+#pragma unroll
+            for (int k = 0; k < 6; k++) nxt[k] = K.in[k][iin];
+        }
+        // the kernarg pointer is laundered through an empty asm every tile: otherwise the compiler hoists the ~50
+        // scalar constant loads and every launch-uniform subexpression out of the tile loop and spills
+        const __attribute__((address_space(4))) SolveArgs* Kp =
+            (const __attribute__((address_space(4))) SolveArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+        if (kSolvePPT > 1) asm volatile("" : "+s"(Kp));
+        const AccK<MIXED> A{(KConst)&Kp->arms[0].v[0], (LdsConst)lds_tab.arm[(MIXED && Kp->arm[ii] != 0) ? 1 : 0],
+                            (UnitAtanTab)&lds_tab.utab[0][0]};
+        int lane_t = lane;  // same for the lane-derived store indices
+        if (kSolvePPT > 1) asm volatile("" : "+v"(lane_t));
+        solve_one<MIXED>(*Kp, A, lds[wave], i, ii, tile0 + (int64_t)it * kBlock + wave * 64, lane_t, cur);
+        if (it + 1 < kSolvePPT) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) cur[k] = nxt[k];
+        }
+    }
+#ifdef RSIK_CLOCK_PROBE
+    // diagnostic build only (scripts/clock_probe.py): lane 0 of every wave overwrites its interval row with the wave's
+    // lifetime in core-clock ticks (s_memtime) and in 100 MHz ticks (s_memrealtime)
+    if (lane == 0 && K.interval && tile0 + threadIdx.x < K.n) {
+        const uint64_t c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+        double2 iv = {(double)(c1 - probe_c0), (double)(r1 - probe_r0)};
+        reinterpret_cast<double2*>(K.interval)[tile0 + threadIdx.x] = iv;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -783,7 +876,8 @@ int rsik_solve(rsik_ctx* ctx, int64_t n, const double* const pose_soa[6], const 
     if (arm) { K.arms[0] = ctx->arms[0]; K.arms[1] = ctx->arms[1]; }
     else { K.arms[0] = ctx->arms[arm_uniform]; K.arms[1] = ctx->arms[arm_uniform]; }
     RSIK_HIP(ctx, hipSetDevice(ctx->device));
-    const int64_t blocks = (n + rsik::kBlock - 1) / rsik::kBlock;
+    const int64_t tile = (int64_t)rsik::kBlock * rsik::kSolvePPT;
+    const int64_t blocks = (n + tile - 1) / tile;
     if (blocks > 0x7fffffffLL) return fail(ctx, RSIK_E_INVALID, "rsik_solve: n too large for one launch");
     dim3 grid((unsigned)blocks), block(rsik::kBlock);
     if (arm) hipLaunchKernelGGL(rsik::solve_kernel<true>, grid, block, 0, ctx->stream, K);
