@@ -100,7 +100,8 @@ enum {
     RSIK_C_INV_F = 47,        /* 1 / forearm_size                                          */
     RSIK_C_INV_TIPZ = 48,     /* 1 / |tip_position[2]|                                     */
     RSIK_C_INV_GRIP = 49,     /* 1 / gripper_size = 1 / |tip_position|                     */
-    RSIK_ARM_CONSTS_COUNT = 50
+    RSIK_C_MAX_LEN_SQ = 50,   /* largest double x with sqrt(x) <= max_arm_length: |v| > max_arm_length <=> v.v > x, bit for bit */
+    RSIK_ARM_CONSTS_COUNT = 51
 };
 
 typedef struct rsik_ctx rsik_ctx;

@@ -8,6 +8,7 @@ Layout of the packed block = the RSIK_C_* offsets of include/rsik.h.
 """
 from __future__ import annotations
 
+import math
 import xml.etree.ElementTree as ET
 from io import StringIO
 from typing import Any, Dict, List
@@ -19,7 +20,7 @@ C_SHOULDER, C_UPPER_ARM, C_FOREARM, C_TIPL, C_MAX_LEN, C_MIN_DIST, C_BACKWARD = 
 C_PROJ_MARGIN, C_NORMAL_MARGIN, C_UPF, C_WRIST_R, C_WRIST_AX, C_MST, C_TSH, C_ES = 11, 12, 13, 14, 15, 16, 25, 28
 C_SING_OFFSET, C_SING_COEFF, C_ELBOW_LIMIT, C_SIDE, C_PLANE_P, C_PLANE_N = 31, 32, 33, 34, 35, 38
 C_PROJ_CENTER, C_PROJ_RADIUS, C_TIP_Z = 41, 44, 45
-C_INV_U, C_INV_F, C_INV_TIPZ, C_INV_GRIP, ARM_CONSTS_COUNT = 46, 47, 48, 49, 50
+C_INV_U, C_INV_F, C_INV_TIPZ, C_INV_GRIP, C_MAX_LEN_SQ, ARM_CONSTS_COUNT = 46, 47, 48, 49, 50, 51
 
 ARM_IDS = {"r_arm": 0, "l_arm": 1}
 
@@ -161,7 +162,22 @@ class ArmGeometry:
             c[C_INV_F] = 1.0 / self.forearm_size
             c[C_INV_TIPZ] = 1.0 / abs(self.tip_position[2])
             c[C_INV_GRIP] = 1.0 / self.gripper_size
+        c[C_MAX_LEN_SQ] = sqrt_threshold(self.max_arm_length)
         return c
+
+
+def sqrt_threshold(limit: float) -> float:
+    """Largest double x with sqrt(x) <= limit (sqrt correctly rounded, hence monotonic): the kernels test
+    `v.v > x` instead of `sqrt(v.v) > limit` (symbolic_ik.py:290) with the same outcome for every input."""
+    limit = float(limit)
+    if not (limit > 0.0) or not math.isfinite(limit):
+        return limit * limit
+    x = limit * limit
+    while math.sqrt(x) > limit:
+        x = math.nextafter(x, 0.0)
+    while math.sqrt(math.nextafter(x, math.inf)) <= limit:
+        x = math.nextafter(x, math.inf)
+    return x
 
 
 def parse_vector(vector_str: str) -> np.ndarray:

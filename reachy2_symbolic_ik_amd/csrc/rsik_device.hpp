@@ -183,10 +183,12 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
     // [D] S:284-307
     V3 gp = pos_in;
     V3 dv = gp - s;
-    const double d0 = norm(dv);  // (the fused kernels exit right after this test, so the sqrt is only paid here)
+    // |dv| > max_arm_length decided on the squared length against the exact threshold (RSIK_C_MAX_LEN_SQ): the
+    // square root is only paid by poses that are projected back
+    const double ss0 = dot_d(dv, dv);
     int st = RSIK_STATE_REACHABLE;
-    if (d0 > A(RSIK_C_MAX_LEN)) {
-        double nd = d0 + pm;
+    if (ss0 > A(RSIK_C_MAX_LEN_SQ)) {
+        double nd = sqrt_cr(ss0) + pm;
         gp = madd(dv * fast_rcp(nd), A(RSIK_C_MAX_LEN), s);
         st = RSIK_STATE_POSE_OUT_OF_REACH;
     }
@@ -209,8 +211,9 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
         else w.x = w.x + diff;
     }
     V3 P = w - s;
-    double dsw = norm(P);
-    double d = dsw;  // get_intersection_circle recomputes the same norm (S:373); only the min-distance branch changes it
+    double dsw, inv_d;  // get_intersection_circle recomputes the same norm (S:373); only the rare branches change it
+    sqrt_rsqrt(dot_d(P, P), dsw, inv_d);
+    double d = dsw;
     V3 self_pos = gp;  // what ends up in self.goal_pose (differs from the local only in the NO_LIMITS far case, Q4)
     if (NO_LIMITS) {
         if (dsw > upf) {  // S:102-105: self.wrist_position moved onto the sphere, self.goal_pose shifted
@@ -219,7 +222,7 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
             self_pos = gp + (nw - w);
             w = nw;
             P = w - s;
-            d = norm(P);
+            sqrt_rsqrt(dot_d(P, P), d, inv_d);
         }
     } else {
         if (dsw > upf) {  // [D] S:157-161
@@ -235,7 +238,7 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
         w = wrist_position(A, Rg, gp);
         self_pos = gp;
         P = w - s;
-        d = norm(P);
+        sqrt_rsqrt(dot_d(P, P), d, inv_d);
     }
 
     // S:366-399 intersection circle of the shoulder sphere (radius u) and the wrist sphere (radius f)
@@ -246,15 +249,17 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
     }
     r.pos = self_pos;
     r.w = w;
-    const double inv_d = fast_rcp(d);
     V3 n2 = P * inv_d;
-    double r2;
+    double r2, ir2;  // radius and its reciprocal (0 for the degenerate circle)
     V3 c2;
     {
         double d2 = d * d, k = d2 - f * f + u * u;
         // [D] the radicand is exactly 0 for a fully extended arm (Q23) and must not become -1e-18 through an fma
         double rad = 4 * d2 * (u * u) - k * k;
-        r2 = (0.5 * inv_d) * ((rad == 0.0) ? 0.0 : sqrt_cr(rad));
+        double srad = 0.0, irad = 0.0;
+        if (rad != 0.0) sqrt_rsqrt(rad, srad, irad);
+        r2 = (0.5 * inv_d) * srad;
+        ir2 = (d + d) * irad;
         c2 = s + n2 * (k * (0.5 * inv_d));
     }
     Frame F2 = frame_from_unit(n2);
@@ -325,7 +330,7 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
     double oy = -dot(a1, p2), oz = -dot(a2, p2);  // translation of T_intersection_torso
     r.ok = true;
     r.state = RSIK_STATE_REACHABLE;
-    const double inv_2qa = fast_rcp(2 * qa);
+    const double inv_2qa = fma(-0.5, qa, 1.0);  // 1 / (2 qa) for qa = |v|^2 = 1 + O(1e-16)
     if (disc == 0) {  // [D] tangent: interval [a, a] (Q8)
         double t = -qb * inv_2qa;
         V3 p = madd(v, t, q);
@@ -339,7 +344,6 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
     double ta = (-qb + sq) * inv_2qa, tb = (-qb - sq) * inv_2qa;
     V3 pa = madd(v, ta, q), pb = madd(v, tb, q);
     // Both points lie on circle 2 (the two circles share the wrist sphere), so (ly, lz) / r2 are unit vectors.
-    const double ir2 = (r2 > 0.0) ? fast_rcp(r2) : 0.0;
     double ly1 = (dot(a1, pa) + oy) * ir2, lz1 = (dot(a2, pa) + oz) * ir2;
     double ly2 = (dot(a1, pb) + oy) * ir2, lz2 = (dot(a2, pb) + oz) * ir2;
     double ang1, ang2;

@@ -76,6 +76,7 @@ __device__ __forceinline__ void stage_tables(SharedTables& S, const ArmC* arms) 
             S.arm[k / RSIK_ARM_CONSTS_COUNT][k % RSIK_ARM_CONSTS_COUNT] = arms[k / RSIK_ARM_CONSTS_COUNT].v[k % RSIK_ARM_CONSTS_COUNT];
     }
     stage_unit_atan_tab(S.utab);
+    stage_sincos_tab();
     __syncthreads();
 }
 template <bool MIXED>
@@ -696,6 +697,8 @@ __global__ __launch_bounds__(kBlock) void joints_state_kernel(const StateArgs K)
 
 __global__ __launch_bounds__(kBlock) void elbow_state_kernel(const StateArgs K) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    stage_sincos_tab();
+    __syncthreads();
     if (i >= K.n) return;
     const double* S = K.solver_state + i * RSIK_SOLVER_STATE_STRIDE;
     Reach r = reach_from_state(S);
@@ -708,6 +711,8 @@ __global__ __launch_bounds__(kBlock) void elbow_state_kernel(const StateArgs K) 
 // Unit-test hook for rsik_math.hpp (rsik_debug_math): op 0 rcp, 1 sqrt_cr, 2 rsqrt, 3 atan2(a,b), 4 sincos(a), 5 a % 2pi
 __global__ void debug_math_kernel(int op, int64_t n, const double* a, const double* b, double* o0, double* o1) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    stage_sincos_tab();
+    __syncthreads();
     if (i >= n) return;
     double x = a[i], r0 = 0.0, r1 = 0.0;
     switch (op) {
