@@ -18,6 +18,15 @@
 
 namespace rsik {
 
+// Conditions that are false for generic input (projections, clamps, exact singularities).  -DRSIK_HOT_ONLY compiles
+// them out: an ANALYSIS build whose static instruction mix is the executed mix of the common path (scripts/isa_hist.py).
+#ifdef RSIK_HOT_ONLY
+#define RSIK_RARE(c) (false)
+#else
+#define RSIK_RARE(c) (__builtin_expect(!!(c), 0))
+#endif
+
+
 constexpr double kPi = 3.141592653589793;  // == math.pi
 constexpr double kTwoPi = 2 * kPi;
 
@@ -110,10 +119,14 @@ struct Frame {
 };
 // u must already be normalised (the reference divides by the norm first, U:66).  The two colinear special cases
 // need |u_y|, |u_z| <~ 1e-8: one rarely-taken branch, kept out of the straight-line code.
-__device__ __forceinline__ bool frame_is_special(V3 u) { return np_isclose(0.0, u.y) && np_isclose(0.0, u.z); }
+// (one max + one compare on the common path: the isclose pair can only hold below 2e-8)
+__device__ __forceinline__ bool frame_is_special(V3 u) {
+    if (!RSIK_RARE(fmax(fabs(u.y), fabs(u.z)) < 2e-8)) return false;
+    return np_isclose(0.0, u.y) && np_isclose(0.0, u.z);
+}
 __device__ __forceinline__ V3 frame_c0(V3 u) {
     V3 c0 = u;  // R00 = 1 - s^2 (1-c)/s^2 = c to rounding
-    if (__builtin_expect(frame_is_special(u), 0)) {
+    if (RSIK_RARE(frame_is_special(u))) {
         if (np_isclose(1.0, u.x)) c0 = {1, 0, 0};
         else if (np_isclose(1.0, -u.x)) c0 = {-1, 0, 0};
     }
@@ -131,7 +144,7 @@ __device__ __forceinline__ Frame frame_from_unit(V3 u) {
     F.c1 = {-u.y, fma(-u.y, yh, 1.0), -yzh};
     F.c2 = {-u.z, -yzh, fma(-u.z, zh, 1.0)};
     // [D] colinear special cases, numpy.isclose semantics with the tolerance scaled by the 2nd argument
-    if (__builtin_expect(frame_is_special(u), 0)) {
+    if (RSIK_RARE(frame_is_special(u))) {
         if (np_isclose(1.0, u.x)) { F.c0 = {1, 0, 0}; F.c1 = {0, 1, 0}; F.c2 = {0, 0, 1}; }
         else if (np_isclose(1.0, -u.x)) { F.c0 = {-1, 0, 0}; F.c1 = {0, 1, 0}; F.c2 = {0, 0, -1}; }
     }
@@ -158,12 +171,26 @@ __device__ __forceinline__ V3 cvec(const Acc& A, int off) {
     return {A(off), A(off + 1), A(off + 2)};
 }
 
-// S:418-425 — wrist = T_torso_goal . (-tip_x, tip_y, tip_z, 1)
+// What the path needs from the goal orientation R: R.(-tip_x, tip_y, tip_z) (wrist offset, S:418-425),
+// R.(-tip_x, tip_y, 0) (the "tip" point of S:808-812 relative to the goal position) and R's first column (S:839).
+// Nine doubles like R itself, but each is only live where it is used (the fused solve kernel parks the last two in
+// LDS while the reachability stage runs).
+struct Goal {
+    V3 woff, toff, xg;
+};
 template <class Acc>
-__device__ __forceinline__ V3 wrist_position(const Acc& A, const Rot& Rg, V3 pos) {
-    V3 tl = cvec(A, RSIK_C_TIPL);
-    return Rg.apply_d(tl, pos);
+__device__ __forceinline__ Goal make_goal(const Acc& A, const Rot& Rg) {
+    const V3 tl = cvec(A, RSIK_C_TIPL);
+    Goal g;
+    // unfused, left to right: wrist = (R.tl) + pos rounds exactly like the reference's 4x4 product (S:422-424)
+    g.woff = {Rg.m[0] * tl.x + Rg.m[1] * tl.y + Rg.m[2] * tl.z, Rg.m[3] * tl.x + Rg.m[4] * tl.y + Rg.m[5] * tl.z,
+              Rg.m[6] * tl.x + Rg.m[7] * tl.y + Rg.m[8] * tl.z};
+    g.toff = {fma(Rg.m[0], tl.x, Rg.m[1] * tl.y), fma(Rg.m[3], tl.x, Rg.m[4] * tl.y), fma(Rg.m[6], tl.x, Rg.m[7] * tl.y)};
+    g.xg = Rg.col0();
+    return g;
 }
+// S:418-425 — wrist = T_torso_goal . (-tip_x, tip_y, tip_z, 1)
+__device__ __forceinline__ V3 wrist_position(const V3& woff, V3 pos) { return woff + pos; }
 
 // SymbolicIK.is_reachable (S:121-282) including is_pose_in_robot_reach (S:284-307),
 // reduce_goal_pose_no_limits (S:337-349), get_intersection_circle (S:366-399),
@@ -172,7 +199,7 @@ __device__ __forceinline__ V3 wrist_position(const Acc& A, const Rot& Rg, V3 pos
 // KEEP = false (fused kernels that only go on when r.ok): the geometry fields of a failed pose are left unwritten
 // instead of being filled with what the reference leaves on `self` (saves the register copies at every early exit).
 template <bool NO_LIMITS, bool KEEP = true, class Acc>
-__device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
+__device__ Reach reach_g(const Acc& A, V3 pos_in, const V3 woff) {
     Reach r;
     r.ok = false;
     r.i0 = r.i1 = __builtin_nan("");
@@ -187,12 +214,12 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
     // square root is only paid by poses that are projected back
     const double ss0 = dot_d(dv, dv);
     int st = RSIK_STATE_REACHABLE;
-    if (ss0 > A(RSIK_C_MAX_LEN_SQ)) {
+    if (RSIK_RARE(ss0 > A(RSIK_C_MAX_LEN_SQ))) {
         double nd = sqrt_cr(ss0) + pm;
         gp = madd(dv * fast_rcp(nd), A(RSIK_C_MAX_LEN), s);
         st = RSIK_STATE_POSE_OUT_OF_REACH;
     }
-    if (gp.x < bl) {
+    if (RSIK_RARE(gp.x < bl)) {
         gp.x = bl;
         st = RSIK_STATE_BACKWARD_POSE;
     }
@@ -202,12 +229,12 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
     if (!NO_LIMITS && st != RSIK_STATE_REACHABLE) return r;
     r.stage = 1;
 
-    V3 w = wrist_position(A, Rg, gp);
+    V3 w = wrist_position(woff, gp);
     // [D] S:146-153 / S:94-98
-    if (w.x < bl) {
+    if (RSIK_RARE(w.x < bl)) {
         double diff = bl - w.x;
         gp.x = gp.x + diff;
-        if (NO_LIMITS) w = wrist_position(A, Rg, gp);
+        if (NO_LIMITS) w = wrist_position(woff, gp);
         else w.x = w.x + diff;
     }
     V3 P = w - s;
@@ -216,7 +243,7 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
     double d = dsw;
     V3 self_pos = gp;  // what ends up in self.goal_pose (differs from the local only in the NO_LIMITS far case, Q4)
     if (NO_LIMITS) {
-        if (dsw > upf) {  // S:102-105: self.wrist_position moved onto the sphere, self.goal_pose shifted
+        if (RSIK_RARE(dsw > upf)) {  // S:102-105: self.wrist_position moved onto the sphere, self.goal_pose shifted
             double nd = fabs(dsw) + pm;
             V3 nw = madd((w - s) * fast_rcp(nd), upf, s);
             self_pos = gp + (nw - w);
@@ -225,24 +252,24 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
             sqrt_rsqrt(dot_d(P, P), d, inv_d);
         }
     } else {
-        if (dsw > upf) {  // [D] S:157-161
+        if (RSIK_RARE(dsw > upf)) {  // [D] S:157-161
             r.state = RSIK_STATE_WRIST_OUT_OF_RANGE;
             if (KEEP) { r.pos = gp; r.w = w; }
             return r;
         }
     }
-    if (dsw < A(RSIK_C_MIN_DIST)) {  // [D] S:166-171 / S:107-112
+    if (RSIK_RARE(dsw < A(RSIK_C_MIN_DIST))) {  // [D] S:166-171 / S:107-112
         double nd = fabs(dsw) + pm;
         V3 nw = madd((w - s) * fast_rcp(nd), A(RSIK_C_MIN_DIST), s);
         gp = gp + (nw - w);
-        w = wrist_position(A, Rg, gp);
+        w = wrist_position(woff, gp);
         self_pos = gp;
         P = w - s;
         sqrt_rsqrt(dot_d(P, P), d, inv_d);
     }
 
     // S:366-399 intersection circle of the shoulder sphere (radius u) and the wrist sphere (radius f)
-    if (d > upf) {  // [D] S:374
+    if (RSIK_RARE(d > upf)) {  // [D] S:374
         r.state = RSIK_STATE_SHOULD_NOT_HAPPEN;
         if (KEEP) { r.pos = self_pos; r.w = w; }
         return r;
@@ -296,22 +323,25 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
 
     const V3 N2 = n2;  // already unit (the reference renormalises: a 1-ulp no-op)
     const double mg = A(RSIK_C_NORMAL_MARGIN);
-    // [D] S:475-483 parallel planes
-    bool par = (fabs(N2.x - N1.x) < mg && fabs(N2.y - N1.y) < mg && fabs(N2.z - N1.z) < mg) ||
-               (fabs(N2.x + N1.x) < mg && fabs(N2.y + N1.y) < mg && fabs(N2.z + N1.z) < mg);
-    if (par) { whole_or_nothing(); return r; }
-
     // S:588-606 + S:570-586: line of intersection of the two planes.  The reference solves
     // [v1, -v2] t = p2 - p1 by least squares; since v1, v2, (p2-p1 minus its v-part) are coplanar the
     // minimiser is the exact intersection: t0 = N2.b / (N2.v1), t1 = N1.b / -(N1.v2), both denominators = |N1 x N2|.
     V3 cr = cross(N1, N2);
-    const double inv_nv = rsqrt_fast(dot(cr, cr));
+    const double crcr = dot(cr, cr);
+    // [D] S:475-483 parallel planes: all three |N2 -+ N1| components below the margin.  That forces
+    // |N1 x N2|^2 <= 3 margin^2, so the six-compare test is only evaluated below that bound.
+    if (RSIK_RARE(crcr < 4.0 * (mg * mg) + 1e-30)) {
+        bool par = (fabs(N2.x - N1.x) < mg && fabs(N2.y - N1.y) < mg && fabs(N2.z - N1.z) < mg) ||
+                   (fabs(N2.x + N1.x) < mg && fabs(N2.y + N1.y) < mg && fabs(N2.z + N1.z) < mg);
+        if (par) { whole_or_nothing(); return r; }
+    }
+    const double inv_nv = rsqrt_fast(crcr);
     V3 v = cr * inv_nv;
     V3 v1 = cross(v, N1);
     V3 b = p2 - p1;
     double t0 = dot(N2, b) * inv_nv;
     double t1 = dot(N1, b) * inv_nv;
-    if (np_isclose(t1, t0)) { whole_or_nothing(); return r; }  // [D] S:582-583 (Q7)
+    if (RSIK_RARE(np_isclose(t1, t0))) { whole_or_nothing(); return r; }  // [D] S:582-583 (Q7)
     V3 q = madd(v1, t0, p1);
 
     // S:608-645 circle 1 (centre p1, radius r1) with the line (q, v)
@@ -331,7 +361,7 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
     r.ok = true;
     r.state = RSIK_STATE_REACHABLE;
     const double inv_2qa = fma(-0.5, qa, 1.0);  // 1 / (2 qa) for qa = |v|^2 = 1 + O(1e-16)
-    if (disc == 0) {  // [D] tangent: interval [a, a] (Q8)
+    if (RSIK_RARE(disc == 0)) {  // [D] tangent: interval [a, a] (Q8)
         double t = -qb * inv_2qa;
         V3 p = madd(v, t, q);
         double ly = dot(a1, p) + oy, lz = dot(a2, p) + oz;
@@ -370,6 +400,11 @@ __device__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
     return r;
 }
 
+template <bool NO_LIMITS, bool KEEP = true, class Acc>
+__device__ __forceinline__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
+    return reach_g<NO_LIMITS, KEEP>(A, pos_in, make_goal(A, Rg).woff);
+}
+
 // S:684-695
 __device__ __forceinline__ V3 elbow_on_circle(const Reach& r, double ct, double st) {
     double y = r.r2 * ct, z = r.r2 * st;
@@ -406,11 +441,11 @@ struct JointsOut {
 // the forearm length by construction; FRESH = false (stored solver state, possibly moved by an earlier projection,
 // Q1) measures it.
 template <bool FRESH, class Acc>
-__device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, double ct, double st, const double* prev) {
+__device__ JointsOut joints_from_theta_g(const Acc& A, Reach& r, const Goal& G, double ct, double st, const double* prev) {
     JointsOut o;
     V3 e = elbow_on_circle(r, ct, st);
     o.projected = false;
-    if (above_singularity_plane(A, e)) {  // S:708-718 -> make_elbow_projection S:647-682
+    if (RSIK_RARE(above_singularity_plane(A, e))) {  // S:708-718 -> make_elbow_projection S:647-682
         V3 Pl = cvec(A, RSIK_C_PLANE_P), v3 = cvec(A, RSIK_C_PLANE_N), pc = cvec(A, RSIK_C_PROJ_CENTER);
         double dist = dot(e - Pl, v3);
         V3 pe = madd(v3, -dist, e);
@@ -420,7 +455,7 @@ __device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, do
         r.pos = r.pos + shift;
         e = ne;
         // S:718 recomputes the wrist from the moved goal; it is the old wrist moved by the same vector (to rounding)
-        r.w = FRESH ? (r.w + shift) : wrist_position(A, Rg, r.pos);
+        r.w = FRESH ? (r.w + shift) : wrist_position(G.woff, r.pos);
         o.projected = true;
     }
     o.elbow = e;
@@ -436,7 +471,7 @@ __device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, do
     // The seven joint angles are pure outputs (no rotation below is built from an angle): they are evaluated together
     // at the end from the normalised direction vectors.
     double cphi, sphi, rho;
-    const bool sing_sp = (q.x == 0 && q.z == 0);
+    const bool sing_sp = RSIK_RARE(q.x == 0 && q.z == 0);
     if (sing_sp) {  // [D] exact singularity: keep the previous pitch
         double s_, c_;
         fast_sincos(prev[0], &s_, &c_);
@@ -460,7 +495,7 @@ __device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, do
     // elbow yaw / pitch (S:780-797)
     V3 pw = to_elbow(r.w);
     double sigma, ca, sa;
-    const bool sing_ey = (pw.y == 0 && pw.z == 0);
+    const bool sing_ey = RSIK_RARE(pw.y == 0 && pw.z == 0);
     if (sing_ey) {  // [D] exact singularity
         fast_sincos(prev[2], &sa, &ca);
         sigma = 0.0;
@@ -482,10 +517,10 @@ __device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, do
     };
     // wrist roll / pitch (S:808-826)
     V3 tl = cvec(A, RSIK_C_TIPL);
-    V3 ptip = Rg.apply_add(V3{tl.x, tl.y, 0.0}, r.pos);
+    V3 ptip = G.toff + r.pos;
     V3 t = to_wrist(ptip);
     double tau, cw, sw, wr_zero = 0.0;
-    const bool tau_zero = (t.x == 0 && t.y == 0);
+    const bool tau_zero = RSIK_RARE(t.x == 0 && t.y == 0);
     if (tau_zero) {
         wr_zero = kPi - fast_atan2(t.y, -t.x);  // +-0 arguments: 0 or pi like the C library
         double w0 = wr_zero > kPi ? wr_zero - kTwoPi : wr_zero;
@@ -503,7 +538,7 @@ __device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, do
     V3 k1 = {-sw, cw, 0.0};
     V3 k2 = {-spp * cw, -spp * sw, cp};
     // wrist yaw (S:839-848): direction of the goal frame's x axis seen from the tip frame
-    V3 xg = Rg.col0();
+    V3 xg = G.xg;
     V3 xs = {dot(cvec(A, RSIK_C_MST + 0), xg), dot(cvec(A, RSIK_C_MST + 3), xg), dot(cvec(A, RSIK_C_MST + 6), xg)};
     V3 xe = {dot(g0, xs), dot(g1, xs), dot(g2, xs)};
     V3 xw = {dot(h0, xe), dot(h1, xe), dot(h2, xe)};
@@ -514,24 +549,31 @@ __device__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, do
     double at[7];
     {
         const double us[7] = {sphi, srs, ca, schi, sw, spp, s6};
-        const double uc[7] = {cphi, cr, -sa, cchi, -cw, cp, c6};
+        const double uc[7] = {cphi, cr, -sa, cchi, cw, cp, c6};
         unit_atan2_n<7>(A.utab, us, uc, at);
     }
-    double wr = tau_zero ? wr_zero : (kPi - at[4]);
-    if (wr > kPi) wr = wr - kTwoPi;
-    o.j[0] = sing_sp ? prev[0] : -at[0];
+    // wrist roll (S:813-816): pi - atan2(t_y, -t_x) wrapped into (-pi, pi] is atan2(t_y, t_x)
+    o.j[0] = -at[0];
     o.j[1] = at[1];
-    o.j[2] = sing_ey ? prev[2] : (-kPi / 2 + at[2]);
-    o.j[3] = -at[3];
-    o.j[4] = wr;
+    o.j[2] = -kPi / 2 + at[2];
+    o.j[3] = fmin(fmax(-at[3], -A(RSIK_C_ELBOW_LIMIT)), A(RSIK_C_ELBOW_LIMIT));  // S:853-861
+    o.j[4] = at[4];
     o.j[5] = -at[5];
     o.j[6] = at[6];
-    const double el = A(RSIK_C_ELBOW_LIMIT);  // S:853-861
-    if (o.j[3] > el) o.j[3] = el;
-    if (o.j[3] < -el) o.j[3] = -el;
+    if (RSIK_RARE(sing_sp || sing_ey || tau_zero)) {  // exact singularities keep the previous / C-library values
+        if (sing_sp) o.j[0] = prev[0];
+        if (sing_ey) o.j[2] = prev[2];
+        if (tau_zero) o.j[4] = wr_zero > kPi ? wr_zero - kTwoPi : wr_zero;
+    }
     o.c4 = cw; o.s4 = sw; o.c5 = cp; o.s5 = -spp;
     o.c6 = c6; o.s6 = s6;
     return o;
+}
+
+template <bool FRESH, class Acc>
+__device__ __forceinline__ JointsOut joints_from_theta(const Acc& A, Reach& r, const Rot& Rg, double ct, double st,
+                                                       const double* prev) {
+    return joints_from_theta_g<FRESH>(A, r, make_goal(A, Rg), ct, st, prev);
 }
 
 // U:93-112 limit_theta_to_interval (previous_theta is normalised by the reference but never used, Q12)

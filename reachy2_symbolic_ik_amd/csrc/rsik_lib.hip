@@ -139,9 +139,12 @@ template <bool MIXED>
 __device__ __forceinline__ void solve_one(SolveArgsK K, const AccK<MIXED>& A, double* lds_wave, int64_t i,
                                           int64_t ii, int64_t wave_base, int lane, const double (&in)[6]) {
     const V3 pos = {in[0], in[1], in[2]};
-    Rot Rg = rot_from_euler(in[3], in[4], in[5]);
-
-    Reach r = reach<false, false>(A, pos, Rg);
+    Goal G;
+    {
+        const Rot Rg = rot_from_euler(in[3], in[4], in[5]);
+        G = make_goal(A, Rg);
+    }
+    Reach r = reach_g<false, false>(A, pos, G.woff);
 
     // joints [64,7] and elbow [64,3] of the wave are staged in LDS (row-major, as they go to HBM) by whichever branch
     // the lane takes, then written out with coalesced rows: failed poses only cost their NaN fill when one exists
@@ -160,7 +163,7 @@ __device__ __forceinline__ void solve_one(SolveArgsK K, const AccK<MIXED>& A, do
                 }
                 fast_sincos(theta, &st, &ct);
             }
-            JointsOut o = joints_from_theta<true>(A, r, Rg, ct, st, (const double*)K.prev);
+            JointsOut o = joints_from_theta_g<true>(A, r, G, ct, st, (const double*)K.prev);
 #pragma unroll
             for (int k = 0; k < 7; k++) jrow[k] = o.j[k];
             erow[0] = o.elbow.x; erow[1] = o.elbow.y; erow[2] = o.elbow.z;
@@ -378,7 +381,7 @@ __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) void control_discrete_
     }
     V3 pos = {K.in[9][ii], K.in[10][ii], K.in[11][ii]};
 
-    Reach r = reach<false>(A, pos, Rg);
+    Reach r = reach<false, false>(A, pos, Rg);
     const double pref = K.pref[slot];
     bool found = false;
     double theta = 0.0;
@@ -552,7 +555,7 @@ __global__ __launch_bounds__(kBlock) void control_continuous_kernel(const Contin
             Reach rc = reach<true>(A, cpos, Rc);
             prev_theta = best_theta_to_current_joints(A, rc, Rc, prev_sol, pref);
         }
-        Reach r = reach<false>(A, pos, Rg);
+        Reach r = reach<false, false>(A, pos, Rg);
         double theta;
         ok = r.ok;
         if (r.ok) {  // C:338-366
@@ -708,7 +711,7 @@ __global__ __launch_bounds__(kBlock) void elbow_state_kernel(const StateArgs K) 
     K.elbow[3 * i] = e.x; K.elbow[3 * i + 1] = e.y; K.elbow[3 * i + 2] = e.z;
 }
 
-// Unit-test hook for rsik_math.hpp (rsik_debug_math): op 0 rcp, 1 sqrt_cr, 2 rsqrt, 3 atan2(a,b), 4 sincos(a), 5 a % 2pi
+// Unit-test hook for rsik_math.hpp (rsik_debug_math): op 0 rcp, 1 sqrt_cr, 2 rsqrt, 3 atan2(a,b), 4 sincos(a), 5 a % 2pi, 6 fp64 FMA issue-rate calibration
 __global__ void debug_math_kernel(int op, int64_t n, const double* a, const double* b, double* o0, double* o1) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     stage_sincos_tab();
@@ -722,6 +725,19 @@ __global__ void debug_math_kernel(int op, int64_t n, const double* a, const doub
         case 3: r0 = fast_atan2(x, b[i]); break;
         case 4: fast_sincos(x, &r0, &r1); break;
         case 5: r0 = pymod_2pi(x); r1 = angle_diff(x, b[i]); break;
+        case 6: {  // fp64 VALU calibration (scripts/valu_peak.py): 8 independent chains x 2048 dependent v_fma_f64
+            double c[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) c[k] = x + k;
+            const double m = b[i];
+#pragma unroll 1
+            for (int it = 0; it < 2048; ++it) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) c[k] = fma(c[k], m, x);
+            }
+            r0 = ((c[0] + c[1]) + (c[2] + c[3])) + ((c[4] + c[5]) + (c[6] + c[7]));
+            break;
+        }
         default: break;
     }
     o0[i] = r0;
@@ -1136,9 +1152,9 @@ int rsik_elbow_from_state(rsik_ctx* ctx, int64_t n, const double* solver_state, 
 
 int rsik_debug_math(rsik_ctx* ctx, int op, int64_t n, const double* a, const double* b, double* out0, double* out1) {
     if (!ctx) return RSIK_E_INVALID;
-    if (n < 0 || op < 0 || op > 5) return fail(ctx, RSIK_E_INVALID, "rsik_debug_math: bad op or n");
+    if (n < 0 || op < 0 || op > 6) return fail(ctx, RSIK_E_INVALID, "rsik_debug_math: bad op or n");
     if (n == 0) return RSIK_OK;
-    if (!a || !out0 || ((op == 3 || op == 5) && !b)) return fail(ctx, RSIK_E_INVALID, "rsik_debug_math: NULL operand");
+    if (!a || !out0 || ((op == 3 || op == 5 || op == 6) && !b)) return fail(ctx, RSIK_E_INVALID, "rsik_debug_math: NULL operand");
     RSIK_HIP(ctx, hipSetDevice(ctx->device));
     dim3 grid, block(rsik::kBlock);
     int rc = launch_dims(ctx, n, &grid, "rsik_debug_math");
