@@ -381,7 +381,15 @@ __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) void control_discrete_
     }
     V3 pos = {K.in[9][ii], K.in[10][ii], K.in[11][ii]};
 
-    Reach r = reach<false, false>(A, pos, Rg);
+    // Of the goal orientation the solver only needs three vectors (Goal); the two that are read again by the joint
+    // stage wait in the output staging slab while the theta search runs (registers are the scarce resource here)
+    Goal G = make_goal(A, Rg);
+    {
+        const double pk[6] = {G.toff.x, G.toff.y, G.toff.z, G.xg.x, G.xg.y, G.xg.z};
+#pragma unroll
+        for (int k = 0; k < 6; k++) lds_out[wave][k * 64 + lane] = pk[k];
+    }
+    Reach r = reach_g<false, false>(A, pos, G.woff);
     const double pref = K.pref[slot];
     bool found = false;
     double theta = 0.0;
@@ -448,7 +456,10 @@ __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) void control_discrete_
         theta = limit_theta_to_interval(theta, K.lim[slot][0], K.lim[slot][1]);
         double st, ct;
         fast_sincos(theta, &st, &ct);
-        JointsOut o = joints_from_theta<true>(A, r, Rg, ct, st, prev);
+        const double* pk = lds_out[wave];
+        G.toff = {pk[0 * 64 + lane], pk[1 * 64 + lane], pk[2 * 64 + lane]};
+        G.xg = {pk[3 * 64 + lane], pk[4 * 64 + lane], pk[5 * 64 + lane]};
+        JointsOut o = joints_from_theta_g<true>(A, r, G, ct, st, prev);
 #pragma unroll
         for (int k = 0; k < 7; k++) jv[k] = o.j[k];
         c4 = o.c4; s4 = o.s4; c5 = o.c5; s5 = o.s5; c6 = o.c6; s6 = o.s6;

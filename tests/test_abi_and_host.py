@@ -149,6 +149,30 @@ def test_control_constructor_errors():
     assert c.symbolic_ik_solver == {} and c.nb_search_points == 20 and c.singularity_offset == -1.01
 
 
+def test_sqrt_threshold_is_exact():
+    """RSIK_C_MAX_LEN_SQ: x > T  <=>  sqrt(x) > L for every double x (sqrt correctly rounded, monotonic), checked on
+    the doubles around T for a spread of limits including the reference's default max_arm_length."""
+    import math
+
+    from reachy2_symbolic_ik_amd.constants import (ArmGeometry, C_MAX_LEN, C_MAX_LEN_SQ, default_ik_parameters,
+                                                   sqrt_threshold)
+
+    rng = np.random.default_rng(7)
+    limits = [0.65, 0.5, 1.0, 0.1, 2.0 ** -3, 3.0] + list(rng.uniform(0.05, 3.0, size=200))
+    for L in limits:
+        T = sqrt_threshold(L)
+        x = T
+        for _ in range(6):  # T and the doubles below it stay inside
+            assert not (math.sqrt(x) > L)
+            x = math.nextafter(x, 0.0)
+        x = T
+        for _ in range(6):  # every double above T is outside
+            x = math.nextafter(x, math.inf)
+            assert math.sqrt(x) > L
+    c = ArmGeometry("r_arm", default_ik_parameters()).pack()
+    assert c[C_MAX_LEN_SQ] == sqrt_threshold(c[C_MAX_LEN])
+
+
 def test_packing_helpers():
     import torch
 

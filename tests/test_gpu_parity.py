@@ -175,6 +175,30 @@ def test_ragged_sizes_match_checker(torch_mod, orc, n):
     assert torch.all(joints[n:] == 777.0) and torch.all(elbow[n:] == 777.0), "store ran past the end of the batch"
 
 
+def test_reach_boundary_ulps(torch_mod, orc):
+    """Goal positions whose distance to the shoulder sits within a few ulps of max_arm_length (the squared-threshold
+    test of the kernels, RSIK_C_MAX_LEN_SQ) and of the backward limit: states must equal the checker's bit for bit."""
+    solver, r, l = make_symbolic(0.03)
+    arm = orc.Arm("r_arm", 0.03)
+    from reachy2_symbolic_ik_amd import constants as K
+
+    c = K.ArmGeometry("r_arm", K.default_ik_parameters(), singularity_offset=0.03).pack()
+    s, L = c[K.C_SHOULDER:K.C_SHOULDER + 3], c[K.C_MAX_LEN]
+    rng = np.random.default_rng(42)
+    dirs = rng.normal(size=(4000, 3))
+    dirs[:, 0] = np.abs(dirs[:, 0]) + 0.2
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    scale = L * (1.0 + rng.integers(-6, 7, size=(4000, 1)) * 2.0 ** -52)
+    pos = s + dirs * scale
+    eul = rng.uniform(-np.pi, np.pi, size=(4000, 3))
+    res = to_np(r.solve_batch(soa(pos, eul, torch_mod)))
+    ref = orc.solve_batch(arm, orc.Arm("l_arm", 0.03), pos, eul)
+    np.testing.assert_array_equal(res["state"], ref["state"])
+    np.testing.assert_array_equal(res["reachable"], ref["reachable"])
+    out = ref["state"] == 1  # RSIK_STATE_POSE_OUT_OF_REACH
+    assert 0.2 < out.mean() < 0.8, "the sample must straddle the boundary"
+
+
 def test_empty_batch(torch_mod):
     solver, r, l = make_symbolic(0.03)
     res = r.solve_batch(torch_mod.zeros((6, 0), dtype=torch_mod.float64, device="cuda"))
