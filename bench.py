@@ -34,6 +34,28 @@ URDF = "config_files/reachy2_ik_minimal.urdf"
 SHOULDER_R = np.array([0.0, -0.2, 0.0])
 
 
+def fp64_valu_calibration(device, n=1 << 20, reps=5):
+    """Wave-instructions/s the GPU sustains on pure independent v_fma_f64 (rsik_debug_math op 6: 8 x 2048 per lane),
+    measured in the same process right after the timed region: the practical fp64 VALU issue peak under the
+    power-managed clock."""
+    import torch
+
+    from reachy2_symbolic_ik_amd.backend import HipSolver
+
+    hs = HipSolver(device)
+    a = torch.rand(n, dtype=torch.float64, device=f"cuda:{device}")
+    b = torch.full((n,), 0.999, dtype=torch.float64, device=f"cuda:{device}")
+    hs.debug_math(6, a, b)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        hs.debug_math(6, a, b)
+    e1.record()
+    torch.cuda.synchronize()
+    return (n / 64) * 8 * 2048 * reps / (e0.elapsed_time(e1) * 1e-3)
+
+
 def _quiet(fn, *a, **k):
     import contextlib
     import io
@@ -180,6 +202,7 @@ def main():
     ap.add_argument("--poses", type=int, default=0, help="poses per GPU (default: the BASELINE size)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-valu-calibration", action="store_true")
     ap.add_argument("--gather-every-step", action="store_true",
                     help="N > 1: all-gather the joint array inside every timed step instead of once at the end")
     ap.add_argument("--graph", action="store_true",
@@ -440,6 +463,16 @@ def main():
             if t and t["poses_per_gpu"] == n:
                 line["roofline"]["traffic"] = t["bytes"]
                 line["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (profiles/r01/traffic.json)"
+            if t and t.get("valu_per_wave") and not args.no_valu_calibration:
+                # the binding limit: executed vector instructions per wave (PMC SQ_INSTS_VALU / SQ_WAVES, committed)
+                # x waves per launch / kernel time, against the pure-FMA issue rate measured live
+                peak = fp64_valu_calibration(local_rank)
+                ach = (n / 64) * t["valu_per_wave"] / (kernel_ms * 1e-3)
+                line["roofline"]["compute"] = {
+                    "bound": "fp64 VALU issue", "achieved": ach, "peak": peak, "unit": "wave-instr/s", "frac": ach / peak,
+                    "valu_instr_per_wave": t["valu_per_wave"],
+                    "peak_source": "live rsik_debug_math op 6 (independent v_fma_f64) on this GPU",
+                }
         except (OSError, ValueError, KeyError):
             pass
         if cfg == 5:
