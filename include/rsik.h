@@ -240,10 +240,25 @@ int rsik_joints_from_state(rsik_ctx *ctx, int64_t n, double *solver_state, const
 /* SymbolicIK.get_elbow_position(theta) on stored state (symbolic_ik.py:684-695). */
 int rsik_elbow_from_state(rsik_ctx *ctx, int64_t n, const double *solver_state, const double *theta, double *elbow);
 
+/* Forward kinematics of the arm: the chain SymbolicIK.get_joints inverts (symbolic_ik.py:728-848):
+ * joints [n,7] -> goal position [n,3] and goal rotation [n,9] (row-major), torso frame.  Either output may be NULL.
+ * The reference has no FK (its examples use placo/reachy2_sdk for that, src/example/test_dk.py); this is the
+ * self-contained monitor of SURVEY 8 f-4. */
+int rsik_forward_kinematics(rsik_ctx *ctx, int64_t n, const double *joints, const uint8_t *arm, int arm_uniform,
+                            double *position, double *rotation);
+/* FK(joints) against the goal it was solved for: err[n,2] = (|position error| in m, rotation error in rad).
+ * goal_soa: 6 columns (px,py,pz,roll,pitch,yaw) for RSIK_GOAL_POSE6, 12 columns (R row-major, t) for RSIK_GOAL_M12.
+ * Rows whose joints are NaN (unreachable poses) give NaN. */
+#define RSIK_GOAL_POSE6 0
+#define RSIK_GOAL_M12 1
+int rsik_fk_residual(rsik_ctx *ctx, int64_t n, int goal_kind, const double *const *goal_soa, const double *joints,
+                     const uint8_t *arm, int arm_uniform, double *err);
+
 /* Test hook: evaluates the kernels' own elementary functions (csrc/rsik_math.hpp) on device arrays so their
  * accuracy can be measured against the host libm.  op: 0 reciprocal, 1 sqrt (out0, out1 two variants),
  * 2 reciprocal sqrt, 3 atan2(a, b), 4 sincos(a) -> out0 = sin, out1 = cos, 5 out0 = a mod 2pi (Python
- * semantics), out1 = angle_diff(a, b) (utils.py:486-490).  Not part of the reference surface. */
+ * semantics), out1 = angle_diff(a, b) (utils.py:486-490), 6 fp64 FMA issue-rate calibration (8 x 2048 dependent fma per element, scripts/valu_peak.py).
+ * Not part of the reference surface. */
 int rsik_debug_math(rsik_ctx *ctx, int op, int64_t n, const double *a, const double *b, double *out0, double *out1);
 
 #ifdef __cplusplus

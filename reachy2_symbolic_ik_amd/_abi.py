@@ -47,8 +47,12 @@ PROTOTYPES = {
     "rsik_reach_state": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp), _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "rsik_joints_from_state": (C.c_int, [_vp, C.c_int64, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     "rsik_elbow_from_state": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp]),
+    "rsik_forward_kinematics": (C.c_int, [_vp, C.c_int64, _vp, _vp, C.c_int, _vp, _vp]),
+    "rsik_fk_residual": (C.c_int, [_vp, C.c_int64, C.c_int, C.POINTER(_vp), _vp, _vp, C.c_int, _vp]),
     "rsik_debug_math": (C.c_int, [_vp, C.c_int, C.c_int64, _vp, _vp, _vp, _vp]),
 }
+
+GOAL_POSE6, GOAL_M12 = 0, 1
 
 SOLVER_STATE_STRIDE = 24
 CONT_STATE_ROWS = 11

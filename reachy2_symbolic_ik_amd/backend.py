@@ -403,6 +403,39 @@ class HipSolver:
                 or tuple(solver_state.shape) != (n, _abi.SOLVER_STATE_STRIDE) or not solver_state.is_contiguous()):
             raise ValueError(f"solver_state must be a contiguous float64 [{n}, {_abi.SOLVER_STATE_STRIDE}] tensor on {self.device}")
 
+    # ------------------------------------------------------------------ forward kinematics
+    def forward_kinematics(self, joints: torch.Tensor, arm: Optional[torch.Tensor] = None, arm_uniform: int = 0):
+        """joints [n,7] -> (goal position [n,3], goal rotation [n,3,3]) in the torso frame (rsik_forward_kinematics)."""
+        n = int(joints.shape[0])
+        joints = self._dev_f64(joints, (n, 7), "joints")
+        if arm is not None:
+            arm = self._dev_u8(arm, n, "arm")
+        pos = torch.empty((n, 3), dtype=_F64, device=self.device)
+        rot = torch.empty((n, 3, 3), dtype=_F64, device=self.device)
+        with torch.cuda.device(self.device):
+            self._bind_stream()
+            self._check(self.lib.rsik_forward_kinematics(self._h, n, _ptr(joints), _ptr(arm), int(arm_uniform), _ptr(pos), _ptr(rot)))
+        return pos, rot
+
+    def fk_residual(self, goal_soa: torch.Tensor, joints: torch.Tensor, arm: Optional[torch.Tensor] = None,
+                    arm_uniform: int = 0) -> torch.Tensor:
+        """FK(joints) against the goals they were solved for: err [n,2] = (position error m, rotation error rad).
+        goal_soa: [6,n] poses (px,py,pz,roll,pitch,yaw) or [12,n] matrices (R row-major, t)."""
+        if goal_soa.dim() != 2 or goal_soa.shape[0] not in (6, 12):
+            raise ValueError("goal_soa must have shape [6, n] or [12, n]")
+        rows, n = int(goal_soa.shape[0]), int(goal_soa.shape[1])
+        goal_soa = self._dev_f64(goal_soa, (rows, n), "goal_soa")
+        joints = self._dev_f64(joints, (n, 7), "joints")
+        if arm is not None:
+            arm = self._dev_u8(arm, n, "arm")
+        err = torch.empty((n, 2), dtype=_F64, device=self.device)
+        cols = (C.c_void_p * rows)(*[goal_soa[k].data_ptr() for k in range(rows)])
+        kind = _abi.GOAL_M12 if rows == 12 else _abi.GOAL_POSE6
+        with torch.cuda.device(self.device):
+            self._bind_stream()
+            self._check(self.lib.rsik_fk_residual(self._h, n, kind, cols, _ptr(joints), _ptr(arm), int(arm_uniform), _ptr(err)))
+        return err
+
     # ------------------------------------------------------------------ test hook
     def debug_math(self, op: int, a: torch.Tensor, b: Optional[torch.Tensor] = None):
         """Evaluates the kernels' own elementary functions (csrc/rsik_math.hpp) on device arrays (rsik_debug_math)."""

@@ -576,6 +576,69 @@ __device__ __forceinline__ JointsOut joints_from_theta(const Acc& A, Reach& r, c
     return joints_from_theta_g<FRESH>(A, r, make_goal(A, Rg), ct, st, prev);
 }
 
+// Forward kinematics of the arm (the chain get_joints inverts, S:728-848):
+//   T_torso_tip = T(s) Ms Ry(j0) Rz(j1) Tx(u) Rx(-j2) Ry(j3) Tx(f) Rz(j4) Ry(j5),  Ms = M_shoulder_torso^T,
+//   goal axes in the tip frame: z_goal = -x_tip, x_goal = (0, sin j6, cos j6);  goal = wrist - R_goal . tip_local.
+// A self-contained check on the device: FK(IK(pose)) == pose.
+struct FkOut {
+    V3 pos;
+    double R[9];  // goal rotation, row-major
+};
+template <class Acc>
+__device__ FkOut forward_kinematics(const Acc& A, const double (&j)[7]) {
+    double sn[7], cs[7];
+    {
+        const double a[4] = {j[0], j[1], j[2], j[3]}, b[3] = {j[4], j[5], j[6]};
+        double s1[4], c1[4], s2[3], c2[3];
+        fast_sincos_n<4>(a, s1, c1);
+        fast_sincos_n<3>(b, s2, c2);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { sn[k] = s1[k]; cs[k] = c1[k]; }
+#pragma unroll
+        for (int k = 0; k < 3; k++) { sn[4 + k] = s2[k]; cs[4 + k] = c2[k]; }
+    }
+    auto mul = [](const double (&X)[9], const double (&Y)[9], double (&Z)[9]) {
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) Z[3 * r + c] = fma(X[3 * r], Y[c], fma(X[3 * r + 1], Y[3 + c], X[3 * r + 2] * Y[6 + c]));
+    };
+    // Gt = Ry(j0) Rz(j1), Ht = Rx(-j2) Ry(j3), Kt = Rz(j4) Ry(j5)
+    const double c0 = cs[0], s0 = sn[0], c1 = cs[1], s1 = sn[1], c2 = cs[2], s2 = sn[2], c3 = cs[3], s3 = sn[3];
+    const double c4 = cs[4], s4 = sn[4], c5 = cs[5], s5 = sn[5];
+    const double Gt[9] = {c0 * c1, -c0 * s1, s0, s1, c1, 0.0, -s0 * c1, s0 * s1, c0};
+    // Rx(-j2) = [[1,0,0],[0,c2,s2],[0,-s2,c2]];  Ry(j3) = [[c3,0,s3],[0,1,0],[-s3,0,c3]]
+    const double H[9] = {c3, 0.0, s3, -s2 * s3, c2, s2 * c3, -c2 * s3, -s2, c2 * c3};
+    // Rz(j4) = [[c4,-s4,0],[s4,c4,0],[0,0,1]];  Ry(j5) = [[c5,0,s5],[0,1,0],[-s5,0,c5]]
+    const double Kt[9] = {c4 * c5, -s4, c4 * s5, s4 * c5, c4, s4 * s5, -s5, 0.0, c5};
+    double Ms[9];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) Ms[3 * r + c] = A(RSIK_C_MST + 3 * c + r);
+    double MG[9], MGH[9], Rt[9];
+    mul(Ms, Gt, MG);
+    mul(MG, H, MGH);
+    mul(MGH, Kt, Rt);
+    const double u = A(RSIK_C_UPPER_ARM), f = A(RSIK_C_FOREARM);
+    // wrist = s + MG . (u e_x + H . f e_x) = s + u MG[:,0] + f MGH[:,0]
+    const V3 sh = cvec(A, RSIK_C_SHOULDER);
+    const V3 w = {fma(u, MG[0], fma(f, MGH[0], sh.x)), fma(u, MG[3], fma(f, MGH[3], sh.y)), fma(u, MG[6], fma(f, MGH[6], sh.z))};
+    // goal axes: x = Rt . (0, s6, c6), z = -Rt[:,0], y = z x x
+    const double s6 = sn[6], c6 = cs[6];
+    const V3 xg = {fma(Rt[1], s6, Rt[2] * c6), fma(Rt[4], s6, Rt[5] * c6), fma(Rt[7], s6, Rt[8] * c6)};
+    const V3 zg = {-Rt[0], -Rt[3], -Rt[6]};
+    const V3 yg = cross(zg, xg);
+    FkOut o;
+    o.R[0] = xg.x; o.R[1] = yg.x; o.R[2] = zg.x;
+    o.R[3] = xg.y; o.R[4] = yg.y; o.R[5] = zg.y;
+    o.R[6] = xg.z; o.R[7] = yg.z; o.R[8] = zg.z;
+    const V3 tl = cvec(A, RSIK_C_TIPL);
+    o.pos = {w.x - fma(o.R[0], tl.x, fma(o.R[1], tl.y, o.R[2] * tl.z)), w.y - fma(o.R[3], tl.x, fma(o.R[4], tl.y, o.R[5] * tl.z)),
+             w.z - fma(o.R[6], tl.x, fma(o.R[7], tl.y, o.R[8] * tl.z))};
+    return o;
+}
+
 // U:93-112 limit_theta_to_interval (previous_theta is normalised by the reference but never used, Q12)
 __device__ __forceinline__ double limit_theta_to_interval(double theta, double l0, double l1) {
     theta = pymod_2pi(theta);

@@ -722,6 +722,56 @@ __global__ __launch_bounds__(kBlock) void elbow_state_kernel(const StateArgs K) 
     K.elbow[3 * i] = e.x; K.elbow[3 * i + 1] = e.y; K.elbow[3 * i + 2] = e.z;
 }
 
+// Forward kinematics and the FK(IK(pose)) residual (a checker-free correctness monitor on the device).
+struct FkArgs {
+    int64_t n;
+    const double* joints;   // [n,7]
+    const uint8_t* arm;
+    int goal_kind;          // residual only: RSIK_GOAL_POSE6 (pose_soa[6]) or RSIK_GOAL_M12 (m12_soa[12])
+    const double* goal[12];
+    double* pos;            // [n,3] or NULL
+    double* rot;            // [n,9] row-major or NULL
+    double* err;            // [n,2]: |position error| (m), rotation error (rad) or NULL
+    ArmC arms[2];
+};
+
+template <bool MIXED>
+__global__ __launch_bounds__(kBlock) void fk_kernel(const FkArgs K) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    __shared__ SharedTables lds_tab;
+    stage_tables<MIXED>(lds_tab, K.arms);
+    if (i >= K.n) return;
+    const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[i] != 0) : false, lds_tab);
+    double j[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) j[k] = K.joints[i * 7 + k];
+    const FkOut o = forward_kinematics(A, j);
+    if (K.pos) { K.pos[3 * i] = o.pos.x; K.pos[3 * i + 1] = o.pos.y; K.pos[3 * i + 2] = o.pos.z; }
+    if (K.rot) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) K.rot[9 * i + k] = o.R[k];
+    }
+    if (K.err) {
+        V3 gp;
+        Rot Rg;
+        if (K.goal_kind == RSIK_GOAL_M12) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) Rg.m[k] = K.goal[k][i];
+            gp = {K.goal[9][i], K.goal[10][i], K.goal[11][i]};
+        } else {
+            gp = {K.goal[0][i], K.goal[1][i], K.goal[2][i]};
+            Rg = rot_from_euler(K.goal[3][i], K.goal[4][i], K.goal[5][i]);
+        }
+        const V3 d = o.pos - gp;
+        double fro = 0.0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) { const double e = o.R[k] - Rg.m[k]; fro = fma(e, e, fro); }
+        // |R1 - R2|_F = 2 sqrt(2) sin(angle / 2): the small-angle value sqrt(fro / 2) is what a monitor needs
+        K.err[2 * i] = sqrt(dot(d, d));
+        K.err[2 * i + 1] = sqrt(0.5 * fro);
+    }
+}
+
 // Unit-test hook for rsik_math.hpp (rsik_debug_math): op 0 rcp, 1 sqrt_cr, 2 rsqrt, 3 atan2(a,b), 4 sincos(a), 5 a % 2pi, 6 fp64 FMA issue-rate calibration
 __global__ void debug_math_kernel(int op, int64_t n, const double* a, const double* b, double* o0, double* o1) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1159,6 +1209,54 @@ int rsik_elbow_from_state(rsik_ctx* ctx, int64_t n, const double* solver_state, 
     hipLaunchKernelGGL(rsik::elbow_state_kernel, grid, block, 0, ctx->stream, K);
     RSIK_HIP(ctx, hipGetLastError());
     return RSIK_OK;
+}
+
+static int launch_fk(rsik_ctx* ctx, rsik::FkArgs& K, int64_t n, const uint8_t* arm, int arm_uniform, const char* who) {
+    int rc = check_arms(ctx, arm, arm_uniform, who);
+    if (rc != RSIK_OK) return rc;
+    K.n = n;
+    K.arm = arm;
+    for (int slot = 0; slot < 2; slot++) K.arms[slot] = ctx->arms[arm ? slot : arm_uniform];
+    RSIK_HIP(ctx, hipSetDevice(ctx->device));
+    dim3 grid, block(rsik::kBlock);
+    rc = launch_dims(ctx, n, &grid, who);
+    if (rc != RSIK_OK) return rc;
+    if (arm) hipLaunchKernelGGL(rsik::fk_kernel<true>, grid, block, 0, ctx->stream, K);
+    else hipLaunchKernelGGL(rsik::fk_kernel<false>, grid, block, 0, ctx->stream, K);
+    RSIK_HIP(ctx, hipGetLastError());
+    return RSIK_OK;
+}
+
+int rsik_forward_kinematics(rsik_ctx* ctx, int64_t n, const double* joints, const uint8_t* arm, int arm_uniform,
+                            double* position, double* rotation) {
+    if (!ctx) return RSIK_E_INVALID;
+    if (n < 0) return fail(ctx, RSIK_E_INVALID, "rsik_forward_kinematics: n < 0");
+    if (n == 0) return RSIK_OK;
+    if (!joints || (!position && !rotation))
+        return fail(ctx, RSIK_E_INVALID, "rsik_forward_kinematics: joints or both outputs are NULL");
+    rsik::FkArgs K;
+    std::memset(&K, 0, sizeof K);
+    K.joints = joints; K.pos = position; K.rot = rotation;
+    return launch_fk(ctx, K, n, arm, arm_uniform, "rsik_forward_kinematics");
+}
+
+int rsik_fk_residual(rsik_ctx* ctx, int64_t n, int goal_kind, const double* const* goal_soa, const double* joints,
+                     const uint8_t* arm, int arm_uniform, double* err) {
+    if (!ctx) return RSIK_E_INVALID;
+    if (n < 0) return fail(ctx, RSIK_E_INVALID, "rsik_fk_residual: n < 0");
+    if (goal_kind != RSIK_GOAL_POSE6 && goal_kind != RSIK_GOAL_M12)
+        return fail(ctx, RSIK_E_INVALID, "rsik_fk_residual: goal_kind must be RSIK_GOAL_POSE6 or RSIK_GOAL_M12");
+    if (n == 0) return RSIK_OK;
+    if (!goal_soa || !joints || !err) return fail(ctx, RSIK_E_INVALID, "rsik_fk_residual: goal_soa / joints / err is NULL");
+    rsik::FkArgs K;
+    std::memset(&K, 0, sizeof K);
+    const int cols = goal_kind == RSIK_GOAL_M12 ? 12 : 6;
+    for (int k = 0; k < cols; k++) {
+        if (!goal_soa[k]) return fail(ctx, RSIK_E_INVALID, "rsik_fk_residual: a goal_soa column is NULL");
+        K.goal[k] = goal_soa[k];
+    }
+    K.goal_kind = goal_kind; K.joints = joints; K.err = err;
+    return launch_fk(ctx, K, n, arm, arm_uniform, "rsik_fk_residual");
 }
 
 int rsik_debug_math(rsik_ctx* ctx, int op, int64_t n, const double* a, const double* b, double* out0, double* out1) {

@@ -183,6 +183,20 @@ class SymbolicIK:
     def is_reachable_batch(self, poses: Any) -> Dict[str, torch.Tensor]:
         return self.solve_batch(poses, theta="none")
 
+    def forward_kinematics_batch(self, joints: Any):
+        """joints [n,7] -> (goal position [n,3], goal rotation [n,3,3]): the chain get_joints inverts
+        (symbolic_ik.py:728-848).  The reference itself has no FK; this is the on-device self-check of SURVEY 8 f-4."""
+        self._upload()
+        j = torch.as_tensor(joints, dtype=torch.float64).to(self._solver.device)
+        return self._solver.forward_kinematics(j.reshape(-1, 7).contiguous(), arm_uniform=self.arm_id)
+
+    def fk_residual_batch(self, poses: Any, joints: Any) -> torch.Tensor:
+        """err [n,2] = (position error m, rotation error rad) of FK(joints) against the poses they were solved for."""
+        self._upload()
+        soa = poses_to_soa(poses, self._solver.device)
+        j = torch.as_tensor(joints, dtype=torch.float64).to(self._solver.device)
+        return self._solver.fk_residual(soa, j.reshape(-1, 7).contiguous(), arm_uniform=self.arm_id)
+
     @staticmethod
     def state_strings(codes: Any) -> list:
         c = codes.cpu().numpy() if isinstance(codes, torch.Tensor) else np.asarray(codes)
