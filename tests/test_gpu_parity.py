@@ -399,6 +399,30 @@ def test_config3_full_size_against_checker(torch_mod, orc, mode, monkeypatch):
     assert frac[0] > 0.5 and frac[6] > 0.1  # both the sweep-hit and the sweep-miss populations are large
 
 
+def test_config4_full_size_mixed_arms_against_checker(torch_mod, orc):
+    """BASELINE config 4 on one GPU: 1 048 576 poses with a per-pose arm byte (l poses = mirrored r poses),
+    the mixed-launch kernel against the CPU checker pose by pose."""
+    from bench import make_config2_poses
+    from reachy2_symbolic_ik_amd import DualArmIK
+
+    n = 1 << 20
+    pos, eul = make_config2_poses(n, seed=20250204)
+    arm_id = (np.random.default_rng(99).uniform(size=n) < 0.5).astype(np.uint8)
+    sgn = np.where(arm_id == 1, -1.0, 1.0)
+    pos = pos * np.stack([np.ones(n), sgn, np.ones(n)], axis=1)
+    eul = eul * np.stack([sgn, np.ones(n), sgn], axis=1)
+    dual = DualArmIK()
+    res = to_np(dual.solve_batch(torch_mod.as_tensor(arm_id).cuda(), soa(pos, eul, torch_mod)))
+    ref = orc.solve_batch(orc.Arm("r_arm", 0.03), orc.Arm("l_arm", 0.03), pos, eul, arm_id=arm_id,
+                          nthreads=max(1, os.cpu_count() or 1))
+    np.testing.assert_array_equal(res["reachable"], ref["reachable"])
+    np.testing.assert_array_equal(res["state"], ref["state"])
+    assert res["reachable"].all() and 0.45 < arm_id.mean() < 0.55
+    for k in ("joints", "interval", "elbow"):
+        err = np.abs(res[k] - ref[k])
+        assert np.max(err) < NORTH_STAR_TOL and np.quantile(err, 0.9999) < 1e-9, k
+
+
 # ------------------------------------------------------------------------------------------ csrc/rsik_math.hpp
 def test_device_math_accuracy(torch_mod):
     """The kernels' own rcp / sqrt / rsqrt / atan2 / sincos / python-modulo against the host libm (float64)."""
