@@ -300,13 +300,12 @@ __device__ Reach reach_g(const Acc& A, V3 pos_in, const V3 woff) {
 
     // S:401-416 wrist-limit circle (cone of half-angle wrist_limit around the hand axis).
     // |w - goal| = |tip| by construction, so the unit normal costs one multiply by a constant.
-    V3 n1 = w - gp;
-    V3 N1 = n1 * A(RSIK_C_INV_GRIP);
-    V3 c1 = madd(N1, A(RSIK_C_WRIST_AX), w);
+    // wrist - goal is the wrist offset R.tip_local itself (every shift above moved both points together).
+    V3 N1 = woff * A(RSIK_C_INV_GRIP);
     double r1 = A(RSIK_C_WRIST_R);
 
-    // S:427-509 are_circles_linked, wrist-centred coordinates
-    V3 p1 = c1 - w, p2 = c2 - w;
+    // S:427-509 are_circles_linked, wrist-centred coordinates: p1 = c1 - w = N1 * axial offset
+    V3 p1 = N1 * A(RSIK_C_WRIST_AX), p2 = c2 - w;
     const V3 f1 = frame_c0(N1);
     // [D] x of T_limitation_torso . p = c0.p + (-c0).p1
     const double tlx = -dot_d(f1, p1);
@@ -344,38 +343,53 @@ __device__ Reach reach_g(const Acc& A, V3 pos_in, const V3 woff) {
     if (RSIK_RARE(np_isclose(t1, t0))) { whole_or_nothing(); return r; }  // [D] S:582-583 (Q7)
     V3 q = madd(v1, t0, p1);
 
-    // S:608-645 circle 1 (centre p1, radius r1) with the line (q, v)
-    V3 wv = q - p1;
-    double qa, qb, disc;
-    {
-        qa = v.x * v.x + v.y * v.y + v.z * v.z;
-        qb = 2 * (v.x * wv.x + v.y * wv.y + v.z * wv.z);
-        double qc = (wv.x * wv.x + wv.y * wv.y + wv.z * wv.z) - r1 * r1;
-        disc = qb * qb - 4 * qa * qc;
-    }
-    if (disc < 0) { whole_or_nothing(); return r; }  // [D]
-
-    // S:511-568 angles of the intersection points in the circle-2 frame
+    // S:608-645 circle 1 (centre p1, radius r1) with the line (q, v); S:511-568 angles of the intersection points
+    // in the circle-2 frame.  q - p1 = t0 v1 with v, v1 orthonormal, so the reference's quadratic
+    // a t^2 + b t + c (a = |v|^2, b = 2 v.(q - p1), c = |q - p1|^2 - r1^2) is t^2 = r1^2 - t0^2 up to rounding.
+    // [D] Its discriminant decides reachable / tangent / limited: within 1e-9 r1^2 of zero the reference's own
+    // arithmetic is evaluated (rare branch), elsewhere both agree on the sign and the roots to O(1e-16).
     V3 a1 = F2.c1, a2 = F2.c2;
-    double oy = -dot(a1, p2), oz = -dot(a2, p2);  // translation of T_intersection_torso
-    r.ok = true;
-    r.state = RSIK_STATE_REACHABLE;
-    const double inv_2qa = fma(-0.5, qa, 1.0);  // 1 / (2 qa) for qa = |v|^2 = 1 + O(1e-16)
-    if (RSIK_RARE(disc == 0)) {  // [D] tangent: interval [a, a] (Q8)
-        double t = -qb * inv_2qa;
-        V3 p = madd(v, t, q);
-        double ly = dot(a1, p) + oy, lz = dot(a2, p) + oz;
-        double ang = fast_atan2(lz, ly);
-        double il = rsqrt_fast(ly * ly + lz * lz);
-        r.i0 = ang; r.i1 = ang; r.ct0 = ly * il; r.st0 = lz * il;
-        return r;
+    const double r1sq = r1 * r1;
+    const double disc4 = fma(-t0, t0, r1sq);
+    double ly1, lz1, ly2, lz2;
+    if (RSIK_RARE(fabs(disc4) < 1e-9 * r1sq)) {
+        V3 wv = q - p1;
+        const double qa = v.x * v.x + v.y * v.y + v.z * v.z;
+        const double qb = 2 * (v.x * wv.x + v.y * wv.y + v.z * wv.z);
+        const double qc = (wv.x * wv.x + wv.y * wv.y + wv.z * wv.z) - r1 * r1;
+        const double disc = qb * qb - 4 * qa * qc;
+        if (disc < 0) { whole_or_nothing(); return r; }  // [D]
+        const double oy = -dot(a1, p2), oz = -dot(a2, p2);  // translation of T_intersection_torso
+        r.ok = true;
+        r.state = RSIK_STATE_REACHABLE;
+        const double inv_2qa = fma(-0.5, qa, 1.0);  // 1 / (2 qa) for qa = |v|^2 = 1 + O(1e-16)
+        if (disc == 0) {  // [D] tangent: interval [a, a] (Q8)
+            double t = -qb * inv_2qa;
+            V3 p = madd(v, t, q);
+            double ly = dot(a1, p) + oy, lz = dot(a2, p) + oz;
+            double ang = fast_atan2(lz, ly);
+            double il = rsqrt_fast(ly * ly + lz * lz);
+            r.i0 = ang; r.i1 = ang; r.ct0 = ly * il; r.st0 = lz * il;
+            return r;
+        }
+        double sq = sqrt_cr(disc);
+        double ta = (-qb + sq) * inv_2qa, tb = (-qb - sq) * inv_2qa;
+        V3 pa = madd(v, ta, q), pb = madd(v, tb, q);
+        ly1 = (dot(a1, pa) + oy) * ir2; lz1 = (dot(a2, pa) + oz) * ir2;
+        ly2 = (dot(a1, pb) + oy) * ir2; lz2 = (dot(a2, pb) + oz) * ir2;
+    } else {
+        if (disc4 < 0) { whole_or_nothing(); return r; }
+        r.ok = true;
+        r.state = RSIK_STATE_REACHABLE;
+        // points q +- h v (the + root first, S:640-644), seen from the circle-2 centre and scaled to the unit circle:
+        // both lie on circle 2 (the two circles share the wrist sphere), so (ly, lz) are unit vectors
+        const double hr = (disc4 * rsqrt_fast(disc4)) * ir2;
+        const V3 dq = q - p2;
+        const double by = dot(a1, dq) * ir2, bz = dot(a2, dq) * ir2;
+        const double vy = dot(a1, v) * hr, vz = dot(a2, v) * hr;
+        ly1 = by + vy; lz1 = bz + vz;
+        ly2 = by - vy; lz2 = bz - vz;
     }
-    double sq = sqrt_cr(disc);
-    double ta = (-qb + sq) * inv_2qa, tb = (-qb - sq) * inv_2qa;
-    V3 pa = madd(v, ta, q), pb = madd(v, tb, q);
-    // Both points lie on circle 2 (the two circles share the wrist sphere), so (ly, lz) / r2 are unit vectors.
-    double ly1 = (dot(a1, pa) + oy) * ir2, lz1 = (dot(a2, pa) + oz) * ir2;
-    double ly2 = (dot(a1, pb) + oy) * ir2, lz2 = (dot(a2, pb) + oz) * ir2;
     double ang1, ang2;
     {
         const double ss[2] = {lz1, lz2}, cc[2] = {ly1, ly2};

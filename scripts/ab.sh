@@ -1,7 +1,21 @@
 #!/bin/bash
-# A/B kernel variants in one GPU session: scripts/ab.sh libA.so libB.so ...
+# A/B kernel variants in one GPU session, interleaved: scripts/ab.sh libA.so libB.so ...   (CFG=3 for config 3)
+# prints every run and, at the end, min / median kernel time per library over ROUNDS rounds.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-for round in 1 2 3; do
+ROUNDS=${ROUNDS:-5}
+LOG=$(mktemp)
+for round in $(seq $ROUNDS); do
 for lib in "$@"; do
-  RSIK_LIB_PATH=$R/$lib timeout 120 python3 $R/bench.py --config ${CFG:-2} --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$lib', round(d['roofline']['kernel_ms']*1000,2),'us', round(d['value']/1e9,2),'G/s')"
+  RSIK_LIB_PATH=$R/$lib timeout 120 python3 $R/bench.py --config ${CFG:-2} --steps ${STEPS:-400} --warmup 20 --no-cpu-baseline --no-valu-calibration 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$lib', round(d['roofline']['kernel_ms']*1000,2),'us', round(d['value']/1e9,2),'G/s')" | tee -a $LOG
 done; done
+python3 - $LOG <<'PY'
+import sys, collections, statistics
+t = collections.defaultdict(list)
+for line in open(sys.argv[1]):
+    p = line.split()
+    if len(p) >= 2:
+        t[p[0]].append(float(p[1]))
+for k, v in t.items():
+    print("== %-28s min %.2f  median %.2f us  (n=%d)" % (k, min(v), statistics.median(v), len(v)))
+PY
+rm -f $LOG
