@@ -24,6 +24,9 @@ import time
 
 import numpy as np
 
+# device-resident kernel-argument buffers (read by the HIP runtime at initialisation; see reachy2_symbolic_ik_amd/__init__.py)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

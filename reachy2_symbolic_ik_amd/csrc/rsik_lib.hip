@@ -85,6 +85,32 @@ __device__ __forceinline__ Acc<MIXED> make_acc(const ArmC* arms, bool isl, Share
     return A;
 }
 
+// Batch inputs are read once and outputs written once: streaming (non-temporal) accesses keep them from displacing
+// each other in L2 and leave fewer dirty lines for the end-of-kernel write-back.
+#ifndef RSIK_NT_STORE
+#define RSIK_NT_STORE 1  // config 2: 45.2 -> 44.7 us per 1 M poses; non-temporal LOADS cost 0.5 us (inputs of back-to-back launches sit in the 256 MB Infinity Cache)
+#endif
+#ifndef RSIK_NT_LOAD
+#define RSIK_NT_LOAD 0
+#endif
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+template <class T>
+__device__ __forceinline__ void st_stream(T* p, T v) {
+#if RSIK_NT_STORE
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+template <class T>
+__device__ __forceinline__ T ld_stream(const T* p) {
+#if RSIK_NT_LOAD
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
 // Writes ROWxW doubles per lane as a contiguous [64*W] slab per wave (row-major [n,W] output).
 template <int W>
 __device__ __forceinline__ void store_rows(double* __restrict__ out, int64_t wave_base, int64_t n, int lane,
@@ -101,7 +127,7 @@ __device__ __forceinline__ void store_rows(double* __restrict__ out, int64_t wav
 #pragma unroll
     for (int k = 0; k < W; k++) {
         int idx = k * 64 + lane;
-        if (idx < total) dst[idx] = lds_wave[idx];
+        if (idx < total) st_stream(dst + idx, lds_wave[idx]);
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -119,7 +145,7 @@ __device__ __forceinline__ void flush_rows(double* __restrict__ out, int64_t wav
 #pragma unroll
     for (int k = 0; k < W; k++) {
         int idx = k * 64 + lane;
-        if (idx < total) dst[idx] = lds_rows[idx];
+        if (idx < total) st_stream(dst + idx, lds_rows[idx]);
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -135,9 +161,16 @@ __device__ __forceinline__ void flush_rows(double* __restrict__ out, int64_t wav
 constexpr int kSolvePPT = RSIK_SOLVE_PPT;
 
 typedef const __attribute__((address_space(4))) SolveArgs& SolveArgsK;  // the kernarg segment itself
+#ifdef RSIK_TIMELINE_PROBE
+#define RSIK_PROBE_PARAM , uint64_t& probe_mid
+#define RSIK_PROBE_ARG , probe_mid
+#else
+#define RSIK_PROBE_PARAM
+#define RSIK_PROBE_ARG
+#endif
 template <bool MIXED>
 __device__ __forceinline__ void solve_one(SolveArgsK K, const AccK<MIXED>& A, double* lds_wave, int64_t i,
-                                          int64_t ii, int64_t wave_base, int lane, const double (&in)[6]) {
+                                          int64_t ii, int64_t wave_base, int lane, const double (&in)[6] RSIK_PROBE_PARAM) {
     const V3 pos = {in[0], in[1], in[2]};
     Goal G;
     {
@@ -173,6 +206,9 @@ __device__ __forceinline__ void solve_one(SolveArgsK K, const AccK<MIXED>& A, do
             for (int k = 0; k < 7; k++) jrow[k] = nan;
             erow[0] = nan; erow[1] = nan; erow[2] = nan;
         }
+#ifdef RSIK_TIMELINE_PROBE
+        probe_mid = __builtin_amdgcn_s_memrealtime();  // all arithmetic done, outputs staged in LDS
+#endif
         if (wave_base < K.n) {
             if (K.joints) flush_rows<7>(K.joints, wave_base, K.n, lane, lds_wave);
             if (K.elbow) flush_rows<3>(K.elbow, wave_base, K.n, lane, lds_wave + 64 * 7);
@@ -180,11 +216,11 @@ __device__ __forceinline__ void solve_one(SolveArgsK K, const AccK<MIXED>& A, do
     }
     if (i < K.n) {
         if (K.interval) {
-            double2 iv = {r.i0, r.i1};
-            reinterpret_cast<double2*>(K.interval)[i] = iv;
+            const f64x2 iv = {r.i0, r.i1};  // one 16-B store per lane
+            st_stream(reinterpret_cast<f64x2*>(K.interval) + i, iv);
         }
-        if (K.reachable) K.reachable[i] = r.ok ? 1 : 0;
-        if (K.state) K.state[i] = (uint8_t)r.state;
+        if (K.reachable) st_stream(K.reachable + i, (uint8_t)(r.ok ? 1 : 0));
+        if (K.state) st_stream(K.state + i, (uint8_t)r.state);
     }
 }
 
@@ -200,15 +236,23 @@ __global__ __launch_bounds__(kBlock, RSIK_SOLVE_MIN_WAVES) void solve_kernel(con
 #ifdef RSIK_CLOCK_PROBE
     const uint64_t probe_c0 = __builtin_readcyclecounter(), probe_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
+#ifdef RSIK_TIMELINE_PROBE
+    const uint64_t probe_r0_early = __builtin_amdgcn_s_memrealtime();
+#endif
     // the six pose loads are issued before the table staging barrier so that their latency overlaps it
     double cur[6];
     {
         const int64_t i0 = tile0 + threadIdx.x;
         const int64_t ii0 = i0 < K.n ? i0 : last;  // tail lanes recompute the last pose; stores are masked
 #pragma unroll
-        for (int k = 0; k < 6; k++) cur[k] = K.in[k][ii0];
+        for (int k = 0; k < 6; k++) cur[k] = ld_stream(K.in[k] + ii0);
     }
     stage_tables<MIXED>(lds_tab, K.arms);
+#ifdef RSIK_TIMELINE_PROBE
+    // diagnostic build only (scripts/timeline_probe.py): 100 MHz timestamps of the wave's phases and its hardware slot
+    const uint64_t probe_t0 = probe_r0_early, probe_t1 = __builtin_amdgcn_s_memrealtime();
+    uint64_t probe_mid = 0;
+#endif
 #pragma unroll 1
     for (int it = 0; it < kSolvePPT; ++it) {
         const int64_t i = tile0 + (int64_t)it * kBlock + threadIdx.x;
@@ -218,7 +262,7 @@ __global__ __launch_bounds__(kBlock, RSIK_SOLVE_MIN_WAVES) void solve_kernel(con
             const int64_t in_ = i + kBlock;
             const int64_t iin = in_ < K.n ? in_ : last;
 #pragma unroll
-            for (int k = 0; k < 6; k++) nxt[k] = K.in[k][iin];
+            for (int k = 0; k < 6; k++) nxt[k] = ld_stream(K.in[k] + iin);
         }
         // the kernarg pointer is laundered through an empty asm every tile: otherwise the compiler hoists the ~50
         // scalar constant loads and every launch-uniform subexpression out of the tile loop and spills
@@ -229,12 +273,27 @@ __global__ __launch_bounds__(kBlock, RSIK_SOLVE_MIN_WAVES) void solve_kernel(con
                             (UnitAtanTab)&lds_tab.utab[0][0]};
         int lane_t = lane;  // same for the lane-derived store indices
         if (kSolvePPT > 1) asm volatile("" : "+v"(lane_t));
-        solve_one<MIXED>(*Kp, A, lds[wave], i, ii, tile0 + (int64_t)it * kBlock + wave * 64, lane_t, cur);
+        solve_one<MIXED>(*Kp, A, lds[wave], i, ii, tile0 + (int64_t)it * kBlock + wave * 64, lane_t, cur RSIK_PROBE_ARG);
         if (it + 1 < kSolvePPT) {
 #pragma unroll
             for (int k = 0; k < 6; k++) cur[k] = nxt[k];
         }
     }
+#ifdef RSIK_TIMELINE_PROBE
+    // lanes 0-2 of every wave overwrite their interval rows with (start, tables staged), (outputs staged, end),
+    // (HW_ID, XCC_ID); PPT = 1 builds only
+    if (lane < 3 && K.interval && tile0 + threadIdx.x < K.n) {
+        __builtin_amdgcn_s_waitcnt(0);  // outstanding stores issued (not necessarily completed)
+        const uint64_t t3 = __builtin_amdgcn_s_memrealtime();
+        const uint32_t hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+        const uint32_t xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); // HW_REG_XCC_ID
+        double2 iv;
+        if (lane == 0) iv = {(double)probe_t0, (double)probe_t1};
+        else if (lane == 1) iv = {(double)probe_mid, (double)t3};
+        else iv = {(double)hw, (double)xcc};
+        reinterpret_cast<double2*>(K.interval)[tile0 + threadIdx.x] = iv;
+    }
+#endif
 #ifdef RSIK_CLOCK_PROBE
     // diagnostic build only (scripts/clock_probe.py): lane 0 of every wave overwrites its interval row with the wave's
     // lifetime in core-clock ticks (s_memtime) and in 100 MHz ticks (s_memrealtime)
