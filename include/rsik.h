@@ -123,6 +123,22 @@ int rsik_sync(rsik_ctx *ctx);
 /* Uploads one arm's constant block (host pointer).  Replaces SymbolicIK.__init__ (symbolic_ik.py:26-83). */
 int rsik_set_arm(rsik_ctx *ctx, int arm, const double *consts_host, int count);
 
+/* ---- per-context options ---- */
+/* RSIK_OPT_EULER_ROUNDTRIP.  ControlIK turns the goal matrix into extrinsic xyz Euler angles
+ * (utils.get_euler_from_homogeneous_matrix, utils.py:84-90, called at control_ik.py:215) and SymbolicIK rebuilds the
+ * rotation from them (symbolic_ik.py:420).  For a proper rotation matrix away from gimbal lock that round trip is the
+ * identity to rounding.  RSIK_EULER_AUTO (default): the control kernels consume M[:3,:3] directly and make the round
+ * trip (SciPy's nearest-rotation / matrix -> quaternion -> Euler algorithms) only where it changes the result — the
+ * matrix is not orthonormal to 1e-12, or the pitch is within 1e-5 of +-pi/2 (at the lock: yaw := 0).
+ * RSIK_EULER_ALWAYS / RSIK_EULER_NEVER force either behaviour. */
+#define RSIK_EULER_AUTO 0
+#define RSIK_EULER_ALWAYS 1
+#define RSIK_EULER_NEVER 2
+#define RSIK_OPT_EULER_ROUNDTRIP 0
+#define RSIK_OPT_COUNT 1
+int rsik_set_option(rsik_ctx *ctx, int option, int value);
+int rsik_get_option(const rsik_ctx *ctx, int option, int *value);
+
 /* ---- device memory helpers for hosts without their own allocator (torch users do not need them) ---- */
 int rsik_malloc(rsik_ctx *ctx, size_t bytes, void **dev_ptr);
 int rsik_free(rsik_ctx *ctx, void *dev_ptr);
@@ -239,6 +255,13 @@ int rsik_joints_from_state(rsik_ctx *ctx, int64_t n, double *solver_state, const
                            const double *theta, const double *previous_joints, double *joints, double *elbow);
 /* SymbolicIK.get_elbow_position(theta) on stored state (symbolic_ik.py:684-695). */
 int rsik_elbow_from_state(rsik_ctx *ctx, int64_t n, const double *solver_state, const double *theta, double *elbow);
+
+/* utils.get_euler_from_homogeneous_matrix for a batch (utils.py:84-90): goal matrices (m12_soa, layout as
+ * rsik_control_discrete) -> pose_soa = 6 device arrays px,py,pz,roll,pitch,yaw (the input layout of rsik_solve),
+ * Euler angles = Rotation.from_matrix(M[:3,:3]).as_euler("xyz").  identity_shortcut != 0 adds ControlIK's
+ * np.allclose(M[:3,:3], I) => [0,0,0] (control_ik.py:212-214). */
+int rsik_matrix_to_pose(rsik_ctx *ctx, int64_t n, const double *const m12_soa[12], int identity_shortcut,
+                        double *const pose_soa[6]);
 
 /* Forward kinematics of the arm: the chain SymbolicIK.get_joints inverts (symbolic_ik.py:728-848):
  * joints [n,7] -> goal position [n,3] and goal rotation [n,9] (row-major), torso frame.  Either output may be NULL.

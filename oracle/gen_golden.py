@@ -533,6 +533,58 @@ def gen_continuous_start(out, n_traj=8, n_steps=150):
     np.savez_compressed(os.path.join(out, "g7_control_continuous_start.npz"), **data)
 
 
+# ----------------------------------------------------------------------------------------
+# G8: goal matrices at the edges of the matrix -> Euler conversion: proper rotations, gimbal lock
+# (pitch at and around +-pi/2, where as_euler sets the third angle to 0), matrices that are not quite orthonormal
+# (from_matrix's quaternion normalisation decides), near-identity matrices (np.allclose shortcut, control_ik.py:212).
+# Records utils.get_euler_from_homogeneous_matrix and the ControlIK discrete result for each.
+# ----------------------------------------------------------------------------------------
+def gen_matrix_edges(out, n=384):
+    import warnings
+
+    from reachy2_symbolic_ik.utils import get_euler_from_homogeneous_matrix
+
+    rng = np.random.default_rng(8)
+    data = {}
+    ctrl = quiet(ControlIK, urdf_path="../config_files/reachy2.urdf")
+    for arm in ARMS:
+        solver = ctrl.symbolic_ik_solver[arm]
+        pos, eul = reachable_poses(rng, solver, arm, 4 * n)
+        kinds = {}
+        kinds["proper"] = np.array([pose_to_matrix(p, e) for p, e in zip(pos[:n], eul[:n])])
+        # gimbal lock: pitch = +-(pi/2 - delta), delta from 0 to 3e-7 (the convention switches at 1e-7 on the
+        # quaternion-derived middle angle)
+        deltas = np.array([0.0, 1e-12, 1e-9, 2e-8, 6e-8, 9e-8, 1.1e-7, 1.5e-7, 3e-7])
+        eg = eul[n:2 * n].copy()
+        sign = np.where(rng.uniform(size=n) < 0.5, -1.0, 1.0)
+        eg[:, 1] = sign * (np.pi / 2 - deltas[np.arange(n) % len(deltas)])
+        kinds["gimbal"] = np.array([pose_to_matrix(p, e) for p, e in zip(pos[n:2 * n], eg)])
+        # not orthonormal: every rotation entry scaled by 1 + U(-1e-3, 1e-3)
+        Mn = np.array([pose_to_matrix(p, e) for p, e in zip(pos[2 * n:3 * n], eul[2 * n:3 * n])])
+        Mn[:, :3, :3] *= 1.0 + rng.uniform(-1e-3, 1e-3, size=(n, 3, 3))
+        kinds["skewed"] = Mn
+        # near the identity: rotations of 1e-9 .. 1e-4 rad around random axes (the allclose shortcut ends near 1e-5)
+        ang = 10.0 ** rng.uniform(-9, -4, size=n)
+        axis = rng.normal(size=(n, 3))
+        axis /= np.linalg.norm(axis, axis=1, keepdims=True)
+        Mi = np.tile(np.eye(4), (n, 1, 1))
+        Mi[:, :3, :3] = R.from_rotvec(axis * ang[:, None]).as_matrix()
+        Mi[:, :3, 3] = pos[3 * n:4 * n]
+        kinds["near_identity"] = Mi
+        for kind, Ms in kinds.items():
+            pre = f"{arm}_{kind}_"
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")  # scipy's gimbal-lock warning
+                eu = np.array([get_euler_from_homogeneous_matrix(M)[1] for M in Ms])
+                res = [control_call(ctrl, arm, M, 20, "unconstrained") for M in Ms]
+            data[pre + "M"] = Ms
+            data[pre + "euler"] = eu
+            data[pre + "joints"] = np.array([r[0] for r in res])
+            data[pre + "reachable"] = np.array([r[1] for r in res], dtype=np.uint8)
+            data[pre + "state"] = np.array([r[2] for r in res], dtype=np.uint8)
+    np.savez_compressed(os.path.join(out, "g8_matrix_edges.npz"), **data)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
@@ -542,7 +594,7 @@ def main():
     os.makedirs(out, exist_ok=True)
     steps = [("g0", gen_constants), ("g1", gen_catalogue), ("g2", gen_sweep), ("g3", gen_reachable),
              ("g4", gen_control), ("g5", gen_helpers), ("g6", gen_continuous),
-             ("g7", gen_continuous_start)]
+             ("g7", gen_continuous_start), ("g8", gen_matrix_edges)]
     for name, fn in steps:
         if args.only and name not in args.only.split(","):
             continue

@@ -231,3 +231,13 @@ def control_continuous_step(arm, cs, M, timed_out, preferred_theta_arg, preferre
                                            float(preferred_theta_self), int(constrained_mode), _d(cj), _d(cp),
                                            float(d_theta_max), float(orbita3d_max_angle), _d(j), C.byref(ok))
     return j, bool(ok.value), st
+
+
+def euler_from_matrix_xyz(M):
+    """utils.get_euler_from_homogeneous_matrix's angles for a batch of [n,4,4] / [n,3,3] matrices."""
+    M = np.asarray(M, dtype=np.float64)
+    R = np.ascontiguousarray(M[:, :3, :3]).reshape(-1, 9)
+    out = np.empty((R.shape[0], 3))
+    for k in range(R.shape[0]):
+        lib().orc_euler_from_matrix_xyz(_d(np.ascontiguousarray(R[k])), _d(out[k]))
+    return out

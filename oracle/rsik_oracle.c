@@ -181,8 +181,42 @@ static quat quat_axis(int axis, double angle) {
     if (axis == 0) q.x = s; else if (axis == 1) q.y = s; else q.z = s;
     return q;
 }
-/* Rotation.from_matrix for a proper rotation matrix (scipy _rotation.pyx from_matrix) */
+/* Rotation.from_matrix, first half (scipy >= 1.12): a matrix whose Gramian M M^T is not the identity
+ * (np.isclose with atol = 1e-12 and the default rtol = 1e-5, i.e. 1e-12 off the diagonal) is replaced by the
+ * solution of the orthogonal Procrustes problem, U V^T of its SVD.  Here U V^T = M (M^T M)^(-1/2), with the inverse
+ * square root taken through a cyclic Jacobi eigen-decomposition of the symmetric 3x3 M^T M. */
+static int gram_is_identity(mat3 M) {
+    mat3 G = mat3_mul(M, mat3_T(M));
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double e = (i == j) ? 1.0 : 0.0;
+            if (!(fabs(G.m[i][j] - e) <= 1e-12 + 1e-5 * e)) return 0;
+        }
+    return 1;
+}
+static mat3 procrustes_rotation(mat3 M) {
+    mat3 S = mat3_mul(mat3_T(M), M), V = mat3_eye();
+    for (int sweep = 0; sweep < 30; sweep++) {
+        double off = fabs(S.m[0][1]) + fabs(S.m[0][2]) + fabs(S.m[1][2]);
+        if (off < 1e-300) break;
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                if (S.m[p][q] == 0.0) continue;
+                double th = (S.m[q][q] - S.m[p][p]) / (2 * S.m[p][q]);
+                double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1));
+                double c = 1 / sqrt(t * t + 1), sn = t * c;
+                mat3 J = mat3_eye();
+                J.m[p][p] = c; J.m[q][q] = c; J.m[p][q] = sn; J.m[q][p] = -sn;
+                S = mat3_mul(mat3_T(J), mat3_mul(S, J));
+                V = mat3_mul(V, J);
+            }
+    }
+    mat3 D = {{{1 / sqrt(S.m[0][0]), 0, 0}, {0, 1 / sqrt(S.m[1][1]), 0}, {0, 0, 1 / sqrt(S.m[2][2])}}};
+    return mat3_mul(M, mat3_mul(V, mat3_mul(D, mat3_T(V))));
+}
+/* Rotation.from_matrix, second half: orthogonal matrix -> quaternion (Markley 2008, scipy _rotation.pyx) */
 static quat quat_from_matrix(mat3 M) {
+    if (!gram_is_identity(M)) M = procrustes_rotation(M);
     double tr = M.m[0][0] + M.m[1][1] + M.m[2][2];
     double dec[4] = {M.m[0][0], M.m[1][1], M.m[2][2], tr};
     int choice = 0;

@@ -33,6 +33,9 @@ PROTOTYPES = {
     "rsik_set_stream": (C.c_int, [_vp, _vp]),
     "rsik_sync": (C.c_int, [_vp]),
     "rsik_set_arm": (C.c_int, [_vp, C.c_int, _dp, C.c_int]),
+    "rsik_set_option": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "rsik_get_option": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
+    "rsik_matrix_to_pose": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp), C.c_int, C.POINTER(_vp)]),
     "rsik_malloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "rsik_free": (C.c_int, [_vp, _vp]),
     "rsik_memcpy_h2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
@@ -53,6 +56,8 @@ PROTOTYPES = {
 }
 
 GOAL_POSE6, GOAL_M12 = 0, 1
+OPT_EULER_ROUNDTRIP = 0
+EULER_AUTO, EULER_ALWAYS, EULER_NEVER = 0, 1, 2
 
 SOLVER_STATE_STRIDE = 24
 CONT_STATE_ROWS = 11

@@ -403,6 +403,32 @@ class HipSolver:
                 or tuple(solver_state.shape) != (n, _abi.SOLVER_STATE_STRIDE) or not solver_state.is_contiguous()):
             raise ValueError(f"solver_state must be a contiguous float64 [{n}, {_abi.SOLVER_STATE_STRIDE}] tensor on {self.device}")
 
+    # ------------------------------------------------------------------ goal matrix <-> Euler pose
+    def set_option(self, option: int, value: int) -> None:
+        """rsik_set_option, e.g. (_abi.OPT_EULER_ROUNDTRIP, 1): the control kernels run goal matrices through the
+        reference's matrix -> Euler -> matrix round trip instead of consuming M[:3,:3] directly."""
+        self._check(self.lib.rsik_set_option(self._h, int(option), int(value)))
+
+    def get_option(self, option: int) -> int:
+        v = C.c_int(0)
+        self._check(self.lib.rsik_get_option(self._h, int(option), C.byref(v)))
+        return int(v.value)
+
+    def matrix_to_pose(self, m12_soa: torch.Tensor, identity_shortcut: bool = False) -> torch.Tensor:
+        """Goal matrices [12,n] (R row-major, t) -> poses [6,n] (px,py,pz,roll,pitch,yaw): a batched
+        utils.get_euler_from_homogeneous_matrix (utils.py:84-90); `identity_shortcut` adds control_ik.py:212-214."""
+        if m12_soa.dim() != 2 or m12_soa.shape[0] != 12:
+            raise ValueError("m12_soa must have shape [12, n]")
+        n = int(m12_soa.shape[1])
+        m12_soa = self._dev_f64(m12_soa, (12, n), "m12_soa")
+        out = torch.empty((6, n), dtype=_F64, device=self.device)
+        cin = (C.c_void_p * 12)(*[m12_soa[k].data_ptr() for k in range(12)])
+        cout = (C.c_void_p * 6)(*[out[k].data_ptr() for k in range(6)])
+        with torch.cuda.device(self.device):
+            self._bind_stream()
+            self._check(self.lib.rsik_matrix_to_pose(self._h, n, cin, 1 if identity_shortcut else 0, cout))
+        return out
+
     # ------------------------------------------------------------------ forward kinematics (SURVEY 8 f-4)
     def forward_kinematics(self, joints: torch.Tensor, arm: Optional[torch.Tensor] = None, arm_uniform: int = 0):
         """joints [n,7] -> (goal position [n,3], goal rotation [n,3,3]) in the torso frame (rsik_forward_kinematics)."""

@@ -106,6 +106,9 @@ class ControlIK:
         self.emergency_state, self.emergency_stop, self.init = "", False, True
         self.singularity_offset, self.singularity_limit_coeff = (0.03 if is_dvt else -1.01), 1.0
         self.orbita3D_max_angle = np.deg2rad(42.5)
+        # not in the reference: how the kernels treat control_ik.py:215's matrix -> Euler -> matrix round trip:
+        # "auto" makes it only where it changes the result (non-orthonormal or gimbal-lock matrices), "always" / "never"
+        self.euler_roundtrip = "auto"
         if is_dvt:
             self._say("DVT mode activated", 0.1)
 
@@ -189,6 +192,13 @@ class ControlIK:
     def _upload_arms(self) -> None:
         for s in self.symbolic_ik_solver.values():
             s._upload()
+        self._solver.set_option(_abi.OPT_EULER_ROUNDTRIP,
+                                {"auto": _abi.EULER_AUTO, "always": _abi.EULER_ALWAYS, "never": _abi.EULER_NEVER}[self.euler_roundtrip])
+
+    def matrices_to_poses(self, M: Any, identity_shortcut: bool = True) -> torch.Tensor:
+        """Batched control_ik.py:212-217: goal matrices ([n,4,4] or [12,n]) -> device poses [6,n]
+        (px,py,pz,roll,pitch,yaw), the input layout of SymbolicIK.solve_batch."""
+        return self._solver.matrix_to_pose(matrices_to_m12_soa(M, self._solver.device), identity_shortcut=identity_shortcut)
 
     # ------------------------------------------------------------------ reference API
     def symbolic_inverse_kinematics(

@@ -112,6 +112,83 @@ __device__ __forceinline__ Rot rot_from_euler(double roll, double pitch, double 
     return r;
 }
 
+// utils.get_euler_from_homogeneous_matrix (U:84-90): Rotation.from_matrix(R).as_euler("xyz").  Follows the two
+// published algorithms SciPy uses, because for inputs that are not exactly orthonormal, and at gimbal lock, the
+// ALGORITHM defines the answer: (0) a matrix whose Gramian M M^T is not the identity (np.isclose, atol 1e-12, default
+// rtol 1e-5: 1e-12 off the diagonal) is replaced by the nearest rotation, U V^T of its SVD (orthogonal Procrustes,
+// SciPy >= 1.12) — computed here as the polar factor by Newton's iteration X <- (X + X^-T) / 2, which converges
+// quadratically to the same matrix; (1) matrix -> quaternion from the largest of (R00, R11, R22, trace) (Markley
+// 2008), normalised; (2) quaternion -> extrinsic xyz angles after
+// Bernardes & Viollet (2022): with a = w - y, b = x + z, c = y + w, d = z - x the middle angle is
+// 2 atan2(|(c, d)|, |(a, b)|) - pi/2 and the outer angles are atan2(b, a) -+ atan2(d, c); within 1e-7 of gimbal lock
+// the third angle is set to 0 and the first takes the whole rotation.  Not on the hot path.
+// np.isclose(M M^T, I, atol=1e-12) with the default rtol = 1e-5: SciPy's test for "already a rotation"
+__device__ __forceinline__ bool gram_is_identity(const double (&m)[9]) {
+    bool orth = true;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = i; j < 3; j++) {
+            const double g = m[3 * i] * m[3 * j] + m[3 * i + 1] * m[3 * j + 1] + m[3 * i + 2] * m[3 * j + 2];
+            const double e = (i == j) ? 1.0 : 0.0;
+            orth = orth && (fabs(g - e) <= 1e-12 + 1e-5 * e);
+        }
+    return orth;
+}
+__device__ inline void nearest_rotation(double (&m)[9]) {
+    for (int it = 0; it < 24; it++) {
+        // cofactors: X^-T = cof(X) / det(X)
+        const double c0 = m[4] * m[8] - m[5] * m[7], c1 = m[5] * m[6] - m[3] * m[8], c2 = m[3] * m[7] - m[4] * m[6];
+        const double c3 = m[2] * m[7] - m[1] * m[8], c4 = m[0] * m[8] - m[2] * m[6], c5 = m[1] * m[6] - m[0] * m[7];
+        const double c6 = m[1] * m[5] - m[2] * m[4], c7 = m[2] * m[3] - m[0] * m[5], c8 = m[0] * m[4] - m[1] * m[3];
+        const double idet = 1.0 / (m[0] * c0 + m[1] * c1 + m[2] * c2);
+        const double cof[9] = {c0, c1, c2, c3, c4, c5, c6, c7, c8};
+        double change = 0.0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const double x = 0.5 * (m[k] + cof[k] * idet);
+            change = fmax(change, fabs(x - m[k]));
+            m[k] = x;
+        }
+        if (change < 1e-15) break;
+    }
+}
+__device__ inline void euler_xyz_from_matrix(const double (&m_in)[9], double (&eul)[3]) {
+    double m[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) m[k] = m_in[k];
+    const bool orth = gram_is_identity(m);
+    if (!orth) nearest_rotation(m);
+    const double tr = m[0] + m[4] + m[8];
+    // pivot = first maximum of (R00, R11, R22, trace), as numpy.argmax picks it
+    int pivot = 0;
+    double top = m[0];
+    if (m[4] > top) { pivot = 1; top = m[4]; }
+    if (m[8] > top) { pivot = 2; top = m[8]; }
+    if (tr > top) pivot = 3;
+    double qx, qy, qz, qw;
+    if (pivot == 3) { qx = m[7] - m[5]; qy = m[2] - m[6]; qz = m[3] - m[1]; qw = 1 + tr; }
+    else if (pivot == 0) { qx = 1 - tr + 2 * m[0]; qy = m[3] + m[1]; qz = m[6] + m[2]; qw = m[7] - m[5]; }
+    else if (pivot == 1) { qy = 1 - tr + 2 * m[4]; qz = m[7] + m[5]; qx = m[1] + m[3]; qw = m[2] - m[6]; }
+    else { qz = 1 - tr + 2 * m[8]; qx = m[2] + m[6]; qy = m[5] + m[7]; qw = m[3] - m[1]; }
+    const double inv = 1.0 / sqrt(qx * qx + qy * qy + qz * qz + qw * qw);
+    qx *= inv; qy *= inv; qz *= inv; qw *= inv;
+    const double a = qw - qy, b = qx + qz, c = qy + qw, d = qz - qx;
+    double mid = 2 * fast_atan2(sqrt(c * c + d * d), sqrt(a * a + b * b));
+    const double half_sum = fast_atan2(b, a), half_diff = fast_atan2(d, c);
+    double first, third;
+    if (fabs(mid) <= 1e-7) { first = 2 * half_sum; third = 0.0; }
+    else if (fabs(mid - kPi) <= 1e-7) { first = -2 * half_diff; third = 0.0; }
+    else { first = half_sum - half_diff; third = half_sum + half_diff; }
+    mid -= kPi / 2;
+    eul[0] = first; eul[1] = mid; eul[2] = third;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (eul[k] < -kPi) eul[k] += kTwoPi;
+        else if (eul[k] > kPi) eul[k] -= kTwoPi;
+    }
+}
+
 // Columns of utils.rotation_matrix_from_vector(n) (U:59-81): the rotation taking e_x to u = n/|n|.
 // c0 is only needed for the "which side of the wrist-limit plane" tests (frame_c0).
 struct Frame {

@@ -305,6 +305,58 @@ __global__ __launch_bounds__(kBlock, RSIK_SOLVE_MIN_WAVES) void solve_kernel(con
 #endif
 }
 
+// C:212-217: M -> goal pose.  np.allclose(R, I) snaps to the identity.  Otherwise the reference converts R to
+// extrinsic xyz Euler angles (U:84-90) and the solver rebuilds the rotation from them (S:420).  For a proper rotation
+// away from gimbal lock that round trip reproduces R to rounding, so R is consumed directly (Q6); the round trip is
+// really made (euler_xyz_from_matrix + rot_from_euler) exactly where it changes the result:
+//   - R is not orthonormal to 1e-12 (SciPy then substitutes the nearest rotation), or
+//   - the pitch is within ~1e-5 of +-pi/2 (inside 1e-7 of the lock SciPy sets yaw := 0, which moves the joints by up
+//     to ~4e-6 rad: measured on the G8 goldens).
+// mode (RSIK_OPT_EULER_ROUNDTRIP): 0 = as above, 1 = always, 2 = never.
+__device__ __forceinline__ void load_m12(const double* const* in, int64_t i, Rot& Rg, V3& pos, int mode) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rg.m[k] = in[k][i];
+    bool eye = true;
+#pragma unroll
+    for (int k = 0; k < 9; k++) eye = eye && np_isclose(Rg.m[k], (k % 4 == 0) ? 1.0 : 0.0);
+    if (eye) {  // C:212-214 np.allclose(R, I)
+#pragma unroll
+        for (int k = 0; k < 9; k++) Rg.m[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    } else {
+        bool rt = mode == 1;
+        if (mode == 0) rt = (fabs(Rg.m[6]) > 1.0 - 1e-10) || !gram_is_identity(Rg.m);
+        if (RSIK_RARE(rt)) {
+            double eul[3];
+            euler_xyz_from_matrix(Rg.m, eul);
+            Rg = rot_from_euler(eul[0], eul[1], eul[2]);
+        }
+    }
+    pos = {in[9][i], in[10][i], in[11][i]};
+}
+
+// utils.get_euler_from_homogeneous_matrix for a batch (U:84-90), optionally with ControlIK's identity shortcut
+// (C:212-214): m12 SoA -> pose SoA (px, py, pz, roll, pitch, yaw), the input layout of rsik_solve.
+struct MatrixToPoseArgs {
+    int64_t n;
+    const double* in[12];
+    double* out[6];
+    int identity_shortcut;
+};
+__global__ __launch_bounds__(kBlock) void matrix_to_pose_kernel(const MatrixToPoseArgs K) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= K.n) return;
+    double m[9], eul[3];
+#pragma unroll
+    for (int k = 0; k < 9; k++) m[k] = K.in[k][i];
+    bool eye = K.identity_shortcut != 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) eye = eye && np_isclose(m[k], (k % 4 == 0) ? 1.0 : 0.0);
+    if (eye) { eul[0] = 0.0; eul[1] = 0.0; eul[2] = 0.0; }
+    else euler_xyz_from_matrix(m, eul);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { K.out[k][i] = K.in[9 + k][i]; K.out[3 + k][i] = eul[k]; }
+}
+
 // ------------------------------------------------------------------------------------------
 // ControlIK discrete mode (C:162-274, C:409-497)
 // ------------------------------------------------------------------------------------------
@@ -315,6 +367,7 @@ struct DiscreteArgs {
     int nb;
     int log2p;            // sweep sub-group width P = 1 << log2p  (P = pow2ceil(min(nb, 64)))
     int sweep_mode;       // 0 auto, 1 always the exhaustive wave-cooperative sweep, 2 always the per-lane search
+    int euler_roundtrip;  // RSIK_OPT_EULER_ROUNDTRIP
     double pref[2];       // preferred theta per arm slot (already mirrored for l, C:252)
     double lim[2][2];     // interval_limit per arm slot (C:225-250)
     double prev_sol[2][7];
@@ -424,21 +477,10 @@ __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) void control_discrete_
     const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[ii] != 0) : false, lds_tab);
     const int slot = MIXED ? (A.isl ? 1 : 0) : 0;
 
-    // C:212-217: M -> pose.  np.allclose(R, I) snaps to the identity; otherwise the reference's Euler
-    // round trip reproduces R to rounding, so R is consumed directly (Q6).
+    // C:212-217: M -> pose (see load_m12)
     Rot Rg;
-#pragma unroll
-    for (int k = 0; k < 9; k++) Rg.m[k] = K.in[k][ii];
-    {
-        bool eye = true;
-#pragma unroll
-        for (int k = 0; k < 9; k++) eye = eye && np_isclose(Rg.m[k], (k % 4 == 0) ? 1.0 : 0.0);
-        if (eye) {
-#pragma unroll
-            for (int k = 0; k < 9; k++) Rg.m[k] = (k % 4 == 0) ? 1.0 : 0.0;
-        }
-    }
-    V3 pos = {K.in[9][ii], K.in[10][ii], K.in[11][ii]};
+    V3 pos;
+    load_m12(K.in, ii, Rg, pos, K.euler_roundtrip);
 
     // Of the goal orientation the solver only needs three vectors (Goal); the two that are read again by the joint
     // stage wait in the output staging slab while the theta search runs (registers are the scarce resource here)
@@ -550,6 +592,7 @@ struct ContinuousArgs {
     const double* cur_pose[12];   // current_pose of a (re)initialising trajectory, NULL columns => goal matrix itself
     const uint8_t* arm;
     const uint8_t* timed_out;     // NULL => nobody timed out
+    int euler_roundtrip;          // RSIK_OPT_EULER_ROUNDTRIP
     double pref_arg[2];           // preferred_theta argument per arm slot (mirrored for l)
     double pref_self[2];          // ControlIK.preferred_theta[name] per arm slot
     double lim[2][2];
@@ -562,19 +605,6 @@ struct ContinuousArgs {
     uint8_t* state;
     ArmC arms[2];
 };
-
-__device__ __forceinline__ void load_m12(const double* const* in, int64_t i, Rot& Rg, V3& pos) {
-#pragma unroll
-    for (int k = 0; k < 9; k++) Rg.m[k] = in[k][i];
-    bool eye = true;
-#pragma unroll
-    for (int k = 0; k < 9; k++) eye = eye && np_isclose(Rg.m[k], (k % 4 == 0) ? 1.0 : 0.0);
-    if (eye) {  // C:212-214 np.allclose(R, I)
-#pragma unroll
-        for (int k = 0; k < 9; k++) Rg.m[k] = (k % 4 == 0) ? 1.0 : 0.0;
-    }
-    pos = {in[9][i], in[10][i], in[11][i]};
-}
 
 template <bool MIXED>
 __global__ __launch_bounds__(kBlock) void control_continuous_kernel(const ContinuousArgs K) {
@@ -610,7 +640,7 @@ __global__ __launch_bounds__(kBlock) void control_continuous_kernel(const Contin
     } else {
         Rot Rg;
         V3 pos;
-        load_m12(K.in, ii, Rg, pos);
+        load_m12(K.in, ii, Rg, pos, K.euler_roundtrip);
         const double pref = K.pref_arg[slot];
         if (K.timed_out && K.timed_out[ii]) { has_prev = false; init = true; }  // C:298-304
         if (!has_prev) {  // C:306-325
@@ -621,7 +651,7 @@ __global__ __launch_bounds__(kBlock) void control_continuous_kernel(const Contin
             has_prev = true;
             Rot Rc;
             V3 cpos;
-            load_m12(K.cur_pose[0] ? K.cur_pose : K.in, ii, Rc, cpos);
+            load_m12(K.cur_pose[0] ? K.cur_pose : K.in, ii, Rc, cpos, K.euler_roundtrip);
             Reach rc = reach<true>(A, cpos, Rc);
             prev_theta = best_theta_to_current_joints(A, rc, Rc, prev_sol, pref);
         }
@@ -874,6 +904,7 @@ struct rsik_ctx {
     hipStream_t stream;
     bool have_arm[2];
     rsik::ArmC arms[2];
+    int options[RSIK_OPT_COUNT];
     std::string err;
 };
 
@@ -916,6 +947,7 @@ int rsik_create(int device_id, rsik_ctx** out) {
     c->device = device_id;
     c->stream = nullptr;
     c->have_arm[0] = c->have_arm[1] = false;
+    for (int k = 0; k < RSIK_OPT_COUNT; k++) c->options[k] = 0;
     *out = c;
     return RSIK_OK;
 }
@@ -947,6 +979,18 @@ int rsik_set_arm(rsik_ctx* ctx, int arm, const double* consts_host, int count) {
         return fail(ctx, RSIK_E_INVALID, "rsik_set_arm: expected RSIK_ARM_CONSTS_COUNT doubles");
     std::memcpy(ctx->arms[arm].v, consts_host, sizeof(double) * RSIK_ARM_CONSTS_COUNT);
     ctx->have_arm[arm] = true;
+    return RSIK_OK;
+}
+
+int rsik_set_option(rsik_ctx* ctx, int option, int value) {
+    if (!ctx) return RSIK_E_INVALID;
+    if (option < 0 || option >= RSIK_OPT_COUNT) return fail(ctx, RSIK_E_INVALID, "rsik_set_option: unknown option");
+    ctx->options[option] = value;
+    return RSIK_OK;
+}
+int rsik_get_option(const rsik_ctx* ctx, int option, int* value) {
+    if (!ctx || !value || option < 0 || option >= RSIK_OPT_COUNT) return RSIK_E_INVALID;
+    *value = ctx->options[option];
     return RSIK_OK;
 }
 
@@ -1089,6 +1133,7 @@ int rsik_control_discrete(rsik_ctx* ctx, int64_t n, const double* const m12_soa[
     K.log2p = lg;
     const char* sm = std::getenv("RSIK_SWEEP_MODE");  // test hook: force one of the two grid-search strategies
     K.sweep_mode = sm ? std::atoi(sm) : 0;
+    K.euler_roundtrip = ctx->options[RSIK_OPT_EULER_ROUNDTRIP];
     for (int slot = 0; slot < 2; slot++) {
         const int a = arm ? slot : arm_uniform;
         control_limits(a, constrained_mode, preferred_theta, K.lim[slot], &K.pref[slot]);
@@ -1139,6 +1184,7 @@ int rsik_control_continuous_step(rsik_ctx* ctx, int64_t n, const double* const m
     }
     K.arm = arm;
     K.timed_out = timed_out;
+    K.euler_roundtrip = ctx->options[RSIK_OPT_EULER_ROUNDTRIP];
     for (int slot = 0; slot < 2; slot++) {
         const int a = arm ? slot : arm_uniform;
         control_limits(a, constrained_mode, preferred_theta, K.lim[slot], &K.pref_arg[slot]);
@@ -1193,6 +1239,32 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         if (e != hipSuccess && rc == RSIK_OK) return hip_fail(ctx, e, "hipFreeAsync");
     }
     return rc;
+}
+
+int rsik_matrix_to_pose(rsik_ctx* ctx, int64_t n, const double* const m12_soa[12], int identity_shortcut,
+                        double* const pose_soa[6]) {
+    if (!ctx) return RSIK_E_INVALID;
+    if (n < 0) return fail(ctx, RSIK_E_INVALID, "rsik_matrix_to_pose: n < 0");
+    if (n == 0) return RSIK_OK;
+    if (!m12_soa || !pose_soa) return fail(ctx, RSIK_E_INVALID, "rsik_matrix_to_pose: NULL column table");
+    rsik::MatrixToPoseArgs K;
+    K.n = n;
+    K.identity_shortcut = identity_shortcut;
+    for (int k = 0; k < 12; k++) {
+        if (!m12_soa[k]) return fail(ctx, RSIK_E_INVALID, "rsik_matrix_to_pose: an m12_soa column is NULL");
+        K.in[k] = m12_soa[k];
+    }
+    for (int k = 0; k < 6; k++) {
+        if (!pose_soa[k]) return fail(ctx, RSIK_E_INVALID, "rsik_matrix_to_pose: a pose_soa column is NULL");
+        K.out[k] = pose_soa[k];
+    }
+    RSIK_HIP(ctx, hipSetDevice(ctx->device));
+    dim3 grid, block(rsik::kBlock);
+    int rc = launch_dims(ctx, n, &grid, "rsik_matrix_to_pose");
+    if (rc != RSIK_OK) return rc;
+    hipLaunchKernelGGL(rsik::matrix_to_pose_kernel, grid, block, 0, ctx->stream, K);
+    RSIK_HIP(ctx, hipGetLastError());
+    return RSIK_OK;
 }
 
 static int fill_state_args(rsik_ctx* ctx, rsik::StateArgs* K, int64_t n, const uint8_t* arm, int arm_uniform,

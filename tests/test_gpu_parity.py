@@ -695,3 +695,67 @@ def test_device_fk_residual_full_size(torch_mod):
     bad = torch_mod.full((8, 7), float("nan"), dtype=torch_mod.float64, device="cuda")
     e = solver.fk_residual(s6[:, :8].contiguous(), bad, arm_uniform=0)
     assert bool(torch_mod.isnan(e).all())
+
+
+# ------------------------------------------------------------------ goal matrix <-> Euler pose
+MATRIX_KINDS = ("proper", "gimbal", "skewed", "near_identity")
+
+
+def _euler_to_matrix(e):
+    ca, sa, cb, sb, cc, sc = np.cos(e[:, 0]), np.sin(e[:, 0]), np.cos(e[:, 1]), np.sin(e[:, 1]), np.cos(e[:, 2]), np.sin(e[:, 2])
+    return np.stack([cc * cb, cc * sb * sa - sc * ca, cc * sb * ca + sc * sa, sc * cb, sc * sb * sa + cc * ca, sc * sb * ca - cc * sa,
+                     -sb, cb * sa, cb * ca], axis=1).reshape(-1, 3, 3)
+
+
+@pytest.mark.parametrize("kind", MATRIX_KINDS)
+def test_matrix_to_pose_golden(golden_dir, torch_mod, kind):
+    """rsik_matrix_to_pose = batched utils.get_euler_from_homogeneous_matrix (utils.py:84-90) against the angles the
+    reference returned (G8): proper rotations, gimbal lock (third angle := 0 within 1e-7 of the lock), matrices that
+    are not orthonormal (nearest rotation first), near-identity matrices."""
+    g = load(golden_dir, "g8_matrix_edges.npz")
+    c = make_control()
+    for arm in ("r_arm", "l_arm"):
+        pre = f"{arm}_{kind}_"
+        M = g[pre + "M"]
+        pose = c.matrices_to_poses(M, identity_shortcut=False).cpu().numpy()
+        np.testing.assert_array_equal(pose[:3].T, M[:, :3, 3])
+        eul, ref = pose[3:].T, g[pre + "euler"]
+        if kind == "gimbal":
+            assert np.max(np.abs(_euler_to_matrix(eul) - _euler_to_matrix(ref))) < 1e-9
+            locked = np.abs(np.abs(ref[:, 1]) - np.pi / 2) < 5e-8
+            assert locked.sum() > 50 and np.all(eul[locked, 2] == 0.0)
+            free = np.abs(np.abs(ref[:, 1]) - np.pi / 2) > 1.2e-7
+            assert free.sum() > 50 and np.all(eul[free, 2] != 0.0) and np.all(ref[free, 2] != 0.0)
+        else:
+            assert np.max(np.abs(eul - ref)) < 1e-12
+        # ControlIK's shortcut (control_ik.py:212-214): allclose(R, I) => angles exactly 0
+        if kind == "near_identity":
+            snap = c.matrices_to_poses(M, identity_shortcut=True).cpu().numpy()[3:].T
+            close = np.array([np.allclose(m[:3, :3], np.eye(3)) for m in M])
+            assert close.sum() > 20 and (~close).sum() > 20
+            assert np.all(snap[close] == 0.0) and np.max(np.abs(snap[~close] - ref[~close])) < 1e-12
+
+
+@pytest.mark.parametrize("kind", MATRIX_KINDS)
+def test_control_discrete_matrix_edges(golden_dir, torch_mod, kind):
+    """ControlIK discrete on the G8 matrices.  The kernels consume the rotation directly and make the reference's
+    matrix -> Euler -> matrix round trip only where it changes the result ("auto", the default): that must reproduce
+    the reference everywhere, like "always".  "never" shows what the round trip is worth: ~4e-6 rad at gimbal lock,
+    ~1e-3 on the deliberately skewed matrices."""
+    g = load(golden_dir, "g8_matrix_edges.npz")
+    for mode in ("auto", "always", "never"):
+        c = make_control()
+        c.euler_roundtrip = mode
+        for arm in ("r_arm", "l_arm"):
+            pre = f"{arm}_{kind}_"
+            res = to_np(c.symbolic_inverse_kinematics_batch(arm, g[pre + "M"]))
+            if mode == "never" and kind in ("skewed", "gimbal"):
+                same = (res["reachable"] == g[pre + "reachable"]) & (g[pre + "reachable"] == 1)
+                assert same.mean() > 0.3
+                err = np.max(np.abs(res["joints"][same] - g[pre + "joints"][same]))
+                assert err > (1e-5 if kind == "skewed" else 1e-7), f"{pre}: the round trip made no difference ({err})"
+                continue
+            np.testing.assert_array_equal(res["reachable"], g[pre + "reachable"])
+            np.testing.assert_array_equal(res["state"], g[pre + "state"])
+            err = np.max(np.abs(res["joints"] - g[pre + "joints"]))
+            assert err < TOL, f"{pre} mode={mode}: {err}"

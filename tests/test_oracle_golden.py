@@ -286,3 +286,37 @@ def test_forward_kinematics_of_reference_joints(golden_dir):
         p_fk, R_fk = forward_kinematics(J[ok], s, off, 0.28, 0.28, 0.10)
         assert np.max(np.abs(p_fk - pos[ok])) < 1e-12
         assert np.max(np.abs(R_fk - Rg[ok])) < 1e-11
+
+
+KINDS = ("proper", "gimbal", "skewed", "near_identity")
+
+
+def euler_to_matrix(e):
+    """Rz(yaw) Ry(pitch) Rx(roll), vectorised (symbolic_ik.py:420 from_euler("xyz"))."""
+    ca, sa, cb, sb, cc, sc = np.cos(e[:, 0]), np.sin(e[:, 0]), np.cos(e[:, 1]), np.sin(e[:, 1]), np.cos(e[:, 2]), np.sin(e[:, 2])
+    return np.stack([cc * cb, cc * sb * sa - sc * ca, cc * sb * ca + sc * sa, sc * cb, sc * sb * sa + cc * ca, sc * sb * ca - cc * sa,
+                     -sb, cb * sa, cb * ca], axis=1).reshape(-1, 3, 3)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_matrix_edges_euler_and_control(golden_dir, kind):
+    """goal matrices at gimbal lock, not quite orthonormal, near the identity (G8).  The checker's
+    matrix -> Euler conversion and its ControlIK discrete result must follow the reference there too."""
+    g = load(golden_dir, "g8_matrix_edges.npz")
+    ar, al = orc.Arm("r_arm", -1.01), orc.Arm("l_arm", -1.01)
+    for k, arm in enumerate(("r_arm", "l_arm")):
+        pre = f"{arm}_{kind}_"
+        M = g[pre + "M"]
+        eul = orc.euler_from_matrix_xyz(M)
+        if kind == "gimbal":
+            # at lock only roll -+ yaw is defined and the recorded angles carry the conditioning of the lock itself
+            # (|d roll| ~ eps / cos(pitch)); the rotation they stand for must agree
+            assert np.max(np.abs(euler_to_matrix(eul) - euler_to_matrix(g[pre + "euler"]))) < 1e-9
+            locked = np.abs(np.abs(g[pre + "euler"][:, 1]) - np.pi / 2) < 5e-8
+            assert locked.sum() > 50 and np.all(eul[locked, 2] == 0.0) and np.all(g[pre + "euler"][locked, 2] == 0.0)
+        else:
+            assert np.max(np.abs(eul - g[pre + "euler"])) < 1e-12
+        res = orc.control_discrete_batch(ar, al, M, arm_id=np.full(len(M), k, np.uint8), nb_search_points=20)
+        np.testing.assert_array_equal(res["reachable"], g[pre + "reachable"])
+        np.testing.assert_array_equal(res["state"], g[pre + "state"])
+        assert np.max(np.abs(res["joints"] - g[pre + "joints"])) < TOL
