@@ -27,6 +27,14 @@ namespace rsik {
 #endif
 
 
+// -DRSIK_ISA_MARKS: named comment lines in the assembly (scripts/isa_sections.py counts instructions per section;
+// the markers pin the schedule at their position, so this is an ANALYSIS build)
+#ifdef RSIK_ISA_MARKS
+#define RSIK_MARK(name) asm volatile("; RSIK_MARK " name)
+#else
+#define RSIK_MARK(name)
+#endif
+
 constexpr double kPi = 3.141592653589793;  // == math.pi
 constexpr double kTwoPi = 2 * kPi;
 
@@ -306,6 +314,7 @@ __device__ Reach reach_g(const Acc& A, V3 pos_in, const V3 woff) {
     if (!NO_LIMITS && st != RSIK_STATE_REACHABLE) return r;
     r.stage = 1;
 
+    RSIK_MARK("reach_wrist");
     V3 w = wrist_position(woff, gp);
     // [D] S:146-153 / S:94-98
     if (RSIK_RARE(w.x < bl)) {
@@ -345,6 +354,7 @@ __device__ Reach reach_g(const Acc& A, V3 pos_in, const V3 woff) {
         sqrt_rsqrt(dot_d(P, P), d, inv_d);
     }
 
+    RSIK_MARK("reach_circle");
     // S:366-399 intersection circle of the shoulder sphere (radius u) and the wrist sphere (radius f)
     if (RSIK_RARE(d > upf)) {  // [D] S:374
         r.state = RSIK_STATE_SHOULD_NOT_HAPPEN;
@@ -366,6 +376,7 @@ __device__ Reach reach_g(const Acc& A, V3 pos_in, const V3 woff) {
         ir2 = (d + d) * irad;
         c2 = s + n2 * (k * (0.5 * inv_d));
     }
+    RSIK_MARK("reach_frame");
     Frame F2 = frame_from_unit(n2);
     r.c2 = c2; r.r2 = r2; r.n2 = n2; r.a1 = F2.c1; r.a2 = F2.c2;
     r.stage = 2;
@@ -375,6 +386,7 @@ __device__ Reach reach_g(const Acc& A, V3 pos_in, const V3 woff) {
         return r;
     }
 
+    RSIK_MARK("reach_limit_side");
     // S:401-416 wrist-limit circle (cone of half-angle wrist_limit around the hand axis).
     // |w - goal| = |tip| by construction, so the unit normal costs one multiply by a constant.
     // wrist - goal is the wrist offset R.tip_local itself (every shift above moved both points together).
@@ -397,6 +409,7 @@ __device__ Reach reach_g(const Acc& A, V3 pos_in, const V3 woff) {
         r.ct0 = -1.0; r.st0 = -1.2246467991473532e-16;  // cos(-pi), sin(-pi) as np.cos/np.sin return them
     };
 
+    RSIK_MARK("reach_line");
     const V3 N2 = n2;  // already unit (the reference renormalises: a 1-ulp no-op)
     const double mg = A(RSIK_C_NORMAL_MARGIN);
     // S:588-606 + S:570-586: line of intersection of the two planes.  The reference solves
@@ -420,6 +433,7 @@ __device__ Reach reach_g(const Acc& A, V3 pos_in, const V3 woff) {
     if (RSIK_RARE(np_isclose(t1, t0))) { whole_or_nothing(); return r; }  // [D] S:582-583 (Q7)
     V3 q = madd(v1, t0, p1);
 
+    RSIK_MARK("reach_circle_line");
     // S:608-645 circle 1 (centre p1, radius r1) with the line (q, v); S:511-568 angles of the intersection points
     // in the circle-2 frame.  q - p1 = t0 v1 with v, v1 orthonormal, so the reference's quadratic
     // a t^2 + b t + c (a = |v|^2, b = 2 v.(q - p1), c = |q - p1|^2 - r1^2) is t^2 = r1^2 - t0^2 up to rounding.
@@ -467,6 +481,7 @@ __device__ Reach reach_g(const Acc& A, V3 pos_in, const V3 woff) {
         ly1 = by + vy; lz1 = bz + vz;
         ly2 = by - vy; lz2 = bz - vz;
     }
+    RSIK_MARK("reach_atan2x2");
     double ang1, ang2;
     {
         const double ss[2] = {lz1, lz2}, cc[2] = {ly1, ly2};
@@ -474,6 +489,7 @@ __device__ Reach reach_g(const Acc& A, V3 pos_in, const V3 woff) {
         unit_atan2_n<2>(A.utab, ss, cc, aa);
         ang1 = aa[0]; ang2 = aa[1];
     }
+    RSIK_MARK("reach_mid_select");
     // S:548-566: the sorted pair [lo, hi] is the interval when the mid-angle point lies on the allowed side of the
     // wrist-limit plane, [hi, lo] otherwise.  The mid angle is symmetric in the two points, so no sort is needed:
     // interval[0] belongs to point 1 exactly when (inside != (ang2 < ang1)).
@@ -533,6 +549,7 @@ struct JointsOut {
 // Q1) measures it.
 template <bool FRESH, class Acc>
 __device__ JointsOut joints_from_theta_g(const Acc& A, Reach& r, const Goal& G, double ct, double st, const double* prev) {
+    RSIK_MARK("joints_elbow");
     JointsOut o;
     V3 e = elbow_on_circle(r, ct, st);
     o.projected = false;
@@ -549,6 +566,7 @@ __device__ JointsOut joints_from_theta_g(const Acc& A, Reach& r, const Goal& G, 
         r.w = FRESH ? (r.w + shift) : wrist_position(G.woff, r.pos);
         o.projected = true;
     }
+    RSIK_MARK("joints_shoulder");
     o.elbow = e;
     const double u = A(RSIK_C_UPPER_ARM), f = A(RSIK_C_FOREARM);
     // shoulder frame: x = M_shoulder_torso . p + P_shoulder_torso (S:728-741)
@@ -583,6 +601,7 @@ __device__ JointsOut joints_from_theta_g(const Acc& A, Reach& r, const Goal& G, 
         V3 a = to_shoulder(p);
         return {dot(g0, a) - u, dot(g1, a), dot(g2, a)};
     };
+    RSIK_MARK("joints_elbow_angles");
     // elbow yaw / pitch (S:780-797)
     V3 pw = to_elbow(r.w);
     double sigma, ca, sa;
@@ -606,6 +625,7 @@ __device__ JointsOut joints_from_theta_g(const Acc& A, Reach& r, const Goal& G, 
         V3 a = to_elbow(p);
         return {dot(h0, a) - f, dot(h1, a), dot(h2, a)};
     };
+    RSIK_MARK("joints_wrist");
     // wrist roll / pitch (S:808-826)
     V3 tl = cvec(A, RSIK_C_TIPL);
     V3 ptip = G.toff + r.pos;
@@ -628,12 +648,14 @@ __device__ JointsOut joints_from_theta_g(const Acc& A, Reach& r, const Goal& G, 
     // K = Ry(wp) Rz(-wr); only rows 1, 2 are needed for the yaw
     V3 k1 = {-sw, cw, 0.0};
     V3 k2 = {-spp * cw, -spp * sw, cp};
+    RSIK_MARK("joints_yaw");
     // wrist yaw (S:839-848): direction of the goal frame's x axis seen from the tip frame
     V3 xg = G.xg;
     V3 xs = {dot(cvec(A, RSIK_C_MST + 0), xg), dot(cvec(A, RSIK_C_MST + 3), xg), dot(cvec(A, RSIK_C_MST + 6), xg)};
     V3 xe = {dot(g0, xs), dot(g1, xs), dot(g2, xs)};
     V3 xw = {dot(h0, xe), dot(h1, xe), dot(h2, xe)};
     double gy = dot(k1, xw), gz = dot(k2, xw);
+    RSIK_MARK("joints_atan2x7");
     // All seven angles are directions of normalised vectors: unit_atan2_n (no division), seven in lock step.
     const double ign = rsqrt_fast(fma(gy, gy, gz * gz));
     const double c6 = gz * ign, s6 = gy * ign;
@@ -643,6 +665,7 @@ __device__ JointsOut joints_from_theta_g(const Acc& A, Reach& r, const Goal& G, 
         const double uc[7] = {cphi, cr, -sa, cchi, cw, cp, c6};
         unit_atan2_n<7>(A.utab, us, uc, at);
     }
+    RSIK_MARK("joints_out");
     // wrist roll (S:813-816): pi - atan2(t_y, -t_x) wrapped into (-pi, pi] is atan2(t_y, t_x)
     o.j[0] = -at[0];
     o.j[1] = at[1];

@@ -69,14 +69,42 @@ struct SharedTables {
     double arm[2][RSIK_ARM_CONSTS_COUNT];
     double utab[kUnitAtanRows][4];
 };
+// All global reads of the staging are issued first and the LDS writes follow, so a workgroup pays ONE memory round trip
+// before its barrier (a copy loop per table serialises one round trip per table: +0.6 us on every wave's start-up).
 template <bool MIXED>
 __device__ __forceinline__ void stage_tables(SharedTables& S, const ArmC* arms) {
+    constexpr int NA = kUnitAtanRows * 4, NS = kSinCosRows * 2, NC = 2 * RSIK_ARM_CONSTS_COUNT;
+    constexpr int RA = (NA + kBlock - 1) / kBlock, RS = (NS + kBlock - 1) / kBlock, RC = (NC + kBlock - 1) / kBlock;
+    const unsigned t = threadIdx.x & (kBlock - 1);  // the launch uses kBlock threads: tells the compiler t < kBlock
+    const double* ga = &c_unit_atan_tab[0][0];
+    const double* gs = &c_sincos_tab[0][0];
+    double va[RA], vs[RS], vc[RC];
+    // chunk r of a table covers elements [r kBlock, (r+1) kBlock): only a table's last chunk can be partial
+#pragma unroll
+    for (int r = 0; r < RA; r++) va[r] = ((r + 1) * kBlock <= NA || t + r * kBlock < NA) ? ga[t + r * kBlock] : 0.0;
+#pragma unroll
+    for (int r = 0; r < RS; r++) vs[r] = ((r + 1) * kBlock <= NS || t + r * kBlock < NS) ? gs[t + r * kBlock] : 0.0;
     if constexpr (MIXED) {
-        for (int k = threadIdx.x; k < 2 * RSIK_ARM_CONSTS_COUNT; k += blockDim.x)
-            S.arm[k / RSIK_ARM_CONSTS_COUNT][k % RSIK_ARM_CONSTS_COUNT] = arms[k / RSIK_ARM_CONSTS_COUNT].v[k % RSIK_ARM_CONSTS_COUNT];
+#pragma unroll
+        for (int r = 0; r < RC; r++) {
+            const unsigned k = t + r * kBlock;
+            vc[r] = ((r + 1) * kBlock <= NC || k < NC) ? arms[k / RSIK_ARM_CONSTS_COUNT].v[k % RSIK_ARM_CONSTS_COUNT] : 0.0;
+        }
     }
-    stage_unit_atan_tab(S.utab);
-    stage_sincos_tab();
+    double* la = &S.utab[0][0];
+    double* ls = &g_sincos_tab[0][0];
+#pragma unroll
+    for (int r = 0; r < RA; r++)
+        if ((r + 1) * kBlock <= NA || t + r * kBlock < NA) la[t + r * kBlock] = va[r];
+#pragma unroll
+    for (int r = 0; r < RS; r++)
+        if ((r + 1) * kBlock <= NS || t + r * kBlock < NS) ls[t + r * kBlock] = vs[r];
+    if constexpr (MIXED) {
+        double* lc = &S.arm[0][0];
+#pragma unroll
+        for (int r = 0; r < RC; r++)
+            if ((r + 1) * kBlock <= NC || t + r * kBlock < NC) lc[t + r * kBlock] = vc[r];
+    }
     __syncthreads();
 }
 template <bool MIXED>
@@ -122,13 +150,37 @@ __device__ __forceinline__ void store_rows(double* __restrict__ out, int64_t wav
     __builtin_amdgcn_wave_barrier();
     int64_t rows = n - wave_base;
     if (rows > 64) rows = 64;
-    const int64_t total = rows * W;
     double* dst = out + wave_base * W;
+    if (__builtin_amdgcn_readfirstlane((int)rows) == 64) {  // every wave but the last: no per-row bounds test
+        double v[W];
 #pragma unroll
-    for (int k = 0; k < W; k++) {
-        int idx = k * 64 + lane;
-        if (idx < total) st_stream(dst + idx, lds_wave[idx]);
+        for (int k = 0; k < W; k++) v[k] = lds_wave[k * 64 + lane];
+#pragma unroll
+        for (int k = 0; k < W; k++) st_stream(dst + k * 64 + lane, v[k]);
+    } else {
+        const int64_t total = rows * W;
+#pragma unroll
+        for (int k = 0; k < W; k++) {
+            int idx = k * 64 + lane;
+            if (idx < total) st_stream(dst + idx, lds_wave[idx]);
+        }
     }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// flush_rows for a wave whose 64 rows all exist (every wave but the last of a launch): the W row reads are issued
+// together and the W stores share one base address, no per-row bounds test.
+template <int W>
+__device__ __forceinline__ void flush_rows_full(double* __restrict__ out, int64_t wave_base, int lane,
+                                                const double* __restrict__ lds_rows) {
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    double v[W];
+#pragma unroll
+    for (int k = 0; k < W; k++) v[k] = lds_rows[k * 64 + lane];
+    double* dst = out + wave_base * W + lane;
+#pragma unroll
+    for (int k = 0; k < W; k++) st_stream(dst + k * 64, v[k]);
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -153,31 +205,57 @@ __device__ __forceinline__ void flush_rows(double* __restrict__ out, int64_t wav
 #ifndef RSIK_SOLVE_MIN_WAVES
 #define RSIK_SOLVE_MIN_WAVES 1
 #endif
-// Poses per thread: a workgroup walks RSIK_SOLVE_PPT consecutive tiles of kBlock poses; the six input columns of the
-// next tile are requested before the current tile is solved, so that only the first tile of a wave sees HBM latency.
-#ifndef RSIK_SOLVE_PPT
-#define RSIK_SOLVE_PPT 1
-#endif
-constexpr int kSolvePPT = RSIK_SOLVE_PPT;
 
-typedef const __attribute__((address_space(4))) SolveArgs& SolveArgsK;  // the kernarg segment itself
-#ifdef RSIK_TIMELINE_PROBE
-#define RSIK_PROBE_PARAM , uint64_t& probe_mid
-#define RSIK_PROBE_ARG , probe_mid
-#else
-#define RSIK_PROBE_PARAM
-#define RSIK_PROBE_ARG
-#endif
+// One workgroup = one tile of kBlock consecutive poses, one pose per lane.  Every global address is a scalar base
+// (column pointer + tile offset, computed on the SALU) plus a small per-lane offset, so the six loads and all the
+// stores share one or two address registers.  Lanes past the end of the batch recompute the last pose; their stores
+// are masked.  (A persistent variant that walks several tiles per workgroup with the next tile prefetched was
+// measured slower at every depth: 46.0 / 47.7 / 52.5 us for 2 / 4 / 8 tiles against 45.5 us, see
+// profiles/r01/timeline/: under the power-managed clock it is the executed instruction count that sets the time, not
+// how well the waves overlap.)
 template <bool MIXED>
-__device__ __forceinline__ void solve_one(SolveArgsK K, const AccK<MIXED>& A, double* lds_wave, int64_t i,
-                                          int64_t ii, int64_t wave_base, int lane, const double (&in)[6] RSIK_PROBE_PARAM) {
+__global__ __launch_bounds__(kBlock, RSIK_SOLVE_MIN_WAVES) void solve_kernel(const SolveArgs K) {
+    __shared__ double lds[kBlock / 64][64 * 10];
+    __shared__ SharedTables lds_tab;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: wave-level tests stay on the SALU
+    const int64_t tile0 = (int64_t)blockIdx.x * kBlock;
+    const int64_t left = K.n - tile0;                                   // >= 1 (grid = ceil(n / kBlock))
+    const unsigned rows = left < kBlock ? (unsigned)left : (unsigned)kBlock;
+    const unsigned t = threadIdx.x & (kBlock - 1);                      // (tells the compiler t < kBlock)
+    const unsigned tt = (t < rows ? t : rows - 1) & (kBlock - 1);       // clamped pose index inside the tile
+    const bool live = t < rows;
+
+#ifdef RSIK_CLOCK_PROBE
+    const uint64_t probe_c0 = __builtin_readcyclecounter(), probe_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef RSIK_TIMELINE_PROBE
+    const uint64_t probe_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // the six pose loads are issued before the table staging so that their latency overlaps it
+    double in[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) in[k] = ld_stream(K.in[k] + tile0 + tt);
+    stage_tables<MIXED>(lds_tab, K.arms);
+#ifdef RSIK_TIMELINE_PROBE
+    const uint64_t probe_t1 = __builtin_amdgcn_s_memrealtime();
+    uint64_t probe_mid = 0;
+#endif
+    const AccK<MIXED> A{(KConst)&((const __attribute__((address_space(4))) SolveArgs*)__builtin_amdgcn_kernarg_segment_ptr())->arms[0].v[0],
+                        (LdsConst)lds_tab.arm[(MIXED && K.arm[tile0 + tt] != 0) ? 1 : 0], (UnitAtanTab)&lds_tab.utab[0][0]};
+    double* lds_wave = lds[wave];
+
     const V3 pos = {in[0], in[1], in[2]};
     Goal G;
     {
+        RSIK_MARK("euler");
         const Rot Rg = rot_from_euler(in[3], in[4], in[5]);
+        RSIK_MARK("goal");
         G = make_goal(A, Rg);
     }
+    RSIK_MARK("reach_start");
     Reach r = reach_g<false, false>(A, pos, G.woff);
+    RSIK_MARK("after_reach");
 
     // joints [64,7] and elbow [64,3] of the wave are staged in LDS (row-major, as they go to HBM) by whichever branch
     // the lane takes, then written out with coalesced rows: failed poses only cost their NaN fill when one exists
@@ -187,16 +265,17 @@ __device__ __forceinline__ void solve_one(SolveArgsK K, const AccK<MIXED>& A, do
         if (r.ok) {
             double ct = r.ct0, st = r.st0;  // theta = interval[0]: cos/sin come straight from the intersection point
             if (K.theta_policy != RSIK_THETA_INTERVAL0) {
-                double theta;
-                if (K.theta_policy == RSIK_THETA_EXPLICIT) theta = K.theta_in[ii];
-                else {
+                const double th_in = K.theta_in[tile0 + tt];
+                double theta = th_in;
+                if (K.theta_policy != RSIK_THETA_EXPLICIT) {
                     double a = r.i0, b = r.i1;
                     if (a > b) b += kTwoPi;
-                    theta = a + K.theta_in[ii] * (b - a);
+                    theta = a + th_in * (b - a);
                 }
                 fast_sincos(theta, &st, &ct);
             }
             JointsOut o = joints_from_theta_g<true>(A, r, G, ct, st, (const double*)K.prev);
+            RSIK_MARK("stores");
 #pragma unroll
             for (int k = 0; k < 7; k++) jrow[k] = o.j[k];
             erow[0] = o.elbow.x; erow[1] = o.elbow.y; erow[2] = o.elbow.z;
@@ -209,81 +288,28 @@ __device__ __forceinline__ void solve_one(SolveArgsK K, const AccK<MIXED>& A, do
 #ifdef RSIK_TIMELINE_PROBE
         probe_mid = __builtin_amdgcn_s_memrealtime();  // all arithmetic done, outputs staged in LDS
 #endif
-        if (wave_base < K.n) {
+        const int64_t wave_base = tile0 + wave * 64;
+        if (rows >= (unsigned)(wave * 64 + 64)) {  // the wave's 64 rows all exist (wave-uniform, scalar)
+            if (K.joints) flush_rows_full<7>(K.joints, wave_base, lane, lds_wave);
+            if (K.elbow) flush_rows_full<3>(K.elbow, wave_base, lane, lds_wave + 64 * 7);
+        } else if (rows > (unsigned)(wave * 64)) {
             if (K.joints) flush_rows<7>(K.joints, wave_base, K.n, lane, lds_wave);
             if (K.elbow) flush_rows<3>(K.elbow, wave_base, K.n, lane, lds_wave + 64 * 7);
         }
     }
-    if (i < K.n) {
+    if (live) {
         if (K.interval) {
             const f64x2 iv = {r.i0, r.i1};  // one 16-B store per lane
-            st_stream(reinterpret_cast<f64x2*>(K.interval) + i, iv);
+            st_stream(reinterpret_cast<f64x2*>(K.interval + 2 * tile0) + t, iv);
         }
-        if (K.reachable) st_stream(K.reachable + i, (uint8_t)(r.ok ? 1 : 0));
-        if (K.state) st_stream(K.state + i, (uint8_t)r.state);
-    }
-}
-
-template <bool MIXED>
-__global__ __launch_bounds__(kBlock, RSIK_SOLVE_MIN_WAVES) void solve_kernel(const SolveArgs K) {
-    __shared__ double lds[kBlock / 64][64 * 10];
-    __shared__ SharedTables lds_tab;
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int64_t tile0 = (int64_t)blockIdx.x * (kBlock * kSolvePPT);
-    const int64_t last = K.n - 1;
-
-#ifdef RSIK_CLOCK_PROBE
-    const uint64_t probe_c0 = __builtin_readcyclecounter(), probe_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
-#ifdef RSIK_TIMELINE_PROBE
-    const uint64_t probe_r0_early = __builtin_amdgcn_s_memrealtime();
-#endif
-    // the six pose loads are issued before the table staging barrier so that their latency overlaps it
-    double cur[6];
-    {
-        const int64_t i0 = tile0 + threadIdx.x;
-        const int64_t ii0 = i0 < K.n ? i0 : last;  // tail lanes recompute the last pose; stores are masked
-#pragma unroll
-        for (int k = 0; k < 6; k++) cur[k] = ld_stream(K.in[k] + ii0);
-    }
-    stage_tables<MIXED>(lds_tab, K.arms);
-#ifdef RSIK_TIMELINE_PROBE
-    // diagnostic build only (scripts/timeline_probe.py): 100 MHz timestamps of the wave's phases and its hardware slot
-    const uint64_t probe_t0 = probe_r0_early, probe_t1 = __builtin_amdgcn_s_memrealtime();
-    uint64_t probe_mid = 0;
-#endif
-#pragma unroll 1
-    for (int it = 0; it < kSolvePPT; ++it) {
-        const int64_t i = tile0 + (int64_t)it * kBlock + threadIdx.x;
-        const int64_t ii = i < K.n ? i : last;
-        double nxt[6];
-        if (it + 1 < kSolvePPT) {
-            const int64_t in_ = i + kBlock;
-            const int64_t iin = in_ < K.n ? in_ : last;
-#pragma unroll
-            for (int k = 0; k < 6; k++) nxt[k] = ld_stream(K.in[k] + iin);
-        }
-        // the kernarg pointer is laundered through an empty asm every tile: otherwise the compiler hoists the ~50
-        // scalar constant loads and every launch-uniform subexpression out of the tile loop and spills
-        const __attribute__((address_space(4))) SolveArgs* Kp =
-            (const __attribute__((address_space(4))) SolveArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-        if (kSolvePPT > 1) asm volatile("" : "+s"(Kp));
-        const AccK<MIXED> A{(KConst)&Kp->arms[0].v[0], (LdsConst)lds_tab.arm[(MIXED && Kp->arm[ii] != 0) ? 1 : 0],
-                            (UnitAtanTab)&lds_tab.utab[0][0]};
-        int lane_t = lane;  // same for the lane-derived store indices
-        if (kSolvePPT > 1) asm volatile("" : "+v"(lane_t));
-        solve_one<MIXED>(*Kp, A, lds[wave], i, ii, tile0 + (int64_t)it * kBlock + wave * 64, lane_t, cur RSIK_PROBE_ARG);
-        if (it + 1 < kSolvePPT) {
-#pragma unroll
-            for (int k = 0; k < 6; k++) cur[k] = nxt[k];
-        }
+        if (K.reachable) st_stream(K.reachable + tile0 + t, (uint8_t)(r.ok ? 1 : 0));
+        if (K.state) st_stream(K.state + tile0 + t, (uint8_t)r.state);
     }
 #ifdef RSIK_TIMELINE_PROBE
-    // lanes 0-2 of every wave overwrite their interval rows with (start, tables staged), (outputs staged, end),
-    // (HW_ID, XCC_ID); PPT = 1 builds only
-    if (lane < 3 && K.interval && tile0 + threadIdx.x < K.n) {
-        __builtin_amdgcn_s_waitcnt(0);  // outstanding stores issued (not necessarily completed)
+    // diagnostic build only (scripts/timeline_probe.py): lanes 0-2 of every wave overwrite their interval rows with
+    // (start, tables staged), (outputs staged, stores issued), (HW_ID, XCC_ID)
+    if (lane < 3 && K.interval && live) {
+        __builtin_amdgcn_s_waitcnt(0);
         const uint64_t t3 = __builtin_amdgcn_s_memrealtime();
         const uint32_t hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
         const uint32_t xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); // HW_REG_XCC_ID
@@ -291,16 +317,16 @@ __global__ __launch_bounds__(kBlock, RSIK_SOLVE_MIN_WAVES) void solve_kernel(con
         if (lane == 0) iv = {(double)probe_t0, (double)probe_t1};
         else if (lane == 1) iv = {(double)probe_mid, (double)t3};
         else iv = {(double)hw, (double)xcc};
-        reinterpret_cast<double2*>(K.interval)[tile0 + threadIdx.x] = iv;
+        reinterpret_cast<double2*>(K.interval)[tile0 + t] = iv;
     }
 #endif
 #ifdef RSIK_CLOCK_PROBE
     // diagnostic build only (scripts/clock_probe.py): lane 0 of every wave overwrites its interval row with the wave's
     // lifetime in core-clock ticks (s_memtime) and in 100 MHz ticks (s_memrealtime)
-    if (lane == 0 && K.interval && tile0 + threadIdx.x < K.n) {
+    if (lane == 0 && K.interval && live) {
         const uint64_t c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
         double2 iv = {(double)(c1 - probe_c0), (double)(r1 - probe_r0)};
-        reinterpret_cast<double2*>(K.interval)[tile0 + threadIdx.x] = iv;
+        reinterpret_cast<double2*>(K.interval)[tile0 + t] = iv;
     }
 #endif
 }
@@ -1061,7 +1087,7 @@ int rsik_solve(rsik_ctx* ctx, int64_t n, const double* const pose_soa[6], const 
     if (arm) { K.arms[0] = ctx->arms[0]; K.arms[1] = ctx->arms[1]; }
     else { K.arms[0] = ctx->arms[arm_uniform]; K.arms[1] = ctx->arms[arm_uniform]; }
     RSIK_HIP(ctx, hipSetDevice(ctx->device));
-    const int64_t tile = (int64_t)rsik::kBlock * rsik::kSolvePPT;
+    const int64_t tile = (int64_t)rsik::kBlock;
     const int64_t blocks = (n + tile - 1) / tile;
     if (blocks > 0x7fffffffLL) return fail(ctx, RSIK_E_INVALID, "rsik_solve: n too large for one launch");
     dim3 grid((unsigned)blocks), block(rsik::kBlock);
