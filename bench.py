@@ -377,14 +377,22 @@ def main():
     graph = None
     if not per_launch and use_graph and cfg != 5:
         hs = {2: lambda: ik.solver, 3: lambda: ctrl._solver, 4: lambda: dual.solver}[cfg]()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            hs._bind_stream()  # the pre-bound launches go to the capture stream
-            for _ in range(args.steps):
-                step_kernel()
-        hs._bind_stream()
-        graph.replay()  # untimed
-        fence()
+        try:
+            graph = torch.cuda.CUDAGraph()
+            # thread-local capture mode: another thread of the process (the RCCL watchdog when N > 1) may touch the
+            # runtime while this thread records the K launches
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                hs._bind_stream()  # the pre-bound launches go to the capture stream
+                for _ in range(args.steps):
+                    step_kernel()
+            hs._bind_stream()
+            graph.replay()  # untimed
+            fence()
+        except Exception as e:  # capture refused: time K eager launches instead (reported in "launch")
+            print(f"bench.py: hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches", file=sys.stderr)
+            graph = None
+            hs._bind_stream()
+            torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps if per_launch else 1)]
     ev_g = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps if per_launch else 0)]
     for pair in ev + [(e,) for e in ev_g]:  # events are created lazily at their first record: not inside the timed region
