@@ -398,7 +398,8 @@ __device__ Reach reach_g(const Acc& A, V3 pos_in, const V3 woff) {
     const V3 f1 = frame_c0(N1);
     // [D] x of T_limitation_torso . p = c0.p + (-c0).p1
     const double tlx = -dot_d(f1, p1);
-    bool side_ok = (dot_d(f1, p2) + tlx) > 0;
+    const double side_val = dot_d(f1, p2) + tlx;
+    bool side_ok = side_val > 0;
     r.state = side_ok ? RSIK_STATE_REACHABLE : RSIK_STATE_LIMITED_BY_WRIST;
     r.ok = side_ok;
     // the circles do not cross: whole circle [-pi, pi] or nothing, decided by the side (S:487-509).  Only the early
@@ -443,6 +444,7 @@ __device__ Reach reach_g(const Acc& A, V3 pos_in, const V3 woff) {
     const double r1sq = r1 * r1;
     const double disc4 = fma(-t0, t0, r1sq);
     double ly1, lz1, ly2, lz2;
+    double by, bz;  // foot of the chord between the two points (their mean), in the unit circle-2 frame
     if (RSIK_RARE(fabs(disc4) < 1e-9 * r1sq)) {
         V3 wv = q - p1;
         const double qa = v.x * v.x + v.y * v.y + v.z * v.z;
@@ -468,6 +470,7 @@ __device__ Reach reach_g(const Acc& A, V3 pos_in, const V3 woff) {
         V3 pa = madd(v, ta, q), pb = madd(v, tb, q);
         ly1 = (dot(a1, pa) + oy) * ir2; lz1 = (dot(a2, pa) + oz) * ir2;
         ly2 = (dot(a1, pb) + oy) * ir2; lz2 = (dot(a2, pb) + oz) * ir2;
+        by = 0.5 * (ly1 + ly2); bz = 0.5 * (lz1 + lz2);
     } else {
         if (disc4 < 0) { whole_or_nothing(); return r; }
         r.ok = true;
@@ -476,7 +479,7 @@ __device__ Reach reach_g(const Acc& A, V3 pos_in, const V3 woff) {
         // both lie on circle 2 (the two circles share the wrist sphere), so (ly, lz) are unit vectors
         const double hr = (disc4 * rsqrt_fast(disc4)) * ir2;
         const V3 dq = q - p2;
-        const double by = dot(a1, dq) * ir2, bz = dot(a2, dq) * ir2;
+        by = dot(a1, dq) * ir2; bz = dot(a2, dq) * ir2;
         const double vy = dot(a1, v) * hr, vz = dot(a2, v) * hr;
         ly1 = by + vy; lz1 = bz + vz;
         ly2 = by - vy; lz2 = bz - vz;
@@ -493,12 +496,22 @@ __device__ Reach reach_g(const Acc& A, V3 pos_in, const V3 woff) {
     // S:548-566: the sorted pair [lo, hi] is the interval when the mid-angle point lies on the allowed side of the
     // wrist-limit plane, [hi, lo] otherwise.  The mid angle is symmetric in the two points, so no sort is needed:
     // interval[0] belongs to point 1 exactly when (inside != (ang2 < ang1)).
-    double am = (ang1 + ang2) / 2;
+    // The point at the mean angle needs no sin/cos: the two points are unit vectors b +- v' with b their chord foot, so
+    // the bisector of the arc between them is b / |b|, and the mean of two angles in (-pi, pi] is the bisector of the arc
+    // that does not cross +-pi, i.e. -b / |b| when the angles are more than pi apart.  (|b| ~ 0: the points are
+    // diametrically opposite and the direction is the mean angle's own, rare branch.)
     double sm, cm;
-    fast_sincos(am, &sm, &cm);
-    double ty = cm * r2, tz = sm * r2;
-    V3 tp = madd(a1, ty, madd(a2, tz, p2));
-    const bool inside = (dot_d(f1, tp) + tlx) > 0;  // [D] S:564
+    const double bb = fma(by, by, bz * bz);
+    if (RSIK_RARE(bb < 1e-12)) {
+        fast_sincos((ang1 + ang2) / 2, &sm, &cm);
+    } else {
+        double ib = rsqrt_fast(bb);
+        ib = (fabs(ang1 - ang2) > kPi) ? -ib : ib;
+        cm = by * ib; sm = bz * ib;
+    }
+    // [D] S:564: x of T_limitation_torso . (p2 + r2 (a1 cos + a2 sin)) > 0; the p2 part is the side test's value
+    const double fa1 = dot(f1, a1), fa2 = dot(f1, a2);
+    const bool inside = fma(r2, fma(cm, fa1, sm * fa2), side_val) > 0;
     const bool first = inside != (ang2 < ang1);
     r.i0 = first ? ang1 : ang2;
     r.i1 = first ? ang2 : ang1;
