@@ -585,6 +585,70 @@ def gen_matrix_edges(out, n=384):
     np.savez_compressed(os.path.join(out, "g8_matrix_edges.npz"), **data)
 
 
+# ----------------------------------------------------------------------------------------
+# G9: non-default geometry.  Every other fixture uses the reference's default arm (tip = [0, 0, 0.10], u = f = 0.28,
+# default limits), so the general formulas (tip with x / y components, unequal segment lengths, other shoulder
+# offsets, other elbow / wrist / backward limits and singularity plane) are pinned here.
+# ----------------------------------------------------------------------------------------
+CUSTOM_GEOMETRY = {
+    "ik_parameters": {
+        "r_shoulder_position": np.array([0.012, -0.185, 0.021]),
+        "r_shoulder_orientation": [-11.0, 3.5, 7.0],
+        "r_upper_arm_size": np.float64(0.305),
+        "r_forearm_size": np.float64(0.262),
+        "r_tip_position": np.array([0.013, -0.008, 0.094]),
+        "l_shoulder_position": np.array([0.012, 0.185, 0.021]),
+        "l_shoulder_orientation": [11.0, 3.5, -7.0],
+        "l_upper_arm_size": np.float64(0.305),
+        "l_forearm_size": np.float64(0.262),
+        "l_tip_position": np.array([0.013, 0.008, 0.094]),
+    },
+    "elbow_limit": 115,
+    "wrist_limit": np.float64(38.0),
+    "backward_limit": 0.035,
+    "singularity_offset": 0.05,
+    "singularity_limit_coeff": 0.8,
+}
+
+
+def gen_custom_geometry(out, n_sweep=6000, n_reach=1536):
+    rng = np.random.default_rng(9)
+    data = {}
+    for arm in ARMS:
+        solver = quiet(SymbolicIK, arm=arm, **CUSTOM_GEOMETRY)
+        for f in ("gripper_size", "max_arm_length", "shoulder_wrist_min_distance", "elbow_singularity_position",
+                  "wrist_singularity_position"):
+            data[f"{arm}_const_{f}"] = np.asarray(getattr(solver, f), dtype=float)
+        sh = CUSTOM_GEOMETRY["ik_parameters"][f"{arm[0]}_shoulder_position"]
+        pos = sh + rng.uniform(-0.7, 0.7, size=(n_sweep, 3))
+        eul = rng.uniform(-np.pi, np.pi, size=(n_sweep, 3))
+        rows = [solve_symbolic(solver, p, e) for p, e in zip(pos, eul)]
+        data[f"{arm}_sweep_pos"] = pos
+        data[f"{arm}_sweep_eul"] = eul
+        for k, v in stack(rows).items():
+            data[f"{arm}_sweep_{k}"] = v
+        P, E = [], []
+        while len(P) < n_reach:
+            pp = sh + rng.uniform(-0.7, 0.7, size=(4096, 3))
+            ee = rng.uniform(-np.pi, np.pi, size=(4096, 3))
+            for p, e in zip(pp, ee):
+                if solver.is_reachable(np.array([p, e]))[0]:
+                    P.append(p)
+                    E.append(e)
+                    if len(P) == n_reach:
+                        break
+        P, E = np.array(P), np.array(E)
+        tu = rng.uniform(0.0, 1.0, size=n_reach)
+        data[f"{arm}_reach_pos"] = P
+        data[f"{arm}_reach_eul"] = E
+        data[f"{arm}_reach_theta_u"] = tu
+        for k, v in stack([solve_symbolic(solver, p, e) for p, e in zip(P, E)]).items():
+            data[f"{arm}_reach_i0_{k}"] = v
+        for k, v in stack([solve_symbolic(solver, p, e, theta_u=u) for p, e, u in zip(P, E, tu)]).items():
+            data[f"{arm}_reach_in_{k}"] = v
+    np.savez_compressed(os.path.join(out, "g9_custom_geometry.npz"), **data)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
@@ -594,7 +658,8 @@ def main():
     os.makedirs(out, exist_ok=True)
     steps = [("g0", gen_constants), ("g1", gen_catalogue), ("g2", gen_sweep), ("g3", gen_reachable),
              ("g4", gen_control), ("g5", gen_helpers), ("g6", gen_continuous),
-             ("g7", gen_continuous_start), ("g8", gen_matrix_edges)]
+             ("g7", gen_continuous_start), ("g8", gen_matrix_edges),
+             ("g9", gen_custom_geometry)]
     for name, fn in steps:
         if args.only and name not in args.only.split(","):
             continue

@@ -778,3 +778,38 @@ def test_host_resident_pipeline_matches_device_path(torch_mod):
         for k in ("joints", "interval"):
             np.testing.assert_array_equal(res[k], ref[k])  # same kernel, same inputs: bit-identical (NaN rows included)
     assert r.solve_batch_host(host[:, :0])["joints"].shape == (0, 7)
+
+
+def test_custom_geometry_golden(golden_dir, torch_mod):
+    """G9: non-default arm (tip with x / y components, u != f, other shoulder offsets, elbow / wrist / backward limits
+    and singularity plane) recorded from the reference with the same constructor arguments: the kernels' general
+    formulas, not only their default-geometry special case.  Uniform launches per arm and one mixed launch."""
+    import contextlib
+    import io
+
+    from test_oracle_golden import CUSTOM_GEOMETRY
+
+    from reachy2_symbolic_ik_amd import DualArmIK, HipSolver, SymbolicIK
+
+    g = load(golden_dir, "g9_custom_geometry.npz")
+    solver = HipSolver(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        iks = {arm: SymbolicIK(arm, solver=solver, **CUSTOM_GEOMETRY) for arm in ("r_arm", "l_arm")}
+        dual = DualArmIK(solver=solver, **CUSTOM_GEOMETRY)
+    for arm, ik in iks.items():
+        for f in ("gripper_size", "max_arm_length", "shoulder_wrist_min_distance", "elbow_singularity_position"):
+            np.testing.assert_allclose(getattr(ik, f), g[f"{arm}_const_{f}"], rtol=0, atol=1e-15)
+        check_symbolic(to_np(ik.solve_batch(soa(g[f"{arm}_sweep_pos"], g[f"{arm}_sweep_eul"], torch_mod))), g, f"{arm}_sweep_")
+        p = soa(g[f"{arm}_reach_pos"], g[f"{arm}_reach_eul"], torch_mod)
+        check_symbolic(to_np(ik.solve_batch(p)), g, f"{arm}_reach_i0_")
+        tu = torch_mod.as_tensor(g[f"{arm}_reach_theta_u"]).cuda()
+        check_symbolic(to_np(ik.solve_batch(p, theta=("fraction", tu))), g, f"{arm}_reach_in_")
+    # both arms in one mixed launch
+    pos = np.concatenate([g["r_arm_reach_pos"], g["l_arm_reach_pos"]])
+    eul = np.concatenate([g["r_arm_reach_eul"], g["l_arm_reach_eul"]])
+    n = len(g["r_arm_reach_pos"])
+    arm_id = np.concatenate([np.zeros(n, np.uint8), np.ones(n, np.uint8)])
+    res = to_np(dual.solve_batch(torch_mod.as_tensor(arm_id).cuda(), soa(pos, eul, torch_mod)))
+    merged = {f"m_{k}": np.concatenate([g[f"r_arm_reach_i0_{k}"], g[f"l_arm_reach_i0_{k}"]]) for k in
+              ("reachable", "state", "interval", "joints", "elbow")}
+    check_symbolic(res, merged, "m_")

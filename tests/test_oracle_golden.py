@@ -320,3 +320,36 @@ def test_matrix_edges_euler_and_control(golden_dir, kind):
         np.testing.assert_array_equal(res["reachable"], g[pre + "reachable"])
         np.testing.assert_array_equal(res["state"], g[pre + "state"])
         assert np.max(np.abs(res["joints"] - g[pre + "joints"])) < TOL
+
+
+CUSTOM_GEOMETRY = dict(  # must match oracle/gen_golden.py CUSTOM_GEOMETRY (G9)
+    ik_parameters={
+        "r_shoulder_position": np.array([0.012, -0.185, 0.021]), "r_shoulder_orientation": [-11.0, 3.5, 7.0],
+        "r_upper_arm_size": 0.305, "r_forearm_size": 0.262, "r_tip_position": np.array([0.013, -0.008, 0.094]),
+        "l_shoulder_position": np.array([0.012, 0.185, 0.021]), "l_shoulder_orientation": [11.0, 3.5, -7.0],
+        "l_upper_arm_size": 0.305, "l_forearm_size": 0.262, "l_tip_position": np.array([0.013, 0.008, 0.094]),
+    },
+    elbow_limit=115, wrist_limit=38.0, backward_limit=0.035, singularity_offset=0.05, singularity_limit_coeff=0.8)
+
+
+def test_custom_geometry(golden_dir):
+    """G9: an arm that is NOT the reference's default one — tip with x / y components, unequal segment lengths, other
+    shoulder offsets and limits — so the general formulas are pinned, not only their default-geometry special case."""
+    g = load(golden_dir, "g9_custom_geometry.npz")
+    ar, al = orc.Arm("r_arm", **CUSTOM_GEOMETRY), orc.Arm("l_arm", **CUSTOM_GEOMETRY)
+    for i, (arm, a) in enumerate((("r_arm", ar), ("l_arm", al))):
+        for f in ("gripper_size", "max_arm_length", "shoulder_wrist_min_distance", "elbow_singularity_position",
+                  "wrist_singularity_position"):
+            np.testing.assert_allclose(a.field(f), g[f"{arm}_const_{f}"], rtol=0, atol=1e-15, err_msg=f"{arm} {f}")
+        n = len(g[f"{arm}_sweep_pos"])
+        res = orc.solve_batch(ar, al, g[f"{arm}_sweep_pos"], g[f"{arm}_sweep_eul"], arm_id=np.full(n, i, np.uint8), nthreads=4)
+        _check_symbolic(res, g, f"{arm}_sweep_")
+        assert set(np.unique(g[f"{arm}_sweep_state"])) >= {0, 1, 2, 3, 4}
+        n = len(g[f"{arm}_reach_pos"])
+        aid = np.full(n, i, np.uint8)
+        res = orc.solve_batch(ar, al, g[f"{arm}_reach_pos"], g[f"{arm}_reach_eul"], arm_id=aid, nthreads=4)
+        _check_symbolic(res, g, f"{arm}_reach_i0_")
+        res = orc.solve_batch(ar, al, g[f"{arm}_reach_pos"], g[f"{arm}_reach_eul"], arm_id=aid, theta_policy=2,
+                              theta_in=g[f"{arm}_reach_theta_u"], nthreads=4)
+        _check_symbolic(res, g, f"{arm}_reach_in_")
+        assert (g[f"{arm}_reach_i0_elbow_len"] == 3).mean() > 0.1  # the projection branch runs with this geometry too
