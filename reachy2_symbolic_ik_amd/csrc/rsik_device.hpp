@@ -274,6 +274,23 @@ __device__ __forceinline__ Goal make_goal(const Acc& A, const Rot& Rg) {
     g.xg = Rg.col0();
     return g;
 }
+// The same three vectors straight from the Euler angles for a tip offset along the goal z axis only (tip_x = tip_y = 0:
+// the reference's default arm and the Reachy 2 URDF): the wrist offset is R's third column times tip_z — bit for bit
+// what make_goal computes then, since its other two products are exact zeros — the "tip" point is the goal position
+// itself, and R's second column is never formed.  Chosen per launch by the host from the uploaded constants.
+template <class Acc>
+__device__ __forceinline__ Goal goal_from_euler_tipz(const Acc& A, double roll, double pitch, double yaw) {
+    const double ang[3] = {roll, pitch, yaw};
+    double sn[3], cs[3];
+    fast_sincos_n<3>(ang, sn, cs);
+    const double sa = sn[0], ca = cs[0], sb = sn[1], cb = cs[1], sc = sn[2], cc = cs[2];
+    const double tz = A(RSIK_C_TIPL + 2);
+    Goal g;
+    g.woff = {fma(cc * sb, ca, sc * sa) * tz, fma(sc * sb, ca, -(cc * sa)) * tz, (cb * ca) * tz};
+    g.toff = {0.0, 0.0, 0.0};
+    g.xg = {cc * cb, sc * cb, -sb};
+    return g;
+}
 // S:418-425 — wrist = T_torso_goal . (-tip_x, tip_y, tip_z, 1)
 __device__ __forceinline__ V3 wrist_position(const V3& woff, V3 pos) { return woff + pos; }
 
@@ -560,7 +577,7 @@ struct JointsOut {
 // FRESH = true: the state comes straight from reach() on the same pose (the fused kernels), so |wrist - elbow| is
 // the forearm length by construction; FRESH = false (stored solver state, possibly moved by an earlier projection,
 // Q1) measures it.
-template <bool FRESH, class Acc>
+template <bool FRESH, bool TIPZ = false, class Acc>
 __device__ JointsOut joints_from_theta_g(const Acc& A, Reach& r, const Goal& G, double ct, double st, const double* prev) {
     RSIK_MARK("joints_elbow");
     JointsOut o;
@@ -641,7 +658,7 @@ __device__ JointsOut joints_from_theta_g(const Acc& A, Reach& r, const Goal& G, 
     RSIK_MARK("joints_wrist");
     // wrist roll / pitch (S:808-826)
     V3 tl = cvec(A, RSIK_C_TIPL);
-    V3 ptip = G.toff + r.pos;
+    V3 ptip = TIPZ ? r.pos : (G.toff + r.pos);  // TIPZ: the tip offset has no x / y part (goal_from_euler_tipz)
     V3 t = to_wrist(ptip);
     double tau, cw, sw, wr_zero = 0.0;
     const bool tau_zero = RSIK_RARE(t.x == 0 && t.y == 0);

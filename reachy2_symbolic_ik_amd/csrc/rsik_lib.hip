@@ -213,7 +213,8 @@ __device__ __forceinline__ void flush_rows(double* __restrict__ out, int64_t wav
 // measured slower at every depth: 46.0 / 47.7 / 52.5 us for 2 / 4 / 8 tiles against 45.5 us, see
 // profiles/r01/timeline/: under the power-managed clock it is the executed instruction count that sets the time, not
 // how well the waves overlap.)
-template <bool MIXED>
+// TIPZ: every arm of the launch has tip_x = tip_y = 0 (goal_from_euler_tipz: -24 fp64 operations per pose).
+template <bool MIXED, bool TIPZ>
 __global__ __launch_bounds__(kBlock, RSIK_SOLVE_MIN_WAVES) void solve_kernel(const SolveArgs K) {
     __shared__ double lds[kBlock / 64][64 * 10];
     __shared__ SharedTables lds_tab;
@@ -247,7 +248,9 @@ __global__ __launch_bounds__(kBlock, RSIK_SOLVE_MIN_WAVES) void solve_kernel(con
 
     const V3 pos = {in[0], in[1], in[2]};
     Goal G;
-    {
+    if constexpr (TIPZ) {
+        G = goal_from_euler_tipz(A, in[3], in[4], in[5]);
+    } else {
         RSIK_MARK("euler");
         const Rot Rg = rot_from_euler(in[3], in[4], in[5]);
         RSIK_MARK("goal");
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(kBlock, RSIK_SOLVE_MIN_WAVES) void solve_kernel(con
                 }
                 fast_sincos(theta, &st, &ct);
             }
-            JointsOut o = joints_from_theta_g<true>(A, r, G, ct, st, (const double*)K.prev);
+            JointsOut o = joints_from_theta_g<true, TIPZ>(A, r, G, ct, st, (const double*)K.prev);
             RSIK_MARK("stores");
 #pragma unroll
             for (int k = 0; k < 7; k++) jrow[k] = o.j[k];
@@ -1091,8 +1094,16 @@ int rsik_solve(rsik_ctx* ctx, int64_t n, const double* const pose_soa[6], const 
     const int64_t blocks = (n + tile - 1) / tile;
     if (blocks > 0x7fffffffLL) return fail(ctx, RSIK_E_INVALID, "rsik_solve: n too large for one launch");
     dim3 grid((unsigned)blocks), block(rsik::kBlock);
-    if (arm) hipLaunchKernelGGL(rsik::solve_kernel<true>, grid, block, 0, ctx->stream, K);
-    else hipLaunchKernelGGL(rsik::solve_kernel<false>, grid, block, 0, ctx->stream, K);
+    // tip offset along the goal z axis only (the default arm / the URDF): the specialised goal stage applies
+    const bool tipz = K.arms[0].v[RSIK_C_TIPL] == 0.0 && K.arms[0].v[RSIK_C_TIPL + 1] == 0.0 &&
+                      K.arms[1].v[RSIK_C_TIPL] == 0.0 && K.arms[1].v[RSIK_C_TIPL + 1] == 0.0 && !std::getenv("RSIK_NO_TIPZ");
+    if (arm) {
+        if (tipz) hipLaunchKernelGGL((rsik::solve_kernel<true, true>), grid, block, 0, ctx->stream, K);
+        else hipLaunchKernelGGL((rsik::solve_kernel<true, false>), grid, block, 0, ctx->stream, K);
+    } else {
+        if (tipz) hipLaunchKernelGGL((rsik::solve_kernel<false, true>), grid, block, 0, ctx->stream, K);
+        else hipLaunchKernelGGL((rsik::solve_kernel<false, false>), grid, block, 0, ctx->stream, K);
+    }
     RSIK_HIP(ctx, hipGetLastError());
     return RSIK_OK;
 }

@@ -813,3 +813,30 @@ def test_custom_geometry_golden(golden_dir, torch_mod):
     merged = {f"m_{k}": np.concatenate([g[f"r_arm_reach_i0_{k}"], g[f"l_arm_reach_i0_{k}"]]) for k in
               ("reachable", "state", "interval", "joints", "elbow")}
     check_symbolic(res, merged, "m_")
+
+
+def test_tip_z_specialisation_is_bit_identical(torch_mod, monkeypatch):
+    """The default arm's tip offset has no x / y component, so rsik_solve launches the specialised goal stage
+    (goal_from_euler_tipz).  RSIK_NO_TIPZ=1 forces the general one: both must give the same bits, for uniform and
+    mixed launches, on all outcomes."""
+    from reachy2_symbolic_ik_amd import DualArmIK
+
+    solver, r, l = make_symbolic(0.03)
+    rng = np.random.default_rng(12)
+    n = 50000
+    pos = np.array([0.0, 0.0, 0.0]) + rng.uniform(-0.7, 0.7, size=(n, 3))
+    eul = rng.uniform(-np.pi, np.pi, size=(n, 3))
+    arm_id = torch_mod.as_tensor((rng.uniform(size=n) < 0.5).astype(np.uint8)).cuda()
+    p = soa(pos, eul, torch_mod)
+    import contextlib
+    import io
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        dual = DualArmIK(solver=solver)
+    fast = [to_np(r.solve_batch(p)), to_np(dual.solve_batch(arm_id, p))]
+    monkeypatch.setenv("RSIK_NO_TIPZ", "1")
+    slow = [to_np(r.solve_batch(p)), to_np(dual.solve_batch(arm_id, p))]
+    for a, b in zip(fast, slow):
+        assert a["reachable"].sum() > 500
+        for k in ("reachable", "state", "interval", "joints", "elbow"):
+            np.testing.assert_array_equal(a[k], b[k])
