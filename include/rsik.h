@@ -280,7 +280,8 @@ int rsik_fk_residual(rsik_ctx *ctx, int64_t n, int goal_kind, const double *cons
 /* Test hook: evaluates the kernels' own elementary functions (csrc/rsik_math.hpp) on device arrays so their
  * accuracy can be measured against the host libm.  op: 0 reciprocal, 1 sqrt (out0, out1 two variants),
  * 2 reciprocal sqrt, 3 atan2(a, b), 4 sincos(a) -> out0 = sin, out1 = cos, 5 out0 = a mod 2pi (Python
- * semantics), out1 = angle_diff(a, b) (utils.py:486-490), 6 fp64 FMA issue-rate calibration (8 x 2048 dependent fma per element, scripts/valu_peak.py).
+ * semantics), out1 = angle_diff(a, b) (utils.py:486-490), 6 fp64 FMA issue-rate calibration (8 x 2048 dependent fma per element, scripts/valu_peak.py),
+ * 7 the solve path's table atan2 of a UNIT vector: out0 = atan2(a, b) for a^2 + b^2 = 1.
  * Not part of the reference surface. */
 int rsik_debug_math(rsik_ctx *ctx, int op, int64_t n, const double *a, const double *b, double *out0, double *out1);
 

@@ -890,14 +890,24 @@ __global__ __launch_bounds__(kBlock) void fk_kernel(const FkArgs K) {
     }
 }
 
-// Unit-test hook for rsik_math.hpp (rsik_debug_math): op 0 rcp, 1 sqrt_cr, 2 rsqrt, 3 atan2(a,b), 4 sincos(a), 5 a % 2pi, 6 fp64 FMA issue-rate calibration
+// Unit-test hook for rsik_math.hpp (rsik_debug_math): op 0 rcp, 1 sqrt_cr, 2 rsqrt, 3 atan2(a,b), 4 sincos(a), 5 a % 2pi, 6 fp64 FMA issue-rate calibration,
+// 7 unit_atan2(s = a, c = b) of a unit vector
 __global__ void debug_math_kernel(int op, int64_t n, const double* a, const double* b, double* o0, double* o1) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ double utab[kUnitAtanRows][4];
     stage_sincos_tab();
+    stage_unit_atan_tab(utab);
     __syncthreads();
     if (i >= n) return;
     double x = a[i], r0 = 0.0, r1 = 0.0;
     switch (op) {
+        case 7: {  // the hot path's atan2: direction angle of the UNIT vector (c, s) = (b, a)
+            const double ss[1] = {x}, cc[1] = {b[i]};
+            double o[1];
+            unit_atan2_n<1>((UnitAtanTab)&utab[0][0], ss, cc, o);
+            r0 = o[0];
+            break;
+        }
         case 0: r0 = fast_rcp(x); break;
         case 1: sqrt_rsqrt(x, r0, r1); r1 = sqrt_cr(x); break;
         case 2: r0 = rsqrt_fast(x); break;
@@ -1429,9 +1439,9 @@ int rsik_fk_residual(rsik_ctx* ctx, int64_t n, int goal_kind, const double* cons
 
 int rsik_debug_math(rsik_ctx* ctx, int op, int64_t n, const double* a, const double* b, double* out0, double* out1) {
     if (!ctx) return RSIK_E_INVALID;
-    if (n < 0 || op < 0 || op > 6) return fail(ctx, RSIK_E_INVALID, "rsik_debug_math: bad op or n");
+    if (n < 0 || op < 0 || op > 7) return fail(ctx, RSIK_E_INVALID, "rsik_debug_math: bad op or n");
     if (n == 0) return RSIK_OK;
-    if (!a || !out0 || ((op == 3 || op == 5 || op == 6) && !b)) return fail(ctx, RSIK_E_INVALID, "rsik_debug_math: NULL operand");
+    if (!a || !out0 || ((op == 3 || op == 5 || op == 6 || op == 7) && !b)) return fail(ctx, RSIK_E_INVALID, "rsik_debug_math: NULL operand");
     RSIK_HIP(ctx, hipSetDevice(ctx->device));
     dim3 grid, block(rsik::kBlock);
     int rc = launch_dims(ctx, n, &grid, "rsik_debug_math");

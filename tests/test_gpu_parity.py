@@ -444,6 +444,12 @@ def test_device_math_accuracy(torch_mod):
     xx = np.concatenate([rng.normal(size=n - 8), [0.0, -0.0, -0.0, 0.0, 0.0, -2.0, 1.0, 3.0]])
     a, _ = hs.debug_math(3, t(yy), t(xx))
     assert np.max(np.abs(a.cpu().numpy() - np.arctan2(yy, xx))) < 4.5e-16
+    # the solve path's own atan2: unit vectors, table rotation + 3-term asin (dropped x^9 term < 5.3e-16 rad)
+    th = np.concatenate([rng.uniform(-np.pi, np.pi, n - 9), np.array([0.0, np.pi / 2, -np.pi / 2, np.pi, np.pi / 4, -3 * np.pi / 4,
+                                                                      1e-9, np.pi - 1e-9, -np.pi + 1e-9])])
+    us, uc = np.sin(th), np.cos(th)
+    ua, _ = hs.debug_math(7, t(us), t(uc))
+    assert np.max(np.abs(ua.cpu().numpy() - np.arctan2(us, uc))) < 1.2e-15
     ang = np.concatenate([rng.uniform(-4 * np.pi, 4 * np.pi, n // 2), rng.uniform(-1e4, 1e4, n // 2 - 4),
                           [0.0, np.pi / 2, -np.pi, np.pi]])
     sn, cs = hs.debug_math(4, t(ang))
