@@ -920,8 +920,8 @@ __device__ double best_theta_to_current_joints(const Acc& A, Reach& r, const Rot
 // each is satisfied on one open arc whose two end angles are phi +- acos(D / R) (R = |(A, B)|, phi = atan2(B, A)).
 // The grid points that pass are therefore at most a few index runs delimited by those four angles and the grid ends,
 // and inside a run |angle_diff(theta_k, preferred)| is smallest either next to the preferred angle or at a run end.
-// So the first-strict-minimum of the reference is among: the two grid ends, the 4 grid points around the preferred
-// angle and the 4 grid points around each arc end (22 evaluations, independent of nb_search_points).  Each candidate is
+// So the first-strict-minimum of the reference is among: the two grid ends, the 2 grid points that bracket the preferred
+// angle and the 2 that bracket each arc end (12 evaluations, independent of nb_search_points).  Each candidate is
 // then judged with the reference's own predicate and distance (same theta_k = linspace value, same is_elbow_ok), so the
 // analytic arcs only propose candidates, they never decide.  `fast_ok` = false (degenerate step) asks the caller to
 // fall back to the exhaustive wave-cooperative sweep.
@@ -973,21 +973,25 @@ __device__ bool grid_theta_candidates(const Acc& A, const Reach& r, double a, do
         // whole wave (wave-uniform branch; e.g. the singularity-plane half never binds with the non-DVT offset, Q18)
         const bool anchor_valid = (j == 0) ? true : ((j <= 2) ? v1 : v2);
         if (!__any(anchor_valid)) continue;
-        double pos = pymod_2pi(ang[j] - a) * inv_step;   // real-valued grid index of the anchor angle
+        double pos = pymod_2pi(ang[j] - a) * inv_step;   // real-valued grid index of the anchor angle, >= 0
         pos = (pos < 2.0e9) ? pos : 0.0;                 // also catches NaN
-        const int k0 = (int)pos - 1;
-        int kk[4];
-        double th[4], sn[4], cs[4];
+        // the two grid points that bracket the anchor.  When the anchor sits within 1e-6 of a grid point its own
+        // rounding could move it across: such a pose goes to the exhaustive sweep instead (fast_ok = false).
+        const int k0 = (int)pos;
+        const double frac = pos - (double)k0;
+        if (anchor_valid && (frac < 1e-6 || frac > 1.0 - 1e-6)) fast_ok = false;
+        int kk[2];
+        double th[2], sn[2], cs[2];
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
+        for (int t = 0; t < 2; t++) {
             int k = k0 + t;
-            k = k < 0 ? 0 : (k > last ? last : k);
+            k = k > last ? last : k;
             kk[t] = k;
             th[t] = theta_of(k);
         }
-        fast_sincos_n<4>(th, sn, cs);
+        fast_sincos_n<2>(th, sn, cs);
 #pragma unroll
-        for (int t = 0; t < 4; t++) judge(kk[t], th[t], sn[t], cs[t]);
+        for (int t = 0; t < 2; t++) judge(kk[t], th[t], sn[t], cs[t]);
     }
     theta_out = best_th;
     return best_k != 0x7fffffff;

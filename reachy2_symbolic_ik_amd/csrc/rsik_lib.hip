@@ -546,12 +546,12 @@ __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) void control_discrete_
     }
     // Two ways to search the grid, chosen per wave (wave-uniform): when only a few lanes need it, the exhaustive
     // wave-cooperative sweep (cost ~ number of such poses); when most lanes need it, every lane searches its own
-    // pose serially — the whole grid if it is short, else the 22 arc-end candidates (grid_theta_candidates).
+    // pose serially — the whole grid if it is short, else the 12 bracketing candidates (grid_theta_candidates).
     const uint64_t need_mask = __ballot(need);
     const int cnt = __popcll(need_mask);
-    const int serial_evals = (K.nb <= 24) ? K.nb : 22;
+    const int serial_evals = (K.nb <= 16) ? K.nb : 12;
     const int coop_rounds = ((cnt + (64 >> K.log2p) - 1) >> (6 - K.log2p)) * ((K.nb + 63) >> 6);
-    bool dense = serial_evals * 70 + (K.nb <= 24 ? 0 : 350) < coop_rounds * 150;
+    bool dense = serial_evals * 70 + (K.nb <= 16 ? 0 : 350) < coop_rounds * 150;
     if (K.sweep_mode == 1) dense = false;
     if (K.sweep_mode == 2) dense = true;
     bool coop = need;
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) void control_discrete_
     bool found_serial = false;
     if (dense && need) {
         const double ga = lds_geo[wave][10][lane], gstep = lds_geo[wave][11][lane], gb = lds_geo[wave][12][lane];
-        if (K.nb <= 24) {
+        if (K.nb <= 16) {
             found_serial = best_discrete_theta_grid(A, r, ga, gstep, gb, K.nb, pref, th_serial);
             coop = false;
         } else {

@@ -361,8 +361,8 @@ def test_control_random(golden_dir, torch_mod, dvt_tag, is_dvt):
 @pytest.mark.parametrize("nb", [2, 3, 10, 20, 25, 33, 64, 65, 100, 200, 1000])
 def test_control_grid_sizes_match_checker(golden_dir, torch_mod, orc, nb, mode, monkeypatch):
     """Grid search strategies (RSIK_SWEEP_MODE: 0 = per-wave choice, 1 = exhaustive wave-cooperative sweep, which packs
-    64/pow2ceil(nb) poses per round and needs extra rounds above 64 points, 2 = per-lane search: whole grid up to 24
-    points, the 22 arc-end candidates above) must all reproduce the reference's first strict minimum."""
+    64/pow2ceil(nb) poses per round and needs extra rounds above 64 points, 2 = per-lane search: whole grid up to 16
+    points, the 12 bracketing candidates above) must all reproduce the reference's first strict minimum."""
     monkeypatch.setenv("RSIK_SWEEP_MODE", mode)
     g = load(golden_dir, "g4_control_discrete.npz")
     c = make_control()
