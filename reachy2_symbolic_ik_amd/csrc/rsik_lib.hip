@@ -416,7 +416,15 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-constexpr int kGeo = 13;  // staged doubles per pose: c2(3) a1(3) a2(3) r2 a step b
+// Per-wave LDS slab of the discrete kernel, kDiscRows rows of 64 doubles (one per lane), so that four workgroups fit in
+// a CU's 160 KB (the staged circle geometry used to sit in its own 13-row array: 47.6 KB per workgroup, 3 per CU):
+//   rows 0-5   the two goal vectors the joint stage reads again (parked during the theta search);
+//              after the search the first 7 * 64 doubles are the [64][7] output staging area
+//   rows 6-16  circle geometry for the wave-cooperative sweep: c2 (3), r2 a1 (3), r2 a2 (3), grid ends a, b
+//              (the step is (b - a) / (nb - 1), recomputed by its readers); the sweep's result for pose p overwrites
+//              a[p], which only p's own sub-group reads, and only before it posts the result
+constexpr int kDiscRows = 17;
+constexpr int kGeoRow0 = 6;
 
 // utils.get_best_discrete_theta (U:334-396) for the poses of one wave that need the grid.
 // Lane-per-pose has already staged the circle geometry of its pose in LDS; here the wave walks the set
@@ -453,10 +461,10 @@ __device__ __forceinline__ void sweep_theta_grid(const DiscreteArgs& K, uint64_t
         const int slot = MIXED ? (isl ? 1 : 0) : 0;
         if (p >= 0) {
             V3 c2 = {geo[0][p], geo[1][p], geo[2][p]};
-            V3 a1 = {geo[3][p], geo[4][p], geo[5][p]};
-            V3 a2 = {geo[6][p], geo[7][p], geo[8][p]};
-            double r2 = geo[9][p];
-            ga = geo[10][p]; gstep = geo[11][p]; gb = geo[12][p];
+            V3 a1 = {geo[3][p], geo[4][p], geo[5][p]};  // r2 a1
+            V3 a2 = {geo[6][p], geo[7][p], geo[8][p]};  // r2 a2
+            ga = geo[9][p]; gb = geo[10][p];
+            gstep = (gb - ga) / (double)(K.nb - 1);
             const double pref = K.pref[slot];
             for (int rd = 0; rd < rounds; rd++) {
                 int k = k0 + (rd << 6);
@@ -464,8 +472,7 @@ __device__ __forceinline__ void sweep_theta_grid(const DiscreteArgs& K, uint64_t
                     double th = (k == K.nb - 1) ? gb : ((double)k * gstep + ga);  // np.linspace (Q11)
                     double st, ct;
                     fast_sincos(th, &st, &ct);
-                    double y = r2 * ct, z = r2 * st;
-                    V3 e = {a1.x * y + a2.x * z + c2.x, a1.y * y + a2.y * z + c2.y, a1.z * y + a2.z * z + c2.z};
+                    V3 e = {a1.x * ct + a2.x * st + c2.x, a1.y * ct + a2.y * st + c2.y, a1.z * ct + a2.z * st + c2.z};
                     if (is_elbow_ok(A, e)) {
                         double dist = fabs(angle_diff(th, pref));
                         if (dist < best_d) { best_d = dist; best_k = k; }
@@ -486,14 +493,15 @@ __device__ __forceinline__ void sweep_theta_grid(const DiscreteArgs& K, uint64_t
     }
 }
 
+#ifndef RSIK_DISC_ATTR
+#define RSIK_DISC_ATTR
+#endif
 #ifndef RSIK_DISC_MIN_WAVES
 #define RSIK_DISC_MIN_WAVES 3  // 168 VGPR (28 B scratch) beats 182 VGPR at 2 waves/SIMD: 37.6 vs 39.0 us on config 3
 #endif
 template <bool MIXED>
-__global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) void control_discrete_kernel(const DiscreteArgs K) {
-    __shared__ double lds_out[kBlock / 64][64 * 7];
-    __shared__ double lds_geo[kBlock / 64][kGeo][64];
-    __shared__ double lds_res[kBlock / 64][64];
+__global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR void control_discrete_kernel(const DiscreteArgs K) {
+    __shared__ double lds_slab[kBlock / 64][kDiscRows][64];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -517,7 +525,7 @@ __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) void control_discrete_
     {
         const double pk[6] = {G.toff.x, G.toff.y, G.toff.z, G.xg.x, G.xg.y, G.xg.z};
 #pragma unroll
-        for (int k = 0; k < 6; k++) lds_out[wave][k * 64 + lane] = pk[k];
+        for (int k = 0; k < 6; k++) lds_slab[wave][k][lane] = pk[k];
     }
     Reach r = reach_g<false, false>(A, pos, G.woff);
     const double pref = K.pref[slot];
@@ -537,12 +545,11 @@ __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) void control_discrete_
         if (fabs(fabs(r.i0) + fabs(r.i1) - kTwoPi) < 0.00001) { a = kPi / 2; b = kPi / 2 + kTwoPi; }
         else if (r.i0 < r.i1) { a = r.i0; b = r.i1; }
         else { a = r.i0; b = r.i1 + kTwoPi; }
-        double step = (b - a) / (double)(K.nb - 1);
-        double (*g)[64] = lds_geo[wave];
+        double (*g)[64] = &lds_slab[wave][kGeoRow0];
         g[0][lane] = r.c2.x; g[1][lane] = r.c2.y; g[2][lane] = r.c2.z;
-        g[3][lane] = r.a1.x; g[4][lane] = r.a1.y; g[5][lane] = r.a1.z;
-        g[6][lane] = r.a2.x; g[7][lane] = r.a2.y; g[8][lane] = r.a2.z;
-        g[9][lane] = r.r2; g[10][lane] = a; g[11][lane] = step; g[12][lane] = b;
+        g[3][lane] = r.r2 * r.a1.x; g[4][lane] = r.r2 * r.a1.y; g[5][lane] = r.r2 * r.a1.z;
+        g[6][lane] = r.r2 * r.a2.x; g[7][lane] = r.r2 * r.a2.y; g[8][lane] = r.r2 * r.a2.z;
+        g[9][lane] = a; g[10][lane] = b;
     }
     // Two ways to search the grid, chosen per wave (wave-uniform): when only a few lanes need it, the exhaustive
     // wave-cooperative sweep (cost ~ number of such poses); when most lanes need it, every lane searches its own
@@ -558,7 +565,8 @@ __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) void control_discrete_
     double th_serial = 0.0;
     bool found_serial = false;
     if (dense && need) {
-        const double ga = lds_geo[wave][10][lane], gstep = lds_geo[wave][11][lane], gb = lds_geo[wave][12][lane];
+        const double ga = lds_slab[wave][kGeoRow0 + 9][lane], gb = lds_slab[wave][kGeoRow0 + 10][lane];
+        const double gstep = (gb - ga) / (double)(K.nb - 1);
         if (K.nb <= 16) {
             found_serial = best_discrete_theta_grid(A, r, ga, gstep, gb, K.nb, pref, th_serial);
             coop = false;
@@ -570,11 +578,11 @@ __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) void control_discrete_
     }
     wave_lds_sync();
     const uint64_t mask = __ballot(coop);
-    sweep_theta_grid<MIXED>(K, mask, lane, A.isl, lds_tab, lds_geo[wave], lds_res[wave]);
+    sweep_theta_grid<MIXED>(K, mask, lane, A.isl, lds_tab, &lds_slab[wave][kGeoRow0], &lds_slab[wave][kGeoRow0 + 9][0]);
     wave_lds_sync();
     int st_code = r.state;
     if (need) {
-        double th = coop ? lds_res[wave][lane] : (found_serial ? th_serial : __builtin_nan(""));
+        double th = coop ? lds_slab[wave][kGeoRow0 + 9][lane] : (found_serial ? th_serial : __builtin_nan(""));
         if (th == th) { found = true; theta = th; }
         else st_code = RSIK_STATE_LIMITED_BY_SHOULDER;  // C:451-452
     }
@@ -586,7 +594,7 @@ __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) void control_discrete_
         theta = limit_theta_to_interval(theta, K.lim[slot][0], K.lim[slot][1]);
         double st, ct;
         fast_sincos(theta, &st, &ct);
-        const double* pk = lds_out[wave];
+        const double* pk = &lds_slab[wave][0][0];
         G.toff = {pk[0 * 64 + lane], pk[1 * 64 + lane], pk[2 * 64 + lane]};
         G.xg = {pk[3 * 64 + lane], pk[4 * 64 + lane], pk[5 * 64 + lane]};
         JointsOut o = joints_from_theta_g<true>(A, r, G, ct, st, prev);
@@ -601,7 +609,7 @@ __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) void control_discrete_
         fast_sincos(jv[6], &s6, &c6);
     }
     bool em = safety_checks(jv, c4, s4, c5, s5, c6, s6, prev, K.max_angle, K.cos_max, K.sin_max);
-    store_rows<7>(K.joints, wave_base, K.n, lane, lds_out[wave], jv);
+    store_rows<7>(K.joints, wave_base, K.n, lane, &lds_slab[wave][0][0], jv);
     if (live) {
         if (K.reachable) K.reachable[i] = found ? 1 : 0;
         if (K.state) K.state[i] = (uint8_t)st_code;
