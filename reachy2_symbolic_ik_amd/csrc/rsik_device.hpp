@@ -799,44 +799,55 @@ __device__ __forceinline__ double limit_theta_to_interval(double theta, double l
 //   beta to the Orbita3D cone, back to XYZ (scipy gimbal conventions: beta within 1e-7 of 0 or pi => gamma := 0);
 //   utils.allow_multiturn (U:493-505); utils.multiturn_safety_check (U:535-568).
 // The wrist angles enter as unit vectors (c, s) so no sin/cos is evaluated for joints that came out of atan2.
-__device__ __forceinline__ bool safety_checks(double (&j)[7], double ca, double sa, double cb, double sb, double cc,
-                                              double sc, const double* prev, double max_angle, double cos_max,
+__device__ __forceinline__ bool safety_checks(UnitAtanTab utab, double (&j)[7], double ca, double sa, double cb, double sb,
+                                              double cc, double sc, const double* prev, double max_angle, double cos_max,
                                               double sin_max) {
-    // W = Rx(a) Ry(b) Rz(c)
+    // W = Rx(a) Ry(b) Rz(c); its third column (W02, W12, W22) = (sin beta cos alpha, sin beta sin alpha, cos beta) is
+    // the wrist axis, so everything about beta in [0, pi] is decided on its cosine / sine, no angle is formed:
+    //   beta <= 1e-7 or pi - beta <= 1e-7 (SciPy's gimbal cases)  <=>  sin beta <= sin(1e-7), sign of cos beta
+    //   beta > max_angle (the only clamp that can act, beta >= 0)   <=>  cos beta < cos(max_angle)
     double W00 = cb * cc, W01 = -cb * sc, W02 = sb;
     double W10 = ca * sc + sa * sb * cc, W12 = -sa * cb;
     double W20 = sa * sc - ca * sb * cc, W21 = sa * cc + ca * sb * sc, W22 = ca * cb;
-    double sbeta = sqrt(W02 * W02 + W12 * W12);  // sin(beta) >= 0, beta in [0, pi]
-    double beta = fast_atan2(sbeta, W22);
+    (void)W01; (void)max_angle;
+    const double sb2 = W02 * W02 + W12 * W12;
     double cal, sal, cga, sga;  // cos/sin of alpha, gamma
-    if (fabs(beta) <= 1e-7) {
-        double ih = rsqrt_fast(W00 * W00 + W10 * W10);
-        cal = W00 * ih; sal = W10 * ih; cga = 1.0; sga = 0.0;
-    } else if (fabs(beta - kPi) <= 1e-7) {
-        double ih = rsqrt_fast(W00 * W00 + W10 * W10);
-        cal = -W00 * ih; sal = -W10 * ih; cga = 1.0; sga = 0.0;
+    double cbe = W22, sbe;
+    if (RSIK_RARE(sb2 <= 9.999999999999965e-15)) {  // sin(1e-7)^2: gamma := 0, alpha takes the whole z rotation
+        const double ih = rsqrt_fast(W00 * W00 + W10 * W10);
+        const double sg = (W22 > 0) ? 1.0 : -1.0;
+        cal = sg * W00 * ih; sal = sg * W10 * ih; cga = 1.0; sga = 0.0;
+        sbe = (sb2 > 0.0) ? sqrt(sb2) : 0.0;
     } else {
-        double isb = fast_rcp(sbeta);
+        const double isb = rsqrt_fast(sb2);
+        sbe = sb2 * isb;
         cal = W02 * isb; sal = W12 * isb;
-        double ih = rsqrt_fast(W20 * W20 + W21 * W21);
+        const double ih = rsqrt_fast(W20 * W20 + W21 * W21);
         cga = -W20 * ih; sga = W21 * ih;
     }
-    const double inb = rsqrt_fast(sbeta * sbeta + W22 * W22);
-    double cbe = W22 * inb, sbe = sbeta * inb;
-    if (beta > max_angle) { cbe = cos_max; sbe = sin_max; }  // beta >= 0 so only the upper clamp can act
-    // W' = Rz(alpha) Ry(beta') Rz(gamma); intrinsic XYZ angles of W'
+    if (cbe < cos_max) { cbe = cos_max; sbe = sin_max; }
+    // W' = Rz(alpha) Ry(beta') Rz(gamma); intrinsic XYZ angles of W': roll = atan2(-V12, V22), pitch = asin(V02),
+    // yaw = atan2(-V01, V00).  (V12, V22) and (V01, V00) both have length cos(pitch) >= cos(max_angle), so one reciprocal
+    // square root makes all three direction vectors unit and the table atan2 applies.
     double V02 = cal * sbe, V12 = sal * sbe, V22 = cbe;
     double V01 = -cal * cbe * sga - sal * cga, V00 = cal * cbe * cga - sal * sga;
     {
-        const double yy[3] = {-V12, V02, -V01};
-        const double xx[3] = {V22, sqrt(fma(-V02, V02, 1.0)), V00};  // middle: asin(V02); |V02| <= sin(max_angle) after the clamp
+        const double cp2 = fma(-V02, V02, 1.0);
+        const double icp = rsqrt_fast(cp2);
+        const double ss[3] = {-V12 * icp, V02, -V01 * icp};
+        const double cs[3] = {V22 * icp, cp2 * icp, V00 * icp};
         double aa[3];
-        fast_atan2_n<3>(yy, xx, aa);
+        unit_atan2_n<3>(utab, ss, cs, aa);
         j[4] = aa[0]; j[5] = aa[1]; j[6] = aa[2];
     }
     bool emergency = false;
+    // utils.allow_multiturn (U:493-505): prev + angle_diff(j, prev); the wrap only acts when they are > pi apart
 #pragma unroll
-    for (int k = 0; k < 7; k++) j[k] = prev[k] + angle_diff(j[k], prev[k]);
+    for (int k = 0; k < 7; k++) {
+        double t = (j[k] - prev[k]) + kPi;
+        if (RSIK_RARE(!(t >= 0.0 && t < kTwoPi))) t = pymod_2pi(t);
+        j[k] = prev[k] + (t - kPi);
+    }
     const double lim = 6 * kPi;
 #pragma unroll
     for (int k = 0; k < 7; k++) {
@@ -938,10 +949,16 @@ __device__ bool grid_theta_candidates(const Acc& A, const Reach& r, double a, do
     const bool v1 = R1s > D1 * D1, v2 = R2s > D2 * D2;  // the constraint really changes sign on the circle
     double ang[5];
     {
-        const double yy[4] = {B1, sqrt(fmax(R1s - D1 * D1, 0.0)), B2, sqrt(fmax(R2s - D2 * D2, 0.0))};
-        const double xx[4] = {A1, D1, A2, D2};
+        // phi = direction of (A, B), alpha = acos(D / R) = direction of (D, sqrt(R^2 - D^2)): both vectors have length R,
+        // so one reciprocal square root per constraint makes them unit and the table atan2 applies.  A constraint that
+        // does not change sign on the circle (v false) gets harmless stand-ins; its angles are not used.
+        const double Rs1 = v1 ? R1s : 1.0, Rs2 = v2 ? R2s : 1.0;
+        const double i1 = rsqrt_fast(Rs1), i2 = rsqrt_fast(Rs2);
+        const double h1 = v1 ? sqrt(R1s - D1 * D1) : 0.0, h2 = v2 ? sqrt(R2s - D2 * D2) : 0.0;
+        const double yy[4] = {(v1 ? B1 : 0.0) * i1, h1 * i1, (v2 ? B2 : 0.0) * i2, h2 * i2};
+        const double xx[4] = {(v1 ? A1 : 1.0) * i1, (v1 ? D1 : 1.0) * i1, (v2 ? A2 : 1.0) * i2, (v2 ? D2 : 1.0) * i2};
         double at[4];
-        fast_atan2_n<4>(yy, xx, at);  // phi_1, alpha_1 = acos(D1/R1), phi_2, alpha_2
+        unit_atan2_n<4>(A.utab, yy, xx, at);  // phi_1, alpha_1, phi_2, alpha_2
         ang[0] = pref;
         ang[1] = v1 ? at[0] + at[1] : a;
         ang[2] = v1 ? at[0] - at[1] : a;

@@ -608,7 +608,7 @@ __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR void co
         fast_sincos(jv[5], &s5, &c5);
         fast_sincos(jv[6], &s6, &c6);
     }
-    bool em = safety_checks(jv, c4, s4, c5, s5, c6, s6, prev, K.max_angle, K.cos_max, K.sin_max);
+    bool em = safety_checks(A.utab, jv, c4, s4, c5, s5, c6, s6, prev, K.max_angle, K.cos_max, K.sin_max);
     store_rows<7>(K.joints, wave_base, K.n, lane, &lds_slab[wave][0][0], jv);
     if (live) {
         if (K.reachable) K.reachable[i] = found ? 1 : 0;
@@ -718,7 +718,7 @@ __global__ __launch_bounds__(kBlock) void control_continuous_kernel(const Contin
         JointsOut o = joints_from_theta<true>(A, r, Rg, cs, sn, prev_sol);
 #pragma unroll
         for (int k = 0; k < 7; k++) jv[k] = o.j[k];
-        bool em = safety_checks(jv, o.c4, o.s4, o.c5, o.s5, o.c6, o.s6, prev_sol, K.max_angle, K.cos_max, K.sin_max);
+        bool em = safety_checks(A.utab, jv, o.c4, o.s4, o.c5, o.s5, o.c6, o.s6, prev_sol, K.max_angle, K.cos_max, K.sin_max);
         emergency = emergency || em;
         if (!init) {  // U:571-589 continuity_check, thresholds C:398
             bool disc = false;
