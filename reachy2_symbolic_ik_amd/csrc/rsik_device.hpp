@@ -954,7 +954,8 @@ __device__ bool grid_theta_candidates(const Acc& A, const Reach& r, double a, do
         // does not change sign on the circle (v false) gets harmless stand-ins; its angles are not used.
         const double Rs1 = v1 ? R1s : 1.0, Rs2 = v2 ? R2s : 1.0;
         const double i1 = rsqrt_fast(Rs1), i2 = rsqrt_fast(Rs2);
-        const double h1 = v1 ? sqrt(R1s - D1 * D1) : 0.0, h2 = v2 ? sqrt(R2s - D2 * D2) : 0.0;
+        const double q1 = v1 ? R1s - D1 * D1 : 1.0, q2 = v2 ? R2s - D2 * D2 : 1.0;  // > 0 where the constraint binds
+        const double h1 = v1 ? q1 * rsqrt_fast(q1) : 0.0, h2 = v2 ? q2 * rsqrt_fast(q2) : 0.0;
         const double yy[4] = {(v1 ? B1 : 0.0) * i1, h1 * i1, (v2 ? B2 : 0.0) * i2, h2 * i2};
         const double xx[4] = {(v1 ? A1 : 1.0) * i1, (v1 ? D1 : 1.0) * i1, (v2 ? A2 : 1.0) * i2, (v2 ? D2 : 1.0) * i2};
         double at[4];

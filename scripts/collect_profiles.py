@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Copies the judged artefacts of scripts/profile.sh runs (gpurun_out/<prefix>_c{2,3,4}) into profiles/r01/ and
+rebuilds profiles/r01/traffic.json (HBM bytes per launch and executed VALU instructions per wave from the PMC passes).
+
+    python scripts/collect_profiles.py r01_s2c s2
+"""
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+prefix, suffix = sys.argv[1], sys.argv[2]
+dest = os.path.join(root, "profiles", "r01")
+
+
+def parse(path):
+    blocks, cur = {}, None
+    for line in open(path):
+        m = re.match(r"pmc\s+(.*) grid=(\d+)", line)
+        if m:
+            cur = (m.group(1).strip(), int(m.group(2)))
+            blocks[cur] = {}
+            continue
+        m = re.match(r"\s+(\w+)\s+median=\s*([\d.]+)", line)
+        if m and cur:
+            blocks[cur][m.group(1)] = float(m.group(2))
+    return blocks
+
+
+out = {"_comment": "HBM bytes per launch and executed vector instructions per wave from rocprofv3 PMC passes (FETCH_SIZE x2 "
+                   "gfx950 correction + WRITE_SIZE, KiB units; SQ_INSTS_VALU / SQ_WAVES), scripts/profile.sh; see "
+                   f"config*_{suffix}_summary.txt"}
+want = {2: ("solve_kernel<false", 1048576, "solve_kernel"), 3: ("control_discrete_kernel<false", 262144, "control_discrete_kernel"),
+        4: ("solve_kernel<true", 1048576, "solve_kernel<mixed>")}
+for c, (kn, grid, label) in want.items():
+    src = os.path.join(root, "gpurun_out", f"{prefix}_c{c}")
+    shutil.copy(os.path.join(src, "summary.txt"), os.path.join(dest, f"config{c}_{suffix}_summary.txt"))
+    shutil.copy(os.path.join(src, "bench.json"), os.path.join(dest, f"bench_config{c}_{suffix}.json"))
+    for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
+        shutil.copy(f, os.path.join(dest, f"config{c}_{suffix}_kernel_stats.csv"))
+    for (name, g), v in parse(os.path.join(src, "summary.txt")).items():
+        if kn in name and g == grid and "FETCH_SIZE" in v:
+            out[str(c)] = {"poses_per_gpu": grid, "kernel": label, "bytes": int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024),
+                           "valu_per_wave": round(v["SQ_INSTS_VALU"] / v["SQ_WAVES"], 1)}
+            print(c, out[str(c)])
+json.dump(out, open(os.path.join(dest, "traffic.json"), "w"), indent=2)
