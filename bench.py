@@ -313,11 +313,12 @@ def main():
             "state": torch.empty((n_steps, n_traj), dtype=torch.uint8, device=dev),
         }
 
-        def step_kernel():  # one "step" of the bench = one 1000-step pass over all trajectories (1000 launches from C)
+        def step_kernel():  # one "step" of the bench = one 1000-step pass over all trajectories (one launch: the kernel walks the steps)
             cont.copy_(cont0)
             ctrl.run_continuous_trajectories("r_arm", traj, cont, first_step_timed_out=True, current_pose=traj[0], out=out)
 
-        workload = f"config5: ControlIK continuous, {n_traj} trajectories x {n_steps} steps, state carried across launches"
+        workload = (f"config5: ControlIK continuous, {n_traj} trajectories x {n_steps} steps per pass, trajectory state carried "
+                    "in registers across the steps of a pass and in HBM across passes / launches")
         kernel_name = "control_continuous_kernel"
         n = n * n_steps  # units per bench step = trajectory-steps
     else:
@@ -501,7 +502,7 @@ def main():
         if cfg == 5:
             line["metric"] = "IK control steps/sec (ControlIK continuous, r_arm trajectories)"
             line["unit"] = "steps/s"
-            line["roofline"]["kernel_ms"] = kernel_ms / 1000  # per launch (1000 launches per bench step)
+            line["roofline"]["kernel_ms"] = kernel_ms / 1000  # per control step (one launch walks the 1000 steps of a pass)
             line["roofline"]["kernel_only_solves_per_s_per_gpu"] = n / (kernel_ms * 1e-3)
         if not args.no_cpu_baseline:
             base = cpu_baseline(cfg, inputs, args.cpu_seconds)

@@ -342,9 +342,9 @@ __global__ __launch_bounds__(kBlock, RSIK_SOLVE_MIN_WAVES) void solve_kernel(con
 //   - the pitch is within ~1e-5 of +-pi/2 (inside 1e-7 of the lock SciPy sets yaw := 0, which moves the joints by up
 //     to ~4e-6 rad: measured on the G8 goldens).
 // mode (RSIK_OPT_EULER_ROUNDTRIP): 0 = as above, 1 = always, 2 = never.
-__device__ __forceinline__ void load_m12(const double* const* in, int64_t i, Rot& Rg, V3& pos, int mode) {
+__device__ __forceinline__ void goal_from_m12(const double (&m)[12], Rot& Rg, V3& pos, int mode) {
 #pragma unroll
-    for (int k = 0; k < 9; k++) Rg.m[k] = in[k][i];
+    for (int k = 0; k < 9; k++) Rg.m[k] = m[k];
     bool eye = true;
 #pragma unroll
     for (int k = 0; k < 9; k++) eye = eye && np_isclose(Rg.m[k], (k % 4 == 0) ? 1.0 : 0.0);
@@ -360,7 +360,13 @@ __device__ __forceinline__ void load_m12(const double* const* in, int64_t i, Rot
             Rg = rot_from_euler(eul[0], eul[1], eul[2]);
         }
     }
-    pos = {in[9][i], in[10][i], in[11][i]};
+    pos = {m[9], m[10], m[11]};
+}
+__device__ __forceinline__ void load_m12(const double* const* in, int64_t i, Rot& Rg, V3& pos, int mode) {
+    double m[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) m[k] = in[k][i];
+    goal_from_m12(m, Rg, pos, mode);
 }
 
 // utils.get_euler_from_homogeneous_matrix for a batch (U:84-90), optionally with ControlIK's identity shortcut
@@ -630,6 +636,10 @@ struct ContinuousArgs {
     const uint8_t* arm;
     const uint8_t* timed_out;     // NULL => nobody timed out
     int euler_roundtrip;          // RSIK_OPT_EULER_ROUNDTRIP
+    // trajectory mode (rsik_control_continuous_run): the kernel itself walks n_steps control steps with the trajectory
+    // state in registers; step s reads in[c] + s * 12 n and writes joints + s * 7 n, reachable / state + s * n
+    int64_t n_steps;              // 1 for rsik_control_continuous_step
+    int first_timed_out;          // non-zero: every trajectory (re)initialises on step 0
     double pref_arg[2];           // preferred_theta argument per arm slot (mirrored for l)
     double pref_self[2];          // ControlIK.preferred_theta[name] per arm slot
     double lim[2][2];
@@ -643,7 +653,9 @@ struct ContinuousArgs {
     ArmC arms[2];
 };
 
-template <bool MIXED>
+// LOOP = false: the single-step kernel (n_steps == 1; no prefetch registers, 2 waves/SIMD for large batches);
+// LOOP = true: trajectory mode, 1 wave/SIMD with the next step's goal matrix in flight.
+template <bool MIXED, bool LOOP>
 __global__ __launch_bounds__(kBlock) void control_continuous_kernel(const ContinuousArgs K) {
     __shared__ double lds_out[kBlock / 64][64 * 7];
     const int lane = threadIdx.x & 63;
@@ -667,76 +679,110 @@ __global__ __launch_bounds__(kBlock) void control_continuous_kernel(const Contin
     bool emergency = K.st[9 * n + ii] != 0.0;
     bool has_prev = K.st[10 * n + ii] != 0.0;
 
-    double jv[7];
-    int st_code = RSIK_STATE_EMPTY;
-    bool ok = false;
-    if (emergency) {  // C:205-210
+    // One launch = K.n_steps control steps (1 for the step entry point).  With 4096 trajectories a launch is one wave
+    // on 64 of the 1024 SIMDs and its time is that wave's latency; walking the steps inside the kernel keeps tables,
+    // constants and the trajectory state on chip and asks for the next step's goal matrix while the current step is
+    // being solved, instead of paying launch + kernarg + staging + state round trip on every step.
+    double m_next[LOOP ? 12 : 1];
+    if constexpr (LOOP) {
 #pragma unroll
-        for (int k = 0; k < 7; k++) jv[k] = prev_sol[k];
-        st_code = RSIK_STATE_EMERGENCY;
-    } else {
-        Rot Rg;
-        V3 pos;
-        load_m12(K.in, ii, Rg, pos, K.euler_roundtrip);
-        const double pref = K.pref_arg[slot];
-        if (K.timed_out && K.timed_out[ii]) { has_prev = false; init = true; }  // C:298-304
-        if (!has_prev) {  // C:306-325
-            if (K.current_joints) {
-#pragma unroll
-                for (int k = 0; k < 7; k++) prev_sol[k] = K.current_joints[ii * 7 + k];
-            }
-            has_prev = true;
-            Rot Rc;
-            V3 cpos;
-            load_m12(K.cur_pose[0] ? K.cur_pose : K.in, ii, Rc, cpos, K.euler_roundtrip);
-            Reach rc = reach<true>(A, cpos, Rc);
-            prev_theta = best_theta_to_current_joints(A, rc, Rc, prev_sol, pref);
-        }
-        Reach r = reach<false, false>(A, pos, Rg);
-        double theta;
-        ok = r.ok;
-        if (r.ok) {  // C:338-366
-            ok = best_discrete_theta_serial(A, r, 10, K.pref_self[slot], theta);  // U:220-264 get_best_continuous_theta2
-            if (!ok) {
-                theta = prev_theta;
-                st_code = RSIK_STATE_LIMITED_BY_SHOULDER;
-            } else if (!(fabs(angle_diff(theta, prev_theta)) < K.d_theta_max)) {
-                double ad = angle_diff(theta, prev_theta);
-                theta = prev_theta + (ad / fabs(ad)) * K.d_theta_max;
-            }
-        } else {  // C:368-388
-            const int st_reach = r.state;
-            r = reach<true>(A, pos, Rg);
-            double ad = angle_diff(pref, prev_theta);  // U:115-127 tend_to_preferred_theta
-            theta = (fabs(ad) < K.d_theta_max) ? pref : (prev_theta + (ad / fabs(ad)) * K.d_theta_max);
-            st_code = st_reach;
-        }
-        theta = limit_theta_to_interval(theta, K.lim[slot][0], K.lim[slot][1]);
-        prev_theta = theta;
-        double sn, cs;
-        fast_sincos(theta, &sn, &cs);
-        JointsOut o = joints_from_theta<true>(A, r, Rg, cs, sn, prev_sol);
-#pragma unroll
-        for (int k = 0; k < 7; k++) jv[k] = o.j[k];
-        bool em = safety_checks(A.utab, jv, o.c4, o.s4, o.c5, o.s5, o.c6, o.s6, prev_sol, K.max_angle, K.cos_max, K.sin_max);
-        emergency = emergency || em;
-        if (!init) {  // U:571-589 continuity_check, thresholds C:398
-            bool disc = false;
-#pragma unroll
-            for (int k = 0; k < 7; k++) disc = disc || (fabs(angle_diff(jv[k], prev_sol[k])) > (k < 4 ? 0.5 : 1.0));
-            if (disc) {
-                emergency = true;
-#pragma unroll
-                for (int k = 0; k < 7; k++) jv[k] = prev_sol[k];
-            }
-        }
-        init = false;
-        if (!emergency) {
-#pragma unroll
-            for (int k = 0; k < 7; k++) prev_sol[k] = jv[k];
-        }
+        for (int k = 0; k < 12; k++) m_next[k] = K.in[k][ii];
     }
-    store_rows<7>(K.joints, wave_base, K.n, lane, lds_out[wave], jv);
+    const int64_t n_steps = LOOP ? K.n_steps : 1;
+    auto one_step = [&](const int64_t step) {
+        double m_cur[12];
+        if constexpr (LOOP) {
+#pragma unroll
+            for (int k = 0; k < 12; k++) m_cur[k] = m_next[k];
+            if (step + 1 < n_steps) {
+#pragma unroll
+                for (int k = 0; k < 12; k++) m_next[k] = K.in[k][(step + 1) * 12 * n + ii];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 12; k++) m_cur[k] = K.in[k][ii];
+        }
+        double jv[7];
+        int st_code = RSIK_STATE_EMPTY;
+        bool ok = false;
+        if (emergency) {  // C:205-210
+#pragma unroll
+            for (int k = 0; k < 7; k++) jv[k] = prev_sol[k];
+            st_code = RSIK_STATE_EMERGENCY;
+        } else {
+            Rot Rg;
+            V3 pos;
+            goal_from_m12(m_cur, Rg, pos, K.euler_roundtrip);
+            const double pref = K.pref_arg[slot];
+            if (step == 0 && (K.first_timed_out || (K.timed_out && K.timed_out[ii]))) { has_prev = false; init = true; }  // C:298-304
+            if (!has_prev) {  // C:306-325
+                if (K.current_joints) {
+#pragma unroll
+                    for (int k = 0; k < 7; k++) prev_sol[k] = K.current_joints[ii * 7 + k];
+                }
+                has_prev = true;
+                Rot Rc;
+                V3 cpos;
+                load_m12(K.cur_pose[0] ? K.cur_pose : K.in, ii, Rc, cpos, K.euler_roundtrip);
+                Reach rc = reach<true>(A, cpos, Rc);
+                prev_theta = best_theta_to_current_joints(A, rc, Rc, prev_sol, pref);
+            }
+            Reach r = reach<false, false>(A, pos, Rg);
+            double theta;
+            ok = r.ok;
+            if (r.ok) {  // C:338-366
+                ok = best_discrete_theta_serial(A, r, 10, K.pref_self[slot], theta);  // U:220-264 get_best_continuous_theta2
+                if (!ok) {
+                    theta = prev_theta;
+                    st_code = RSIK_STATE_LIMITED_BY_SHOULDER;
+                } else if (!(fabs(angle_diff(theta, prev_theta)) < K.d_theta_max)) {
+                    double ad = angle_diff(theta, prev_theta);
+                    theta = prev_theta + (ad / fabs(ad)) * K.d_theta_max;
+                }
+            } else {  // C:368-388
+                const int st_reach = r.state;
+                r = reach<true>(A, pos, Rg);
+                double ad = angle_diff(pref, prev_theta);  // U:115-127 tend_to_preferred_theta
+                theta = (fabs(ad) < K.d_theta_max) ? pref : (prev_theta + (ad / fabs(ad)) * K.d_theta_max);
+                st_code = st_reach;
+            }
+            theta = limit_theta_to_interval(theta, K.lim[slot][0], K.lim[slot][1]);
+            prev_theta = theta;
+            double sn, cs;
+            fast_sincos(theta, &sn, &cs);
+            JointsOut o = joints_from_theta<true>(A, r, Rg, cs, sn, prev_sol);
+#pragma unroll
+            for (int k = 0; k < 7; k++) jv[k] = o.j[k];
+            bool em = safety_checks(A.utab, jv, o.c4, o.s4, o.c5, o.s5, o.c6, o.s6, prev_sol, K.max_angle, K.cos_max, K.sin_max);
+            emergency = emergency || em;
+            if (!init) {  // U:571-589 continuity_check, thresholds C:398
+                bool disc = false;
+#pragma unroll
+                for (int k = 0; k < 7; k++) disc = disc || (fabs(angle_diff(jv[k], prev_sol[k])) > (k < 4 ? 0.5 : 1.0));
+                if (disc) {
+                    emergency = true;
+#pragma unroll
+                    for (int k = 0; k < 7; k++) jv[k] = prev_sol[k];
+                }
+            }
+            init = false;
+            if (!emergency) {
+#pragma unroll
+                for (int k = 0; k < 7; k++) prev_sol[k] = jv[k];
+            }
+        }
+        store_rows<7>(K.joints + step * 7 * n, wave_base, K.n, lane, lds_out[wave], jv);
+        if (live) {
+            if (K.reachable) K.reachable[step * n + i] = ok ? 1 : 0;
+            if (K.state) K.state[step * n + i] = (uint8_t)st_code;
+        }
+    };
+    if constexpr (LOOP) {
+#pragma unroll 1
+        for (int64_t step = 0; step < n_steps; ++step) one_step(step);
+    } else {
+        one_step(0);
+    }
     if (live) {
         K.st[0 * n + i] = prev_theta;
 #pragma unroll
@@ -744,8 +790,6 @@ __global__ __launch_bounds__(kBlock) void control_continuous_kernel(const Contin
         K.st[8 * n + i] = init ? 1.0 : 0.0;
         K.st[9 * n + i] = emergency ? 1.0 : 0.0;
         K.st[10 * n + i] = has_prev ? 1.0 : 0.0;
-        if (K.reachable) K.reachable[i] = ok ? 1 : 0;
-        if (K.state) K.state[i] = (uint8_t)st_code;
     }
 }
 
@@ -1210,32 +1254,31 @@ int rsik_control_discrete(rsik_ctx* ctx, int64_t n, const double* const m12_soa[
     return RSIK_OK;
 }
 
-int rsik_control_continuous_step(rsik_ctx* ctx, int64_t n, const double* const m12_soa[12],
-                                 const double* const current_pose_m12_soa[12], const uint8_t* arm, int arm_uniform,
-                                 const uint8_t* timed_out, double preferred_theta, const double* preferred_theta_self_host,
-                                 int constrained_mode, double d_theta_max, const double* current_joints,
-                                 double orbita3d_max_angle, double* cont_state, double* joints, uint8_t* reachable,
-                                 uint8_t* state) {
-    if (!ctx) return RSIK_E_INVALID;
-    if (n < 0) return fail(ctx, RSIK_E_INVALID, "rsik_control_continuous_step: n < 0");
+// One launch of the continuous-mode kernel covering n_steps control steps (1 for the step entry point).
+static int launch_continuous(rsik_ctx* ctx, const char* who, int64_t n, int64_t n_steps, const double* const m12_soa[12],
+                             const double* const current_pose_m12_soa[12], const uint8_t* arm, int arm_uniform,
+                             const uint8_t* timed_out, int first_timed_out, double preferred_theta,
+                             const double* preferred_theta_self_host, int constrained_mode, double d_theta_max,
+                             const double* current_joints, double orbita3d_max_angle, double* cont_state, double* joints,
+                             uint8_t* reachable, uint8_t* state) {
     if (constrained_mode != RSIK_MODE_UNCONSTRAINED && constrained_mode != RSIK_MODE_LOW_ELBOW)
-        return fail(ctx, RSIK_E_INVALID, "rsik_control_continuous_step: unknown constrained_mode");
-    if (!preferred_theta_self_host)
-        return fail(ctx, RSIK_E_INVALID, "rsik_control_continuous_step: preferred_theta_self_host is NULL");
-    int rc = check_arms(ctx, arm, arm_uniform, "rsik_control_continuous_step");
+        return fail(ctx, RSIK_E_INVALID, std::string(who) + ": unknown constrained_mode");
+    if (!preferred_theta_self_host) return fail(ctx, RSIK_E_INVALID, std::string(who) + ": preferred_theta_self_host is NULL");
+    int rc = check_arms(ctx, arm, arm_uniform, who);
     if (rc != RSIK_OK) return rc;
-    if (n == 0) return RSIK_OK;
-    if (!m12_soa || !cont_state || !joints)
-        return fail(ctx, RSIK_E_INVALID, "rsik_control_continuous_step: m12_soa / cont_state / joints is NULL");
+    if (n == 0 || n_steps == 0) return RSIK_OK;
+    if (!m12_soa || !cont_state || !joints) return fail(ctx, RSIK_E_INVALID, std::string(who) + ": m12_soa / cont_state / joints is NULL");
     rsik::ContinuousArgs K;
     std::memset(&K, 0, sizeof K);
     K.n = n;
+    K.n_steps = n_steps;
+    K.first_timed_out = first_timed_out;
     for (int k = 0; k < 12; k++) {
-        if (!m12_soa[k]) return fail(ctx, RSIK_E_INVALID, "rsik_control_continuous_step: an m12_soa column is NULL");
+        if (!m12_soa[k]) return fail(ctx, RSIK_E_INVALID, std::string(who) + ": an m12_soa column is NULL");
         K.in[k] = m12_soa[k];
         K.cur_pose[k] = current_pose_m12_soa ? current_pose_m12_soa[k] : nullptr;
         if (current_pose_m12_soa && !current_pose_m12_soa[k])
-            return fail(ctx, RSIK_E_INVALID, "rsik_control_continuous_step: a current_pose column is NULL");
+            return fail(ctx, RSIK_E_INVALID, std::string(who) + ": a current_pose column is NULL");
     }
     K.arm = arm;
     K.timed_out = timed_out;
@@ -1254,14 +1297,33 @@ int rsik_control_continuous_step(rsik_ctx* ctx, int64_t n, const double* const m
     K.st = cont_state; K.joints = joints; K.reachable = reachable; K.state = state;
     RSIK_HIP(ctx, hipSetDevice(ctx->device));
     dim3 grid, block(rsik::kBlock);
-    rc = launch_dims(ctx, n, &grid, "rsik_control_continuous_step");
+    rc = launch_dims(ctx, n, &grid, who);
     if (rc != RSIK_OK) return rc;
-    if (arm) hipLaunchKernelGGL(rsik::control_continuous_kernel<true>, grid, block, 0, ctx->stream, K);
-    else hipLaunchKernelGGL(rsik::control_continuous_kernel<false>, grid, block, 0, ctx->stream, K);
+    if (n_steps > 1) {
+        if (arm) hipLaunchKernelGGL((rsik::control_continuous_kernel<true, true>), grid, block, 0, ctx->stream, K);
+        else hipLaunchKernelGGL((rsik::control_continuous_kernel<false, true>), grid, block, 0, ctx->stream, K);
+    } else {
+        if (arm) hipLaunchKernelGGL((rsik::control_continuous_kernel<true, false>), grid, block, 0, ctx->stream, K);
+        else hipLaunchKernelGGL((rsik::control_continuous_kernel<false, false>), grid, block, 0, ctx->stream, K);
+    }
     RSIK_HIP(ctx, hipGetLastError());
     return RSIK_OK;
 }
 
+int rsik_control_continuous_step(rsik_ctx* ctx, int64_t n, const double* const m12_soa[12],
+                                 const double* const current_pose_m12_soa[12], const uint8_t* arm, int arm_uniform,
+                                 const uint8_t* timed_out, double preferred_theta, const double* preferred_theta_self_host,
+                                 int constrained_mode, double d_theta_max, const double* current_joints,
+                                 double orbita3d_max_angle, double* cont_state, double* joints, uint8_t* reachable,
+                                 uint8_t* state) {
+    if (!ctx) return RSIK_E_INVALID;
+    if (n < 0) return fail(ctx, RSIK_E_INVALID, "rsik_control_continuous_step: n < 0");
+    return launch_continuous(ctx, "rsik_control_continuous_step", n, 1, m12_soa, current_pose_m12_soa, arm, arm_uniform,
+                             timed_out, 0, preferred_theta, preferred_theta_self_host, constrained_mode, d_theta_max,
+                             current_joints, orbita3d_max_angle, cont_state, joints, reachable, state);
+}
+
+// The whole trajectory batch in ONE launch: the kernel walks the n_steps control steps itself (control_continuous_kernel).
 int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const double* m12_steps,
                                 const double* const current_pose_m12_soa[12], const uint8_t* arm, int arm_uniform,
                                 int first_step_timed_out, double preferred_theta, const double* preferred_theta_self_host,
@@ -1272,26 +1334,26 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     if (n < 0 || n_steps < 0) return fail(ctx, RSIK_E_INVALID, "rsik_control_continuous_run: negative size");
     if (n == 0 || n_steps == 0) return RSIK_OK;
     if (!m12_steps || !joints_steps) return fail(ctx, RSIK_E_INVALID, "rsik_control_continuous_run: NULL buffer");
-    uint8_t* flags = nullptr;
-    if (first_step_timed_out) {  // one-off [n] array of ones for the first launch
-        RSIK_HIP(ctx, hipSetDevice(ctx->device));
-        RSIK_HIP(ctx, hipMallocAsync(reinterpret_cast<void**>(&flags), (size_t)n, ctx->stream));
-        RSIK_HIP(ctx, hipMemsetAsync(flags, 1, (size_t)n, ctx->stream));
-    }
+    const double* cols[12];
+    for (int c = 0; c < 12; c++) cols[c] = m12_steps + (size_t)c * (size_t)n;  // step 0; step s is 12 n doubles further
+    // Batches that fill the chip many times over gain nothing from the in-kernel time loop and lose its 1 wave/SIMD
+    // occupancy: they go step by step (one launch per step, state through HBM), like a streaming caller would.
+    const char* force = std::getenv("RSIK_CONT_RUN_MODE");  // test hook: "loop" / "steps"
+    const bool stepwise = force ? (std::strcmp(force, "steps") == 0) : (n >= (int64_t)1 << 19);
+    if (!stepwise)
+        return launch_continuous(ctx, "rsik_control_continuous_run", n, n_steps, cols, current_pose_m12_soa, arm, arm_uniform,
+                                 nullptr, first_step_timed_out ? 1 : 0, preferred_theta, preferred_theta_self_host,
+                                 constrained_mode, d_theta_max, current_joints, orbita3d_max_angle, cont_state,
+                                 joints_steps, reachable_steps, state_steps);
     int rc = RSIK_OK;
     for (int64_t k = 0; k < n_steps && rc == RSIK_OK; k++) {
-        const double* cols[12];
         for (int c = 0; c < 12; c++) cols[c] = m12_steps + ((size_t)k * 12 + c) * (size_t)n;
-        rc = rsik_control_continuous_step(ctx, n, cols, k == 0 ? current_pose_m12_soa : nullptr, arm, arm_uniform,
-                                          k == 0 ? flags : nullptr, preferred_theta, preferred_theta_self_host,
-                                          constrained_mode, d_theta_max, k == 0 ? current_joints : nullptr,
-                                          orbita3d_max_angle, cont_state, joints_steps + (size_t)k * n * 7,
-                                          reachable_steps ? reachable_steps + (size_t)k * n : nullptr,
-                                          state_steps ? state_steps + (size_t)k * n : nullptr);
-    }
-    if (flags) {
-        hipError_t e = hipFreeAsync(flags, ctx->stream);
-        if (e != hipSuccess && rc == RSIK_OK) return hip_fail(ctx, e, "hipFreeAsync");
+        rc = launch_continuous(ctx, "rsik_control_continuous_run", n, 1, cols, k == 0 ? current_pose_m12_soa : nullptr, arm,
+                               arm_uniform, nullptr, (k == 0 && first_step_timed_out) ? 1 : 0, preferred_theta,
+                               preferred_theta_self_host, constrained_mode, d_theta_max, k == 0 ? current_joints : nullptr,
+                               orbita3d_max_angle, cont_state, joints_steps + (size_t)k * n * 7,
+                               reachable_steps ? reachable_steps + (size_t)k * n : nullptr,
+                               state_steps ? state_steps + (size_t)k * n : nullptr);
     }
     return rc;
 }

@@ -603,8 +603,12 @@ def test_control_continuous_against_checker_dvt_and_emergency(torch_mod, orc):
         assert n_em == sum(s.emergency_stop for s in states) and n_em > 0
 
 
-def test_continuous_run_equals_stepwise(golden_dir, torch_mod):
-    """rsik_control_continuous_run (all steps from one host call) against G7 and against the step-by-step API."""
+@pytest.mark.parametrize("run_mode", ["loop", "steps"])
+def test_continuous_run_equals_stepwise(golden_dir, torch_mod, run_mode, monkeypatch):
+    """rsik_control_continuous_run against G7 and against the step-by-step API, both ways it can issue the work: one
+    launch whose kernel walks all steps with the trajectory state in registers ("loop", what small batches get) and
+    one launch per step ("steps", what chip-filling batches get)."""
+    monkeypatch.setenv("RSIK_CONT_RUN_MODE", run_mode)
     g = load(golden_dir, "g7_control_continuous_start.npz")
     c = make_control()
     for arm in ("r_arm", "l_arm"):
