@@ -208,3 +208,39 @@ def test_utils_format_helpers():
     np.testing.assert_allclose(pos, [0.55, -0.3, -0.15])
     np.testing.assert_allclose(eul, [0.3, -0.7, 1.1], atol=1e-14)
     assert np.allclose(get_euler_from_homogeneous_matrix(M, degrees=True)[1], np.degrees([0.3, -0.7, 1.1]))
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/rsik.h is the drop-in boundary: it must compile as C99 and as C++ on its own, and a C program that
+    only knows the header must link against librsik_hip.so and run the calls that need no GPU."""
+    import shutil
+    import subprocess
+
+    from reachy2_symbolic_ik_amd import _abi
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inc = os.path.join(root, "include")
+    src = tmp_path / "use_rsik.c"
+    src.write_text(
+        '#include "rsik.h"\n#include <stdio.h>\n'
+        "int main(void) {\n"
+        "    rsik_ctx *ctx = 0;\n"
+        "    if (rsik_abi_version() != RSIK_ABI_VERSION) return 1;\n"
+        "    if (rsik_arm_consts_count() != RSIK_ARM_CONSTS_COUNT) return 2;\n"
+        "    int rc = rsik_create(rsik_device_count() > 0 ? 0 : 1 << 20, &ctx);\n"
+        '    printf("devices=%d create=%d msg=%s\\n", rsik_device_count(), rc, rsik_last_error(ctx));\n'
+        "    if (rsik_device_count() <= 0 && rc != RSIK_E_NO_DEVICE) return 3;\n"
+        "    if (ctx) rsik_destroy(ctx);\n"
+        "    return 0;\n}\n")
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc is part of the image"
+    subprocess.check_call([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", inc, "-fsyntax-only", str(src)])
+    gxx = shutil.which("g++")
+    subprocess.check_call([gxx, "-std=c++17", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", "-x", "c++", str(src)])
+    _abi.load()  # built
+    libdir = os.path.dirname(_abi.LIB_PATH)
+    exe = tmp_path / "use_rsik"
+    subprocess.check_call([gcc, "-std=c99", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-lrsik_hip",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr

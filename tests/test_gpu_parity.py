@@ -850,3 +850,43 @@ def test_tip_z_specialisation_is_bit_identical(torch_mod, monkeypatch):
         assert a["reachable"].sum() > 500
         for k in ("reachable", "state", "interval", "joints", "elbow"):
             np.testing.assert_array_equal(a[k], b[k])
+
+
+def test_solve_is_hipgraph_capturable(torch_mod, orc):
+    """the launches are plain kernel launches on the context's stream, so a caller can record them in a
+    hipGraph and replay it on new data in the same buffers (what bench.py does for its K timed steps)."""
+    solver, r, l = make_symbolic(0.03)
+    rng = np.random.default_rng(21)
+    n = 5000
+
+    def batch():
+        pos = np.array([0.0, -0.2, 0.0]) + rng.uniform(-0.7, 0.7, size=(n, 3))
+        return pos, rng.uniform(-np.pi, np.pi, size=(n, 3))
+
+    pos, eul = batch()
+    buf = soa(pos, eul, torch_mod)
+    out = {"joints": torch_mod.empty((n, 7), dtype=torch_mod.float64, device="cuda"),
+           "interval": torch_mod.empty((n, 2), dtype=torch_mod.float64, device="cuda"),
+           "reachable": torch_mod.empty((n,), dtype=torch_mod.uint8, device="cuda"),
+           "state": torch_mod.empty((n,), dtype=torch_mod.uint8, device="cuda")}
+    plan = r.solve_batch(buf, want_elbow=False, out=out, plan_only=True)
+    plan["launch"]()
+    torch_mod.cuda.synchronize()
+    g = torch_mod.cuda.CUDAGraph()
+    with torch_mod.cuda.graph(g, capture_error_mode="thread_local"):
+        solver._bind_stream()
+        plan["launch"]()
+        plan["launch"]()
+    solver._bind_stream()
+    for _ in range(2):
+        pos, eul = batch()
+        buf.copy_(soa(pos, eul, torch_mod))
+        for k in out:
+            out[k].zero_()
+        g.replay()
+        torch_mod.cuda.synchronize()
+        ref = orc.solve_batch(orc.Arm("r_arm", 0.03), orc.Arm("l_arm", 0.03), pos, eul)
+        np.testing.assert_array_equal(out["reachable"].cpu().numpy(), ref["reachable"])
+        np.testing.assert_array_equal(out["state"].cpu().numpy(), ref["state"])
+        m = ref["reachable"].astype(bool)
+        assert m.sum() > 100 and np.max(np.abs(out["joints"].cpu().numpy()[m] - ref["joints"][m])) < TOL
