@@ -495,7 +495,8 @@ def main():
                 line["roofline"]["compute"] = {
                     "bound": "fp64 VALU issue", "achieved": ach, "peak": peak, "unit": "wave-instr/s", "frac": ach / peak,
                     "valu_instr_per_wave": t["valu_per_wave"],
-                    "peak_source": "live rsik_debug_math op 6 (independent v_fma_f64) on this GPU",
+                    "peak_source": "live rsik_debug_math op 6 (independent v_fma_f64) on this GPU: the sustained rate of pure fp64 "
+                                   "FMAs under the power-managed clock; a mix that contains cheaper instructions can exceed it",
                 }
         except (OSError, ValueError, KeyError):
             pass

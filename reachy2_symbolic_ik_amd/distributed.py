@@ -44,11 +44,40 @@ def all_gather_rows(local: torch.Tensor, n_total: int, group: Optional[dist.Proc
 
 def solve_sharded(solve_fn: Callable[[torch.Tensor], Dict[str, torch.Tensor]], columns: torch.Tensor,
                   group: Optional[dist.ProcessGroup] = None,
-                  gather: Iterable[str] = ("joints", "reachable", "state")) -> Dict[str, torch.Tensor]:
+                  gather: Iterable[str] = ("joints", "reachable", "state"), chunks: int = 1) -> Dict[str, torch.Tensor]:
     """columns: the full SoA input [C, n] (present on every rank).  Each rank solves its block with `solve_fn`
-    (e.g. SymbolicIK.solve_batch) and the arrays named in `gather` are all-gathered; returns full-size arrays."""
+    (e.g. SymbolicIK.solve_batch) and the arrays named in `gather` are all-gathered; returns full-size arrays.
+
+    chunks > 1: the block is solved in `chunks` pieces and the all-gather of piece k is issued
+    asynchronously as soon as its solve has been queued, so it travels over xGMI while piece k+1 is being solved; every
+    piece lands directly in its place of the full-size result (no staging copy)."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     n = int(columns.shape[1])
     lo, hi = shard_range(n, rank, world)
-    local = solve_fn(columns[:, lo:hi].contiguous())
-    return {k: all_gather_rows(local[k], n, group) for k in gather}
+    gather = tuple(gather)
+    if chunks <= 1:
+        local = solve_fn(columns[:, lo:hi].contiguous())
+        return {k: all_gather_rows(local[k], n, group) for k in gather}
+    s = shard_size(n, world)
+    cs = (s + chunks - 1) // chunks          # rows per piece; every rank cuts its (padded) block at the same places
+    full: Dict[str, torch.Tensor] = {}
+    pending = []
+    for c in range(chunks):
+        a, b = c * cs, min((c + 1) * cs, s)  # piece rows inside a block
+        if a >= b:
+            break
+        mine_lo, mine_hi = min(lo + a, hi), min(lo + b, hi)
+        local = solve_fn(columns[:, mine_lo:mine_hi].contiguous())
+        for k in gather:
+            t = local[k]
+            if k not in full:
+                full[k] = t.new_zeros((world * s,) + tuple(t.shape[1:]))
+            piece = t
+            if t.shape[0] != b - a:          # short / empty trailing piece of a short trailing block: pad
+                piece = t.new_zeros((b - a,) + tuple(t.shape[1:]))
+                piece[: t.shape[0]] = t
+            views = [full[k][r * s + a: r * s + b] for r in range(world)]
+            pending.append(dist.all_gather(views, piece.contiguous(), group=group, async_op=True))
+    for w in pending:
+        w.wait()
+    return {k: full[k][:n] for k in gather}

@@ -55,6 +55,11 @@ def _worker(rank, world, port, n, seed, result_dir):
 
         full = solve_sharded(solve_fn, cols)
         ref = orc.solve_batch(ar, al, pos, eul, arm_id=arm)
+        for chunks in (2, 3, 5):  # pieces solved one after the other, each all-gathered asynchronously into place
+            piecewise = solve_sharded(solve_fn, cols, chunks=chunks)
+            for k in ("joints", "reachable", "state"):
+                assert piecewise[k].shape == full[k].shape
+                np.testing.assert_array_equal(np.nan_to_num(piecewise[k].numpy(), nan=-99.0), np.nan_to_num(full[k].numpy(), nan=-99.0))
         assert full["joints"].shape == (n, 7) and full["reachable"].shape == (n,)
         np.testing.assert_array_equal(full["reachable"].numpy(), ref["reachable"])
         np.testing.assert_array_equal(full["state"].numpy(), ref["state"])
