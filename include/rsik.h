@@ -243,9 +243,11 @@ int rsik_control_continuous_run(rsik_ctx *ctx, int64_t n, int64_t n_steps, const
  * (symbolic_ik.py:714-718).  That state lives in a caller-owned device array, one row of
  * RSIK_SOLVER_STATE_STRIDE doubles per solver instance:
  *   0-2 goal position, 3-5 goal euler, 6-8 wrist position, 9-11 circle centre, 12 circle radius,
- *   13-15 circle normal, 16-18 elbow position of the last get_joints, 19 projection flag, 20-23 reserved.
+ *   13-15 circle normal, 16-18 elbow position of the last get_joints, 19 projection flag,
+ *   20-21 interval, 22 reachable (0/1), 23 state code of the last is_reachable (so that a scalar caller can fetch a
+ *   call's results and the updated state with one download), 24-30 joints of the last get_joints, 31 reserved.
  */
-#define RSIK_SOLVER_STATE_STRIDE 24
+#define RSIK_SOLVER_STATE_STRIDE 32
 
 /* SymbolicIK.is_reachable (no_limits == 0, symbolic_ik.py:121-282) or is_reachable_no_limits
  * (no_limits != 0, symbolic_ik.py:85-119).  Only the fields the reference would have assigned are
@@ -253,7 +255,8 @@ int rsik_control_continuous_run(rsik_ctx *ctx, int64_t n, int64_t n_steps, const
 int rsik_reach_state(rsik_ctx *ctx, int64_t n, const double *const pose_soa[6], const uint8_t *arm, int arm_uniform,
                      int no_limits, double *solver_state, double *interval, uint8_t *reachable, uint8_t *state);
 /* SymbolicIK.get_joints(theta, previous_joints) on stored state (symbolic_ik.py:697-863); updates the
- * row like the reference updates self.  previous_joints: [n,7] device or NULL for zeros. */
+ * row like the reference updates self.  previous_joints: [n,7] device or NULL for zeros.  joints / elbow may be NULL
+ * (the row's slots 24-30 / 16-18 carry them too). */
 int rsik_joints_from_state(rsik_ctx *ctx, int64_t n, double *solver_state, const uint8_t *arm, int arm_uniform,
                            const double *theta, const double *previous_joints, double *joints, double *elbow);
 /* SymbolicIK.get_elbow_position(theta) on stored state (symbolic_ik.py:684-695). */

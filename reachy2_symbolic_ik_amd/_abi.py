@@ -59,7 +59,7 @@ GOAL_POSE6, GOAL_M12 = 0, 1
 OPT_EULER_ROUNDTRIP = 0
 EULER_AUTO, EULER_ALWAYS, EULER_NEVER = 0, 1, 2
 
-SOLVER_STATE_STRIDE = 24
+SOLVER_STATE_STRIDE = 32
 CONT_STATE_ROWS = 11
 
 

@@ -200,6 +200,58 @@ class ControlIK:
         (px,py,pz,roll,pitch,yaw), the input layout of SymbolicIK.solve_batch."""
         return self._solver.matrix_to_pose(matrices_to_m12_soa(M, self._solver.device), identity_shortcut=identity_shortcut)
 
+    # One scalar call = one pinned upload (goal matrix + whatever else the call reads), one launch, one download (joints,
+    # flags and, in continuous mode, the trajectory state), one stream synchronisation.  Device layout of the packed
+    # buffer, in doubles: [0:11] continuous state, [11:23] goal matrix (12), [23:35] current pose (12), [35:42]
+    # current_joints, [42:49] joints out, then 8 bytes: reachable, state, emergency, timed_out.
+    def _scalar_io(self):
+        io = getattr(self, "_io", None)
+        if io is None:
+            import ctypes as C
+
+            dev = self._solver.device
+            nd = 50
+            h = torch.empty(nd, dtype=torch.float64).pin_memory()
+            d = torch.empty(nd, dtype=torch.float64, device=dev)
+            base = d.data_ptr()
+            io = self._io = {
+                "h": h, "h_np": h.numpy(), "h_bytes": h.numpy().view(np.uint8), "d": d,
+                "state": C.c_void_p(base), "m_cols": (C.c_void_p * 12)(*[base + 8 * (11 + k) for k in range(12)]),
+                "cp_cols": (C.c_void_p * 12)(*[base + 8 * (23 + k) for k in range(12)]),
+                "cj": C.c_void_p(base + 8 * 35), "joints": C.c_void_p(base + 8 * 42),
+                "reachable": C.c_void_p(base + 8 * 49), "code": C.c_void_p(base + 8 * 49 + 1),
+                "emergency": C.c_void_p(base + 8 * 49 + 2), "timed_out": C.c_void_p(base + 8 * 49 + 3),
+                "pts": np.zeros(2), "ps": np.zeros((2, 7)),
+            }
+        return io
+
+    @staticmethod
+    def _pack_m12(dst: np.ndarray, M: np.ndarray) -> None:
+        dst[0:9] = M[:3, :3].reshape(9)
+        dst[9:12] = M[:3, 3]
+
+    def _discrete_scalar(self, name: str, M: np.ndarray, current_joints: Any, constrained_mode: str, preferred_theta: float):
+        import ctypes as C
+
+        io = self._scalar_io()
+        hn = io["h_np"]
+        self._pack_m12(hn[11:23], M)
+        hn[35:42] = current_joints
+        sv = self._solver
+        io["ps"][:] = self._previous_sol_2x7()
+        self._upload_arms()
+        with torch.cuda.device(sv.device):
+            io["d"].copy_(io["h"], non_blocking=True)
+            sv._bind_stream()
+            sv._check(sv.lib.rsik_control_discrete(
+                sv._h, 1, io["m_cols"], None, ARM_IDS[name], int(self.nb_search_points), float(preferred_theta),
+                _abi.MODES[constrained_mode], io["ps"].ctypes.data_as(C.POINTER(C.c_double)), io["cj"],
+                float(self.orbita3D_max_angle), io["joints"], io["reachable"], io["code"], io["emergency"]))
+            io["h"].copy_(io["d"], non_blocking=True)
+            torch.cuda.current_stream(sv.device).synchronize()
+        flags = io["h_bytes"][8 * 49: 8 * 49 + 4]
+        return hn[42:49].tolist(), bool(flags[0]), STATE_STRINGS[int(flags[1])], bool(flags[2])
+
     # ------------------------------------------------------------------ reference API
     def symbolic_inverse_kinematics(
         self,
@@ -232,13 +284,11 @@ class ControlIK:
                 constrained_mode, d_theta_max, preferred_theta)
         elif control_type == "discrete":
             M = np.asarray(M, dtype=np.float64)
-            res = self.symbolic_inverse_kinematics_batch(
-                name, M.reshape(1, 4, 4), constrained_mode=constrained_mode,
-                current_joints=np.asarray(current_joints, dtype=np.float64).reshape(1, 7), preferred_theta=preferred_theta)
-            ik_joints = res["joints"][0].cpu().numpy().tolist()
-            is_reachable = bool(res["reachable"].item())
-            state = STATE_STRINGS[int(res["state"].item())]
-            if bool(res["emergency"].item()):
+            if name not in self.symbolic_ik_solver:
+                raise KeyError(name)
+            ik_joints, is_reachable, state, emergency = self._discrete_scalar(
+                name, M, np.asarray(current_joints, dtype=np.float64).reshape(7), constrained_mode, preferred_theta)
+            if emergency:
                 self.emergency_stop = True
                 self.emergency_state += "\nEMERGENCY STOP: multiturn limit reached"
         else:
@@ -253,24 +303,39 @@ class ControlIK:
         t = time.time()
         timed_out = abs(t - self.last_call_t[name]) > self.call_timeout
         self.last_call_t[name] = t
-        st = self._solver.new_continuous_state(1)
-        host = np.zeros(_abi.CONT_STATE_ROWS)
-        host[0] = self.previous_theta[name]
+        import ctypes as C
+
+        io = self._scalar_io()
+        hn = io["h_np"]
+        hn[0] = self.previous_theta[name]
         has_prev = len(self.previous_sol[name]) == 7
-        if has_prev:
-            host[1:8] = self.previous_sol[name]
-        host[8] = 1.0 if self.init else 0.0
-        host[9] = 0.0
-        host[10] = 1.0 if has_prev else 0.0
-        st.copy_(torch.as_tensor(host.reshape(-1, 1)))
+        hn[1:8] = self.previous_sol[name] if has_prev else 0.0
+        hn[8] = 1.0 if self.init else 0.0
+        hn[9] = 0.0
+        hn[10] = 1.0 if has_prev else 0.0
+        self._pack_m12(hn[11:23], M)
+        self._pack_m12(hn[23:35], current_pose)
         cj = np.asarray(current_joints, dtype=np.float64)
-        cj_t = torch.as_tensor(cj.reshape(1, 7)) if cj.size == 7 else None
-        res = self.symbolic_inverse_kinematics_continuous_batch(
-            name, M.reshape(1, 4, 4), st, timed_out=np.array([1 if timed_out else 0], dtype=np.uint8),
-            current_joints=cj_t, current_pose=current_pose.reshape(1, 4, 4), constrained_mode=constrained_mode,
-            d_theta_max=d_theta_max, preferred_theta=preferred_theta)
-        back = st[:, 0].cpu().numpy()
-        ik_joints = res["joints"][0].cpu().numpy()
+        has_cj = cj.size == 7
+        if has_cj:
+            hn[35:42] = cj.reshape(7)
+        io["h_bytes"][8 * 49 + 3] = 1 if timed_out else 0
+        io["pts"][:] = [self.preferred_theta.get("r_arm", -4 * np.pi / 6), self.preferred_theta.get("l_arm", -np.pi + 4 * np.pi / 6)]
+        sv = self._solver
+        self._upload_arms()
+        with torch.cuda.device(sv.device):
+            io["d"].copy_(io["h"], non_blocking=True)
+            sv._bind_stream()
+            sv._check(sv.lib.rsik_control_continuous_step(
+                sv._h, 1, io["m_cols"], io["cp_cols"], None, ARM_IDS[name], io["timed_out"], float(preferred_theta),
+                io["pts"].ctypes.data_as(C.POINTER(C.c_double)), _abi.MODES[constrained_mode], float(d_theta_max),
+                io["cj"] if has_cj else None, float(self.orbita3D_max_angle), io["state"], io["joints"], io["reachable"],
+                io["code"]))
+            io["h"].copy_(io["d"], non_blocking=True)
+            torch.cuda.current_stream(sv.device).synchronize()
+        back = hn[0:11]
+        ik_joints = hn[42:49].copy()
+        flags = io["h_bytes"][8 * 49: 8 * 49 + 2]
         self.previous_theta[name] = float(back[0])
         self.init = bool(back[8])
         if back[9] != 0.0:
@@ -280,7 +345,7 @@ class ControlIK:
             self.previous_sol[name] = copy.deepcopy(ik_joints)
         else:
             self.previous_sol[name] = back[1:8].copy()
-        return ik_joints, bool(res["reachable"].item()), STATE_STRINGS[int(res["state"].item())]
+        return ik_joints, bool(flags[0]), STATE_STRINGS[int(flags[1])]
 
     # ------------------------------------------------------------------ MI355X-native batch API
     def new_continuous_state(self, name: Any, n: int) -> torch.Tensor:

@@ -798,7 +798,8 @@ __global__ __launch_bounds__(kBlock) void control_continuous_kernel(const Contin
 // `self.wrist_position`, `self.intersection_circle` between is_reachable() and the returned closure, Q1).
 // State row layout (RSIK_SOLVER_STATE_STRIDE doubles):
 //   0-2 goal position, 3-5 goal euler, 6-8 wrist, 9-11 circle centre, 12 radius, 13-15 circle normal,
-//   16-18 elbow position of the last get_joints, 19 projection-fired flag, 20-23 reserved.
+//   16-18 elbow position of the last get_joints, 19 projection-fired flag, 20-21 interval, 22 reachable, 23 state code of
+//   the last is_reachable, 24-30 joints of the last get_joints, 31 reserved.
 // ------------------------------------------------------------------------------------------
 struct StateArgs {
     int64_t n;
@@ -836,6 +837,8 @@ __global__ __launch_bounds__(kBlock) void reach_state_kernel(const StateArgs K) 
         S[9] = r.c2.x; S[10] = r.c2.y; S[11] = r.c2.z; S[12] = r.r2;
         S[13] = r.n2.x; S[14] = r.n2.y; S[15] = r.n2.z;
     }
+    // the call's results also go into the row, so a scalar caller needs ONE download per call
+    S[20] = r.i0; S[21] = r.i1; S[22] = r.ok ? 1.0 : 0.0; S[23] = (double)r.state;
     if (K.interval) { K.interval[2 * i] = r.i0; K.interval[2 * i + 1] = r.i1; }
     if (K.reachable) K.reachable[i] = r.ok ? 1 : 0;
     if (K.state) K.state[i] = (uint8_t)r.state;
@@ -870,8 +873,12 @@ __global__ __launch_bounds__(kBlock) void joints_state_kernel(const StateArgs K)
     double st, ct;
     fast_sincos(K.theta[i], &st, &ct);
     JointsOut o = joints_from_theta<false>(A, r, Rg, ct, st, prev);
+    if (K.joints) {
 #pragma unroll
-    for (int k = 0; k < 7; k++) K.joints[i * 7 + k] = o.j[k];
+        for (int k = 0; k < 7; k++) K.joints[i * 7 + k] = o.j[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 7; k++) S[24 + k] = o.j[k];
     S[0] = r.pos.x; S[1] = r.pos.y; S[2] = r.pos.z;
     S[6] = r.w.x; S[7] = r.w.y; S[8] = r.w.z;
     S[16] = o.elbow.x; S[17] = o.elbow.y; S[18] = o.elbow.z;
@@ -1427,8 +1434,8 @@ int rsik_joints_from_state(rsik_ctx* ctx, int64_t n, double* solver_state, const
     int rc = fill_state_args(ctx, &K, n, arm, arm_uniform, "rsik_joints_from_state");
     if (rc != RSIK_OK) return rc;
     if (n == 0) return RSIK_OK;
-    if (!solver_state || !theta || !joints)
-        return fail(ctx, RSIK_E_INVALID, "rsik_joints_from_state: solver_state / theta / joints is NULL");
+    if (!solver_state || !theta)  // joints may be NULL: the row's slots 24-30 carry them too
+        return fail(ctx, RSIK_E_INVALID, "rsik_joints_from_state: solver_state / theta is NULL");
     K.solver_state = solver_state; K.theta = theta; K.prev = previous_joints; K.joints = joints; K.elbow = elbow;
     RSIK_HIP(ctx, hipSetDevice(ctx->device));
     dim3 grid, block(rsik::kBlock);

@@ -90,22 +90,51 @@ class SymbolicIK:
         # several SymbolicIK objects may share one context; make sure *this* arm's constants are current
         self._solver.set_arm(self.arm_id, self.consts)
 
-    def _sync_attributes(self) -> None:
-        s = self._state[0].cpu().numpy()
+    # One scalar call = one pinned-buffer upload, one launch, one download of the solver-state row (which carries the
+    # call's results, include/rsik.h RSIK_SOLVER_STATE_STRIDE), one stream synchronisation.
+    def _scalar_io(self):
+        io = getattr(self, "_io", None)
+        if io is None:
+            import ctypes as C
+
+            dev = self._solver.device
+            h_in = torch.empty(8, dtype=torch.float64).pin_memory()
+            d_in = torch.empty(8, dtype=torch.float64, device=dev)
+            h_state = torch.empty(_abi.SOLVER_STATE_STRIDE, dtype=torch.float64).pin_memory()
+            d_elbow = torch.empty(3, dtype=torch.float64, device=dev)
+            h_elbow = torch.empty(3, dtype=torch.float64).pin_memory()
+            base = d_in.data_ptr()
+            io = self._io = {
+                "h_in": h_in, "h_in_np": h_in.numpy(), "d_in": d_in, "h_state": h_state, "h_state_np": h_state.numpy(),
+                "d_elbow": d_elbow, "h_elbow": h_elbow, "h_elbow_np": h_elbow.numpy(),
+                "cols": (C.c_void_p * 6)(*[base + 8 * k for k in range(6)]),
+                "theta": C.c_void_p(base), "prev": C.c_void_p(base + 8), "state": C.c_void_p(self._state.data_ptr()),
+                "elbow": C.c_void_p(d_elbow.data_ptr()), "stream": torch.cuda.current_stream(dev),
+            }
+        return io
+
+    def _finish(self, io) -> np.ndarray:
+        io["h_state"].copy_(self._state[0], non_blocking=True)
+        torch.cuda.current_stream(self._solver.device).synchronize()
+        s = io["h_state_np"]
         self.goal_pose = np.array([s[0:3], s[3:6]])
         self.wrist_position = s[6:9].copy()
         self.intersection_circle = (s[9:12].copy(), float(s[12]), s[13:16].copy())
+        return s
 
     def _reach_scalar(self, goal_pose: Any, no_limits: bool):
-        pose = np.asarray([np.asarray(goal_pose[0], dtype=np.float64), np.asarray(goal_pose[1], dtype=np.float64)])
-        soa = torch.as_tensor(pose.reshape(6, 1)).to(self._solver.device)
+        io = self._scalar_io()
+        io["h_in_np"][0:3] = goal_pose[0]
+        io["h_in_np"][3:6] = goal_pose[1]
+        sv = self._solver
         self._upload()
-        r = self._solver.reach_state(soa, self._state, arm_uniform=self.arm_id, no_limits=no_limits)
-        ok = bool(r["reachable"].item())
-        code = int(r["state"].item())
-        interval = r["interval"][0].cpu().numpy()
-        self._sync_attributes()
-        return ok, interval, code
+        with torch.cuda.device(sv.device):
+            io["d_in"].copy_(io["h_in"], non_blocking=True)
+            sv._bind_stream()
+            sv._check(sv.lib.rsik_reach_state(sv._h, 1, io["cols"], None, self.arm_id, 1 if no_limits else 0, io["state"],
+                                              None, None, None))
+            s = self._finish(io)
+        return bool(s[22] != 0.0), s[20:22].copy(), int(s[23])
 
     def is_reachable(self, goal_pose: npt.NDArray[np.float64]) -> Tuple[bool, npt.NDArray[np.float64], Optional[Any], str]:
         """symbolic_ik.py:121-282."""
@@ -126,13 +155,17 @@ class SymbolicIK:
     ) -> Tuple[npt.NDArray[np.float64], npt.NDArray[np.float64]]:
         """symbolic_ik.py:697-863 — reads and (when the elbow projection fires) updates the state left by the
         last is_reachable*() call, exactly like the reference's bound method."""
+        io = self._scalar_io()
+        io["h_in_np"][0] = theta
+        io["h_in_np"][1:8] = previous_joints
+        sv = self._solver
         self._upload()
-        th = torch.tensor([float(theta)], dtype=torch.float64, device=self._solver.device)
-        pj = torch.as_tensor(np.asarray(previous_joints, dtype=np.float64).reshape(1, 7)).to(self._solver.device)
-        r = self._solver.joints_from_state(self._state, th, arm_uniform=self.arm_id, previous_joints=pj)
-        joints = r["joints"][0].cpu().numpy()
-        s = self._state[0].cpu().numpy()
-        self._sync_attributes()
+        with torch.cuda.device(sv.device):
+            io["d_in"].copy_(io["h_in"], non_blocking=True)
+            sv._bind_stream()
+            sv._check(sv.lib.rsik_joints_from_state(sv._h, 1, io["state"], None, self.arm_id, io["theta"], io["prev"], None, None))
+            s = self._finish(io)
+        joints = s[24:31].copy()
         if s[19] != 0.0:  # Q2: 3 components after a projection, [x, y, z, 1] otherwise
             self.elbow_position = s[16:19].copy()
         else:
@@ -141,8 +174,16 @@ class SymbolicIK:
 
     def get_elbow_position(self, theta: float) -> npt.NDArray[np.float64]:
         """symbolic_ik.py:684-695."""
-        th = torch.tensor([float(theta)], dtype=torch.float64, device=self._solver.device)
-        e = self._solver.elbow_from_state(self._state, th)[0].cpu().numpy()
+        io = self._scalar_io()
+        io["h_in_np"][0] = theta
+        sv = self._solver
+        with torch.cuda.device(sv.device):
+            io["d_in"].copy_(io["h_in"], non_blocking=True)
+            sv._bind_stream()
+            sv._check(sv.lib.rsik_elbow_from_state(sv._h, 1, io["state"], io["theta"], io["elbow"]))
+            io["h_elbow"].copy_(io["d_elbow"], non_blocking=True)
+            torch.cuda.current_stream(sv.device).synchronize()
+        e = io["h_elbow_np"]
         return np.array([e[0], e[1], e[2], 1.0])
 
     def get_wrist_position(self, goal_pose: npt.NDArray[np.float64]) -> npt.NDArray[np.float64]:

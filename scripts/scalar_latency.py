@@ -8,10 +8,14 @@ with contextlib.redirect_stdout(io.StringIO()):
     c = ControlIK(urdf_path="config_files/reachy2_ik_minimal.urdf")
 pose = np.array([[0.3, -0.1, 0.1], [np.radians(20), np.radians(-50), np.radians(20)]])
 pose2 = np.array([[0.55, -0.3, -0.15], [0, -np.pi / 2, 0]])
-def timeit(fn, n=500):
-    fn(); t = time.perf_counter()
-    for _ in range(n): fn()
-    return (time.perf_counter() - t) / n * 1e6
+def timeit(fn, batches=10, n=100):
+    """median over batches of n calls (a process sees one ~75 ms one-off runtime stall in its first second)"""
+    fn(); out = []
+    for _ in range(batches):
+        t = time.perf_counter()
+        for _ in range(n): fn()
+        out.append((time.perf_counter() - t) / n * 1e6)
+    return sorted(out)[len(out) // 2]
 print("is_reachable            %.1f us" % timeit(lambda: ik.is_reachable(pose2)))
 ok, itv, fn, st = ik.is_reachable(pose2)
 print("get_joints              %.1f us" % timeit(lambda: fn(itv[0])))
