@@ -623,6 +623,17 @@ def test_continuous_run_equals_stepwise(golden_dir, torch_mod, run_mode, monkeyp
         assert np.max(np.abs(res["joints"] - np.swapaxes(J, 0, 1))) < 1e-7
         out, st2 = _run_continuous(c, arm, Ms, start_joints=g[f"{arm}_start_joints"][sel], start_pose=g[f"{arm}_start_pose"][sel])
         assert torch_mod.equal(st, st2)
+    # both arms' trajectories in ONE mixed launch (per-trajectory arm byte)
+    sel = {a: ~g[f"{a}_is_dvt"].astype(bool) for a in ("r_arm", "l_arm")}
+    cat = lambda k: np.concatenate([g[f"r_arm_{k}"][sel["r_arm"]], g[f"l_arm_{k}"][sel["l_arm"]]])  # noqa: E731
+    Ms, J, F, S = cat("M"), cat("joints"), cat("reachable"), cat("state")
+    arm_id = torch_mod.as_tensor(np.concatenate([np.zeros(sel["r_arm"].sum(), np.uint8), np.ones(sel["l_arm"].sum(), np.uint8)])).cuda()
+    st = c.new_continuous_state(arm_id, Ms.shape[0])
+    res = to_np(c.run_continuous_trajectories(arm_id, np.swapaxes(Ms, 0, 1), st, first_step_timed_out=True,
+                                              current_joints=cat("start_joints"), current_pose=cat("start_pose")))
+    np.testing.assert_array_equal(res["reachable"], F.T)
+    np.testing.assert_array_equal(res["state"], S.T)
+    assert np.max(np.abs(res["joints"] - np.swapaxes(J, 0, 1))) < 1e-7
 
 
 # ------------------------------------------------------------------------------------------ oracle-free properties
