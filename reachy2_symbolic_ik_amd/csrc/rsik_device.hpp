@@ -687,8 +687,13 @@ __device__ JointsOut joints_from_theta_g(const Acc& A, Reach& r, const Goal& G, 
     double gy = dot(k1, xw), gz = dot(k2, xw);
     RSIK_MARK("joints_atan2x7");
     // All seven angles are directions of normalised vectors: unit_atan2_n (no division), seven in lock step.
-    const double ign = rsqrt_fast(fma(gy, gy, gz * gz));
-    const double c6 = gz * ign, s6 = gy * ign;
+    // (gy, gz) is the goal x axis seen in the plane normal to the tip axis.  With a tip offset along the goal z axis
+    // (TIPZ) the tip axis IS the goal z axis, the goal x axis is orthogonal to it and (gy, gz) is a unit vector already.
+    double c6 = gz, s6 = gy;
+    if (!TIPZ) {
+        const double ign = rsqrt_fast(fma(gy, gy, gz * gz));
+        c6 = gz * ign; s6 = gy * ign;
+    }
     double at[7];
     {
         const double us[7] = {sphi, srs, ca, schi, sw, spp, s6};
