@@ -905,3 +905,33 @@ def test_solve_is_hipgraph_capturable(torch_mod, orc):
         np.testing.assert_array_equal(out["state"].cpu().numpy(), ref["state"])
         m = ref["reachable"].astype(bool)
         assert m.sum() > 100 and np.max(np.abs(out["joints"].cpu().numpy()[m] - ref["joints"][m])) < TOL
+
+
+def test_c_program_through_the_abi(tmp_path, torch_mod):
+    """examples/solve_from_c.c: a plain C host (no HIP headers, no Python, no torch in the process) drives the library
+    through include/rsik.h alone and gets what the Python drop-in class gets."""
+    import shutil
+    import subprocess
+
+    from reachy2_symbolic_ik_amd import _abi
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    solver, r, l = make_symbolic(0.03)
+    consts = tmp_path / "consts.bin"
+    np.ascontiguousarray(r.consts, dtype=np.float64).tofile(consts)
+    exe = tmp_path / "solve_from_c"
+    libdir = os.path.dirname(_abi.LIB_PATH)
+    subprocess.check_call([shutil.which("gcc"), "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "solve_from_c.c"), "-o", str(exe), "-L", libdir, "-lrsik_hip",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lm"])
+    out = subprocess.run([str(exe), str(consts)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    rows = np.array([[float(x) for x in line.split()] for line in out.stdout.strip().splitlines()])
+    pos = np.array([[0.55, -0.3, -0.15], [0.3, -0.1, 0.1], [-0.3, -0.2, 0.0], [1.5, -0.2, 0.0]])
+    eul = np.array([[0, -np.pi / 2, 0], np.radians([20, -50, 20]), [0, 0, 0], [0, 0, 0]])
+    ref = to_np(r.solve_batch(soa(pos, eul, torch_mod)))
+    np.testing.assert_array_equal(rows[:, 0], ref["reachable"])
+    np.testing.assert_array_equal(rows[:, 1], ref["state"])
+    assert list(rows[:, 0]) == [1, 1, 0, 0] and list(rows[:, 1]) == [0, 0, 2, 1]  # reachable x2, backward, out of reach
+    np.testing.assert_array_equal(rows[:, 2:4], ref["interval"])
+    np.testing.assert_array_equal(rows[:, 4:11], ref["joints"])
