@@ -404,6 +404,7 @@ struct DiscreteArgs {
     int sweep_mode;       // 0 auto, 1 always the exhaustive wave-cooperative sweep, 2 always the per-lane search
     int euler_roundtrip;  // RSIK_OPT_EULER_ROUNDTRIP
     double pref[2];       // preferred theta per arm slot (already mirrored for l, C:252)
+    double pref_cs[2], pref_sn[2];  // its cosine / sine (host libm, once per launch)
     double lim[2][2];     // interval_limit per arm slot (C:225-250)
     double prev_sol[2][7];
     const double* current_joints;
@@ -540,8 +541,7 @@ __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR void co
     bool need = false;
     if (r.ok) {  // U:357-364 preferred-theta shortcut
         if (is_valid_angle(pref, r.i0, r.i1)) {
-            double st, ct;
-            fast_sincos(pref, &st, &ct);
+            const double st = K.pref_sn[slot], ct = K.pref_cs[slot];  // launch-uniform: not evaluated per lane
             if (is_elbow_ok(A, elbow_on_circle(r, ct, st))) { found = true; theta = pref; }
         }
         need = !found;
@@ -1243,6 +1243,8 @@ int rsik_control_discrete(rsik_ctx* ctx, int64_t n, const double* const m12_soa[
     for (int slot = 0; slot < 2; slot++) {
         const int a = arm ? slot : arm_uniform;
         control_limits(a, constrained_mode, preferred_theta, K.lim[slot], &K.pref[slot]);
+        K.pref_cs[slot] = std::cos(K.pref[slot]);  // np.cos / np.sin of the reference (U:359-360), once per launch
+        K.pref_sn[slot] = std::sin(K.pref[slot]);
         for (int k = 0; k < 7; k++) K.prev_sol[slot][k] = previous_sol_host[7 * a + k];
         K.arms[slot] = ctx->arms[a];
     }
