@@ -67,13 +67,13 @@ struct AccK {
 // Workgroup-shared read-only data: the per-arm blocks (mixed launches) and the unit-vector atan2 table.
 struct SharedTables {
     double arm[2][RSIK_ARM_CONSTS_COUNT];
-    double utab[kUnitAtanRows][4];
+    double utab[3][kUnitAtanRows];  // column-major, see unit_atan2_n
 };
 // All global reads of the staging are issued first and the LDS writes follow, so a workgroup pays ONE memory round trip
 // before its barrier (a copy loop per table serialises one round trip per table: +0.6 us on every wave's start-up).
 template <bool MIXED>
 __device__ __forceinline__ void stage_tables(SharedTables& S, const ArmC* arms) {
-    constexpr int NA = kUnitAtanRows * 4, NS = kSinCosRows * 2, NC = 2 * RSIK_ARM_CONSTS_COUNT;
+    constexpr int NA = kUnitAtanRows * 3, NS = kSinCosRows * 2, NC = 2 * RSIK_ARM_CONSTS_COUNT;
     constexpr int RA = (NA + kBlock - 1) / kBlock, RS = (NS + kBlock - 1) / kBlock, RC = (NC + kBlock - 1) / kBlock;
     const unsigned t = threadIdx.x & (kBlock - 1);  // the launch uses kBlock threads: tells the compiler t < kBlock
     const double* ga = &c_unit_atan_tab[0][0];
@@ -953,7 +953,7 @@ __global__ __launch_bounds__(kBlock) void fk_kernel(const FkArgs K) {
 // 7 unit_atan2(s = a, c = b) of a unit vector
 __global__ void debug_math_kernel(int op, int64_t n, const double* a, const double* b, double* o0, double* o1) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    __shared__ double utab[kUnitAtanRows][4];
+    __shared__ double utab[3][kUnitAtanRows];
     stage_sincos_tab();
     stage_unit_atan_tab(utab);
     __syncthreads();
