@@ -54,13 +54,24 @@ struct Acc {
 };
 // Same, with the uniform block addressed through an explicit kernarg-segment (constant address space) pointer.
 typedef const __attribute__((address_space(4))) double* KConst;
-template <bool MIXED>
+// Entries of the constant block that can differ between a right and a left arm that are mirror images of each other
+// (everything with a y component or a handedness: shoulder y, tip y, the shoulder frame, the elbow singularity y, the
+// side sign, the projection plane).  In a mixed launch whose two blocks agree everywhere else (checked by the host:
+// SolveArgs.mirror) only these come from the per-lane LDS copy; the rest are the same scalar loads as in a
+// uniform launch (a mixed launch reads ~85 constants per wave, ~35 of them from this shared set).
+__host__ __device__ constexpr bool arm_const_is_sided(int i) {
+    return i == RSIK_C_SHOULDER + 1 || i == RSIK_C_TIPL + 1 || (i >= RSIK_C_MST && i < RSIK_C_TSH + 3) || i == RSIK_C_ES + 1 ||
+           i == RSIK_C_SIDE || (i >= RSIK_C_PLANE_P && i < RSIK_C_PROJ_CENTER + 3);
+}
+// MIXED: 0 = one arm for the whole launch, 1 = per-lane arm, every constant from LDS, 2 = per-lane arm, mirrored blocks
+template <int MIXED>
 struct AccK {
     KConst k;
     LdsConst lds;
     UnitAtanTab utab;
     __device__ __forceinline__ double operator()(int i) const {
-        if constexpr (MIXED) return lds[i];
+        if constexpr (MIXED == 1) return lds[i];
+        else if constexpr (MIXED == 2) return arm_const_is_sided(i) ? lds[i] : k[i];
         else return k[i];
     }
 };
@@ -214,7 +225,7 @@ __device__ __forceinline__ void flush_rows(double* __restrict__ out, int64_t wav
 // profiles/r01/timeline/: under the power-managed clock it is the executed instruction count that sets the time, not
 // how well the waves overlap.)
 // TIPZ: every arm of the launch has tip_x = tip_y = 0 (goal_from_euler_tipz: -24 fp64 operations per pose).
-template <bool MIXED, bool TIPZ>
+template <int MIXED, bool TIPZ>
 __global__ __launch_bounds__(kBlock, RSIK_SOLVE_MIN_WAVES) void solve_kernel(const SolveArgs K) {
     __shared__ double lds[kBlock / 64][64 * 10];
     __shared__ SharedTables lds_tab;
@@ -237,13 +248,13 @@ __global__ __launch_bounds__(kBlock, RSIK_SOLVE_MIN_WAVES) void solve_kernel(con
     double in[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) in[k] = ld_stream(K.in[k] + tile0 + tt);
-    stage_tables<MIXED>(lds_tab, K.arms);
+    stage_tables<(MIXED != 0)>(lds_tab, K.arms);
 #ifdef RSIK_TIMELINE_PROBE
     const uint64_t probe_t1 = __builtin_amdgcn_s_memrealtime();
     uint64_t probe_mid = 0;
 #endif
     const AccK<MIXED> A{(KConst)&((const __attribute__((address_space(4))) SolveArgs*)__builtin_amdgcn_kernarg_segment_ptr())->arms[0].v[0],
-                        (LdsConst)lds_tab.arm[(MIXED && K.arm[tile0 + tt] != 0) ? 1 : 0], (UnitAtanTab)&lds_tab.utab[0][0]};
+                        (LdsConst)lds_tab.arm[(MIXED != 0 && K.arm[tile0 + tt] != 0) ? 1 : 0], (UnitAtanTab)&lds_tab.utab[0][0]};
     double* lds_wave = lds[wave];
 
     const V3 pos = {in[0], in[1], in[2]};
@@ -1166,12 +1177,21 @@ int rsik_solve(rsik_ctx* ctx, int64_t n, const double* const pose_soa[6], const 
     // tip offset along the goal z axis only (the default arm / the URDF): the specialised goal stage applies
     const bool tipz = K.arms[0].v[RSIK_C_TIPL] == 0.0 && K.arms[0].v[RSIK_C_TIPL + 1] == 0.0 &&
                       K.arms[1].v[RSIK_C_TIPL] == 0.0 && K.arms[1].v[RSIK_C_TIPL + 1] == 0.0 && !std::getenv("RSIK_NO_TIPZ");
+    // mixed launch: do the two blocks agree in everything that has no handedness (arm_const_is_sided)?
+    bool mirror = arm != nullptr && !std::getenv("RSIK_NO_MIRROR");
+    for (int i = 0; mirror && i < RSIK_ARM_CONSTS_COUNT; i++)
+        if (!rsik::arm_const_is_sided(i) && std::memcmp(&K.arms[0].v[i], &K.arms[1].v[i], sizeof(double)) != 0) mirror = false;
     if (arm) {
-        if (tipz) hipLaunchKernelGGL((rsik::solve_kernel<true, true>), grid, block, 0, ctx->stream, K);
-        else hipLaunchKernelGGL((rsik::solve_kernel<true, false>), grid, block, 0, ctx->stream, K);
+        if (mirror) {
+            if (tipz) hipLaunchKernelGGL((rsik::solve_kernel<2, true>), grid, block, 0, ctx->stream, K);
+            else hipLaunchKernelGGL((rsik::solve_kernel<2, false>), grid, block, 0, ctx->stream, K);
+        } else {
+            if (tipz) hipLaunchKernelGGL((rsik::solve_kernel<1, true>), grid, block, 0, ctx->stream, K);
+            else hipLaunchKernelGGL((rsik::solve_kernel<1, false>), grid, block, 0, ctx->stream, K);
+        }
     } else {
-        if (tipz) hipLaunchKernelGGL((rsik::solve_kernel<false, true>), grid, block, 0, ctx->stream, K);
-        else hipLaunchKernelGGL((rsik::solve_kernel<false, false>), grid, block, 0, ctx->stream, K);
+        if (tipz) hipLaunchKernelGGL((rsik::solve_kernel<0, true>), grid, block, 0, ctx->stream, K);
+        else hipLaunchKernelGGL((rsik::solve_kernel<0, false>), grid, block, 0, ctx->stream, K);
     }
     RSIK_HIP(ctx, hipGetLastError());
     return RSIK_OK;

@@ -865,6 +865,13 @@ def test_tip_z_specialisation_matches_general_path(torch_mod, monkeypatch):
         np.testing.assert_array_equal(a["joints"][:, :6], b["joints"][:, :6])
         m = a["reachable"].astype(bool)
         assert np.max(np.abs(a["joints"][m, 6] - b["joints"][m, 6])) < 2e-15
+    # mixed launches of mirror-image arms read the constants without handedness as scalars (RSIK_NO_MIRROR=1: all per
+    # lane from LDS): the same bits either way
+    monkeypatch.delenv("RSIK_NO_TIPZ")
+    monkeypatch.setenv("RSIK_NO_MIRROR", "1")
+    c = to_np(dual.solve_batch(arm_id, p))
+    for k in ("reachable", "state", "interval", "joints", "elbow"):
+        np.testing.assert_array_equal(c[k], fast[1][k])
 
 
 def test_solve_is_hipgraph_capturable(torch_mod, orc):
