@@ -649,6 +649,76 @@ def gen_custom_geometry(out, n_sweep=6000, n_reach=1536):
     np.savez_compressed(os.path.join(out, "g9_custom_geometry.npz"), **data)
 
 
+# ----------------------------------------------------------------------------------------
+# G10: ControlIK built from a URDF that is NOT the Reachy 2 one (tests/golden/custom_arm.urdf, test data written for
+# this repo): pins URDF -> parameters -> constants -> discrete / continuous control for a non-default geometry.
+# ----------------------------------------------------------------------------------------
+def gen_custom_urdf_control(out, n=512, n_traj=4, n_steps=200):
+    urdf = open(os.path.join(out, "custom_arm.urdf")).read()
+    rng = np.random.default_rng(10)
+    data = {}
+    real_time = ref_control_mod.time
+    for arm in ARMS:
+        ctrl = quiet(ControlIK, urdf=urdf)
+        solver = ctrl.symbolic_ik_solver[arm]
+        for f in ("shoulder_position", "shoulder_orientation_offset", "upper_arm_size", "forearm_size", "tip_position"):
+            data[f"{arm}_param_{f}"] = np.asarray(getattr(solver, f), dtype=float)
+        sh = np.asarray(solver.shoulder_position, dtype=float)
+        P, E = [], []
+        while len(P) < n // 2:
+            pp = sh + rng.uniform(-0.7, 0.7, size=(2048, 3))
+            ee = rng.uniform(-np.pi, np.pi, size=(2048, 3))
+            for p, e in zip(pp, ee):
+                if solver.is_reachable(np.array([p, e]))[0]:
+                    P.append(p)
+                    E.append(e)
+                    if len(P) == n // 2:
+                        break
+        pos = np.concatenate([np.array(P), sh + rng.uniform(-0.7, 0.7, size=(n - n // 2, 3))])
+        eul = np.concatenate([np.array(E), rng.uniform(-np.pi, np.pi, size=(n - n // 2, 3))])
+        Ms = np.array([pose_to_matrix(p, e) for p, e in zip(pos, eul)])
+        data[f"{arm}_M"] = Ms
+        for key, nb, mode in (("u20", 20, "unconstrained"), ("l64", 64, "low_elbow")):
+            res = [control_call(ctrl, arm, M, nb, mode) for M in Ms]
+            data[f"{arm}_{key}_joints"] = np.array([r[0] for r in res])
+            data[f"{arm}_{key}_reachable"] = np.array([r[1] for r in res], dtype=np.uint8)
+            data[f"{arm}_{key}_state"] = np.array([r[2] for r in res], dtype=np.uint8)
+        # continuous mode from explicit generic starts (see G7)
+        phases = rng.uniform(0.0, 40.0, size=n_traj)
+        cur_j = rng.uniform(-0.6, 0.6, size=(n_traj, 7))
+        TM = np.zeros((n_traj, n_steps, 4, 4))
+        P0 = np.zeros((n_traj, 4, 4))
+        J = np.zeros((n_traj, n_steps, 7))
+        F = np.zeros((n_traj, n_steps), dtype=np.uint8)
+        S = np.zeros((n_traj, n_steps), dtype=np.uint8)
+        for k in range(n_traj):
+            clock = FakeClock()
+            ref_control_mod.time = clock
+            try:
+                c2 = quiet(ControlIK, urdf=urdf)
+                p0, e0 = trajectory_pose(11.0 + phases[k] - 0.3, arm)
+                P0[k] = pose_to_matrix(p0 * np.array([0.8, 1.0, 1.0]) + rng.uniform(-0.02, 0.02, 3), e0 + rng.uniform(-0.1, 0.1, 3))
+                for i in range(n_steps):
+                    pos_i, eul_i = trajectory_pose(i / 120.0 + 11.0 + phases[k], arm)
+                    M = pose_to_matrix(pos_i, eul_i)
+                    TM[k, i] = M
+                    clock.t += 1.0 / 120.0
+                    kw = dict(current_joints=list(cur_j[k]), current_pose=P0[k]) if i == 0 else {}
+                    j, ok, st = quiet(c2.symbolic_inverse_kinematics, arm, M, "continuous", d_theta_max=0.01, **kw)
+                    J[k, i] = np.array(j, dtype=float)
+                    F[k, i] = bool(ok)
+                    S[k, i] = STATE_CODES.get(st, 8)
+            finally:
+                ref_control_mod.time = real_time
+        data[f"{arm}_traj_M"] = TM
+        data[f"{arm}_traj_start_pose"] = P0
+        data[f"{arm}_traj_start_joints"] = cur_j
+        data[f"{arm}_traj_joints"] = J
+        data[f"{arm}_traj_reachable"] = F
+        data[f"{arm}_traj_state"] = S
+    np.savez_compressed(os.path.join(out, "g10_custom_urdf_control.npz"), **data)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
@@ -659,7 +729,7 @@ def main():
     steps = [("g0", gen_constants), ("g1", gen_catalogue), ("g2", gen_sweep), ("g3", gen_reachable),
              ("g4", gen_control), ("g5", gen_helpers), ("g6", gen_continuous),
              ("g7", gen_continuous_start), ("g8", gen_matrix_edges),
-             ("g9", gen_custom_geometry)]
+             ("g9", gen_custom_geometry), ("g10", gen_custom_urdf_control)]
     for name, fn in steps:
         if args.only and name not in args.only.split(","):
             continue

@@ -942,3 +942,46 @@ def test_c_program_through_the_abi(tmp_path, torch_mod):
     assert list(rows[:, 0]) == [1, 1, 0, 0] and list(rows[:, 1]) == [0, 0, 2, 1]  # reachable x2, backward, out of reach
     np.testing.assert_array_equal(rows[:, 2:4], ref["interval"])
     np.testing.assert_array_equal(rows[:, 4:11], ref["joints"])
+
+
+def test_custom_urdf_control_golden(golden_dir, torch_mod):
+    """G10: ControlIK(urdf=<a URDF that is not the Reachy 2 one>) — URDF -> parameters -> constants -> kernels for a
+    non-default geometry: discrete mode (two grid sizes / constrained modes, uniform and mixed launches) and continuous
+    trajectories (trajectory mode, both arms in one mixed launch)."""
+    import contextlib
+    import io
+
+    from reachy2_symbolic_ik_amd import ControlIK
+
+    g = load(golden_dir, "g10_custom_urdf_control.npz")
+    urdf = open(os.path.join(golden_dir, "custom_arm.urdf")).read()
+    with contextlib.redirect_stdout(io.StringIO()):
+        c = ControlIK(urdf=urdf)
+    for arm in ("r_arm", "l_arm"):
+        s = c.symbolic_ik_solver[arm]
+        np.testing.assert_array_equal(s.shoulder_position, g[f"{arm}_param_shoulder_position"])
+        np.testing.assert_array_equal(np.asarray(s.shoulder_orientation_offset, dtype=float), g[f"{arm}_param_shoulder_orientation_offset"])
+        np.testing.assert_array_equal(s.tip_position, g[f"{arm}_param_tip_position"])
+        assert s.upper_arm_size == g[f"{arm}_param_upper_arm_size"] and s.forearm_size == g[f"{arm}_param_forearm_size"]
+    for key, nb, mode in (("u20", 20, "unconstrained"), ("l64", 64, "low_elbow")):
+        c.nb_search_points = nb
+        for arm in ("r_arm", "l_arm"):
+            res = to_np(c.symbolic_inverse_kinematics_batch(arm, g[f"{arm}_M"], constrained_mode=mode))
+            np.testing.assert_array_equal(res["reachable"], g[f"{arm}_{key}_reachable"])
+            np.testing.assert_array_equal(res["state"], g[f"{arm}_{key}_state"])
+            assert np.max(np.abs(res["joints"] - g[f"{arm}_{key}_joints"])) < TOL
+        M = np.concatenate([g["r_arm_M"], g["l_arm_M"]])
+        arm_id = torch_mod.as_tensor(np.concatenate([np.zeros(len(g["r_arm_M"]), np.uint8), np.ones(len(g["l_arm_M"]), np.uint8)])).cuda()
+        res = to_np(c.symbolic_inverse_kinematics_batch(arm_id, M, constrained_mode=mode))
+        np.testing.assert_array_equal(res["state"], np.concatenate([g[f"r_arm_{key}_state"], g[f"l_arm_{key}_state"]]))
+        assert np.max(np.abs(res["joints"] - np.concatenate([g[f"r_arm_{key}_joints"], g[f"l_arm_{key}_joints"]]))) < TOL
+    cat = lambda k: np.concatenate([g[f"r_arm_traj_{k}"], g[f"l_arm_traj_{k}"]])  # noqa: E731
+    Ms, J, F, S = cat("M"), cat("joints"), cat("reachable"), cat("state")
+    nt = len(g["r_arm_traj_M"])
+    arm_id = torch_mod.as_tensor(np.concatenate([np.zeros(nt, np.uint8), np.ones(nt, np.uint8)])).cuda()
+    st = c.new_continuous_state(arm_id, Ms.shape[0])
+    res = to_np(c.run_continuous_trajectories(arm_id, np.swapaxes(Ms, 0, 1), st, first_step_timed_out=True,
+                                              current_joints=cat("start_joints"), current_pose=cat("start_pose")))
+    np.testing.assert_array_equal(res["reachable"], F.T)
+    np.testing.assert_array_equal(res["state"], S.T)
+    assert np.max(np.abs(res["joints"] - np.swapaxes(J, 0, 1))) < 1e-7

@@ -353,3 +353,44 @@ def test_custom_geometry(golden_dir):
                               theta_in=g[f"{arm}_reach_theta_u"], nthreads=4)
         _check_symbolic(res, g, f"{arm}_reach_in_")
         assert (g[f"{arm}_reach_i0_elbow_len"] == 3).mean() > 0.1  # the projection branch runs with this geometry too
+
+
+def _custom_urdf_arms(golden_dir):
+    from reachy2_symbolic_ik_amd.constants import get_ik_parameters_from_urdf
+
+    urdf = open(os.path.join(golden_dir, "custom_arm.urdf")).read()
+    params = get_ik_parameters_from_urdf(urdf, ["r", "l"])
+    return params, {arm: orc.Arm(arm, -1.01, ik_parameters=params) for arm in ("r_arm", "l_arm")}
+
+
+def test_custom_urdf_control(golden_dir):
+    """G10: ControlIK constructed from a URDF that is not the Reachy 2 one (tests/golden/custom_arm.urdf): the parsed
+    parameters, the discrete results (two grid sizes / constrained modes) and continuous trajectories."""
+    g = load(golden_dir, "g10_custom_urdf_control.npz")
+    g0 = load(golden_dir, "g0_constants.npz")
+    params, arms = _custom_urdf_arms(golden_dir)
+    for i, arm in enumerate(("r_arm", "l_arm")):
+        a = arm[0]
+        for f, key in (("shoulder_position", "shoulder_position"), ("shoulder_orientation_offset", "shoulder_orientation"),
+                       ("upper_arm_size", "upper_arm_size"), ("forearm_size", "forearm_size"), ("tip_position", "tip_position")):
+            np.testing.assert_array_equal(np.asarray(params[f"{a}_{key}"], dtype=float), g[f"{arm}_param_{f}"])
+        M = g[f"{arm}_M"]
+        aid = np.full(len(M), i, np.uint8)
+        for key, nb, mode in (("u20", 20, 0), ("l64", 64, 1)):
+            res = orc.control_discrete_batch(arms["r_arm"], arms["l_arm"], M, arm_id=aid, nb_search_points=nb, constrained_mode=mode)
+            np.testing.assert_array_equal(res["reachable"], g[f"{arm}_{key}_reachable"])
+            np.testing.assert_array_equal(res["state"], g[f"{arm}_{key}_state"])
+            assert np.max(np.abs(res["joints"] - g[f"{arm}_{key}_joints"])) < TOL
+        assert set(np.unique(g[f"{arm}_u20_state"])) >= {0, 1, 2, 3, 4, 6}
+        Ms, J, F, S = g[f"{arm}_traj_M"], g[f"{arm}_traj_joints"], g[f"{arm}_traj_reachable"], g[f"{arm}_traj_state"]
+        for k in range(Ms.shape[0]):
+            cs = orc.ContinuousState(g0[f"{arm}_urdf_previous_theta_init"], g0[f"{arm}_urdf_previous_sol"])
+            prev_pose = g[f"{arm}_traj_start_pose"][k]
+            for s in range(Ms.shape[1]):
+                cur = g[f"{arm}_traj_start_joints"][k] if s == 0 else cs.previous_sol
+                j, ok, st = orc.control_continuous_step(arms[arm], cs, Ms[k, s], timed_out=(s == 0), preferred_theta_arg=-4 * np.pi / 6,
+                                                        preferred_theta_self=g0[f"{arm}_urdf_preferred_theta"],
+                                                        constrained_mode=0, current_joints=cur, current_pose=prev_pose)
+                prev_pose = Ms[k, s]
+                assert ok == bool(F[k, s]) and st == S[k, s], (arm, k, s)
+                assert np.max(np.abs(j - J[k, s])) < 1e-7, (arm, k, s)
