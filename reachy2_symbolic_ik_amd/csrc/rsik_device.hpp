@@ -88,8 +88,11 @@ __device__ __forceinline__ double angle_diff(double a, double b) {
     return pymod_2pi(d + kPi) - kPi;
 }
 // U:468-474
+// Interval ends on this path always lie in [-pi, pi] (atan2 results, +-pi for the whole circle, the host-wrapped
+// interval limits), where `i0 % 2pi == i1 % 2pi` (U:469) holds exactly when i0 == i1 or the pair is {-pi, pi}
+// (-pi + 2pi == pi exactly in binary64): no modulo needed.
 __device__ __forceinline__ bool is_valid_angle(double angle, double i0, double i1) {
-    if (pymod_2pi(i0) == pymod_2pi(i1)) return true;
+    if (i0 == i1 || (fabs(i0) == kPi && fabs(i1) == kPi)) return true;
     if (i0 < i1) return (i0 <= angle) && (angle <= i1);
     return (i0 <= angle) || (angle <= i1);
 }
