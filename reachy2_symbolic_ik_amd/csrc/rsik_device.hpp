@@ -78,8 +78,10 @@ __device__ __forceinline__ bool np_isclose(double a, double b) { return fabs(a -
 __device__ __forceinline__ double pymod_2pi(double a) {
     double q = floor(a * 0.15915494309189535);
     double m = fma(-q, kTwoPi, a);
-    if (m < 0) m += kTwoPi;
-    if (m >= kTwoPi) m -= kTwoPi;
+    if (RSIK_RARE(!(m >= 0 && m < kTwoPi))) {  // a / 2pi rounded across an integer (or a is not finite)
+        if (m < 0) m += kTwoPi;
+        if (m >= kTwoPi) m -= kTwoPi;
+    }
     return m;
 }
 // U:486-490
