@@ -356,9 +356,12 @@ __global__ __launch_bounds__(kBlock, RSIK_SOLVE_MIN_WAVES) void solve_kernel(con
 __device__ __forceinline__ void goal_from_m12(const double (&m)[12], Rot& Rg, V3& pos, int mode) {
 #pragma unroll
     for (int k = 0; k < 9; k++) Rg.m[k] = m[k];
-    bool eye = true;
+    // np.allclose(R, I) needs all nine entries close; R00 alone rules it out for nearly every goal
+    bool eye = RSIK_RARE(np_isclose(Rg.m[0], 1.0));
+    if (eye) {
 #pragma unroll
-    for (int k = 0; k < 9; k++) eye = eye && np_isclose(Rg.m[k], (k % 4 == 0) ? 1.0 : 0.0);
+        for (int k = 1; k < 9; k++) eye = eye && np_isclose(Rg.m[k], (k % 4 == 0) ? 1.0 : 0.0);
+    }
     if (eye) {  // C:212-214 np.allclose(R, I)
 #pragma unroll
         for (int k = 0; k < 9; k++) Rg.m[k] = (k % 4 == 0) ? 1.0 : 0.0;
