@@ -703,7 +703,18 @@ __global__ __launch_bounds__(kBlock) void control_continuous_kernel(const Contin
         for (int k = 0; k < 12; k++) m_next[k] = K.in[k][ii];
     }
     const int64_t n_steps = LOOP ? K.n_steps : 1;
+#ifdef RSIK_CONT_PROBE
+    // diagnostic build only: core-clock ticks per phase of a control step, summed over the steps (lane 0 of each wave
+    // writes them over its trajectory's state rows 1-6 at the end)
+    uint64_t pc[6] = {0, 0, 0, 0, 0, 0};
+#define RSIK_CP(k) { const uint64_t now_ = __builtin_readcyclecounter(); pc[k] += now_ - pt; pt = now_; }
+#else
+#define RSIK_CP(k)
+#endif
     auto one_step = [&](const int64_t step) {
+#ifdef RSIK_CONT_PROBE
+        uint64_t pt = __builtin_readcyclecounter();
+#endif
         double m_cur[12];
         if constexpr (LOOP) {
 #pragma unroll
@@ -741,7 +752,9 @@ __global__ __launch_bounds__(kBlock) void control_continuous_kernel(const Contin
                 Reach rc = reach<true>(A, cpos, Rc);
                 prev_theta = best_theta_to_current_joints(A, rc, Rc, prev_sol, pref);
             }
+            RSIK_CP(0);  // goal matrix, start-up branch
             Reach r = reach<false, false>(A, pos, Rg);
+            RSIK_CP(1);  // reach with limits
             double theta;
             ok = r.ok;
             if (r.ok) {  // C:338-366
@@ -760,11 +773,13 @@ __global__ __launch_bounds__(kBlock) void control_continuous_kernel(const Contin
                 theta = (fabs(ad) < K.d_theta_max) ? pref : (prev_theta + (ad / fabs(ad)) * K.d_theta_max);
                 st_code = st_reach;
             }
+            RSIK_CP(2);  // 10-point grid (reachable lanes) + no-limits reach (the others)
             theta = limit_theta_to_interval(theta, K.lim[slot][0], K.lim[slot][1]);
             prev_theta = theta;
             double sn, cs;
             fast_sincos(theta, &sn, &cs);
             JointsOut o = joints_from_theta<true>(A, r, Rg, cs, sn, prev_sol);
+            RSIK_CP(3);  // theta limit + joints
 #pragma unroll
             for (int k = 0; k < 7; k++) jv[k] = o.j[k];
             bool em = safety_checks(A.utab, jv, o.c4, o.s4, o.c5, o.s5, o.c6, o.s6, prev_sol, K.max_angle, K.cos_max, K.sin_max);
@@ -784,12 +799,14 @@ __global__ __launch_bounds__(kBlock) void control_continuous_kernel(const Contin
 #pragma unroll
                 for (int k = 0; k < 7; k++) prev_sol[k] = jv[k];
             }
+            RSIK_CP(4);  // safety checks + continuity
         }
         store_rows<7>(K.joints + step * 7 * n, wave_base, K.n, lane, lds_out[wave], jv);
         if (live) {
             if (K.reachable) K.reachable[step * n + i] = ok ? 1 : 0;
             if (K.state) K.state[step * n + i] = (uint8_t)st_code;
         }
+        RSIK_CP(5);  // stores
     };
     if constexpr (LOOP) {
 #pragma unroll 1
@@ -804,8 +821,15 @@ __global__ __launch_bounds__(kBlock) void control_continuous_kernel(const Contin
         K.st[8 * n + i] = init ? 1.0 : 0.0;
         K.st[9 * n + i] = emergency ? 1.0 : 0.0;
         K.st[10 * n + i] = has_prev ? 1.0 : 0.0;
+#ifdef RSIK_CONT_PROBE
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) K.st[(1 + k) * n + i] = (double)pc[k];
+        }
+#endif
     }
 }
+#undef RSIK_CP
 
 // ------------------------------------------------------------------------------------------
 // Solver-state kernels: the scalar drop-in API (SymbolicIK objects keep `self.goal_pose`,
