@@ -33,8 +33,8 @@ def parse(path):
 out = {"_comment": "HBM bytes per launch and executed vector instructions per wave from rocprofv3 PMC passes (FETCH_SIZE x2 "
                    "gfx950 correction + WRITE_SIZE, KiB units; SQ_INSTS_VALU / SQ_WAVES), scripts/profile.sh; see "
                    f"config*_{suffix}_summary.txt"}
-want = {2: ("solve_kernel<false", 1048576, "solve_kernel"), 3: ("control_discrete_kernel<false", 262144, "control_discrete_kernel"),
-        4: ("solve_kernel<true", 1048576, "solve_kernel<mixed>")}
+want = {2: ("solve_kernel<0,", 1048576, "solve_kernel"), 3: ("control_discrete_kernel<false", 262144, "control_discrete_kernel"),
+        4: ("solve_kernel<2,", 1048576, "solve_kernel<mixed>")}
 for c, (kn, grid, label) in want.items():
     src = os.path.join(root, "gpurun_out", f"{prefix}_c{c}")
     shutil.copy(os.path.join(src, "summary.txt"), os.path.join(dest, f"config{c}_{suffix}_summary.txt"))
