@@ -434,6 +434,42 @@ __device__ Reach reach_g(const Acc& A, V3 pos_in, const V3 woff) {
 
     RSIK_MARK("reach_line");
     const V3 N2 = n2;  // already unit (the reference renormalises: a 1-ulp no-op)
+    // Closed form of S:427-568 for the generic case.  A point of the elbow circle, e(theta) - w = p2 + r2 (a1 cos + a2 sin),
+    // is on the allowed side of the wrist-limit plane iff N1.(e - w) > N1.p1 (the test the reference applies to its
+    // mid-angle point, S:564), i.e. iff  A' cos(theta) + B' sin(theta) > D'  with A' = N1.a1, B' = N1.a2,
+    // D' = (N1.p1 - N1.p2) / r2 = -side_val / r2: one arc, centred at phi = atan2(B', A'), of half-width
+    // alpha = acos(D' / R'), R' = |(A', B')| = |N1 x N2|.  The interval is [phi - alpha, phi + alpha]; both ends are formed
+    // as unit vectors (angle addition) and go through the table atan2, which also delivers them in (-pi, pi] so that
+    // interval[0] > interval[1] means wrap-around exactly as in the reference.  No plane-plane line, no circle-line
+    // intersection, no mid-point test: ~70 instead of ~135 fp64 operations.
+    // The reference's own arithmetic (below) still decides everything that is decided by rounding: planes parallel to
+    // 1e-6 (R'^2 < 1e-12), tangency (|R'^2 - D'^2| < 1e-8), the degenerate circle (r2 = 0) and the neighbourhood of its
+    // isclose(t1, t0) early exit (Q7; t0 |N1 x N2| = N2.b, t1 |N1 x N2| = N1.b = side_val).
+    {
+        const double Ap = dot(N1, F2.c1), Bp = dot(N1, F2.c2);
+        const double R2 = fma(Ap, Ap, Bp * Bp);
+        const double Dp = -side_val * ir2;
+        const double disc = fma(-Dp, Dp, R2);
+        const double n2b = dot(N2, p2) - A(RSIK_C_WRIST_AX) * dot(N1, N2);
+        const bool exact = (ir2 == 0.0) || (R2 < 1e-12) || (fabs(disc) < 1e-8) ||
+                           (fabs(side_val - n2b) <= 2e-8 + 2e-5 * fabs(n2b));
+        if (!RSIK_RARE(exact)) {
+            if (disc < 0) { whole_or_nothing(); return r; }
+            r.ok = true;
+            r.state = RSIK_STATE_REACHABLE;
+            const double iR = rsqrt_fast(R2);
+            const double cphi = Ap * iR, sphi = Bp * iR;
+            const double cal = Dp * iR, sal = (disc * rsqrt_fast(disc)) * iR;
+            const double c0 = fma(cphi, cal, sphi * sal), s0 = fma(sphi, cal, -(cphi * sal));
+            const double c1 = fma(cphi, cal, -(sphi * sal)), s1 = fma(sphi, cal, cphi * sal);
+            const double ss[2] = {s0, s1}, cc[2] = {c0, c1};
+            double aa[2];
+            unit_atan2_n<2>(A.utab, ss, cc, aa);
+            r.i0 = aa[0]; r.i1 = aa[1];
+            r.ct0 = c0; r.st0 = s0;
+            return r;
+        }
+    }
     const double mg = A(RSIK_C_NORMAL_MARGIN);
     // S:588-606 + S:570-586: line of intersection of the two planes.  The reference solves
     // [v1, -v2] t = p2 - p1 by least squares; since v1, v2, (p2-p1 minus its v-part) are coplanar the
