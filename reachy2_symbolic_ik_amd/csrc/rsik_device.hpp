@@ -628,11 +628,13 @@ __device__ JointsOut joints_from_theta_g(const Acc& A, Reach& r, const Goal& G, 
     V3 e = elbow_on_circle(r, ct, st);
     o.projected = false;
     if (RSIK_RARE(above_singularity_plane(A, e))) {  // S:708-718 -> make_elbow_projection S:647-682
-        V3 Pl = cvec(A, RSIK_C_PLANE_P), v3 = cvec(A, RSIK_C_PLANE_N), pc = cvec(A, RSIK_C_PROJ_CENTER);
-        double dist = dot(e - Pl, v3);
-        V3 pe = madd(v3, -dist, e);
-        V3 V = pe - pc;
-        V3 ne = madd(normalized(V), A(RSIK_C_PROJ_RADIUS), pc);
+        // project the elbow onto the plane and snap it to the circle (centre pc, in the plane) cut out of the shoulder sphere:
+        // the in-plane vector from pc is measured directly (the plane point of S:657 is only needed for the distance, and
+        // pc - P_limits is orthogonal to the normal)
+        const V3 v3 = cvec(A, RSIK_C_PLANE_N), pc = cvec(A, RSIK_C_PROJ_CENTER);
+        const V3 d1 = e - pc;
+        const V3 V = madd(v3, -dot(d1, v3), d1);
+        const V3 ne = madd(V, A(RSIK_C_PROJ_RADIUS) * rsqrt_fast(dot(V, V)), pc);
         const V3 shift = ne - e;
         r.pos = r.pos + shift;
         e = ne;
