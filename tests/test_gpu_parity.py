@@ -985,3 +985,60 @@ def test_custom_urdf_control_golden(golden_dir, torch_mod):
     np.testing.assert_array_equal(res["reachable"], F.T)
     np.testing.assert_array_equal(res["state"], S.T)
     assert np.max(np.abs(res["joints"] - np.swapaxes(J, 0, 1))) < 1e-7
+
+
+def test_interval_closed_form_hands_over_at_decision_boundaries(torch_mod, orc):
+    """reach: the theta interval comes from a closed form ([phi - alpha, phi + alpha]) except where rounding decides the
+    outcome, which is left to the reference's own arithmetic (tangency |R'^2 - D'^2| < 1e-8, near-parallel planes, ...).
+    Poses are walked across the reachable / "limited by wrist" boundary (found by bisection on the checker, to the last
+    bit of the pitch angle) at offsets from 1e-2 down to 1e-13 rad on both sides: flags must stay bit-exact and the
+    interval within tolerance through the hand-over between the two code paths.  (Within ~1e-15 rad of the boundary —
+    a few ulps of the angle — the outcome is decided by the last bit of sin / cos of the input angle itself, where the
+    kernels' sincos, within 3e-16 of libm, is not bit-identical to NumPy's: 60 of 160 such poses differ, with the old
+    code path as with the new one; that is outside what "bit-exact flags" can mean for a different sincos.)"""
+    solver, r, l = make_symbolic(0.03)
+    ar, al = orc.Arm("r_arm", 0.03), orc.Arm("l_arm", 0.03)
+    rng = np.random.default_rng(77)
+    base_pos, base_eul, lo_hi = [], [], []
+    # pairs (reachable pose, limited-by-wrist pose) that differ in the pitch angle only
+    while len(base_pos) < 40:
+        pos = np.array([0.0, -0.2, 0.0]) + rng.uniform(-0.5, 0.5, 3)
+        eul = rng.uniform(-np.pi, np.pi, 3)
+        pitches = np.linspace(-np.pi, np.pi, 181)
+        P = np.tile(pos, (len(pitches), 1))
+        E = np.tile(eul, (len(pitches), 1))
+        E[:, 1] = pitches
+        st = orc.solve_batch(ar, al, P, E, theta_policy=3)["state"]
+        idx = [k for k in range(len(pitches) - 1) if {int(st[k]), int(st[k + 1])} == {0, 4}]
+        if idx:
+            k = idx[0]
+            base_pos.append(pos); base_eul.append(eul); lo_hi.append((pitches[k], pitches[k + 1], int(st[k])))
+    P, E = [], []
+    for pos, eul, (a, b, sa) in zip(base_pos, base_eul, lo_hi):
+        for _ in range(60):  # bisection on the checker: the boundary pitch to the last bit
+            m = 0.5 * (a + b)
+            e = eul.copy(); e[1] = m
+            s = int(orc.solve_batch(ar, al, pos[None], e[None], theta_policy=3)["state"][0])
+            if s == sa:
+                a = m
+            else:
+                b = m
+        for off in 10.0 ** -np.arange(2, 14):
+            for sgn in (-1.0, 1.0):
+                e = eul.copy(); e[1] = a + sgn * off
+                P.append(pos); E.append(e)
+                e2 = eul.copy(); e2[1] = b + sgn * off
+                P.append(pos); E.append(e2)
+    P, E = np.array(P), np.array(E)
+    res = to_np(r.solve_batch(soa(P, E, torch_mod)))
+    ref = orc.solve_batch(ar, al, P, E)
+    np.testing.assert_array_equal(res["reachable"], ref["reachable"])
+    np.testing.assert_array_equal(res["state"], ref["state"])
+    assert set(np.unique(ref["state"])) >= {0, 4} and 0.2 < ref["reachable"].mean() < 0.8
+    m = ref["reachable"].astype(bool)
+    # next to tangency the interval ends are ill-conditioned (d angle ~ d disc / (2 sqrt(disc))): 1e-7 there, TOL elsewhere
+    width = np.abs(((ref["interval"][:, 1] - ref["interval"][:, 0] + np.pi) % (2 * np.pi)) - np.pi)
+    tight = m & (width < 1e-3)
+    assert np.max(np.abs(res["interval"][m & ~tight] - ref["interval"][m & ~tight])) < TOL
+    if tight.any():
+        assert np.max(np.abs(res["interval"][tight] - ref["interval"][tight])) < 1e-7
