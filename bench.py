@@ -493,10 +493,12 @@ def main():
                 peak = fp64_valu_calibration(local_rank)
                 ach = (n / 64) * t["valu_per_wave"] / (kernel_ms * 1e-3)
                 line["roofline"]["compute"] = {
-                    "bound": "fp64 VALU issue", "achieved": ach, "peak": peak, "unit": "wave-instr/s", "frac": ach / peak,
+                    "bound": "fp64 VALU issue under the power-managed clock", "achieved": ach, "unit": "wave-instr/s",
                     "valu_instr_per_wave": t["valu_per_wave"],
-                    "peak_source": "live rsik_debug_math op 6 (independent v_fma_f64) on this GPU: the sustained rate of pure fp64 "
-                                   "FMAs under the power-managed clock; a mix that contains cheaper instructions can exceed it",
+                    # not a hard ceiling: the rate the chip sustains on PURE fp64 FMAs (the most expensive instruction);
+                    # a kernel whose mix contains cheaper instructions (moves, compares, integer) can issue faster
+                    "fma_only_rate": peak, "ratio_to_fma_only_rate": ach / peak,
+                    "fma_only_rate_source": "live rsik_debug_math op 6 (independent v_fma_f64) on this GPU, right after the timed region",
                 }
         except (OSError, ValueError, KeyError):
             pass
