@@ -1,24 +1,31 @@
 #!/usr/bin/env python3
 """bench.py — IK solves/s of the MI355X-native analytic solve path.
 
-    python bench.py --gpus N --steps K --warmup W [--config 2|3]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W [--config 2|3|4|5]
+
+`--gpus N` with N > 1 starts the N ranks itself (one child process per GPU, RCCL rendezvous on 127.0.0.1) unless it is
+already running under torchrun (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`), in which
+case RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment.  The parent never touches the GPU.
 
 One "step" = one pass of the hot path over one resident batch:
-  config 2 (default, the configuration BASELINE.json's metric is quoted on): r_arm
-    SymbolicIK.is_reachable + theta_to_joints_func(theta = interval[0]) on 1 048 576 random REACHABLE poses per GPU
-    (SoA float64 in HBM), outputs joints [n,7], interval [n,2], reachable, state  -> 122 algorithmic B/pose.
+  config 2 (default at N = 1, the configuration BASELINE.json's metric is quoted on): r_arm SymbolicIK.is_reachable +
+    theta_to_joints_func(theta = interval[0]) on 1 048 576 random REACHABLE poses per GPU (SoA float64 in HBM), outputs
+    joints [n,7], interval [n,2], reachable, state -> 122 algorithmic B/pose.
   config 3: ControlIK discrete mode, 64-point elbow sweep, 262 144 wrist-reachable goal matrices per GPU -> 154 B/pose.
-With N > 1 every rank solves its own shard (weak scaling, no data-path collective: poses are independent).  The north
-star's RCCL all-gather is "only for the final joint array": it runs ONCE after the K timed steps, is timed on its own
-and reported as `final_all_gather_ms` / `one_batch_end_to_end_solves_per_s`; `--gather-every-step` puts it inside
-every step instead (then `value` is communication-bound: 56 B/pose to every GPU over xGMI).
+  config 4 (default at N > 1, BASELINE.json's multi-GPU configuration): r_arm + l_arm mixed batch (per-pose arm byte),
+    1 048 576 poses per GPU = 8 M poses at N = 8, each GPU solves its shard and the joint array (+ state byte) is
+    all-gathered over xGMI with RCCL INSIDE every step, stripe by stripe behind the kernel (`--chunks`), so `value` is
+    the end-to-end rate of "shard, solve, all-gather"; kernel-only, gather-only and end-to-end figures are all in the
+    line.  `--gather final` keeps the collective out of the K timed steps (one final all-gather, timed on its own).
+  config 5: ControlIK continuous mode, 4096 trajectories x 1000 control steps per pass.
 
-Prints ONE JSON line on rank 0 (see the repo prompt's bench contract) carrying `roofline` and `cpu_baseline`.
+Prints ONE JSON line on rank 0 (the repo prompt's bench contract) carrying `roofline` and `cpu_baseline`.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,31 +39,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+XGMI_LINK_GBS, XGMI_LINKS = 153.0, 7  # per-direction per-link rate and links per GPU (point-to-point mesh)
+NOMINAL_VALU_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 4  # 256 CUs x 4 SIMDs, one wave64 vector instruction per 4 cycles at 2.4 GHz
 BYTES_PER_POSE = {2: 48 + 56 + 16 + 1 + 1, 3: 96 + 56 + 1 + 1, 4: 49 + 56 + 16 + 1 + 1, 5: 96 + 58 + 2 * 88}
+GATHER_BYTES_PER_POSE = 56 + 1  # joints [7] f64 + state u8 (reachable == (state == 0) for rsik_solve)
 URDF = "config_files/reachy2_ik_minimal.urdf"
 SHOULDER_R = np.array([0.0, -0.2, 0.0])
-
-
-def fp64_valu_calibration(device, n=1 << 20, reps=5):
-    """Wave-instructions/s the GPU sustains on pure independent v_fma_f64 (rsik_debug_math op 6: 8 x 2048 per lane),
-    measured in the same process right after the timed region: the practical fp64 VALU issue peak under the
-    power-managed clock."""
-    import torch
-
-    from reachy2_symbolic_ik_amd.backend import HipSolver
-
-    hs = HipSolver(device)
-    a = torch.rand(n, dtype=torch.float64, device=f"cuda:{device}")
-    b = torch.full((n,), 0.999, dtype=torch.float64, device=f"cuda:{device}")
-    hs.debug_math(6, a, b)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        hs.debug_math(6, a, b)
-    e1.record()
-    torch.cuda.synchronize()
-    return (n / 64) * 8 * 2048 * reps / (e0.elapsed_time(e1) * 1e-3)
+PROFILE_COUNTERS = os.path.join(ROOT, "profiles", "r02", "counters.json")
 
 
 def _quiet(fn, *a, **k):
@@ -67,6 +56,7 @@ def _quiet(fn, *a, **k):
         return fn(*a, **k)
 
 
+# ------------------------------------------------------------------------------------------ synthetic workloads
 def make_config2_poses(n, seed=20250204, device=0):
     """pos = s_r + U(-0.7,0.7)^3, eul = U(-pi,pi)^3, keep the first n whose is_reachable state
     is "reachable".  The filter is the product's own HIP kernel (theta policy "none")."""
@@ -87,6 +77,17 @@ def make_config2_poses(n, seed=20250204, device=0):
         E.append(eul[ok])
         have += int(ok.sum())
     return np.concatenate(P)[:n].copy(), np.concatenate(E)[:n].copy()
+
+
+def make_config4_poses(n, seed=20250204, device=0):
+    """the config-2 generator, arm id per pose 50/50, l poses = mirror images of r poses
+    (pose_l = (x, -y, z; -roll, pitch, -yaw), the G5 rule), so both arms have equal reachability."""
+    pos, eul = make_config2_poses(n, seed=seed, device=device)
+    arm_id = (np.random.default_rng(seed + 99).uniform(size=n) < 0.5).astype(np.uint8)
+    sgn = np.where(arm_id == 1, -1.0, 1.0)
+    pos = pos * np.stack([np.ones(n), sgn, np.ones(n)], axis=1)
+    eul = eul * np.stack([sgn, np.ones(n), sgn], axis=1)
+    return pos, eul, arm_id
 
 
 def make_config3_matrices(n, seed=20250204, device=0):
@@ -143,9 +144,14 @@ def make_config5_trajectories(n_traj, n_steps, seed=20250204, device=0):
     return torch.stack(rows, dim=1).contiguous()
 
 
-def cpu_baseline(config, inputs, seconds):
-    """Times the CPU checker (oracle/, a C restatement of the reference path = kind "port") on the host cores,
-    on a bounded sample of the SAME workload.  Reported baseline, not the target."""
+# ------------------------------------------------------------------------------------------ CPU baseline leg (+ parity check)
+def cpu_baseline(config, sample, seconds, gpu=None):
+    """Times the CPU checker (oracle/, a C restatement of the reference path = kind "port") on the host cores, on a
+    bounded sample of the SAME workload: once as the portable build that travels with the repo (gcc -O2, baseline
+    x86-64) and once rebuilt on this host with gcc -O3 -march=native (bit-identical results, FP contraction off in
+    both).  Reported baseline, not the target.  `gpu` = the GPU's outputs for the rows of `sample`: since the checker's
+    results are at hand they are compared (flags exact, joints <= 1e-6 rad) — with N > 1 the sample rows come from EVERY
+    rank's part of the all-gathered arrays."""
     from oracle import oracle as orc
 
     try:
@@ -154,26 +160,25 @@ def cpu_baseline(config, inputs, seconds):
         avail = os.cpu_count() or 1
     avail = max(1, min(avail, orc.lib().orc_max_threads()))
     if config in (2, 4):
-        pos, eul = inputs[0], inputs[1]
-        m = min(len(pos), 1 << 18)
-        pos, eul = np.ascontiguousarray(pos[:m]), np.ascontiguousarray(eul[:m])
-        arm_id = None if config == 2 else np.ascontiguousarray(inputs[2][:m])
+        pos, eul = np.ascontiguousarray(sample["pos"]), np.ascontiguousarray(sample["eul"])
+        m = len(pos)
+        arm_id = None if sample.get("arm") is None else np.ascontiguousarray(sample["arm"])
         ar, al = orc.Arm("r_arm", 0.03), orc.Arm("l_arm", 0.03)
-        run = lambda nt: orc.solve_batch(ar, al, pos, eul, arm_id=arm_id, nthreads=nt)  # noqa: E731
-    elif config == 5:
-        return None  # the checker's continuous step is a per-trajectory state machine driven from Python: not timed
-    else:
-        M = np.ascontiguousarray(inputs[: min(len(inputs), 1 << 17)])
+        run = lambda nt, L=None: orc.solve_batch(ar, al, pos, eul, arm_id=arm_id, nthreads=nt, L=L)  # noqa: E731
+    elif config == 3:
+        M = np.ascontiguousarray(sample["M"])
         m = len(M)
         ar, al = orc.Arm("r_arm", -1.01), orc.Arm("l_arm", -1.01)
-        run = lambda nt: orc.control_discrete_batch(ar, al, M, nb_search_points=64, nthreads=nt)  # noqa: E731
+        run = lambda nt, L=None: orc.control_discrete_batch(ar, al, M, nb_search_points=64, nthreads=nt, L=L)  # noqa: E731
+    else:
+        return None  # config 5: the checker's continuous step is a per-trajectory state machine driven from Python: not timed
 
-    def rate(nt, budget):
-        run(nt)
+    def rate(nt, budget, L=None):
+        run(nt, L)
         t0 = time.perf_counter()
         passes = 0
         while True:
-            run(nt)
+            run(nt, L)
             passes += 1
             el = time.perf_counter() - t0
             if el >= budget or passes >= 2000:
@@ -182,54 +187,240 @@ def cpu_baseline(config, inputs, seconds):
     # the host may expose more logical CPUs than the container's CPU quota: probe a few thread counts briefly,
     # then spend the remaining budget on the best one
     cands = sorted({c for c in (1, 8, 16, 32, 64, 128, avail) if c <= avail})
-    probe = {c: rate(c, 0.7)[0] for c in cands}
+    probe = {c: rate(c, 0.5)[0] for c in cands}
     best = max(probe, key=probe.get)
-    value, passes, el = rate(best, max(1.0, seconds - 0.7 * len(cands)))
-    return {
-        "value": value,
-        "unit": "solves/s",
-        "cores": best,
-        "kind": "port",
-        "single_thread": probe[1],
-        "sample": f"first {m} poses of the workload x {passes} passes ({el:.1f} s) with OpenMP {best} threads "
-                  f"(best of {cands}; 1 thread: {probe[1]:.0f} solves/s); C restatement built gcc -O2 -ffp-contract=off",
+    left = max(2.0, seconds - 0.5 * len(cands))
+    value, passes, el = rate(best, left / 2)
+    base = {
+        "value": value, "unit": "solves/s", "cores": best, "kind": "port", "single_thread": probe[1],
+        "portable_build": {"value": value, "flags": "gcc -O2 -ffp-contract=off (built in the build container, travels with the repo)",
+                           "single_thread": probe[1]},
+        "sample": f"{m} poses of the workload x {passes} passes ({el:.1f} s) with OpenMP {best} threads "
+                  f"(best of {cands}; 1 thread: {probe[1]:.0f} solves/s)",
     }
+    try:
+        Ln = orc.native_lib()
+        nat1 = rate(1, 0.5, Ln)[0]
+        natv, npass, nel = rate(best, left / 2, Ln)
+        base["native_build"] = {"value": natv, "flags": "gcc -O3 -march=native -ffp-contract=off (built on this host)",
+                                "single_thread": nat1, "passes": npass, "seconds": nel}
+        if natv > value:
+            base["value"], base["single_thread"] = natv, nat1
+            base["sample"] += f"; value = the native build ({natv:.0f} solves/s; portable build {value:.0f})"
+    except Exception as e:  # no gcc on the box: the portable figure stands
+        base["native_build"] = {"error": f"{type(e).__name__}: {e}"}
+    if gpu is not None:
+        ref = run(best)
+        np.testing.assert_array_equal(gpu["state"], ref["state"], err_msg="GPU state codes differ from the checker")
+        ok = ref["reachable"].astype(bool)
+        if "reachable" in gpu:
+            np.testing.assert_array_equal(gpu["reachable"], ref["reachable"], err_msg="GPU flags differ from the checker")
+        err = float(np.max(np.abs(gpu["joints"][ok] - ref["joints"][ok]), initial=0.0))
+        assert err < 1e-6, f"GPU joints differ from the checker by {err} rad"
+        base["parity_on_sample"] = {"rows": int(m), "reachable_rows": int(ok.sum()), "flags_and_states": "bit-exact",
+                                    "max_abs_joint_error_rad": err}
+    return base
 
 
-def main():
+# ------------------------------------------------------------------------------------------ measurement helpers
+def fp64_valu_calibration(hs, n=1 << 20, reps=5):
+    """Wave-instructions/s the GPU sustains on pure independent v_fma_f64 (rsik_debug_math op 6: 8 x 2048 per lane),
+    measured in the same process right after the timed region: an fp64 reference rate under the power-managed clock."""
+    import torch
+
+    a = torch.rand(n, dtype=torch.float64, device=hs.device)
+    b = torch.full((n,), 0.999, dtype=torch.float64, device=hs.device)
+    hs.debug_math(6, a, b)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        hs.debug_math(6, a, b)
+    e1.record()
+    torch.cuda.synchronize()
+    return (n / 64) * 8 * 2048 * reps / (e0.elapsed_time(e1) * 1e-3)
+
+
+def clock_ghz(core, real):
+    c, r = core.cpu().numpy(), real.cpu().numpy()
+    ok = r > 0
+    return float(np.median(c[ok] / r[ok]) * 0.1) if ok.any() else None
+
+
+def sustained_phase(hs, launch_all, load_seconds, monitor_seconds):
+    """Replays the step back to back for `load_seconds`, then keeps replaying while a clock monitor (rsik_debug_math
+    op 8, one wave per workgroup on a side stream) samples the shader clock for `monitor_seconds`.  Returns the clock the
+    chip HOLDS under this kernel's load and the step time measured in that window."""
+    import torch
+
+    side = torch.cuda.Stream(device=hs.device)
+    t_end = time.perf_counter() + load_seconds
+    while time.perf_counter() < t_end:
+        for _ in range(128):
+            launch_all()
+    core, real = hs.clock_monitor(monitor_seconds, 64, side)
+    done = torch.cuda.Event()
+    done.record(side)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    count = 0
+    while not done.query() and count < 4_000_000:
+        for _ in range(128):
+            launch_all()
+        count += 128
+    e1.record()
+    torch.cuda.synchronize()
+    return clock_ghz(core, real), e0.elapsed_time(e1) / max(count, 1)
+
+
+def first_launches_clock(hs, launch_all, k):
+    """Shader clock over the first k back-to-back steps after an idle gap (what a short timed region sees)."""
+    import torch
+
+    side = torch.cuda.Stream(device=hs.device)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(k):
+        launch_all()
+    e1.record()
+    e1.synchronize()
+    est = e0.elapsed_time(e1) * 1e-3
+    time.sleep(0.2)  # idle, like the barrier + synchronize in front of a timed region
+    core, real = hs.clock_monitor(est * 0.8, 16, side)
+    for _ in range(k):
+        launch_all()
+    torch.cuda.synchronize()
+    return clock_ghz(core, real)
+
+
+def committed_counters(cfg, n, build_id):
+    """rocprofv3 PMC results committed under profiles/ (HBM bytes per launch, executed vector instructions per wave).
+    Only used when they were collected with THIS build of the library and this workload size."""
+    try:
+        with open(PROFILE_COUNTERS) as fh:
+            doc = json.load(fh)
+        t = doc.get(str(cfg))
+        if t and t["poses_per_gpu"] == n and doc.get("build_id") == build_id:
+            return t
+        return {"stale": f"profiles/r02/counters.json was collected with another build or size (library {build_id})"}
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+# ------------------------------------------------------------------------------------------ launcher (N > 1 without torchrun)
+def launch_ranks(n_ranks, argv):
+    """Starts one child process per GPU and waits for them.  The parent has not imported torch nor touched the GPU (a
+    process that has initialised HIP must never be replaced or forked into GPU work on this platform)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc, alive = 0, set(range(n_ranks))
+    try:
+        while alive:
+            for r in sorted(alive):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                alive.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    print(f"bench.py: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr)
+                    for q in alive:
+                        procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:  # exactly the processes started above
+            if p.poll() is None:
+                p.terminate()
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+    return rc
+
+
+def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=0, help="timed steps (default 1000; config 5: 20)")
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (default 1000; config 5 and N > 1: 20)")
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5])
+    ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5], help="default: 2 at N = 1, 4 at N > 1")
     ap.add_argument("--poses", type=int, default=0, help="poses per GPU (default: the BASELINE size)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-valu-calibration", action="store_true")
-    ap.add_argument("--gather-every-step", action="store_true",
-                    help="N > 1: all-gather the joint array inside every timed step instead of once at the end")
+    ap.add_argument("--no-extras", action="store_true", help="skip the cold-HBM, sustained-clock and calibration phases (A/B timing)")
+    ap.add_argument("--gather", choices=["step", "final", "none"], default="step",
+                    help="N > 1: all-gather joints + state inside every timed step (default), once after them, or never")
+    ap.add_argument("--gather-every-step", action="store_true", help="same as --gather step")
+    ap.add_argument("--chunks", type=int, default=4,
+                    help="N > 1 with --gather step: stripes per shard; stripe c's all-gather travels while stripe c + 1 is solved")
     ap.add_argument("--launch", choices=["auto", "eager", "graph"], default="auto",
-                    help="how the K timed steps are issued: K pre-bound launches from Python (eager) or one replay of a "
-                         "hipGraph holding the K launches (graph).  auto = graph from 100 steps on: the replay has a fixed "
-                         "start-up cost (46 vs 41 us per step at K = 50) but removes the gaps between launches and the "
-                         "dependence on the host's launch rate (37.7 vs 39.8 us at K = 1000)")
+                    help="N = 1: K pre-bound launches from Python (eager) or one replay of a hipGraph holding the K launches; "
+                         "auto = graph from 100 steps on (the replay has a fixed start-up cost but removes the launch gaps)")
     ap.add_argument("--graph", action="store_true", help="same as --launch graph")
-    args = ap.parse_args()
-    if not args.steps:
-        args.steps = 20 if args.config == 5 else 1000
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--single-device", action="store_true", help="every rank uses GPU 0 (with --backend gloo: rehearsal on a 1-GPU box)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="ranks only meet, all-reduce their rank numbers on the CPU and print the line's skeleton (launcher self-test, no GPU)")
+    ap.add_argument("--lib", default="", help="alternative build of librsik_hip.so (A/B timing, probe builds)")
+    args = ap.parse_args(argv)
     if args.graph:
         args.launch = "graph"
-    use_graph = args.launch == "graph" or (args.launch == "auto" and args.steps >= 100)
+    if args.gather_every_step:
+        args.gather = "step"
+    return args
+
+
+def rendezvous_only(args, world, rank):
+    import torch
+    import torch.distributed as dist
+
+    dist.init_process_group(backend="gloo")
+    t = torch.tensor([float(rank)], dtype=torch.float64)
+    dist.all_reduce(t)
+    assert float(t[0]) == world * (world - 1) / 2
+    if rank == 0:
+        print(json.dumps({"metric": "launcher self-test", "n_gpus": world, "rank_sum": float(t[0]), "gpus_flag": args.gpus}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------ one rank
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    in_group = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if not in_group and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, argv))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                         f"(or without torchrun: bench.py starts the ranks itself)")
+    if args.rendezvous_only:
+        return rendezvous_only(args, world, rank)
+
+    cfg = args.config or (4 if world > 1 else 2)
+    if not args.steps:
+        args.steps = 20 if (cfg == 5 or world > 1) else 1000
+    if args.lib:
+        from reachy2_symbolic_ik_amd import _abi
+
+        _abi.use_library(args.lib)
 
     import torch
 
     from reachy2_symbolic_ik_amd import ControlIK, SymbolicIK
+    from reachy2_symbolic_ik_amd.distributed import ShardedBuffers, ShardPlan, gather_stripe
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if os.environ.get("RSIK_BENCH_SINGLE_DEVICE"):
-        local_rank = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -238,128 +429,157 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        # RSIK_BENCH_BACKEND=gloo + RSIK_BENCH_SINGLE_DEVICE=1: exercise the multi-process path on a 1-GPU box (tests only)
-        backend = os.environ.get("RSIK_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
+        if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
-            dist.init_process_group(backend=backend)
-    n_gpus = world
-    cfg = args.config
+            dist.init_process_group(backend=args.backend)
     n = args.poses or {2: 1 << 20, 3: 1 << 18, 4: 1 << 20, 5: 4096}[cfg]
+    gather_mode = args.gather if (world > 1 and cfg != 5) else "none"
+    chunks = max(1, args.chunks) if gather_mode == "step" else 1
+    if n % chunks:
+        raise SystemExit(f"--poses {n} must be a multiple of --chunks {chunks}")
+    rpp = n // chunks  # rows per piece
+    plan = ShardPlan(world * n, world, chunks)
+    assert plan.rows_per_piece == rpp
+    f64, u8 = torch.float64, torch.uint8
 
-    # ---- synthetic inputs, resident in HBM before the timed region
-    if cfg == 2:
-        base_n = min(n, 1 << 20)
-        pos, eul = make_config2_poses(base_n, seed=20250204 + rank, device=local_rank)
-        if n > base_n:  # size sweeps beyond the BASELINE size reuse the same reachable poses (timing only)
-            reps = (n + base_n - 1) // base_n
-            pos, eul = np.tile(pos, (reps, 1))[:n], np.tile(eul, (reps, 1))[:n]
-        inputs = (pos, eul)
-        ik = _quiet(SymbolicIK, "r_arm", device=local_rank)
-        soa = torch.as_tensor(np.ascontiguousarray(np.concatenate([pos.T, eul.T], axis=0))).to(dev)
-        assert soa.is_contiguous()
-        out = {
-            "joints": torch.empty((n, 7), dtype=torch.float64, device=dev),
-            "interval": torch.empty((n, 2), dtype=torch.float64, device=dev),
-            "reachable": torch.empty((n,), dtype=torch.uint8, device=dev),
-            "state": torch.empty((n,), dtype=torch.uint8, device=dev),
-        }
-        plan = ik.solve_batch(soa, want_elbow=False, out=out, plan_only=True)
-        step_kernel = plan["launch"]  # one rsik_solve call with pre-bound arguments
-        workload = f"config2: r_arm is_reachable + theta_to_joints_func(interval[0]), {n} random reachable poses per GPU"
-        kernel_name = "solve_kernel"
-    elif cfg == 4:
-        from reachy2_symbolic_ik_amd import DualArmIK
+    def local_to_global(i):  # row i of this rank's shard -> row of the all-gathered array (block-cyclic over stripes)
+        return (i // rpp) * plan.stripe_rows + rank * rpp + (i % rpp)
 
-        pos, eul = make_config2_poses(n, seed=20250204 + rank, device=local_rank)
-        arm_id = (np.random.default_rng(99 + rank).uniform(size=n) < 0.5).astype(np.uint8)
-        sgn = np.where(arm_id == 1, -1.0, 1.0)
-        pos = pos * np.stack([np.ones(n), sgn, np.ones(n)], axis=1)      # l poses = mirror of r poses (G5 rule)
-        eul = eul * np.stack([sgn, np.ones(n), sgn], axis=1)
-        inputs = (pos, eul, arm_id)
-        dual = _quiet(DualArmIK, device=local_rank)
+    # ---- synthetic inputs, resident in HBM before the timed region; outputs; one pre-bound launch per stripe
+    gathered_names = ("joints", "state")
+    bufs = None
+    sample_local = {}
+    hs = None
+    if cfg in (2, 4):
+        if cfg == 2:
+            base_n = min(n, 1 << 20)
+            pos, eul = make_config2_poses(base_n, seed=20250204 + rank, device=local_rank)
+            if n > base_n:  # size sweeps beyond the BASELINE size reuse the same reachable poses (timing only)
+                reps = (n + base_n - 1) // base_n
+                pos, eul = np.tile(pos, (reps, 1))[:n], np.tile(eul, (reps, 1))[:n]
+            arm_id = None
+            solver_obj = _quiet(SymbolicIK, "r_arm", device=local_rank)
+            hs = solver_obj.solver
+            workload = f"config2: r_arm is_reachable + theta_to_joints_func(interval[0]), {n} random reachable poses per GPU"
+            kernel_name = "solve_kernel"
+        else:
+            from reachy2_symbolic_ik_amd import DualArmIK
+
+            pos, eul, arm_id = make_config4_poses(n, seed=20250204 + rank, device=local_rank)
+            solver_obj = _quiet(DualArmIK, device=local_rank)
+            hs = solver_obj.solver
+            workload = f"config4: r_arm + l_arm mixed (per-pose arm byte), {n} reachable poses per GPU, theta = interval[0]"
+            kernel_name = "solve_kernel<mixed>"
         soa = torch.as_tensor(np.ascontiguousarray(np.concatenate([pos.T, eul.T], axis=0))).to(dev)
-        arm_t = torch.as_tensor(arm_id).to(dev)
-        out = {
-            "joints": torch.empty((n, 7), dtype=torch.float64, device=dev),
-            "interval": torch.empty((n, 2), dtype=torch.float64, device=dev),
-            "reachable": torch.empty((n,), dtype=torch.uint8, device=dev),
-            "state": torch.empty((n,), dtype=torch.uint8, device=dev),
-        }
-        plan = dual.solve_batch(arm_t, soa, want_elbow=False, out=out, plan_only=True)
-        step_kernel = plan["launch"]
-        workload = f"config4: r_arm + l_arm mixed (per-pose arm byte), {n} reachable poses per GPU, theta = interval[0]"
-        kernel_name = "solve_kernel<mixed>"
-    elif cfg == 5:
-        n_steps = 1000
-        n_traj = n
-        traj = make_config5_trajectories(n_traj, n_steps, seed=20250204 + rank, device=local_rank)
-        inputs = None
+        arm_t = None if arm_id is None else torch.as_tensor(arm_id).to(dev)
+        sample_local = {"pos": pos, "eul": eul, "arm": arm_id}
+
+        def make_set(soa_t, arm_tt, shared=None):
+            """Output buffers + one pre-bound rsik_solve launch per stripe for one resident copy of the inputs."""
+            if world > 1:
+                sb = shared or ShardedBuffers(plan, rank, {"joints": ((7,), f64), "state": ((), u8)}, dev)
+                o = {"interval": torch.empty((n, 2), dtype=f64, device=dev), "reachable": torch.empty((n,), dtype=u8, device=dev)}
+            else:
+                sb = None
+                o = {"joints": torch.empty((n, 7), dtype=f64, device=dev), "interval": torch.empty((n, 2), dtype=f64, device=dev),
+                     "reachable": torch.empty((n,), dtype=u8, device=dev), "state": torch.empty((n,), dtype=u8, device=dev)}
+            launches, keep = [], []
+            for c in range(chunks):
+                a, b = c * rpp, (c + 1) * rpp
+                if sb is not None:
+                    pv = sb.piece_views(c)
+                    po = {"joints": pv["joints"], "state": pv["state"], "interval": o["interval"][a:b], "reachable": o["reachable"][a:b]}
+                else:
+                    po = {k: v[a:b] for k, v in o.items()}
+                if arm_tt is None:
+                    p = solver_obj.solve_batch(soa_t[:, a:b], want_elbow=False, out=po, plan_only=True)
+                else:
+                    p = solver_obj.solve_batch(arm_tt[a:b], soa_t[:, a:b], want_elbow=False, out=po, plan_only=True)
+                launches.append(p["launch"])
+                keep.append(p)
+            return {"out": o, "bufs": sb, "launches": launches, "keep": keep, "inputs": (soa_t, arm_tt)}
+
+        main_set = make_set(soa, arm_t)
+        out, bufs, launches = main_set["out"], main_set["bufs"], main_set["launches"]
+        units = n
+    elif cfg == 3:
+        from reachy2_symbolic_ik_amd.control_ik import matrices_to_m12_soa
+
+        M = make_config3_matrices(n, seed=20250204 + rank, device=local_rank)
+        sample_local = {"M": M}
         ctrl = _quiet(ControlIK, urdf_path=URDF, device=local_rank)
+        ctrl.nb_search_points = 64
+        hs = ctrl._solver
+        m12 = matrices_to_m12_soa(M, dev)
+
+        def make_set(m12_t, _unused=None, shared=None):
+            if world > 1:
+                sb = shared or ShardedBuffers(plan, rank, {"joints": ((7,), f64), "state": ((), u8)}, dev)
+                o = {"reachable": torch.empty((n,), dtype=u8, device=dev), "emergency": torch.empty((n,), dtype=u8, device=dev)}
+            else:
+                sb = None
+                o = {"joints": torch.empty((n, 7), dtype=f64, device=dev), "reachable": torch.empty((n,), dtype=u8, device=dev),
+                     "state": torch.empty((n,), dtype=u8, device=dev), "emergency": torch.empty((n,), dtype=u8, device=dev)}
+            launches, keep = [], []
+            for c in range(chunks):
+                a, b = c * rpp, (c + 1) * rpp
+                if sb is not None:
+                    pv = sb.piece_views(c)
+                    po = {"joints": pv["joints"], "state": pv["state"], "reachable": o["reachable"][a:b], "emergency": o["emergency"][a:b]}
+                else:
+                    po = {k: v[a:b] for k, v in o.items()}
+                p = ctrl.symbolic_inverse_kinematics_batch("r_arm", m12_t[:, a:b], out=po, plan_only=True)
+                launches.append(p["launch"])
+                keep.append(p)
+            return {"out": o, "bufs": sb, "launches": launches, "keep": keep, "inputs": (m12_t, None)}
+
+        main_set = make_set(m12)
+        out, bufs, launches = main_set["out"], main_set["bufs"], main_set["launches"]
+        workload = f"config3: r_arm ControlIK discrete, 64-point theta sweep, {n} wrist-reachable goal matrices per GPU"
+        kernel_name = "control_discrete_kernel"
+        units = n
+    else:
+        n_steps, n_traj = 1000, n
+        traj = make_config5_trajectories(n_traj, n_steps, seed=20250204 + rank, device=local_rank)
+        ctrl = _quiet(ControlIK, urdf_path=URDF, device=local_rank)
+        hs = ctrl._solver
         cont = ctrl.new_continuous_state("r_arm", n_traj)
         cont0 = cont.clone()
-        out = {
-            "joints": torch.empty((n_traj, 7), dtype=torch.float64, device=dev),
-            "reachable": torch.empty((n_traj,), dtype=torch.uint8, device=dev),
-            "state": torch.empty((n_traj,), dtype=torch.uint8, device=dev),
-        }
-        first = torch.ones((n_traj,), dtype=torch.uint8, device=dev)
-        none = torch.zeros((n_traj,), dtype=torch.uint8, device=dev)
+        out = {"joints": torch.empty((n_steps, n_traj, 7), dtype=f64, device=dev),
+               "reachable": torch.empty((n_steps, n_traj), dtype=u8, device=dev),
+               "state": torch.empty((n_steps, n_traj), dtype=u8, device=dev)}
 
-        out = {
-            "joints": torch.empty((n_steps, n_traj, 7), dtype=torch.float64, device=dev),
-            "reachable": torch.empty((n_steps, n_traj), dtype=torch.uint8, device=dev),
-            "state": torch.empty((n_steps, n_traj), dtype=torch.uint8, device=dev),
-        }
-
-        def step_kernel():  # one "step" of the bench = one 1000-step pass over all trajectories (one launch: the kernel walks the steps)
+        def one_pass(stream=None):  # one bench "step" = one 1000-step pass over all trajectories
             cont.copy_(cont0)
             ctrl.run_continuous_trajectories("r_arm", traj, cont, first_step_timed_out=True, current_pose=traj[0], out=out)
 
+        launches = [one_pass]
         workload = (f"config5: ControlIK continuous, {n_traj} trajectories x {n_steps} steps per pass, trajectory state carried "
-                    "in registers across the steps of a pass and in HBM across passes / launches")
+                    "on chip across the steps of a pass and in HBM across passes / launches")
         kernel_name = "control_continuous_kernel"
-        n = n * n_steps  # units per bench step = trajectory-steps
-    else:
-        M = make_config3_matrices(n, seed=20250204 + rank, device=local_rank)
-        inputs = M
-        ctrl = _quiet(ControlIK, urdf_path=URDF, device=local_rank)
-        ctrl.nb_search_points = 64
-        from reachy2_symbolic_ik_amd.control_ik import matrices_to_m12_soa
+        units = n * n_steps  # trajectory-steps per bench step
 
-        m12 = matrices_to_m12_soa(M, dev)
-        out = {
-            "joints": torch.empty((n, 7), dtype=torch.float64, device=dev),
-            "reachable": torch.empty((n,), dtype=torch.uint8, device=dev),
-            "state": torch.empty((n,), dtype=torch.uint8, device=dev),
-            "emergency": torch.empty((n,), dtype=torch.uint8, device=dev),
-        }
-        plan = ctrl.symbolic_inverse_kinematics_batch("r_arm", m12, out=out, plan_only=True)
-        step_kernel = plan["launch"]  # one rsik_control_discrete call with pre-bound arguments
-        workload = f"config3: r_arm ControlIK discrete, 64-point theta sweep, {n} wrist-reachable goal matrices per GPU"
-        kernel_name = "control_discrete_kernel"
+    def launch_all(stream=None):
+        for f in launches:
+            f(stream)
 
-    gathered = None
-    if world > 1:
-        from reachy2_symbolic_ik_amd.distributed import all_gather_rows
-
-        rows = out["joints"].shape[0]
-        gathered = {
-            "joints": torch.empty((world * rows, 7), dtype=torch.float64, device=dev),
-            "reachable": torch.empty((world * rows,), dtype=torch.uint8, device=dev),
-        }
-
-    def gather():  # the final joint array (+ flags) is all-gathered over xGMI (RCCL)
-        all_gather_rows(out["joints"], world * out["joints"].shape[0], out=gathered["joints"])
-        all_gather_rows(out["reachable"], world * out["reachable"].shape[0], out=gathered["reachable"])
-
-    every_step = world > 1 and args.gather_every_step
+    def gather_all(async_op=True):
+        works = []
+        for c in range(chunks):
+            works += gather_stripe(bufs, c, gathered_names, async_op=async_op)
+        return works
 
     def step():
-        step_kernel()
-        if every_step:
-            gather()
+        if gather_mode == "step":
+            works = []
+            for c, f in enumerate(launches):
+                f()
+                works += gather_stripe(bufs, c, gathered_names, async_op=True)
+            for w in works:  # the compute stream waits for the collectives (the next step rewrites their buffers)
+                w.wait()
+        else:
+            launch_all()
 
     def fence():
         torch.cuda.synchronize()
@@ -370,87 +590,130 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    # ---- timed region: exactly K steps; per-launch kernel time from events on the launch stream
-    # N = 1: K back-to-back pre-bound launches (or, with --graph, one replay of a captured hipGraph) bracketed by ONE
-    # event pair: kernel time = elapsed / K, including the ~1.5 us kernel boundaries;
-    # N > 1: one event pair per launch so the all-gather is excluded from the kernel time.
-    per_launch = every_step
+
+    # ---- timed region: exactly K steps, bracketed by barrier + synchronize on both sides
+    use_graph = world == 1 and cfg != 5 and (args.launch == "graph" or (args.launch == "auto" and args.steps >= 100))
     graph = None
-    if not per_launch and use_graph and cfg != 5:
-        hs = {2: lambda: ik.solver, 3: lambda: ctrl._solver, 4: lambda: dual.solver}[cfg]()
+    if use_graph:
         try:
             graph = torch.cuda.CUDAGraph()
-            # thread-local capture mode: another thread of the process (the RCCL watchdog when N > 1) may touch the
-            # runtime while this thread records the K launches
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                hs._bind_stream()  # the pre-bound launches go to the capture stream
+                cs = torch.cuda.current_stream(dev).cuda_stream  # the pre-bound launches go to the capture stream
                 for _ in range(args.steps):
-                    step_kernel()
-            hs._bind_stream()
+                    launch_all(cs)
             graph.replay()  # untimed
             fence()
         except Exception as e:  # capture refused: time K eager launches instead (reported in "launch")
             print(f"bench.py: hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches", file=sys.stderr)
             graph = None
-            hs._bind_stream()
             torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps if per_launch else 1)]
-    ev_g = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps if per_launch else 0)]
-    for pair in ev + [(e,) for e in ev_g]:  # events are created lazily at their first record: not inside the timed region
-        for e in pair:
-            e.record()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); e1.record()  # events are created lazily at their first record: not inside the timed region
     fence()
     t0 = time.perf_counter()
-    if not per_launch:
-        ev[0][0].record()
+    e0.record()
     if graph is not None:
         graph.replay()  # exactly K launches of the hot path
     else:
-        for k in range(args.steps):
-            if per_launch:
-                ev[k][0].record()
-            step_kernel()
-            if per_launch:
-                ev[k][1].record()
-                gather()
-                ev_g[k].record()
-    if not per_launch:
-        ev[0][1].record()
+        for _ in range(args.steps):
+            step()
+    e1.record()
     fence()
     elapsed = time.perf_counter() - t0
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) / (1 if per_launch else args.steps)
-    gather_ms = float(np.mean([ev[k][1].elapsed_time(ev_g[k]) for k in range(len(ev_g))])) if ev_g else 0.0
-    if world > 1 and not every_step:  # the final joint array, gathered once (outside the K timed steps)
-        gather()  # warm-up of the communicator
-        fence()
-        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        g0.record()
-        gather()
-        g1.record()
-        fence()
-        gather_ms = g0.elapsed_time(g1)
-        assert torch.equal(gathered["joints"][rank * out["joints"].shape[0]:(rank + 1) * out["joints"].shape[0]], out["joints"])
-    if world > 1:
-        t = torch.tensor([elapsed, kernel_ms, gather_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms, gather_ms = float(t[0]), float(t[1]), float(t[2])
+    step_ms_events = e0.elapsed_time(e1) / args.steps
 
-    # sanity: the timed outputs are real results (flags all "reachable" for config 2)
-    n_ok = int(out["reachable"].sum().item())
+    # ---- kernel-only and gather-only legs (N > 1), each on its own: same buffers, same launches
+    kernel_ms, gather_ms, final_gather_ms = step_ms_events, 0.0, None
+    if world > 1:
+        k2 = max(5, min(args.steps, 50))
+        fence()
+        e0.record()
+        for _ in range(k2):
+            launch_all()
+        e1.record()
+        fence()
+        kernel_ms = e0.elapsed_time(e1) / k2
+        if gather_mode != "none":
+            for w in gather_all():
+                w.wait()
+            fence()
+            e0.record()
+            for _ in range(k2):
+                for w in gather_all():
+                    w.wait()
+            e1.record()
+            fence()
+            gather_ms = e0.elapsed_time(e1) / k2
+            if gather_mode == "final":
+                final_gather_ms = gather_ms
+            # every rank's rows must have arrived where the partition says: a checksum of checksums over the ranks
+            launch_all()
+            for w in gather_all():
+                w.wait()
+            torch.cuda.synchronize()
+            mine = torch.stack([bufs.piece_views(c)["joints"].view(torch.int64).sum() for c in range(chunks)]).sum().reshape(1)
+            sums = torch.empty((world,), dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(sums, mine)
+            for r in range(world):
+                got = sum(int(bufs.full["joints"][plan.piece(r, c)[0]: plan.piece(r, c)[1]].view(torch.int64).sum()) for c in range(chunks))
+                got = (got + (1 << 63)) % (1 << 64) - (1 << 63)
+                assert got == int(sums[r]), f"rank {rank}: rows gathered from rank {r} do not match what it solved"
+        t = torch.tensor([elapsed, kernel_ms, gather_ms, step_ms_events], dtype=f64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms, gather_ms, step_ms_events = (float(v) for v in t)
+
+    # sanity: the timed outputs are real results
     if cfg in (2, 4):
+        n_ok = int(out["reachable"].sum().item())
         assert n_ok == n, f"{n - n_ok} poses of the reachable workload came back unreachable"
-        assert bool(torch.isfinite(out["joints"]).all()), "non-finite joints"
+        jj = bufs.full["joints"] if bufs is not None else out["joints"]
+        assert bool(torch.isfinite(jj).all()), "non-finite joints"
+    if cfg == 5:  # every step of every trajectory produced joints; the reachable / fallback mix is the generator's
+        assert bool(torch.isfinite(out["joints"]).all()), "non-finite joints in the trajectory batch"
+        frac_ok = float(out["reachable"].to(torch.float32).mean().item())
+        assert 0.05 < frac_ok < 0.95, f"unexpected reachable fraction {frac_ok}"
+
+    # ---- the rows the CPU-baseline leg re-solves, and the GPU's results for them
+    sample, gpu_rows = None, None
+    if not args.no_cpu_baseline and cfg != 5:
+        m = min(n, 1 << 18 if cfg in (2, 4) else 1 << 17)
+        if world == 1:
+            sample = {k: (None if v is None else v[:m]) for k, v in sample_local.items()}
+            gpu_rows = {k: out[k][:m].cpu().numpy() for k in ("joints", "state", "reachable")}
+        elif gather_mode != "none":
+            # the inputs of every rank travel to rank 0 (untimed) so that the checked rows come from all parts of the
+            # gathered arrays: m / world consecutive rows of every rank's first stripe
+            per = max(1, min(m // world, rpp))
+            keys = [k for k, v in sample_local.items() if v is not None]
+            sample = {}
+            for k in keys:
+                loc = torch.as_tensor(np.ascontiguousarray(sample_local[k][:per])).to(dev)
+                full = torch.empty((world,) + tuple(loc.shape), dtype=loc.dtype, device=dev)
+                dist.all_gather_into_tensor(full, loc)
+                sample[k] = full.reshape((world * per,) + tuple(loc.shape[1:])).cpu().numpy()
+            if "arm" in sample_local and sample_local["arm"] is None:
+                sample["arm"] = None
+            rows = torch.as_tensor(np.concatenate([plan.piece(r, 0)[0] + np.arange(per) for r in range(world)])).to(dev)
+            gpu_rows = {k: bufs.full[k][rows].cpu().numpy() for k in gathered_names}
 
     if rank == 0:
-        total = n * n_gpus * args.steps
+        total = units * world * args.steps
         value = total / elapsed
         bpp = BYTES_PER_POSE[cfg]
-        achieved = bpp * n / (kernel_ms * 1e-3) / 1e9
+        achieved = bpp * units / (kernel_ms * 1e-3) / 1e9
+        collective = "none"
+        if world > 1:
+            collective = {"step": f"RCCL all-gather of joints [n,7] f64 + state u8 inside every step, {chunks} stripes per shard, "
+                                  "stripe c in flight while stripe c + 1 is solved",
+                          "final": "none in the timed steps; one final RCCL all-gather of joints [n,7] f64 + state u8 (timed separately)",
+                          "none": "none"}[gather_mode]
+            if args.backend != "nccl":
+                collective += f" [backend {args.backend}: rehearsal, not RCCL]"
         line = {
             "metric": "IK solves/sec (7-DoF r_arm, batched poses)",
             "value": value,
             "unit": "solves/s",
-            "n_gpus": n_gpus,
+            "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -460,10 +723,9 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "launch": "hipGraph replay of K captured launches" if graph is not None else "eager",
-            "config": {"workload": workload, "poses_per_gpu": n, "theta_policy": {2: "interval[0]", 3: "discrete sweep nb=64", 4: "interval[0]", 5: "continuous, d_theta_max=0.01"}[cfg],
-                       "collective": "none" if world == 1 else (
-                           "RCCL all-gather of joints [n,7] f64 + reachable u8 inside every step" if every_step else
-                           "none in the timed steps; one final RCCL all-gather of joints [n,7] f64 + reachable u8 (timed separately)")},
+            "config": {"workload": workload, "poses_per_gpu": n,
+                       "theta_policy": {2: "interval[0]", 3: "discrete sweep nb=64", 4: "interval[0]", 5: "continuous, d_theta_max=0.01"}[cfg],
+                       "collective": collective},
             "roofline": {
                 "bound": "hbm",
                 "kernel": kernel_name,
@@ -474,43 +736,100 @@ def main():
                 "traffic": None,
                 "algorithmic_bytes_per_pose": bpp,
                 "kernel_ms": kernel_ms,
-                "kernel_only_solves_per_s_per_gpu": n / (kernel_ms * 1e-3),
-                "final_all_gather_ms": gather_ms if world > 1 else None,
-                "gather_only_solves_per_s": (n * n_gpus / (gather_ms * 1e-3)) if (world > 1 and gather_ms > 0) else None,
-                "one_batch_end_to_end_solves_per_s": (n * n_gpus / ((kernel_ms + gather_ms) * 1e-3)) if world > 1 else None,
-                "note": "fp64 VALU-bound path (see DESIGN.md): HBM fraction is reported as the contract asks, VALU issue is the binding limit",
+                "kernel_timing": ("HIP events on the launch stream around the K timed steps (one pair)" if world == 1 else
+                                  "HIP events around a kernel-only replay of the same launches, no collective in flight"),
+                "kernel_only_solves_per_s_per_gpu": units / (kernel_ms * 1e-3),
+                "note": "fp64 VALU-bound path (DESIGN.md section 4): the HBM fraction is reported as the contract asks; `compute` holds the binding limit",
             },
         }
-        try:  # HBM traffic per launch as measured by the committed rocprofv3 PMC passes (same workload size only)
-            with open(os.path.join(ROOT, "profiles", "r01", "traffic.json")) as fh:
-                t = json.load(fh).get(str(cfg))
-            if t and t["poses_per_gpu"] == n:
-                line["roofline"]["traffic"] = t["bytes"]
-                line["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (profiles/r01/traffic.json)"
-            if t and t.get("valu_per_wave") and not args.no_valu_calibration:
-                # the binding limit: executed vector instructions per wave (PMC SQ_INSTS_VALU / SQ_WAVES, committed)
-                # x waves per launch / kernel time, against the pure-FMA issue rate measured live
-                peak = fp64_valu_calibration(local_rank)
-                ach = (n / 64) * t["valu_per_wave"] / (kernel_ms * 1e-3)
-                line["roofline"]["compute"] = {
-                    "bound": "fp64 VALU issue under the power-managed clock", "achieved": ach, "unit": "wave-instr/s",
-                    "valu_instr_per_wave": t["valu_per_wave"],
-                    # not a hard ceiling: the rate the chip sustains on PURE fp64 FMAs (the most expensive instruction);
-                    # a kernel whose mix contains cheaper instructions (moves, compares, integer) can issue faster
-                    "fma_only_rate": peak, "ratio_to_fma_only_rate": ach / peak,
-                    "fma_only_rate_source": "live rsik_debug_math op 6 (independent v_fma_f64) on this GPU, right after the timed region",
-                }
-        except (OSError, ValueError, KeyError):
-            pass
+        if world > 1:
+            recv = GATHER_BYTES_PER_POSE * n * (world - 1)
+            links = min(world - 1, XGMI_LINKS)
+            line["multi_gpu"] = {
+                "kernel_only_solves_per_s": units * world / (kernel_ms * 1e-3),
+                "gather_only_ms": gather_ms if gather_mode != "none" else None,
+                "gather_only_solves_per_s": (units * world / (gather_ms * 1e-3)) if gather_ms > 0 else None,
+                "end_to_end_ms_per_step": (elapsed / args.steps * 1e3) if gather_mode == "step" else (kernel_ms + (final_gather_ms or 0.0)),
+                "end_to_end_solves_per_s": value if gather_mode == "step" else units * world / ((kernel_ms + (final_gather_ms or 0.0)) * 1e-3),
+                "value_is": "end-to-end (solve + all-gather in every step)" if gather_mode == "step" else "kernel-only steps (no collective in the timed region)",
+                "gather_bytes_received_per_gpu": recv,
+                "xgmi": {"achieved": (recv / (gather_ms * 1e-3) / 1e9) if gather_ms > 0 else None, "unit": "GB/s received per GPU",
+                         "peak": links * XGMI_LINK_GBS, "links_usable": links,
+                         "frac": (recv / (gather_ms * 1e-3) / 1e9 / (links * XGMI_LINK_GBS)) if gather_ms > 0 else None},
+                "gathered_rows_checked": "checksum of every rank's rows against the solving rank's own checksum" if gather_mode != "none" else None,
+            }
         if cfg == 5:
             line["metric"] = "IK control steps/sec (ControlIK continuous, r_arm trajectories)"
             line["unit"] = "steps/s"
             line["roofline"]["kernel_ms"] = kernel_ms / 1000  # per control step (one launch walks the 1000 steps of a pass)
-            line["roofline"]["kernel_only_solves_per_s_per_gpu"] = n / (kernel_ms * 1e-3)
-        if not args.no_cpu_baseline:
-            base = cpu_baseline(cfg, inputs, args.cpu_seconds)
-            if base is not None:
-                line["cpu_baseline"] = base
+
+        # ---- what bounds the kernel: counters committed with this build, live clock, cold-HBM run
+        build_id = hs.build_id()
+        line["library_build"] = build_id
+        cnt = committed_counters(cfg, n, build_id)
+        if cnt and "bytes" in cnt:
+            line["roofline"]["traffic"] = cnt["bytes"]
+            line["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) / WRITE_SIZE of this build (profiles/r02/counters.json)"
+        elif cnt and "stale" in cnt:
+            line["roofline"]["traffic_note"] = cnt["stale"]
+        if not args.no_extras and world == 1 and cfg != 5:
+            extras = {}
+            # (a) cold HBM: rotate over distinct resident copies of the batch whose combined footprint exceeds the
+            # 256 MiB Infinity Cache, so that every launch's inputs and outputs really come from / go to HBM
+            footprint = bpp * n
+            sets_needed = max(3, int(np.ceil(320 * 2**20 / footprint)) + 1)
+            if sets_needed <= 64:
+                sets = [main_set] + [make_set(main_set["inputs"][0].clone(), None if main_set["inputs"][1] is None else main_set["inputs"][1].clone())
+                                     for _ in range(sets_needed - 1)]
+                for s in sets:
+                    for f in s["launches"]:
+                        f()
+                torch.cuda.synchronize()
+                kc = max(args.steps, 3 * sets_needed)
+                kc -= kc % sets_needed
+                e0.record()
+                for k in range(kc):
+                    for f in sets[k % sets_needed]["launches"]:
+                        f()
+                e1.record()
+                torch.cuda.synchronize()
+                cold_ms = e0.elapsed_time(e1) / kc
+                extras["cold"] = {"kernel_ms": cold_ms, "sets": sets_needed, "footprint_MB_total": sets_needed * footprint / 1e6, "launches": kc}
+                line["roofline"]["kernel_ms_cold"] = cold_ms
+                line["roofline"]["achieved_cold"] = bpp * n / (cold_ms * 1e-3) / 1e9
+                line["roofline"]["frac_cold"] = line["roofline"]["achieved_cold"] / HBM_PEAK_GBS
+                line["roofline"]["cold_note"] = (f"{sets_needed} distinct resident batches ({sets_needed * footprint / 2**20:.0f} MiB of inputs + outputs) "
+                                                 "solved round-robin: nothing a launch touches is still in the 256 MiB Infinity Cache")
+                del sets
+            # (b) the shader clock the chip holds under this kernel (s_memtime / s_memrealtime in a monitor wave on a side
+            # stream, no stamp in the product kernel), after >= 2 s of back-to-back launches, and over a short burst
+            try:
+                ghz_burst = first_launches_clock(hs, launch_all, max(8, min(args.steps, 64)))
+                ghz, sustained_ms = sustained_phase(hs, launch_all, 2.0, 0.5)
+                extras["clock"] = {"sustained_ghz": ghz, "sustained_kernel_ms": sustained_ms, "first_launches_ghz": ghz_burst,
+                                   "method": "rsik_debug_math op 8: d(s_memtime)/d(s_memrealtime) of 64 monitor waves on a side stream"}
+            except Exception as e:
+                extras["clock"] = {"error": f"{type(e).__name__}: {e}"}
+            # (c) vector-instruction issue: executed instructions per wave (PMC, committed with this build) x waves per
+            # launch / kernel time, against the NOMINAL issue peak (2.4 GHz) and against the clock just measured
+            if cnt and cnt.get("valu_per_wave"):
+                vpw = cnt["valu_per_wave"]
+                ach = (n / 64) * vpw / (kernel_ms * 1e-3)
+                comp = {"bound": "fp64 VALU issue", "valu_instr_per_wave": vpw, "achieved": ach, "unit": "wave-instr/s",
+                        "peak_nominal": NOMINAL_VALU_WAVE_INSTR_PER_S, "frac_nominal": ach / NOMINAL_VALU_WAVE_INSTR_PER_S}
+                ck = extras.get("clock", {})
+                if ck.get("sustained_ghz") and ck.get("sustained_kernel_ms"):
+                    ach_s = (n / 64) * vpw / (ck["sustained_kernel_ms"] * 1e-3)
+                    peak_s = 1024 * ck["sustained_ghz"] * 1e9 / 4
+                    comp["sustained"] = {"achieved": ach_s, "peak_at_measured_clock": peak_s, "frac_at_measured_clock": ach_s / peak_s}
+                if not args.no_valu_calibration:
+                    fma = fp64_valu_calibration(hs)
+                    comp["fma_only_rate"] = fma
+                    comp["ratio_to_fma_only_rate"] = ach / fma
+                line["roofline"]["compute"] = comp
+            line["extras"] = extras
+        if sample is not None:
+            line["cpu_baseline"] = cpu_baseline(cfg, sample, args.cpu_seconds, gpu=gpu_rows)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RSIK_ABI_VERSION 1
+#define RSIK_ABI_VERSION 2
 
 /* ---- status codes ---- */
 #define RSIK_OK 0
@@ -108,6 +108,9 @@ typedef struct rsik_ctx rsik_ctx;
 
 /* ---- lifecycle ---- */
 int rsik_abi_version(void);
+/* "RSIK_SRC_HASH=<32 hex digits>": hash of the sources and flags the library was built from (csrc/build.py), so a host
+ * can refuse a stale binary.  Not in the reference (pure Python, nothing to build). */
+const char *rsik_build_id(void);
 int rsik_arm_consts_count(void);
 /* Number of HIP devices visible; 0 when there is none (never fails). */
 int rsik_device_count(void);
@@ -135,7 +138,25 @@ int rsik_set_arm(rsik_ctx *ctx, int arm, const double *consts_host, int count);
 #define RSIK_EULER_ALWAYS 1
 #define RSIK_EULER_NEVER 2
 #define RSIK_OPT_EULER_ROUNDTRIP 0
-#define RSIK_OPT_COUNT 1
+/* Kernel-variant selectors.  Every value gives the same results (to rounding where a comment says so); the defaults
+ * (0) let the library choose.  They exist so that tests can force each variant in turn and A/B timings can pin one.
+ *   RSIK_OPT_SWEEP_MODE     rsik_control_discrete's grid search (utils.py:366-396): 0 = chosen per wave, 1 = always the
+ *                           exhaustive wave-cooperative sweep, 2 = always the per-lane search
+ *   RSIK_OPT_NO_TIPZ        non-zero: never use the goal stage specialised for tip_x = tip_y = 0
+ *   RSIK_OPT_NO_MIRROR      non-zero: mixed r/l launches read every constant per lane (no mirror-image shortcut)
+ *   RSIK_OPT_CONT_RUN_MODE  rsik_control_continuous_run: 0 = by batch size, 1 = always one launch walking all steps,
+ *                           2 = always one launch per step
+ *   RSIK_OPT_CONT_GROUP     rsik_control_continuous_*: 0 = by batch size, 1 = one trajectory per lane, 2 = one trajectory
+ *                           per 16-lane group (small batches: 16x more waves, grid points evaluated in parallel) */
+#define RSIK_OPT_SWEEP_MODE 1
+#define RSIK_OPT_NO_TIPZ 2
+#define RSIK_OPT_NO_MIRROR 3
+#define RSIK_OPT_CONT_RUN_MODE 4
+#define RSIK_CONT_RUN_AUTO 0
+#define RSIK_CONT_RUN_LOOP 1
+#define RSIK_CONT_RUN_STEPS 2
+#define RSIK_OPT_CONT_GROUP 5
+#define RSIK_OPT_COUNT 6
 int rsik_set_option(rsik_ctx *ctx, int option, int value);
 int rsik_get_option(const rsik_ctx *ctx, int option, int *value);
 
@@ -283,11 +304,30 @@ int rsik_forward_kinematics(rsik_ctx *ctx, int64_t n, const double *joints, cons
 int rsik_fk_residual(rsik_ctx *ctx, int64_t n, int goal_kind, const double *const *goal_soa, const double *joints,
                      const uint8_t *arm, int arm_uniform, double *err);
 
+/*
+ * Multi-GPU.  Poses are independent, so a job is sharded across the GPUs of a node — one process and one
+ * rsik context per GPU — with no data-path collective; the only exchange is the all-gather of the final arrays
+ * (joints [n,7], state [n]) over RCCL / xGMI.  The reference has nothing distributed (single-threaded Python).  Python
+ * hosts use torch.distributed (backend "nccl" = RCCL, reachy2_symbolic_ik_amd/distributed.py); these four entry points
+ * give a C host the same step without linking RCCL itself (librccl.so is opened with dlopen on first use).
+ *   rsik_comm_unique_id   fills 128 bytes (ncclUniqueId) on ONE rank; the host carries them to the others
+ *   rsik_comm_init_rank   collective over all ranks: creates this rank's communicator on the context's GPU
+ *   rsik_allgather        every rank contributes bytes_per_rank bytes at `send`; rank r's block lands at
+ *                         recv + r * bytes_per_rank on every rank (send may be recv + rank * bytes_per_rank: in place).
+ *                         Enqueued on the context's stream like the kernels; device pointers.
+ */
+int rsik_comm_unique_id(void *id128);
+int rsik_comm_init_rank(rsik_ctx *ctx, int nranks, int rank, const void *id128, void **comm);
+int rsik_comm_destroy(rsik_ctx *ctx, void *comm);
+int rsik_allgather(rsik_ctx *ctx, void *comm, const void *send, void *recv, size_t bytes_per_rank);
+
 /* Test hook: evaluates the kernels' own elementary functions (csrc/rsik_math.hpp) on device arrays so their
  * accuracy can be measured against the host libm.  op: 0 reciprocal, 1 sqrt (out0, out1 two variants),
  * 2 reciprocal sqrt, 3 atan2(a, b), 4 sincos(a) -> out0 = sin, out1 = cos, 5 out0 = a mod 2pi (Python
  * semantics), out1 = angle_diff(a, b) (utils.py:486-490), 6 fp64 FMA issue-rate calibration (8 x 2048 dependent fma per element, scripts/valu_peak.py),
- * 7 the solve path's table atan2 of a UNIT vector: out0 = atan2(a, b) for a^2 + b^2 = 1.
+ * 7 the solve path's table atan2 of a UNIT vector: out0 = atan2(a, b) for a^2 + b^2 = 1,
+ * 8 clock monitor: n waves each wait a[0] ticks of the 100 MHz counter (clamped to 5 s); out0[w] = shader-clock ticks,
+ *   out1[w] = 100 MHz ticks that passed (core clock = out0 / out1 x 100 MHz); run it on a side stream beside a load.
  * Not part of the reference surface. */
 int rsik_debug_math(rsik_ctx *ctx, int op, int64_t n, const double *a, const double *b, double *out0, double *out1);
 

@@ -37,6 +37,44 @@ def build(force=False):
 
 
 _lib = None
+_native = None
+
+
+def _bind(L):
+    L.orc_arm_ndoubles.restype = C.c_int
+    L.orc_solver_ndoubles.restype = C.c_int
+    L.orc_max_threads.restype = C.c_int
+    L.orc_angle_diff.restype = C.c_double
+    L.orc_angle_diff.argtypes = [C.c_double, C.c_double]
+    L.orc_pymod.restype = C.c_double
+    L.orc_pymod.argtypes = [C.c_double, C.c_double]
+    L.orc_limit_theta_to_interval.restype = C.c_double
+    L.orc_limit_theta_to_interval.argtypes = [C.c_double, C.c_double, _dp]
+    L.orc_is_valid_angle.restype = C.c_int
+    L.orc_is_valid_angle.argtypes = [C.c_double, _dp]
+    L.orc_get_best_theta_to_current_joints.restype = C.c_double
+    L.orc_get_best_theta_to_current_joints.argtypes = [_dp, _dp, _dp, C.c_int, C.c_double]
+    L.orc_arm_init.argtypes = [_dp, C.c_int, _dp, _dp, C.c_double, C.c_double, _dp] + [C.c_double] * 7
+    L.orc_arm_init_default.argtypes = [_dp, C.c_int, C.c_double]
+    L.orc_is_reachable.restype = C.c_int
+    L.orc_is_reachable.argtypes = [_dp, _dp, _dp, _dp, _ip, _dp]
+    L.orc_is_reachable_no_limits.restype = C.c_int
+    L.orc_is_reachable_no_limits.argtypes = [_dp, _dp, _dp, _dp]
+    L.orc_get_elbow_position.argtypes = [_dp, C.c_double, _dp]
+    L.orc_get_joints.restype = C.c_int
+    L.orc_get_joints.argtypes = [_dp, _dp, C.c_double, _dp, _dp, _dp]
+    L.orc_limit_orbita3d_joints.argtypes = [_dp, C.c_double, _dp]
+    L.orc_rotation_matrix_from_vector.argtypes = [_dp, _dp]
+    L.orc_euler_from_matrix_xyz.argtypes = [_dp, _dp]
+    L.orc_control_discrete.restype = C.c_int
+    L.orc_control_discrete.argtypes = [_dp, _dp, C.c_int, C.c_double, C.c_int, _dp, _dp, C.c_double, C.c_double, _dp, _ip, _ip]
+    L.orc_control_continuous_step.restype = C.c_int
+    L.orc_control_continuous_step.argtypes = [_dp, _dp, _dp, C.c_int, C.c_double, C.c_double, C.c_int, _dp, _dp,
+                                              C.c_double, C.c_double, _dp, _ip]
+    L.orc_solve_batch.argtypes = [_dp, _dp, C.c_long] + [_dp] * 6 + [_u8p, C.c_int, _dp, _dp, _dp, _dp, _dp, _u8p, _u8p, _u8p, C.c_int]
+    L.orc_control_discrete_batch.argtypes = [_dp, _dp, C.c_long, _dp, _u8p, C.c_int, C.c_double, C.c_int, _dp, _dp,
+                                             C.c_double, _dp, _u8p, _u8p, _u8p, C.c_int]
+    return L
 
 
 def lib():
@@ -44,42 +82,34 @@ def lib():
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
             build()
-        L = C.CDLL(_LIB_PATH)
-        L.orc_arm_ndoubles.restype = C.c_int
-        L.orc_solver_ndoubles.restype = C.c_int
-        L.orc_max_threads.restype = C.c_int
-        L.orc_angle_diff.restype = C.c_double
-        L.orc_angle_diff.argtypes = [C.c_double, C.c_double]
-        L.orc_pymod.restype = C.c_double
-        L.orc_pymod.argtypes = [C.c_double, C.c_double]
-        L.orc_limit_theta_to_interval.restype = C.c_double
-        L.orc_limit_theta_to_interval.argtypes = [C.c_double, C.c_double, _dp]
-        L.orc_is_valid_angle.restype = C.c_int
-        L.orc_is_valid_angle.argtypes = [C.c_double, _dp]
-        L.orc_get_best_theta_to_current_joints.restype = C.c_double
-        L.orc_get_best_theta_to_current_joints.argtypes = [_dp, _dp, _dp, C.c_int, C.c_double]
-        L.orc_arm_init.argtypes = [_dp, C.c_int, _dp, _dp, C.c_double, C.c_double, _dp] + [C.c_double] * 7
-        L.orc_arm_init_default.argtypes = [_dp, C.c_int, C.c_double]
-        L.orc_is_reachable.restype = C.c_int
-        L.orc_is_reachable.argtypes = [_dp, _dp, _dp, _dp, _ip, _dp]
-        L.orc_is_reachable_no_limits.restype = C.c_int
-        L.orc_is_reachable_no_limits.argtypes = [_dp, _dp, _dp, _dp]
-        L.orc_get_elbow_position.argtypes = [_dp, C.c_double, _dp]
-        L.orc_get_joints.restype = C.c_int
-        L.orc_get_joints.argtypes = [_dp, _dp, C.c_double, _dp, _dp, _dp]
-        L.orc_limit_orbita3d_joints.argtypes = [_dp, C.c_double, _dp]
-        L.orc_rotation_matrix_from_vector.argtypes = [_dp, _dp]
-        L.orc_euler_from_matrix_xyz.argtypes = [_dp, _dp]
-        L.orc_control_discrete.restype = C.c_int
-        L.orc_control_discrete.argtypes = [_dp, _dp, C.c_int, C.c_double, C.c_int, _dp, _dp, C.c_double, C.c_double, _dp, _ip, _ip]
-        L.orc_control_continuous_step.restype = C.c_int
-        L.orc_control_continuous_step.argtypes = [_dp, _dp, _dp, C.c_int, C.c_double, C.c_double, C.c_int, _dp, _dp,
-                                                  C.c_double, C.c_double, _dp, _ip]
-        L.orc_solve_batch.argtypes = [_dp, _dp, C.c_long] + [_dp] * 6 + [_u8p, C.c_int, _dp, _dp, _dp, _dp, _dp, _u8p, _u8p, _u8p, C.c_int]
-        L.orc_control_discrete_batch.argtypes = [_dp, _dp, C.c_long, _dp, _u8p, C.c_int, C.c_double, C.c_int, _dp, _dp,
-                                                 C.c_double, _dp, _u8p, _u8p, _u8p, C.c_int]
-        _lib = L
+        _lib = _bind(C.CDLL(_LIB_PATH))
     return _lib
+
+
+def native_lib():
+    """The same C restatement compiled for THIS host's CPU (gcc -O3 -march=native, FP contraction still off, so the
+    results are the portable build's bit for bit): the faster of the two CPU baselines bench.py reports.  The file name
+    carries a hash of the CPU's model and flags, so a library built on another machine is never loaded."""
+    global _native
+    if _native is None:
+        import hashlib
+
+        try:
+            with open("/proc/cpuinfo") as fh:
+                info = [ln for ln in fh.read().splitlines() if ln.startswith(("model name", "flags"))][:2]
+        except OSError:
+            info = []
+        tag = hashlib.sha256("\n".join(info).encode()).hexdigest()[:12]
+        out_dir = os.path.join(_HERE, "_native")
+        path = os.path.join(out_dir, f"librsik_oracle_{tag}.so")
+        src = os.path.join(_HERE, "rsik_oracle.c")
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            os.makedirs(out_dir, exist_ok=True)
+            subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-std=c99", "-ffp-contract=off", "-fno-fast-math",
+                                   "-fopenmp", src, "-o", path + ".tmp", "-shared", "-lm"])
+            os.replace(path + ".tmp", path)
+        _native = _bind(C.CDLL(path))
+    return _native
 
 
 def _d(a):
@@ -164,7 +194,7 @@ class Solver:
                                                           float(preferred_theta))
 
 
-def solve_batch(arm_r, arm_l, pos, eul, arm_id=None, theta_policy=0, theta_in=None, previous_joints=None, nthreads=1):
+def solve_batch(arm_r, arm_l, pos, eul, arm_id=None, theta_policy=0, theta_in=None, previous_joints=None, nthreads=1, L=None):
     pos, eul = _f64(pos), _f64(eul)
     n = pos.shape[0]
     cols = [np.ascontiguousarray(pos[:, k]) for k in range(3)] + [np.ascontiguousarray(eul[:, k]) for k in range(3)]
@@ -173,14 +203,14 @@ def solve_batch(arm_r, arm_l, pos, eul, arm_id=None, theta_policy=0, theta_in=No
     aid = None if arm_id is None else np.ascontiguousarray(arm_id, dtype=np.uint8)
     th = _f64(theta_in)
     pj = _f64(previous_joints)
-    lib().orc_solve_batch(_d(arm_r.buf), _d(arm_l.buf), n, *[_d(c) for c in cols], _u8(aid), int(theta_policy), _d(th),
+    (L or lib()).orc_solve_batch(_d(arm_r.buf), _d(arm_l.buf), n, *[_d(c) for c in cols], _u8(aid), int(theta_policy), _d(th),
                           _d(pj), _d(joints), _d(interval), _d(elbow), _u8(reach), _u8(state), _u8(proj), int(nthreads))
     return dict(joints=joints, interval=interval, elbow=elbow, reachable=reach, state=state, projected=proj)
 
 
 def control_discrete_batch(arm_r, arm_l, M, arm_id=None, nb_search_points=20, preferred_theta=-4 * np.pi / 6,
                            constrained_mode=0, previous_sol=None, current_joints=None,
-                           orbita3d_max_angle=float(np.deg2rad(42.5)), nthreads=1):
+                           orbita3d_max_angle=float(np.deg2rad(42.5)), nthreads=1, L=None):
     M = np.ascontiguousarray(M, dtype=np.float64).reshape(-1, 16)
     n = M.shape[0]
     if previous_sol is None:
@@ -191,7 +221,7 @@ def control_discrete_batch(arm_r, arm_l, M, arm_id=None, nb_search_points=20, pr
     aid = None if arm_id is None else np.ascontiguousarray(arm_id, dtype=np.uint8)
     joints = np.empty((n, 7)); reach = np.empty(n, dtype=np.uint8); state = np.empty(n, dtype=np.uint8)
     em = np.empty(n, dtype=np.uint8)
-    lib().orc_control_discrete_batch(_d(arm_r.buf), _d(arm_l.buf), n, _d(M), _u8(aid), int(nb_search_points),
+    (L or lib()).orc_control_discrete_batch(_d(arm_r.buf), _d(arm_l.buf), n, _d(M), _u8(aid), int(nb_search_points),
                                      float(preferred_theta), int(constrained_mode), _d(ps), _d(cj),
                                      float(orbita3d_max_angle), _d(joints), _u8(reach), _u8(state), _u8(em), int(nthreads))
     return dict(joints=joints, reachable=reach, state=state, emergency=em)

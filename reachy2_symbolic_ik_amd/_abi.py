@@ -9,9 +9,22 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# RSIK_LIB_PATH: alternative build of the same ABI (A/B timing of kernel variants); default = the in-tree library
-LIB_PATH = os.environ.get("RSIK_LIB_PATH") or os.path.join(_HERE, "csrc", "librsik_hip.so")
+_lib = None
+LIB_PATH = os.path.join(_HERE, "csrc", "librsik_hip.so")
 
+
+def use_library(path: str) -> None:
+    """Loads an alternative build of the same ABI instead of the in-tree library (A/B timing of kernel variants,
+    diagnostic probe builds: `bench.py --lib`, scripts/*).  Must be called before the first load()."""
+    global LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("use_library() must be called before the HIP library is loaded")
+    if not os.path.exists(path):
+        raise FileNotFoundError(path)
+    LIB_PATH = os.path.abspath(path)
+
+
+ABI_VERSION = 2
 RSIK_OK = 0
 RSIK_E_INVALID, RSIK_E_NO_DEVICE, RSIK_E_HIP, RSIK_E_NOT_SET = -1, -2, -3, -4
 
@@ -25,6 +38,7 @@ _dp = C.POINTER(C.c_double)
 # name -> (restype, argtypes); every symbol include/rsik.h declares
 PROTOTYPES = {
     "rsik_abi_version": (C.c_int, []),
+    "rsik_build_id": (C.c_char_p, []),
     "rsik_arm_consts_count": (C.c_int, []),
     "rsik_device_count": (C.c_int, []),
     "rsik_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
@@ -53,10 +67,15 @@ PROTOTYPES = {
     "rsik_forward_kinematics": (C.c_int, [_vp, C.c_int64, _vp, _vp, C.c_int, _vp, _vp]),
     "rsik_fk_residual": (C.c_int, [_vp, C.c_int64, C.c_int, C.POINTER(_vp), _vp, _vp, C.c_int, _vp]),
     "rsik_debug_math": (C.c_int, [_vp, C.c_int, C.c_int64, _vp, _vp, _vp, _vp]),
+    "rsik_comm_unique_id": (C.c_int, [_vp]),
+    "rsik_comm_init_rank": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.POINTER(_vp)]),
+    "rsik_comm_destroy": (C.c_int, [_vp, _vp]),
+    "rsik_allgather": (C.c_int, [_vp, _vp, _vp, _vp, C.c_size_t]),
 }
 
 GOAL_POSE6, GOAL_M12 = 0, 1
-OPT_EULER_ROUNDTRIP = 0
+OPT_EULER_ROUNDTRIP, OPT_SWEEP_MODE, OPT_NO_TIPZ, OPT_NO_MIRROR, OPT_CONT_RUN_MODE, OPT_CONT_GROUP = 0, 1, 2, 3, 4, 5
+CONT_RUN_AUTO, CONT_RUN_LOOP, CONT_RUN_STEPS = 0, 1, 2
 EULER_AUTO, EULER_ALWAYS, EULER_NEVER = 0, 1, 2
 
 SOLVER_STATE_STRIDE = 32
@@ -69,24 +88,33 @@ class RsikError(RuntimeError):
         self.code = code
 
 
-_lib = None
-
-
 def load() -> C.CDLL:
-    """Loads the HIP library; raises if it has not been built (no fallback)."""
+    """Loads the HIP library; raises if it has not been built (no fallback).  The in-tree library must have been
+    built from the sources next to it (embedded source hash, build.py): a stale one is rebuilt when hipcc is there,
+    and refused otherwise, so that tests and benchmarks never validate or time an old binary."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise ImportError(
-                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                "(hipcc --offload-arch=gfx950).  reachy2_symbolic_ik_amd has no CPU fallback."
-            )
+        in_tree = LIB_PATH == os.path.join(_HERE, "csrc", "librsik_hip.so")
+        if in_tree:
+            from . import build as _build
+
+            if _build.needs_build():
+                try:
+                    _build.build()
+                except Exception as e:  # no hipcc, or the compile failed
+                    state = "is missing" if not os.path.exists(LIB_PATH) else "was built from other sources than the ones next to it"
+                    raise ImportError(
+                        f"{LIB_PATH} {state} and could not be rebuilt ({e}): build it with "
+                        "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950).  "
+                        "reachy2_symbolic_ik_amd has no CPU fallback.") from e
+        elif not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing")
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if lib.rsik_abi_version() != 1:
+        if lib.rsik_abi_version() != ABI_VERSION:
             raise ImportError("librsik_hip.so ABI version mismatch")
         _lib = lib
     return _lib

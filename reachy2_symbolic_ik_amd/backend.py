@@ -42,6 +42,8 @@ class HipSolver:
             raise _abi.RsikError(rc, (self.lib.rsik_last_error(None) or b"").decode())
         self._h = h
         self._arms_set = [False, False]
+        self._arm_blocks = [None, None]
+        self._arm_gen = 0  # bumped whenever an arm's constants really change: plans made before are then stale
 
     def close(self) -> None:
         if getattr(self, "_h", None):
@@ -66,8 +68,13 @@ class HipSolver:
         c = np.ascontiguousarray(consts, dtype=np.float64)
         if c.shape != (ARM_CONSTS_COUNT,):
             raise ValueError(f"expected {ARM_CONSTS_COUNT} constants, got {c.shape}")
+        old = self._arm_blocks[arm_id]
+        if old is not None and old.tobytes() == c.tobytes():
+            return
         self._check(self.lib.rsik_set_arm(self._h, int(arm_id), c.ctypes.data_as(C.POINTER(C.c_double)), c.size))
         self._arms_set[arm_id] = True
+        self._arm_blocks[arm_id] = c.copy()
+        self._arm_gen += 1
 
     def synchronize(self) -> None:
         self._check(self.lib.rsik_sync(self._h))
@@ -81,6 +88,18 @@ class HipSolver:
             raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
         return t.contiguous()
 
+    def _dev_cols(self, t: torch.Tensor, rows: int, n: int, name: str) -> torch.Tensor:
+        """SoA input [rows, n]: the ABI takes one pointer per column array, so any view whose rows are unit-stride
+        (e.g. a column slice columns[:, lo:hi] of a larger batch) is passed as it is, without a copy."""
+        if not isinstance(t, torch.Tensor):
+            t = torch.as_tensor(np.asarray(t, dtype=np.float64))
+        t = t.to(device=self.device, dtype=_F64)
+        if tuple(t.shape) != (rows, n):
+            raise ValueError(f"{name}: expected shape {(rows, n)}, got {tuple(t.shape)}")
+        if n > 1 and t.stride(1) != 1:
+            t = t.contiguous()
+        return t
+
     def _dev_u8(self, t, n: int, name: str) -> torch.Tensor:
         if not isinstance(t, torch.Tensor):
             t = torch.as_tensor(np.asarray(t, dtype=np.uint8))
@@ -88,6 +107,20 @@ class HipSolver:
         if tuple(t.shape) != (n,):
             raise ValueError(f"{name}: expected shape ({n},), got {tuple(t.shape)}")
         return t.contiguous()
+
+    def _out_buf(self, out: Optional[Dict[str, torch.Tensor]], name: str, shape: Sequence[int], dtype: torch.dtype) -> torch.Tensor:
+        """The caller's `out[name]` if given — it must be exactly what the kernel writes (this device, dtype, shape,
+        contiguous: the kernels get a raw pointer) — else a fresh buffer."""
+        t = None if out is None else out.get(name, None)
+        shape = tuple(int(v) for v in shape)
+        if t is None:
+            return torch.empty(shape, dtype=dtype, device=self.device)
+        if not isinstance(t, torch.Tensor):
+            raise ValueError(f"out[{name!r}] must be a torch tensor")
+        if t.device != self.device or t.dtype != dtype or tuple(t.shape) != shape or not t.is_contiguous():
+            raise ValueError(f"out[{name!r}] must be a contiguous {dtype} tensor of shape {shape} on {self.device}; got "
+                             f"{t.dtype} {tuple(t.shape)} on {t.device}{'' if t.is_contiguous() else ' (not contiguous)'}")
+        return t
 
     # ------------------------------------------------------------------ rsik_solve
     def solve(
@@ -108,7 +141,7 @@ class HipSolver:
         if pose_soa.dim() != 2 or pose_soa.shape[0] != 6:
             raise ValueError("pose_soa must have shape [6, n]")
         n = int(pose_soa.shape[1])
-        pose_soa = self._dev_f64(pose_soa, (6, n), "pose_soa")
+        pose_soa = self._dev_cols(pose_soa, 6, n, "pose_soa")
         if arm is not None:
             arm = self._dev_u8(arm, n, "arm")
         if theta_policy in (_abi.THETA_EXPLICIT, _abi.THETA_FRACTION):
@@ -117,27 +150,12 @@ class HipSolver:
             theta_in = self._dev_f64(theta_in, (n,), "theta_in")
         else:
             theta_in = None
-        if out is None:
-            out = {}
-        dev = self.device
         none = theta_policy == _abi.THETA_NONE
-        joints = None if none else out.get("joints", None)
-        if not none and joints is None:
-            joints = torch.empty((n, 7), dtype=_F64, device=dev)
-        elbow = None
-        if not none and want_elbow:
-            elbow = out.get("elbow", None)
-            if elbow is None:
-                elbow = torch.empty((n, 3), dtype=_F64, device=dev)
-        interval = out.get("interval", None)
-        if interval is None:
-            interval = torch.empty((n, 2), dtype=_F64, device=dev)
-        reachable = out.get("reachable", None)
-        if reachable is None:
-            reachable = torch.empty((n,), dtype=_U8, device=dev)
-        state = out.get("state", None)
-        if state is None:
-            state = torch.empty((n,), dtype=_U8, device=dev)
+        joints = None if none else self._out_buf(out, "joints", (n, 7), _F64)
+        elbow = self._out_buf(out, "elbow", (n, 3), _F64) if (not none and want_elbow) else None
+        interval = self._out_buf(out, "interval", (n, 2), _F64)
+        reachable = self._out_buf(out, "reachable", (n,), _U8)
+        state = self._out_buf(out, "state", (n,), _U8)
         cols = (C.c_void_p * 6)(*[pose_soa[k].data_ptr() for k in range(6)])
         prev = None
         if previous_joints is not None:
@@ -162,15 +180,22 @@ class HipSolver:
         return res
 
     def plan(self, fn_name: str, *args):
-        """Binds one C-ABI call with all its arguments once; the returned callable re-issues exactly that launch on the
-        stream that was current at planning time (a few microseconds of host time per call — the hot loop of a
-        caller that re-solves resident buffers, e.g. bench.py).  Keep the tensors alive while the plan is used."""
+        """Binds one C-ABI call with all its arguments once; the returned callable re-issues exactly that launch (a few
+        microseconds of host time per call — the hot loop of a caller that re-solves resident buffers, e.g. bench.py).
+        `launch()` enqueues on the stream that was current at PLANNING time, whatever other calls have done to the
+        context's stream since; `launch(stream=handle)` enqueues on another hipStream_t (a capture stream when the
+        launches are recorded into a hipGraph).  The plan is tied to the arm constants uploaded at planning time: it
+        raises if set_arm() has changed them since.  Keep the tensors alive while the plan is used."""
         fn = getattr(self.lib, fn_name)
+        set_stream = self.lib.rsik_set_stream
         with torch.cuda.device(self.device):
-            self._bind_stream()
-        h, check = self._h, self._check
+            planned = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        h, check, gen = self._h, self._check, self._arm_gen
 
-        def launch() -> None:
+        def launch(stream: Optional[int] = None) -> None:
+            if self._arm_gen != gen:
+                raise RuntimeError("HipSolver.plan: the arm constants were changed after this launch was planned")
+            set_stream(h, planned if stream is None else C.c_void_p(stream))
             rc = fn(h, *args)
             if rc != _abi.RSIK_OK:
                 check(rc)
@@ -196,7 +221,7 @@ class HipSolver:
         if m12_soa.dim() != 2 or m12_soa.shape[0] != 12:
             raise ValueError("m12_soa must have shape [12, n]")
         n = int(m12_soa.shape[1])
-        m12_soa = self._dev_f64(m12_soa, (12, n), "m12_soa")
+        m12_soa = self._dev_cols(m12_soa, 12, n, "m12_soa")
         if nb_search_points < 2:
             raise ValueError("nb_search_points must be >= 2")
         if arm is not None:
@@ -206,21 +231,10 @@ class HipSolver:
         ps = np.ascontiguousarray(previous_sol, dtype=np.float64)
         if ps.shape != (2, 7):
             raise ValueError("previous_sol must have shape (2, 7)")
-        if out is None:
-            out = {}
-        dev = self.device
-        joints = out.get("joints", None)
-        if joints is None:
-            joints = torch.empty((n, 7), dtype=_F64, device=dev)
-        reachable = out.get("reachable", None)
-        if reachable is None:
-            reachable = torch.empty((n,), dtype=_U8, device=dev)
-        state = out.get("state", None)
-        if state is None:
-            state = torch.empty((n,), dtype=_U8, device=dev)
-        emergency = out.get("emergency", None)
-        if emergency is None:
-            emergency = torch.empty((n,), dtype=_U8, device=dev)
+        joints = self._out_buf(out, "joints", (n, 7), _F64)
+        reachable = self._out_buf(out, "reachable", (n,), _U8)
+        state = self._out_buf(out, "state", (n,), _U8)
+        emergency = self._out_buf(out, "emergency", (n,), _U8)
         cols = (C.c_void_p * 12)(*[m12_soa[k].data_ptr() for k in range(12)])
         cargs = (n, cols, _ptr(arm), int(arm_uniform), int(nb_search_points), float(preferred_theta), int(constrained_mode),
                  ps.ctypes.data_as(C.POINTER(C.c_double)), _ptr(current_joints), float(orbita3d_max_angle), _ptr(joints),
@@ -276,17 +290,9 @@ class HipSolver:
         pts = np.ascontiguousarray(preferred_theta_self, dtype=np.float64)
         if pts.shape != (2,):
             raise ValueError("preferred_theta_self must have 2 entries (r, l)")
-        if out is None:
-            out = {}
-        joints = out.get("joints", None)
-        if joints is None:
-            joints = torch.empty((n, 7), dtype=_F64, device=self.device)
-        reachable = out.get("reachable", None)
-        if reachable is None:
-            reachable = torch.empty((n,), dtype=_U8, device=self.device)
-        state = out.get("state", None)
-        if state is None:
-            state = torch.empty((n,), dtype=_U8, device=self.device)
+        joints = self._out_buf(out, "joints", (n, 7), _F64)
+        reachable = self._out_buf(out, "reachable", (n,), _U8)
+        state = self._out_buf(out, "state", (n,), _U8)
         cols = (C.c_void_p * 12)(*[m12_soa[k].data_ptr() for k in range(12)])
         with torch.cuda.device(self.device):
             self._bind_stream()
@@ -331,17 +337,9 @@ class HipSolver:
             current_pose_m12 = self._dev_f64(current_pose_m12, (12, n), "current_pose_m12")
             cp = (C.c_void_p * 12)(*[current_pose_m12[k].data_ptr() for k in range(12)])
         pts = np.ascontiguousarray(preferred_theta_self, dtype=np.float64)
-        if out is None:
-            out = {}
-        joints = out.get("joints", None)
-        if joints is None:
-            joints = torch.empty((n_steps, n, 7), dtype=_F64, device=self.device)
-        reachable = out.get("reachable", None)
-        if reachable is None:
-            reachable = torch.empty((n_steps, n), dtype=_U8, device=self.device)
-        state = out.get("state", None)
-        if state is None:
-            state = torch.empty((n_steps, n), dtype=_U8, device=self.device)
+        joints = self._out_buf(out, "joints", (n_steps, n, 7), _F64)
+        reachable = self._out_buf(out, "reachable", (n_steps, n), _U8)
+        state = self._out_buf(out, "state", (n_steps, n), _U8)
         with torch.cuda.device(self.device):
             self._bind_stream()
             self._check(self.lib.rsik_control_continuous_run(
@@ -461,6 +459,28 @@ class HipSolver:
             self._bind_stream()
             self._check(self.lib.rsik_fk_residual(self._h, n, kind, cols, _ptr(joints), _ptr(arm), int(arm_uniform), _ptr(err)))
         return err
+
+    # ------------------------------------------------------------------ measurement hooks
+    def clock_monitor(self, seconds: float, n_waves: int = 64, stream: Optional[torch.cuda.Stream] = None):
+        """Starts rsik_debug_math op 8 on `stream` (a side stream, so that it runs BESIDE whatever the main stream is
+        doing): n_waves one-wave workgroups each wait `seconds` (clamped to 5 s) and report shader-clock and 100 MHz
+        ticks.  Returns (core_ticks, real_ticks) device tensors, valid once `stream` has been synchronised;
+        core clock in GHz = core_ticks / real_ticks * 0.1."""
+        ticks = torch.tensor([float(seconds) * 1e8], dtype=_F64, device=self.device)
+        o0 = torch.zeros((n_waves,), dtype=_F64, device=self.device)
+        o1 = torch.zeros((n_waves,), dtype=_F64, device=self.device)
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        st.wait_stream(torch.cuda.current_stream(self.device))  # the tick count must have been written
+        with torch.cuda.device(self.device):
+            self._check(self.lib.rsik_set_stream(self._h, C.c_void_p(st.cuda_stream)))
+            self._check(self.lib.rsik_debug_math(self._h, 8, int(n_waves), _ptr(ticks), None, _ptr(o0), _ptr(o1)))
+            self._bind_stream()
+        for t in (ticks, o0, o1):
+            t.record_stream(st)
+        return o0, o1
+
+    def build_id(self) -> str:
+        return (self.lib.rsik_build_id() or b"").decode()
 
     # ------------------------------------------------------------------ test hook
     def debug_math(self, op: int, a: torch.Tensor, b: Optional[torch.Tensor] = None):

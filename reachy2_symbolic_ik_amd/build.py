@@ -1,7 +1,9 @@
 """Builds csrc/librsik_hip.so in-tree with hipcc for gfx950 (no JIT cache: the .so travels with the repo)."""
 from __future__ import annotations
 
+import hashlib
 import os
+import re
 import shutil
 import subprocess
 
@@ -24,19 +26,42 @@ def hipcc() -> str:
     return exe
 
 
+def source_hash() -> str:
+    """sha256 over every source file the library is compiled from plus the compiler flags.  The build embeds it
+    (-DRSIK_SOURCE_HASH, returned by rsik_build_id()), so a library that was built from other sources — e.g. a stale
+    .so that travelled to the GPU box after an edit — is recognised whatever the file times say."""
+    h = hashlib.sha256()
+    for d in DEPS:
+        with open(os.path.join(CSRC, d), "rb") as fh:
+            h.update(d.encode() + b"\0" + fh.read() + b"\0")
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    return h.hexdigest()[:32]
+
+
+_MARK = re.compile(rb"RSIK_SRC_HASH=([0-9a-f]{32})")
+
+
+def built_hash(path: str = OUT) -> str:
+    """The source hash embedded in a built library ("" if there is none), read from the file without loading it."""
+    try:
+        with open(path, "rb") as fh:
+            m = _MARK.search(fh.read())
+    except OSError:
+        return ""
+    return m.group(1).decode() if m else ""
+
+
 def needs_build() -> bool:
-    if not os.path.exists(OUT):
-        return True
-    t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+    return built_hash() != source_hash()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     if force or needs_build():
-        cmd = [hipcc()] + HIPCC_FLAGS + SOURCES + ["-o", OUT]
+        cmd = [hipcc()] + HIPCC_FLAGS + [f'-DRSIK_SOURCE_HASH="{source_hash()}"'] + SOURCES + ["-o", OUT + ".tmp"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd, cwd=CSRC)
+        os.replace(OUT + ".tmp", OUT)
     return OUT
 
 

@@ -6,6 +6,8 @@
 // Per-arm constants travel in the kernarg segment (scalar loads, wave-uniform).
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1030,6 +1032,31 @@ __global__ void debug_math_kernel(int op, int64_t n, const double* a, const doub
     if (o1) o1[i] = r1;
 }
 
+// rsik_debug_math op 8: clock monitor.  Each wave of the launch records the shader-clock counter (s_memtime) and the
+// constant 100 MHz counter (s_memrealtime), sleeps until `ticks[0]` 100 MHz ticks have passed and records both again:
+// core clock = d(s_memtime) / d(s_memrealtime) x 100 MHz.  Launched on a side stream while the kernel under study
+// runs on the main one it reads the clock the chip holds UNDER THAT LOAD without a single stamp in a product kernel
+// (MI355X_MICROARCH.md, DVFS give-back (6)).  The wait is bounded twice: by the tick count (clamped to 5 s) and by an
+// iteration budget, so every wave exits.
+__global__ void clock_monitor_kernel(const double* ticks, int64_t n_waves, double* core_ticks, double* real_ticks) {
+    const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (w >= n_waves) return;
+    double want = ticks[0];
+    want = want < 0.0 ? 0.0 : (want > 5.0e8 ? 5.0e8 : want);
+    const uint64_t dur = (uint64_t)want;
+    const uint64_t r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_readcyclecounter();
+    uint64_t r = r0;
+    for (int guard = 0; guard < 4000000 && r - r0 < dur; ++guard) {
+        __builtin_amdgcn_s_sleep(127);
+        r = __builtin_amdgcn_s_memrealtime();
+    }
+    const uint64_t c1 = __builtin_readcyclecounter();
+    if ((threadIdx.x & 63) == 0) {
+        core_ticks[w] = (double)(c1 - c0);
+        real_ticks[w] = (double)(r - r0);
+    }
+}
+
 }  // namespace rsik
 
 // =====================================================================================
@@ -1063,6 +1090,10 @@ static int hip_fail(rsik_ctx* ctx, hipError_t e, const char* what) {
 extern "C" {
 
 int rsik_abi_version(void) { return RSIK_ABI_VERSION; }
+#ifndef RSIK_SOURCE_HASH
+#define RSIK_SOURCE_HASH "00000000000000000000000000000000"
+#endif
+const char* rsik_build_id(void) { return "RSIK_SRC_HASH=" RSIK_SOURCE_HASH; }
 int rsik_arm_consts_count(void) { return RSIK_ARM_CONSTS_COUNT; }
 
 int rsik_device_count(void) {
@@ -1121,6 +1152,8 @@ int rsik_set_arm(rsik_ctx* ctx, int arm, const double* consts_host, int count) {
 int rsik_set_option(rsik_ctx* ctx, int option, int value) {
     if (!ctx) return RSIK_E_INVALID;
     if (option < 0 || option >= RSIK_OPT_COUNT) return fail(ctx, RSIK_E_INVALID, "rsik_set_option: unknown option");
+    static const int max_value[RSIK_OPT_COUNT] = {RSIK_EULER_NEVER, 2, 1, 1, RSIK_CONT_RUN_STEPS, 2};
+    if (value < 0 || value > max_value[option]) return fail(ctx, RSIK_E_INVALID, "rsik_set_option: value out of range");
     ctx->options[option] = value;
     return RSIK_OK;
 }
@@ -1203,9 +1236,9 @@ int rsik_solve(rsik_ctx* ctx, int64_t n, const double* const pose_soa[6], const 
     dim3 grid((unsigned)blocks), block(rsik::kBlock);
     // tip offset along the goal z axis only (the default arm / the URDF): the specialised goal stage applies
     const bool tipz = K.arms[0].v[RSIK_C_TIPL] == 0.0 && K.arms[0].v[RSIK_C_TIPL + 1] == 0.0 &&
-                      K.arms[1].v[RSIK_C_TIPL] == 0.0 && K.arms[1].v[RSIK_C_TIPL + 1] == 0.0 && !std::getenv("RSIK_NO_TIPZ");
+                      K.arms[1].v[RSIK_C_TIPL] == 0.0 && K.arms[1].v[RSIK_C_TIPL + 1] == 0.0 && !ctx->options[RSIK_OPT_NO_TIPZ];
     // mixed launch: do the two blocks agree in everything that has no handedness (arm_const_is_sided)?
-    bool mirror = arm != nullptr && !std::getenv("RSIK_NO_MIRROR");
+    bool mirror = arm != nullptr && !ctx->options[RSIK_OPT_NO_MIRROR];
     for (int i = 0; mirror && i < RSIK_ARM_CONSTS_COUNT; i++)
         if (!rsik::arm_const_is_sided(i) && std::memcmp(&K.arms[0].v[i], &K.arms[1].v[i], sizeof(double)) != 0) mirror = false;
     if (arm) {
@@ -1284,8 +1317,7 @@ int rsik_control_discrete(rsik_ctx* ctx, int64_t n, const double* const m12_soa[
     int lg = 0;
     while ((1 << lg) < nb_search_points && lg < 6) lg++;
     K.log2p = lg;
-    const char* sm = std::getenv("RSIK_SWEEP_MODE");  // test hook: force one of the two grid-search strategies
-    K.sweep_mode = sm ? std::atoi(sm) : 0;
+    K.sweep_mode = ctx->options[RSIK_OPT_SWEEP_MODE];  // 0 unless a test / A-B run forces one of the two strategies
     K.euler_roundtrip = ctx->options[RSIK_OPT_EULER_ROUNDTRIP];
     for (int slot = 0; slot < 2; slot++) {
         const int a = arm ? slot : arm_uniform;
@@ -1394,8 +1426,8 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     for (int c = 0; c < 12; c++) cols[c] = m12_steps + (size_t)c * (size_t)n;  // step 0; step s is 12 n doubles further
     // Batches that fill the chip many times over gain nothing from the in-kernel time loop and lose its 1 wave/SIMD
     // occupancy: they go step by step (one launch per step, state through HBM), like a streaming caller would.
-    const char* force = std::getenv("RSIK_CONT_RUN_MODE");  // test hook: "loop" / "steps"
-    const bool stepwise = force ? (std::strcmp(force, "steps") == 0) : (n >= (int64_t)1 << 19);
+    const int force = ctx->options[RSIK_OPT_CONT_RUN_MODE];
+    const bool stepwise = force != RSIK_CONT_RUN_AUTO ? (force == RSIK_CONT_RUN_STEPS) : (n >= (int64_t)1 << 19);
     if (!stepwise)
         return launch_continuous(ctx, "rsik_control_continuous_run", n, n_steps, cols, current_pose_m12_soa, arm, arm_uniform,
                                  nullptr, first_step_timed_out ? 1 : 0, preferred_theta, preferred_theta_self_host,
@@ -1565,15 +1597,108 @@ int rsik_fk_residual(rsik_ctx* ctx, int64_t n, int goal_kind, const double* cons
 
 int rsik_debug_math(rsik_ctx* ctx, int op, int64_t n, const double* a, const double* b, double* out0, double* out1) {
     if (!ctx) return RSIK_E_INVALID;
-    if (n < 0 || op < 0 || op > 7) return fail(ctx, RSIK_E_INVALID, "rsik_debug_math: bad op or n");
+    if (n < 0 || op < 0 || op > 8) return fail(ctx, RSIK_E_INVALID, "rsik_debug_math: bad op or n");
     if (n == 0) return RSIK_OK;
     if (!a || !out0 || ((op == 3 || op == 5 || op == 6 || op == 7) && !b)) return fail(ctx, RSIK_E_INVALID, "rsik_debug_math: NULL operand");
     RSIK_HIP(ctx, hipSetDevice(ctx->device));
     dim3 grid, block(rsik::kBlock);
+    if (op == 8) {  // clock monitor: n waves, one per 64-thread workgroup so that they spread over the chip
+        if (!out1 || n > 4096) return fail(ctx, RSIK_E_INVALID, "rsik_debug_math: op 8 needs out1 and n <= 4096 waves");
+        hipLaunchKernelGGL(rsik::clock_monitor_kernel, dim3((unsigned)n), dim3(64), 0, ctx->stream, a, n, out0, out1);
+        RSIK_HIP(ctx, hipGetLastError());
+        return RSIK_OK;
+    }
     int rc = launch_dims(ctx, n, &grid, "rsik_debug_math");
     if (rc != RSIK_OK) return rc;
     hipLaunchKernelGGL(rsik::debug_math_kernel, grid, block, 0, ctx->stream, op, n, a, b, out0, out1);
     RSIK_HIP(ctx, hipGetLastError());
+    return RSIK_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Multi-GPU: the all-gather of the final arrays over RCCL, for hosts without torch.distributed.
+// librccl is opened at run time (dlopen), so single-GPU users never need it installed.
+// ------------------------------------------------------------------------------------------
+namespace {
+struct NcclUid { char internal[128]; };  // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
+struct Rccl {
+    void* so = nullptr;
+    int (*GetUniqueId)(NcclUid*) = nullptr;
+    int (*CommInitRank)(void**, int, NcclUid, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string err;
+};
+Rccl* rccl() {
+    static Rccl R;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char* nm : names) {
+            R.so = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+            if (R.so) break;
+        }
+        if (!R.so) { R.err = "librccl.so not found (dlopen)"; return &R; }
+        R.GetUniqueId = (int (*)(NcclUid*))dlsym(R.so, "ncclGetUniqueId");
+        R.CommInitRank = (int (*)(void**, int, NcclUid, int))dlsym(R.so, "ncclCommInitRank");
+        R.CommDestroy = (int (*)(void*))dlsym(R.so, "ncclCommDestroy");
+        R.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(R.so, "ncclAllGather");
+        R.GetErrorString = (const char* (*)(int))dlsym(R.so, "ncclGetErrorString");
+        if (!R.GetUniqueId || !R.CommInitRank || !R.CommDestroy || !R.AllGather) R.err = "librccl.so lacks an expected symbol";
+    }
+    return &R;
+}
+int rccl_fail(rsik_ctx* ctx, const char* what, int code) {
+    Rccl* R = rccl();
+    return fail(ctx, RSIK_E_HIP, std::string(what) + ": " + ((R->GetErrorString && code) ? R->GetErrorString(code) : R->err.c_str()));
+}
+}  // namespace
+
+int rsik_comm_unique_id(void* id128) {
+    Rccl* R = rccl();
+    if (!id128 || !R->err.empty()) return fail(nullptr, RSIK_E_HIP, "rsik_comm_unique_id: " + (id128 ? R->err : std::string("NULL buffer")));
+    NcclUid u;
+    int rc = R->GetUniqueId(&u);
+    if (rc != 0) return rccl_fail(nullptr, "ncclGetUniqueId", rc);
+    std::memcpy(id128, u.internal, sizeof u.internal);
+    return RSIK_OK;
+}
+
+int rsik_comm_init_rank(rsik_ctx* ctx, int nranks, int rank, const void* id128, void** comm) {
+    if (!ctx) return RSIK_E_INVALID;
+    if (!id128 || !comm || nranks < 1 || rank < 0 || rank >= nranks) return fail(ctx, RSIK_E_INVALID, "rsik_comm_init_rank: bad argument");
+    Rccl* R = rccl();
+    if (!R->err.empty()) return fail(ctx, RSIK_E_HIP, "rsik_comm_init_rank: " + R->err);
+    RSIK_HIP(ctx, hipSetDevice(ctx->device));
+    NcclUid u;
+    std::memcpy(u.internal, id128, sizeof u.internal);
+    *comm = nullptr;
+    int rc = R->CommInitRank(comm, nranks, u, rank);
+    if (rc != 0) return rccl_fail(ctx, "ncclCommInitRank", rc);
+    return RSIK_OK;
+}
+
+int rsik_comm_destroy(rsik_ctx* ctx, void* comm) {
+    if (!ctx) return RSIK_E_INVALID;
+    if (!comm) return RSIK_OK;
+    Rccl* R = rccl();
+    if (!R->err.empty()) return fail(ctx, RSIK_E_HIP, "rsik_comm_destroy: " + R->err);
+    int rc = R->CommDestroy(comm);
+    if (rc != 0) return rccl_fail(ctx, "ncclCommDestroy", rc);
+    return RSIK_OK;
+}
+
+int rsik_allgather(rsik_ctx* ctx, void* comm, const void* send, void* recv, size_t bytes_per_rank) {
+    if (!ctx) return RSIK_E_INVALID;
+    if (!comm || !recv || (!send && bytes_per_rank)) return fail(ctx, RSIK_E_INVALID, "rsik_allgather: NULL argument");
+    if (bytes_per_rank == 0) return RSIK_OK;
+    Rccl* R = rccl();
+    if (!R->err.empty()) return fail(ctx, RSIK_E_HIP, "rsik_allgather: " + R->err);
+    RSIK_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = R->AllGather(send, recv, bytes_per_rank, /*ncclInt8*/ 0, comm, ctx->stream);
+    if (rc != 0) return rccl_fail(ctx, "ncclAllGather", rc);
     return RSIK_OK;
 }
 

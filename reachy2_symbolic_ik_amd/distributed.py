@@ -1,11 +1,19 @@
-"""Multi-GPU: poses are independent, so the batch is block-sharded across ranks (one process per GPU) with no
-data-path collective; the only exchange is the all-gather of the final arrays (RCCL over xGMI on MI355X —
-torch.distributed backend "nccl"; "gloo" in the CPU tests).  The reference has nothing distributed
-(single-threaded Python, one pose per call); this is the SURVEY 8(e) design.
+"""Multi-GPU: poses are independent, so the batch is sharded across ranks (one process per GPU) with no data-path
+collective; the only exchange is the all-gather of the final arrays (RCCL over xGMI on MI355X — torch.distributed
+backend "nccl"; "gloo" in the CPU tests).  The reference has nothing distributed (single-threaded Python, one pose
+per call); this is the SURVEY 8(e) design.
+
+Partition (`ShardPlan`): the pose array is cut into `chunks` consecutive stripes of world * rows_per_piece rows and
+rank r owns rows [r * rows_per_piece, (r + 1) * rows_per_piece) of every stripe (block-cyclic; chunks = 1 is the plain
+contiguous block split of SURVEY 8(e)).  The all-gather of stripe c is then ONE all_gather_into_tensor whose output is
+the contiguous stripe c of the full-size result in natural pose order, and whose input is this rank's own rows of that
+stripe — the kernels write there directly, so there is no staging copy on either side — and it travels over xGMI
+while the kernel solves stripe c + 1.
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, Iterable, Optional, Tuple
+from dataclasses import dataclass
+from typing import Callable, Dict, Iterable, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -24,9 +32,44 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, min(lo + s, n)
 
 
+@dataclass(frozen=True)
+class ShardPlan:
+    """Block-cyclic partition of n rows over `world` ranks in `chunks` stripes (see the module docstring)."""
+    n: int
+    world: int
+    chunks: int = 1
+
+    @property
+    def rows_per_piece(self) -> int:
+        return max(1, (self.n + self.world * self.chunks - 1) // (self.world * self.chunks))
+
+    @property
+    def stripe_rows(self) -> int:
+        return self.world * self.rows_per_piece
+
+    @property
+    def padded_rows(self) -> int:
+        """Rows of the full-size result buffer (rows >= n are padding, never read back)."""
+        return self.chunks * self.stripe_rows
+
+    def piece(self, rank: int, c: int) -> Tuple[int, int]:
+        """Global rows [lo, lo + rows_per_piece) that `rank` owns in stripe c (may reach past n: padding)."""
+        lo = c * self.stripe_rows + rank * self.rows_per_piece
+        return lo, lo + self.rows_per_piece
+
+    def owned(self, rank: int) -> List[Tuple[int, int]]:
+        """The real (clipped to n) row ranges of `rank`, stripe by stripe."""
+        out = []
+        for c in range(self.chunks):
+            lo, hi = self.piece(rank, c)
+            out.append((min(lo, self.n), min(hi, self.n)))
+        return out
+
+
 def all_gather_rows(local: torch.Tensor, n_total: int, group: Optional[dist.ProcessGroup] = None,
                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """All-gathers row-sharded `local` ([rows_of_this_rank, ...]) into the full [n_total, ...] tensor on every rank."""
+    """All-gathers row-sharded `local` ([rows_of_this_rank, ...], contiguous block split) into the full [n_total, ...]
+    tensor on every rank."""
     world = dist.get_world_size(group)
     s = shard_size(n_total, world)
     tail = tuple(local.shape[1:])
@@ -42,42 +85,68 @@ def all_gather_rows(local: torch.Tensor, n_total: int, group: Optional[dist.Proc
     return out[:n_total]
 
 
-def solve_sharded(solve_fn: Callable[[torch.Tensor], Dict[str, torch.Tensor]], columns: torch.Tensor,
-                  group: Optional[dist.ProcessGroup] = None,
-                  gather: Iterable[str] = ("joints", "reachable", "state"), chunks: int = 1) -> Dict[str, torch.Tensor]:
-    """columns: the full SoA input [C, n] (present on every rank).  Each rank solves its block with `solve_fn`
-    (e.g. SymbolicIK.solve_batch) and the arrays named in `gather` are all-gathered; returns full-size arrays.
+class ShardedBuffers:
+    """Full-size result arrays of a sharded solve, [plan.padded_rows, ...] each, in natural pose order.
+    `piece_views(c)` are this rank's rows of stripe c (what the kernels write), `stripe_views(c)` the whole stripe
+    (what the all-gather of stripe c fills)."""
 
-    chunks > 1: the block is solved in `chunks` pieces and the all-gather of piece k is issued
-    asynchronously as soon as its solve has been queued, so it travels over xGMI while piece k+1 is being solved; every
-    piece lands directly in its place of the full-size result (no staging copy)."""
+    def __init__(self, plan: ShardPlan, rank: int, spec: Dict[str, Tuple[Tuple[int, ...], torch.dtype]], device) -> None:
+        self.plan, self.rank = plan, rank
+        self.full = {k: torch.zeros((plan.padded_rows,) + tuple(tail), dtype=dt, device=device) for k, (tail, dt) in spec.items()}
+
+    def piece_views(self, c: int) -> Dict[str, torch.Tensor]:
+        lo, hi = self.plan.piece(self.rank, c)
+        return {k: t[lo:hi] for k, t in self.full.items()}
+
+    def stripe_views(self, c: int) -> Dict[str, torch.Tensor]:
+        lo = c * self.plan.stripe_rows
+        return {k: t[lo: lo + self.plan.stripe_rows] for k, t in self.full.items()}
+
+    def result(self) -> Dict[str, torch.Tensor]:
+        return {k: t[: self.plan.n] for k, t in self.full.items()}
+
+
+def gather_stripe(buffers: ShardedBuffers, c: int, names: Iterable[str], group: Optional[dist.ProcessGroup] = None,
+                  async_op: bool = True) -> list:
+    """Issues the all-gather of stripe c for the named arrays: one all_gather_into_tensor per array, IN PLACE (the
+    input is this rank's slice of the output, which is NCCL's / RCCL's in-place all-gather: no copy of the local
+    rows).  Returns the work handles (empty when async_op is False)."""
+    works = []
+    pieces, stripes = buffers.piece_views(c), buffers.stripe_views(c)
+    in_place = dist.get_backend(group) == "nccl"
+    for k in names:
+        src = pieces[k] if in_place else pieces[k].clone()  # gloo (CPU tests) does not promise in-place semantics
+        w = dist.all_gather_into_tensor(stripes[k], src, group=group, async_op=async_op)
+        if async_op:
+            works.append(w)
+    return works
+
+
+def solve_sharded(solve_fn: Callable[[torch.Tensor, Dict[str, torch.Tensor]], None], columns: torch.Tensor,
+                  spec: Optional[Dict[str, Tuple[Tuple[int, ...], torch.dtype]]] = None,
+                  group: Optional[dist.ProcessGroup] = None, gather: Iterable[str] = ("joints", "state"),
+                  chunks: int = 1) -> Dict[str, torch.Tensor]:
+    """columns: the full SoA input [C, n] (present on every rank).  Every rank solves the rows it owns, stripe by
+    stripe, with `solve_fn(columns[:, lo:hi], out)` — `out[k]` are [hi - lo, ...] views into the full-size result that
+    the solve must fill (e.g. SymbolicIK.solve_batch(cols, out=out)) — and the arrays named in `gather` are
+    all-gathered; returns the full-size arrays [n, ...] in pose order on every rank.
+
+    chunks > 1: the all-gather of stripe c is issued asynchronously as soon as its solve has been queued,
+    so it travels over xGMI while stripe c + 1 is being solved."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     n = int(columns.shape[1])
-    lo, hi = shard_range(n, rank, world)
+    plan = ShardPlan(n, world, max(1, int(chunks)))
     gather = tuple(gather)
-    if chunks <= 1:
-        local = solve_fn(columns[:, lo:hi].contiguous())
-        return {k: all_gather_rows(local[k], n, group) for k in gather}
-    s = shard_size(n, world)
-    cs = (s + chunks - 1) // chunks          # rows per piece; every rank cuts its (padded) block at the same places
-    full: Dict[str, torch.Tensor] = {}
+    if spec is None:
+        spec = {"joints": ((7,), torch.float64), "state": ((), torch.uint8)}
+    buffers = ShardedBuffers(plan, rank, {k: spec[k] for k in gather}, columns.device)
     pending = []
-    for c in range(chunks):
-        a, b = c * cs, min((c + 1) * cs, s)  # piece rows inside a block
-        if a >= b:
-            break
-        mine_lo, mine_hi = min(lo + a, hi), min(lo + b, hi)
-        local = solve_fn(columns[:, mine_lo:mine_hi].contiguous())
-        for k in gather:
-            t = local[k]
-            if k not in full:
-                full[k] = t.new_zeros((world * s,) + tuple(t.shape[1:]))
-            piece = t
-            if t.shape[0] != b - a:          # short / empty trailing piece of a short trailing block: pad
-                piece = t.new_zeros((b - a,) + tuple(t.shape[1:]))
-                piece[: t.shape[0]] = t
-            views = [full[k][r * s + a: r * s + b] for r in range(world)]
-            pending.append(dist.all_gather(views, piece.contiguous(), group=group, async_op=True))
+    for c in range(plan.chunks):
+        lo, hi = plan.owned(rank)[c]
+        if hi > lo:
+            views = {k: v[: hi - lo] for k, v in buffers.piece_views(c).items()}
+            solve_fn(columns[:, lo:hi], views)
+        pending += gather_stripe(buffers, c, gather, group, async_op=True)
     for w in pending:
         w.wait()
-    return {k: full[k][:n] for k in gather}
+    return buffers.result()

@@ -23,14 +23,15 @@ _THETA_POLICIES = {"interval0": _abi.THETA_INTERVAL0, "explicit": _abi.THETA_EXP
 
 
 def poses_to_soa(poses: Any, device: torch.device) -> torch.Tensor:
-    """[n,2,3] (position, xyz-euler) or [6,n] -> contiguous [6,n] float64 on `device`."""
+    """[n,2,3] (position, xyz-euler) or [6,n] -> [6,n] float64 on `device` with unit-stride rows (a column slice of a
+    larger SoA batch is passed through as a view: the ABI takes one pointer per column array)."""
     t = poses if isinstance(poses, torch.Tensor) else torch.as_tensor(np.asarray(poses, dtype=np.float64))
     t = t.to(device=device, dtype=torch.float64)
     if t.dim() == 3 and tuple(t.shape[1:]) == (2, 3):
         t = t.reshape(t.shape[0], 6).t()
     elif not (t.dim() == 2 and t.shape[0] == 6):
         raise ValueError("poses must have shape [n,2,3] or [6,n]")
-    return t.contiguous()
+    return t if (t.shape[1] <= 1 or t.stride(1) == 1) else t.contiguous()
 
 
 class SymbolicIK:

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Core clock and wave lifetime of solve_kernel under load, from a -DRSIK_CLOCK_PROBE build (diagnostic only):
 
-    hipcc ... -DRSIK_CLOCK_PROBE rsik_lib.hip -o probe.so;  RSIK_LIB_PATH=$PWD/probe.so python scripts/clock_probe.py
+    hipcc ... -DRSIK_CLOCK_PROBE rsik_lib.hip -o probe.so;  python scripts/clock_probe.py --lib probe.so
 """
 import os
 import sys
@@ -9,6 +9,18 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+def _lib_arg():
+    """--lib PATH: the probe build to load instead of the in-tree library (must happen before the package loads it)."""
+    if "--lib" in sys.argv:
+        k = sys.argv.index("--lib")
+        from reachy2_symbolic_ik_amd import _abi
+
+        _abi.use_library(sys.argv[k + 1])
+        del sys.argv[k: k + 2]
+
+
+_lib_arg()
 import bench  # noqa: E402
 from reachy2_symbolic_ik_amd import SymbolicIK  # noqa: E402
 

@@ -2,7 +2,7 @@
 """Where a control step's time goes in trajectory mode (config 5), from a -DRSIK_CONT_PROBE build (diagnostic only):
 
     hipcc ... -DRSIK_CONT_PROBE rsik_lib.hip -o build/variants/probe_cont.so
-    RSIK_LIB_PATH=$PWD/build/variants/probe_cont.so python scripts/cont_probe.py
+    python scripts/cont_probe.py --lib build/variants/probe_cont.so
 """
 import os
 import sys
@@ -11,6 +11,18 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+def _lib_arg():
+    """--lib PATH: the probe build to load instead of the in-tree library (must happen before the package loads it)."""
+    if "--lib" in sys.argv:
+        k = sys.argv.index("--lib")
+        from reachy2_symbolic_ik_amd import _abi
+
+        _abi.use_library(sys.argv[k + 1])
+        del sys.argv[k: k + 2]
+
+
+_lib_arg()
 import bench  # noqa: E402
 from reachy2_symbolic_ik_amd import ControlIK  # noqa: E402
 

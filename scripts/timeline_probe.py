@@ -2,7 +2,7 @@
 """Per-wave timeline of solve_kernel from a -DRSIK_TIMELINE_PROBE build (diagnostic only):
 
     hipcc ... -DRSIK_TIMELINE_PROBE rsik_lib.hip -o build/variants/probe_timeline.so
-    RSIK_LIB_PATH=$PWD/build/variants/probe_timeline.so python scripts/timeline_probe.py [n]
+    python scripts/timeline_probe.py --lib build/variants/probe_timeline.so [n]
 
 Every wave reports four 100 MHz timestamps (start, tables staged + pose loaded, outputs staged in LDS, stores issued)
 and its hardware slot.  Prints the launch span, the phase durations, how many waves are resident / computing over
@@ -15,6 +15,18 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+def _lib_arg():
+    """--lib PATH: the probe build to load instead of the in-tree library (must happen before the package loads it)."""
+    if "--lib" in sys.argv:
+        k = sys.argv.index("--lib")
+        from reachy2_symbolic_ik_amd import _abi
+
+        _abi.use_library(sys.argv[k + 1])
+        del sys.argv[k: k + 2]
+
+
+_lib_arg()
 import bench  # noqa: E402
 from reachy2_symbolic_ik_amd import SymbolicIK  # noqa: E402
 

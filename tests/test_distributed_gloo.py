@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from reachy2_symbolic_ik_amd.distributed import all_gather_rows, shard_range, shard_size, solve_sharded
+from reachy2_symbolic_ik_amd.distributed import ShardPlan, all_gather_rows, shard_range, shard_size, solve_sharded
 
 
 def test_shard_ranges_cover_everything():
@@ -22,6 +22,27 @@ def test_shard_ranges_cover_everything():
             s = shard_size(n, world)
             assert all(hi - lo <= s for lo, hi in spans)
             assert all(lo == min(r * s, n) for r, (lo, hi) in enumerate(spans))
+
+
+def test_block_cyclic_plan_covers_everything_once():
+    for n in (1, 2, 7, 257, 1000, 1 << 20):
+        for world in (1, 2, 3, 8):
+            for chunks in (1, 2, 4, 5):
+                plan = ShardPlan(n, world, chunks)
+                assert plan.padded_rows >= n and plan.padded_rows == chunks * world * plan.rows_per_piece
+                seen = np.zeros(plan.padded_rows, dtype=np.int32)
+                for r in range(world):
+                    for c in range(chunks):
+                        lo, hi = plan.piece(r, c)
+                        assert hi - lo == plan.rows_per_piece and c * plan.stripe_rows <= lo and hi <= (c + 1) * plan.stripe_rows
+                        seen[lo:hi] += 1
+                    for (lo, hi), (plo, phi) in zip(plan.owned(r), [plan.piece(r, c) for c in range(chunks)]):
+                        assert lo == min(plo, n) and hi == min(phi, n)
+                assert np.all(seen == 1)  # every row of the padded result belongs to exactly one (rank, stripe)
+            if world > 0:
+                plan1 = ShardPlan(n, world, 1)
+                if n % world == 0:  # one stripe = the contiguous block split of SURVEY 8(e)
+                    assert [plan1.owned(r)[0] for r in range(world)] == [shard_range(n, r, world) for r in range(world)]
 
 
 def _free_port():
@@ -45,19 +66,19 @@ def _worker(rank, world, port, n, seed, result_dir):
         cols = torch.as_tensor(np.ascontiguousarray(np.concatenate([pos.T, eul.T, arm[None].astype(np.float64)], axis=0)))
         ar, al = orc.Arm("r_arm", 0.03), orc.Arm("l_arm", 0.03)
 
-        def solve_fn(c):
+        def solve_fn(c, out):  # fills the [rows, ...] views it is handed, like SymbolicIK.solve_batch(cols, out=out)
             c = c.numpy()
-            if c.shape[1] == 0:
-                return {"joints": torch.empty((0, 7), dtype=torch.float64), "reachable": torch.empty((0,), dtype=torch.uint8),
-                        "state": torch.empty((0,), dtype=torch.uint8)}
             r = orc.solve_batch(ar, al, c[:3].T, c[3:6].T, arm_id=c[6].astype(np.uint8))
-            return {k: torch.as_tensor(r[k]) for k in ("joints", "reachable", "state")}
+            for k in out:
+                out[k].copy_(torch.as_tensor(r[k]))
 
-        full = solve_sharded(solve_fn, cols)
+        spec = {"joints": ((7,), torch.float64), "reachable": ((), torch.uint8), "state": ((), torch.uint8)}
+        names = ("joints", "reachable", "state")
+        full = solve_sharded(solve_fn, cols, spec=spec, gather=names)
         ref = orc.solve_batch(ar, al, pos, eul, arm_id=arm)
-        for chunks in (2, 3, 5):  # pieces solved one after the other, each all-gathered asynchronously into place
-            piecewise = solve_sharded(solve_fn, cols, chunks=chunks)
-            for k in ("joints", "reachable", "state"):
+        for chunks in (2, 3, 5):  # stripes solved one after the other, each all-gathered asynchronously into place
+            piecewise = solve_sharded(solve_fn, cols, spec=spec, gather=names, chunks=chunks)
+            for k in names:
                 assert piecewise[k].shape == full[k].shape
                 np.testing.assert_array_equal(np.nan_to_num(piecewise[k].numpy(), nan=-99.0), np.nan_to_num(full[k].numpy(), nan=-99.0))
         assert full["joints"].shape == (n, 7) and full["reachable"].shape == (n,)
@@ -80,3 +101,44 @@ def test_sharded_solve_world2_gloo(tmp_path, n):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), n, 1234 + n, str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / f"ok_{r}") for r in range(world))
+
+
+# ------------------------------------------------------------------------------------------ bench.py's own launcher
+def _run_bench(*argv, env=None):
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], env=e, capture_output=True, text=True, timeout=300)
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus N` must itself become N ranks (the parent never touches the GPU) and print ONE line with
+    n_gpus = N.  --rendezvous-only stops each rank after the process-group rendezvous (gloo, CPU): what is under test
+    is the launcher, which is the same code path the GPU run takes."""
+    import json
+
+    for n in (2, 3):
+        p = _run_bench("--gpus", str(n), "--rendezvous-only")
+        assert p.returncode == 0, p.stderr
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == n and d["rank_sum"] == n * (n - 1) / 2
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    p = _run_bench("--gpus", "2", "--rendezvous-only", env={"WORLD_SIZE": "3", "RANK": "0"})
+    assert p.returncode != 0 and "--gpus 2 but WORLD_SIZE=3" in p.stderr
+
+
+def test_bench_launcher_propagates_a_failing_rank():
+    # no GPU here: every rank stops with "needs an MI355X", and the launcher must hand that failure on
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    p = _run_bench("--gpus", "2", "--steps", "1", "--warmup", "0")
+    assert p.returncode != 0

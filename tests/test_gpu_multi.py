@@ -1,0 +1,258 @@
+"""GPU tests of the multi-process / multi-GPU path and of the host-side guards added around the C ABI.
+
+On the 1-GPU box the two-rank runs use torch.distributed's gloo backend with both ranks on GPU 0 (`bench.py --backend
+gloo --single-device`): every line of the sharding, stripe-pipelined all-gather and rank-0 verification code runs, only
+the transport differs.  The RCCL (backend "nccl") variants run when the box has two GPUs and are skipped otherwise.
+"""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*argv, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+def _check_two_rank_line(d, gather):
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["workload"].startswith("config4")
+    m = d["multi_gpu"]
+    assert m["kernel_only_solves_per_s"] > 0
+    if gather == "none":
+        assert m["gather_only_ms"] is None
+    else:
+        assert m["gather_only_ms"] > 0 and m["end_to_end_solves_per_s"] > 0 and m["gathered_rows_checked"]
+        # rank 0 re-solved rows taken from BOTH ranks' parts of the gathered array with the CPU checker
+        par = d["cpu_baseline"]["parity_on_sample"]
+        assert par["rows"] >= 2 * 1024 and par["max_abs_joint_error_rad"] < 1e-6
+    if gather == "step":
+        assert abs(m["end_to_end_solves_per_s"] - d["value"]) < 1e-6 * d["value"]
+
+
+@pytest.mark.parametrize("gather", ["step", "final", "none"])
+def test_bench_two_ranks_gloo_one_gpu(gather):
+    """`bench.py --gpus 2` starts its own ranks; config 4 (mixed r/l) is the N > 1 default."""
+    d = _bench("--gpus", "2", "--backend", "gloo", "--single-device", "--poses", "32768", "--steps", "3", "--warmup", "1",
+               "--cpu-seconds", "2", "--gather", gather, "--chunks", "4")
+    _check_two_rank_line(d, gather)
+
+
+def test_bench_two_ranks_gloo_config3_and_config5():
+    d = _bench("--gpus", "2", "--backend", "gloo", "--single-device", "--config", "3", "--poses", "16384", "--steps", "2",
+               "--warmup", "1", "--cpu-seconds", "2", "--chunks", "2")
+    assert d["n_gpus"] == 2 and d["cpu_baseline"]["parity_on_sample"]["max_abs_joint_error_rad"] < 1e-6
+    d = _bench("--gpus", "2", "--backend", "gloo", "--single-device", "--config", "5", "--poses", "256", "--steps", "1", "--warmup", "1")
+    assert d["n_gpus"] == 2 and d["unit"] == "steps/s" and d["config"]["collective"] == "none"
+
+
+def test_bench_two_ranks_rccl():
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    d = _bench("--gpus", "2", "--poses", "262144", "--steps", "5", "--warmup", "2", "--cpu-seconds", "2")
+    _check_two_rank_line(d, "step")
+    assert "rehearsal" not in d["config"]["collective"] and d["multi_gpu"]["xgmi"]["achieved"] > 0
+
+
+def _rccl_worker(rank, world, port, result_dir):
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        from oracle import oracle as orc
+        from reachy2_symbolic_ik_amd import DualArmIK
+        from reachy2_symbolic_ik_amd.distributed import solve_sharded
+
+        import contextlib
+        import io
+
+        rng = np.random.default_rng(5)
+        n = 100003  # not a multiple of world * chunks: the last stripe is padded
+        pos = np.array([0.25, 0.0, -0.15]) + rng.uniform(-0.3, 0.3, size=(n, 3))
+        eul = np.array([0, -np.pi / 2, 0]) + rng.uniform(-0.8, 0.8, size=(n, 3))
+        arm = (rng.uniform(size=n) < 0.5).astype(np.uint8)
+        pos[:, 1] += np.where(arm == 1, 0.2, -0.2)
+        with contextlib.redirect_stdout(io.StringIO()):
+            dual = DualArmIK(device=rank)
+        cols = torch.as_tensor(np.ascontiguousarray(np.concatenate([pos.T, eul.T], axis=0))).cuda()
+        arm_t = torch.as_tensor(arm).cuda()
+        lo_of = {}
+
+        def solve_fn(c, out):
+            lo = (c.data_ptr() - cols.data_ptr()) // 8  # the column slice's first row
+            lo_of[lo] = True
+            dual.solve_batch(arm_t[lo: lo + c.shape[1]], c, want_elbow=False, out=out)
+
+        ref = orc.solve_batch(orc.Arm("r_arm", 0.03), orc.Arm("l_arm", 0.03), pos, eul, arm_id=arm, nthreads=8)
+        for chunks in (1, 4):
+            full = solve_sharded(solve_fn, cols, gather=("joints", "state"), chunks=chunks)
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(full["state"].cpu().numpy(), ref["state"])
+            ok = ref["reachable"].astype(bool)
+            assert np.max(np.abs(full["joints"].cpu().numpy()[ok] - ref["joints"][ok])) < 1e-9
+        open(os.path.join(result_dir, f"ok_{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_solve_sharded_rccl_two_gpus(tmp_path):
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_rccl_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert all(os.path.exists(tmp_path / f"ok_{r}") for r in range(2))
+
+
+def test_c_abi_allgather_single_rank():
+    """rsik_comm_* / rsik_allgather (include/rsik.h): a one-rank communicator on GPU 0 — unique id, init, the all-gather
+    (out of place and in place) on the context's stream, destroy.  With one rank the collective is a copy, which is
+    enough to show that librccl is found, the by-value ncclUniqueId call is laid out correctly and the stream is used."""
+    import torch
+
+    from reachy2_symbolic_ik_amd import HipSolver
+
+    hs = HipSolver(0)
+    L = hs.lib
+    uid = (C.c_char * 128)()
+    assert L.rsik_comm_unique_id(C.cast(uid, C.c_void_p)) == 0
+    comm = C.c_void_p()
+    hs._check(L.rsik_comm_init_rank(hs._h, 1, 0, C.cast(uid, C.c_void_p), C.byref(comm)))
+    assert comm.value
+    src = torch.arange(7 * 1000, dtype=torch.float64, device="cuda").reshape(1000, 7)
+    dst = torch.zeros_like(src)
+    hs._bind_stream()
+    hs._check(L.rsik_allgather(hs._h, comm, src.data_ptr(), dst.data_ptr(), src.numel() * 8))
+    hs._check(L.rsik_allgather(hs._h, comm, src.data_ptr(), src.data_ptr(), src.numel() * 8))  # in place
+    torch.cuda.synchronize()
+    assert torch.equal(src, dst)
+    assert L.rsik_allgather(hs._h, None, src.data_ptr(), dst.data_ptr(), 8) != 0  # NULL communicator is an error, not a crash
+    hs._check(L.rsik_comm_destroy(hs._h, comm))
+
+
+def test_out_buffers_are_validated():
+    """Caller-supplied `out` tensors reach the kernels as raw pointers: wrong dtype / shape / device / layout must
+    raise instead of corrupting memory."""
+    import contextlib
+    import io
+
+    import torch
+
+    from reachy2_symbolic_ik_amd import ControlIK, SymbolicIK
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        ik = SymbolicIK("r_arm")
+        c = ControlIK(urdf_path="config_files/reachy2_ik_minimal.urdf")
+    n = 64
+    poses = torch.zeros((6, n), dtype=torch.float64, device="cuda")
+    good = lambda: {"joints": torch.empty((n, 7), dtype=torch.float64, device="cuda")}  # noqa: E731
+    ik.solve_batch(poses, out=good())
+    bad = [
+        {"joints": torch.empty((n, 7), dtype=torch.float32, device="cuda")},
+        {"joints": torch.empty((n - 1, 7), dtype=torch.float64, device="cuda")},
+        {"joints": torch.empty((n, 7), dtype=torch.float64)},
+        {"joints": torch.empty((n, 14), dtype=torch.float64, device="cuda")[:, ::2]},
+        {"reachable": torch.empty((n,), dtype=torch.int32, device="cuda")},
+        {"interval": torch.empty((2, n), dtype=torch.float64, device="cuda").t()},
+    ]
+    for o in bad:
+        with pytest.raises(ValueError):
+            ik.solve_batch(poses, out=o)
+    M = np.tile(np.eye(4), (n, 1, 1))
+    for o in bad[:4] + [{"emergency": torch.empty((n,), dtype=torch.float64, device="cuda")}]:
+        with pytest.raises(ValueError):
+            c.symbolic_inverse_kinematics_batch("r_arm", M, out=o)
+    st = c.new_continuous_state("r_arm", n)
+    with pytest.raises(ValueError):
+        c.symbolic_inverse_kinematics_continuous_batch("r_arm", M, st, out=bad[0])
+    with pytest.raises(ValueError):
+        c.run_continuous_trajectories("r_arm", np.tile(np.eye(4), (3, n, 1, 1)), st, out={"joints": torch.empty((n, 3, 7), dtype=torch.float64, device="cuda")})
+    # a column slice of a larger SoA batch is consumed in place (no copy) and gives the same answer
+    big = torch.rand((6, 4 * n), dtype=torch.float64, device="cuda") * 0.2
+    a = ik.solve_batch(big[:, n: 2 * n])
+    b = ik.solve_batch(big[:, n: 2 * n].contiguous())
+    assert torch.equal(a["state"], b["state"]) and torch.equal(a["interval"].nan_to_num(9.0), b["interval"].nan_to_num(9.0))
+
+
+def test_plan_keeps_its_stream_and_notices_new_constants():
+    import contextlib
+    import io
+
+    import torch
+
+    from reachy2_symbolic_ik_amd import HipSolver, SymbolicIK
+
+    hs = HipSolver(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ik = SymbolicIK("r_arm", solver=hs)
+    rng = np.random.default_rng(3)
+    n = 4096
+    pos = np.array([0.0, -0.2, 0.0]) + rng.uniform(-0.5, 0.5, size=(n, 3))
+    poses = torch.as_tensor(np.ascontiguousarray(np.concatenate([pos.T, rng.uniform(-3, 3, size=(n, 3)).T]))).cuda()
+    out = {"state": torch.full((n,), 255, dtype=torch.uint8, device="cuda")}
+    plan = ik.solve_batch(poses, out=out, plan_only=True)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):  # another call leaves the context bound to a side stream ...
+        ik.solve_batch(poses)
+    plan["launch"]()               # ... the plan still goes to the stream it was planned on
+    torch.cuda.current_stream().synchronize()
+    ref = ik.solve_batch(poses)["state"]
+    torch.cuda.synchronize()
+    assert torch.equal(out["state"], ref)
+    with contextlib.redirect_stdout(io.StringIO()):
+        other = SymbolicIK("r_arm", singularity_offset=-1.01, solver=hs)  # same arm slot, other constants
+    other.solve_batch(poses)
+    with pytest.raises(RuntimeError):
+        plan["launch"]()
+
+
+def test_options_are_validated_and_build_id_matches_sources():
+    from reachy2_symbolic_ik_amd import HipSolver, _abi, build
+
+    hs = HipSolver(0)
+    for opt, bad in ((_abi.OPT_SWEEP_MODE, 3), (_abi.OPT_NO_TIPZ, 2), (_abi.OPT_CONT_RUN_MODE, 5), (99, 0), (_abi.OPT_SWEEP_MODE, -1)):
+        with pytest.raises(_abi.RsikError):
+            hs.set_option(opt, bad)
+    hs.set_option(_abi.OPT_SWEEP_MODE, 2)
+    assert hs.get_option(_abi.OPT_SWEEP_MODE) == 2
+    assert hs.build_id() == "RSIK_SRC_HASH=" + build.source_hash()  # the library in use was built from the sources next to it
+
+
+def test_clock_monitor_reports_a_plausible_clock():
+    import torch
+
+    from reachy2_symbolic_ik_amd import HipSolver
+
+    hs = HipSolver(0)
+    side = torch.cuda.Stream()
+    core, real = hs.clock_monitor(0.02, 8, side)
+    a = torch.rand(1 << 20, dtype=torch.float64, device="cuda")
+    for _ in range(20):
+        hs.debug_math(6, a, a)
+    torch.cuda.synchronize()
+    ghz = (core / real * 0.1).cpu().numpy()
+    assert np.all(real.cpu().numpy() >= 0.02e8 * 0.99) and np.all((ghz > 0.3) & (ghz < 2.6)), ghz

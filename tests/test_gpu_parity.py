@@ -31,6 +31,12 @@ def orc():
     return o
 
 
+def _abi_mod():
+    from reachy2_symbolic_ik_amd import _abi
+
+    return _abi
+
+
 def load(golden_dir, name):
     return np.load(os.path.join(golden_dir, name))
 
@@ -357,15 +363,15 @@ def test_control_random(golden_dir, torch_mod, dvt_tag, is_dvt):
                 assert np.max(np.abs(np.array(j) - g[pre + "var_joints"][k])) < TOL
 
 
-@pytest.mark.parametrize("mode", ["0", "1", "2"])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("nb", [2, 3, 10, 20, 25, 33, 64, 65, 100, 200, 1000])
-def test_control_grid_sizes_match_checker(golden_dir, torch_mod, orc, nb, mode, monkeypatch):
-    """Grid search strategies (RSIK_SWEEP_MODE: 0 = per-wave choice, 1 = exhaustive wave-cooperative sweep, which packs
+def test_control_grid_sizes_match_checker(golden_dir, torch_mod, orc, nb, mode):
+    """Grid search strategies (rsik_set_option RSIK_OPT_SWEEP_MODE: 0 = per-wave choice, 1 = exhaustive wave-cooperative sweep, which packs
     64/pow2ceil(nb) poses per round and needs extra rounds above 64 points, 2 = per-lane search: whole grid up to 16
     points, the 12 bracketing candidates above) must all reproduce the reference's first strict minimum."""
-    monkeypatch.setenv("RSIK_SWEEP_MODE", mode)
     g = load(golden_dir, "g4_control_discrete.npz")
     c = make_control()
+    c._solver.set_option(_abi_mod().OPT_SWEEP_MODE, mode)
     c.nb_search_points = nb
     ar, al = orc.Arm("r_arm", -1.01), orc.Arm("l_arm", -1.01)
     M = np.concatenate([g["std_r_arm_M"][900:1300], g["std_l_arm_M"][900:1300]])
@@ -377,16 +383,15 @@ def test_control_grid_sizes_match_checker(golden_dir, torch_mod, orc, nb, mode, 
     assert np.max(np.abs(res["joints"] - ref["joints"])) < TOL
 
 
-@pytest.mark.parametrize("mode", ["1", "2"])
-def test_config3_full_size_against_checker(torch_mod, orc, mode, monkeypatch):
+@pytest.mark.parametrize("mode", [1, 2])
+def test_config3_full_size_against_checker(torch_mod, orc, mode):
     """BASELINE config 3 at full size: 262 144 wrist-reachable goal matrices, 64-point sweep, with either grid-search
     strategy forced."""
     from bench import make_config3_matrices
 
-    monkeypatch.setenv("RSIK_SWEEP_MODE", mode)
-
     M = make_config3_matrices(1 << 18, seed=20250204)
     c = make_control()
+    c._solver.set_option(_abi_mod().OPT_SWEEP_MODE, mode)
     c.nb_search_points = 64
     res = to_np(c.symbolic_inverse_kinematics_batch("r_arm", M))
     ref = orc.control_discrete_batch(orc.Arm("r_arm", -1.01), orc.Arm("l_arm", -1.01), M, nb_search_points=64,
@@ -604,13 +609,14 @@ def test_control_continuous_against_checker_dvt_and_emergency(torch_mod, orc):
 
 
 @pytest.mark.parametrize("run_mode", ["loop", "steps"])
-def test_continuous_run_equals_stepwise(golden_dir, torch_mod, run_mode, monkeypatch):
+def test_continuous_run_equals_stepwise(golden_dir, torch_mod, run_mode):
     """rsik_control_continuous_run against G7 and against the step-by-step API, both ways it can issue the work: one
     launch whose kernel walks all steps with the trajectory state in registers ("loop", what small batches get) and
     one launch per step ("steps", what chip-filling batches get)."""
-    monkeypatch.setenv("RSIK_CONT_RUN_MODE", run_mode)
     g = load(golden_dir, "g7_control_continuous_start.npz")
     c = make_control()
+    A = _abi_mod()
+    c._solver.set_option(A.OPT_CONT_RUN_MODE, {"loop": A.CONT_RUN_LOOP, "steps": A.CONT_RUN_STEPS}[run_mode])
     for arm in ("r_arm", "l_arm"):
         sel = ~g[f"{arm}_is_dvt"].astype(bool)
         Ms, J, F, S = (g[f"{arm}_{k}"][sel] for k in ("M", "joints", "reachable", "state"))
@@ -836,10 +842,10 @@ def test_custom_geometry_golden(golden_dir, torch_mod):
     check_symbolic(res, merged, "m_")
 
 
-def test_tip_z_specialisation_matches_general_path(torch_mod, monkeypatch):
+def test_tip_z_specialisation_matches_general_path(torch_mod):
     """The default arm's tip offset has no x / y component, so rsik_solve launches the specialised stages
     (goal_from_euler_tipz; no renormalisation of the wrist-yaw direction, which is a unit vector by construction then).
-    RSIK_NO_TIPZ=1 forces the general path: flags, intervals, elbows and the first six joints must be the same bits,
+    RSIK_OPT_NO_TIPZ forces the general path: flags, intervals, elbows and the first six joints must be the same bits,
     the wrist yaw the same to rounding, for uniform and mixed launches, on all outcomes."""
     from reachy2_symbolic_ik_amd import DualArmIK
 
@@ -856,7 +862,7 @@ def test_tip_z_specialisation_matches_general_path(torch_mod, monkeypatch):
     with contextlib.redirect_stdout(io.StringIO()):
         dual = DualArmIK(solver=solver)
     fast = [to_np(r.solve_batch(p)), to_np(dual.solve_batch(arm_id, p))]
-    monkeypatch.setenv("RSIK_NO_TIPZ", "1")
+    solver.set_option(_abi_mod().OPT_NO_TIPZ, 1)
     slow = [to_np(r.solve_batch(p)), to_np(dual.solve_batch(arm_id, p))]
     for a, b in zip(fast, slow):
         assert a["reachable"].sum() > 500
@@ -865,10 +871,10 @@ def test_tip_z_specialisation_matches_general_path(torch_mod, monkeypatch):
         np.testing.assert_array_equal(a["joints"][:, :6], b["joints"][:, :6])
         m = a["reachable"].astype(bool)
         assert np.max(np.abs(a["joints"][m, 6] - b["joints"][m, 6])) < 2e-15
-    # mixed launches of mirror-image arms read the constants without handedness as scalars (RSIK_NO_MIRROR=1: all per
+    # mixed launches of mirror-image arms read the constants without handedness as scalars (RSIK_OPT_NO_MIRROR: all per
     # lane from LDS): the same bits either way
-    monkeypatch.delenv("RSIK_NO_TIPZ")
-    monkeypatch.setenv("RSIK_NO_MIRROR", "1")
+    solver.set_option(_abi_mod().OPT_NO_TIPZ, 0)
+    solver.set_option(_abi_mod().OPT_NO_MIRROR, 1)
     c = to_np(dual.solve_batch(arm_id, p))
     for k in ("reachable", "state", "interval", "joints", "elbow"):
         np.testing.assert_array_equal(c[k], fast[1][k])
