@@ -688,9 +688,9 @@ def main(argv=None):
             sample = {}
             for k in keys:
                 loc = torch.as_tensor(np.ascontiguousarray(sample_local[k][:per])).to(dev)
-                full = torch.empty((world,) + tuple(loc.shape), dtype=loc.dtype, device=dev)
+                full = torch.empty((world * per,) + tuple(loc.shape[1:]), dtype=loc.dtype, device=dev)
                 dist.all_gather_into_tensor(full, loc)
-                sample[k] = full.reshape((world * per,) + tuple(loc.shape[1:])).cpu().numpy()
+                sample[k] = full.cpu().numpy()
             if "arm" in sample_local and sample_local["arm"] is None:
                 sample["arm"] = None
             rows = torch.as_tensor(np.concatenate([plan.piece(r, 0)[0] + np.arange(per) for r in range(world)])).to(dev)
@@ -707,7 +707,7 @@ def main(argv=None):
                                   "stripe c in flight while stripe c + 1 is solved",
                           "final": "none in the timed steps; one final RCCL all-gather of joints [n,7] f64 + state u8 (timed separately)",
                           "none": "none"}[gather_mode]
-            if args.backend != "nccl":
+            if args.backend != "nccl" and gather_mode != "none":
                 collective += f" [backend {args.backend}: rehearsal, not RCCL]"
         line = {
             "metric": "IK solves/sec (7-DoF r_arm, batched poses)",

@@ -485,36 +485,30 @@ def _run_continuous(c, arm, Ms, start_joints=None, start_pose=None):
 
 def test_control_continuous_golden_default_start(golden_dir, torch_mod):
     """G6: 6 trajectories x 400 steps per arm recorded from the reference with a fake clock, started from the
-    constructor's default arms-along-the-body configuration; all trajectories of an arm advance together, one kernel
-    launch per control step, state carried in HBM between launches.
+    constructor's default arms-along-the-body configuration — the one every real ControlIK() caller starts from
+    (control_ik.py:31-35, 296-325); all trajectories of an arm advance together, one kernel launch per control step,
+    state carried in HBM between launches.
 
-    For that default configuration the reference's start-up ternary search (utils.py:302-319) compares two distances
-    that are equal up to rounding (the optimum -pi/2 is centred between mid1 and mid2 at one iteration), so which
-    half it keeps is decided by the last bit of NumPy's arithmetic; any theta within the search tolerance (0.01) is
-    an equally valid outcome.  Flags and states must match exactly; theta and joints must agree exactly from the
-    step at which the rate-limited theta has re-converged (it moves d_theta_max per step), and stay within the
-    tolerance before."""
+    The default pose is the fully extended arm: is_reachable_no_limits pulls the wrist back onto the u + f sphere
+    (symbolic_ik.py:102-105) and the elbow circle has a radius of 5.3e-5 m, so the start-up ternary search
+    (utils.py:302-319) compares joint sets whose elbow-yaw / wrist-yaw split is conditioned like 1e-16 / 5e-5.  Its 16
+    comparisons differ by >= 3e-4 rad (recorded from the reference: iteration 14 f1 - f2 = -3.2e-4, 15: +4.5e-4), far
+    above that noise: the kernels take the reference's branch at every iteration and land on its theta,
+    -1.575442041685776 (r) — asserted here from step 0: flags and states exact, carried theta <= 1e-9, joints <= 1e-7
+    (north-star bar 1e-6)."""
     g = load(golden_dir, "g6_control_continuous.npz")
     c = make_control()
-    frac = {}
     for arm in ("r_arm", "l_arm"):
         Ms, J, F, S, TH = g[f"{arm}_M"], g[f"{arm}_joints"], g[f"{arm}_reachable"], g[f"{arm}_state"], g[f"{arm}_previous_theta"]
         out, st = _run_continuous(c, arm, Ms)
-        n_conv = 0
         for i, res in enumerate(out):
             np.testing.assert_array_equal(res["reachable"], F[:, i], err_msg=f"{arm} step {i}")
             np.testing.assert_array_equal(res["state"], S[:, i], err_msg=f"{arm} step {i}")
-            dth = res["theta"] - TH[:, i]
-            dth = np.abs(dth - 2 * np.pi * np.round(dth / (2 * np.pi)))  # theta is re-wrapped to (-pi, pi] every step
-            assert np.max(dth) < 0.01 + 1e-12, (arm, i)
-            conv = dth < 1e-9
-            assert np.max(np.abs(res["joints"][conv] - J[:, i][conv]), initial=0.0) < 1e-7, (arm, i)
-            assert np.max(np.abs(res["joints"] - J[:, i])) < 0.05
-            n_conv += int(conv.sum())
-        frac[arm] = n_conv / (len(out) * Ms.shape[0])
+            assert np.max(np.abs(res["theta"] - TH[:, i])) < 1e-9, (arm, i)
+            assert np.max(np.abs(res["joints"] - J[:, i])) < 1e-7, (arm, i)
         assert st[9].sum().item() == 0  # no emergency stop on these trajectories
-    # a trajectory re-converges when its theta reaches a target both runs share (interval end, preferred theta ...)
-    assert max(frac.values()) > 0.5 and min(frac.values()) > 0.05, frac
+    # the theta the start-up search must find (first step: previous_theta moves d_theta_max = 0.01 towards its target)
+    assert abs(abs(g["r_arm_previous_theta"][0, 0] - (-1.575442041685776)) - 0.01) < 1e-12
 
 
 def test_control_continuous_golden_explicit_start(golden_dir, torch_mod):
@@ -557,9 +551,8 @@ def test_control_continuous_scalar_api(golden_dir, torch_mod, monkeypatch):
             Clock.t += 1.0 / 120.0
             j, ok, st = c.symbolic_inverse_kinematics(arm, Ms[i], "continuous", d_theta_max=0.01)
             assert ok == bool(F[i]) and st == STATE_STRINGS[S[i]], (arm, i)
-            dth = abs(c.previous_theta[arm] - g[f"{arm}_previous_theta"][0, i])
-            assert dth < 0.01 + 1e-12  # default start: see test_control_continuous_golden_default_start
-            assert np.max(np.abs(np.asarray(j) - J[i])) < (1e-7 if dth < 1e-9 else 0.05), (arm, i)
+            assert abs(c.previous_theta[arm] - g[f"{arm}_previous_theta"][0, i]) < 1e-9, (arm, i)
+            assert np.max(np.abs(np.asarray(j) - J[i])) < 1e-7, (arm, i)
         assert not c.emergency_stop and not c.init
 
 
@@ -640,6 +633,49 @@ def test_continuous_run_equals_stepwise(golden_dir, torch_mod, run_mode):
     np.testing.assert_array_equal(res["reachable"], F.T)
     np.testing.assert_array_equal(res["state"], S.T)
     assert np.max(np.abs(res["joints"] - np.swapaxes(J, 0, 1))) < 1e-7
+
+
+def test_config5_full_size_against_checker(torch_mod, orc):
+    """BASELINE config 5 at its stated size: 4096 trajectories x 1000 control steps in one rsik_control_continuous_run
+    call (bench.py's generator and call), a 96-trajectory subsample re-walked step by step by the CPU checker's state
+    machine: flags and state codes exact, joints <= 1e-7 at every one of the 96 000 trajectory-steps, and the carried
+    state at the end; the other trajectories through size-independent properties (finite joints everywhere, every step
+    within the continuity thresholds of control_ik.py:398 from its predecessor, no emergency stop)."""
+    from bench import URDF as BENCH_URDF
+    from bench import make_config5_trajectories
+
+    n_traj, n_steps = 4096, 1000
+    traj = make_config5_trajectories(n_traj, n_steps, seed=20250204)
+    c = make_control()
+    assert BENCH_URDF == URDF
+    st = c.new_continuous_state("r_arm", n_traj)
+    res = c.run_continuous_trajectories("r_arm", traj, st, first_step_timed_out=True, current_pose=traj[0])
+    torch_mod.cuda.synchronize()
+    J = res["joints"].cpu().numpy()
+    F = res["reachable"].cpu().numpy()
+    S = res["state"].cpu().numpy()
+    assert np.isfinite(J).all() and st[9].sum().item() == 0
+    step = np.abs(np.diff(J, axis=0))
+    assert step[..., :4].max() <= 0.5 and step[..., 4:].max() <= 1.0
+    frac = F.mean()
+    assert 0.2 < frac < 0.5  # SURVEY 8(d): 66 % of the steps take the unreachable fallback on this generator
+    sub = np.arange(0, n_traj, n_traj // 96)[:96]
+    M12 = traj[:, :, torch_mod.as_tensor(sub).cuda()].cpu().numpy()          # [n_steps, 12, 96]
+    a = orc.Arm("r_arm", -1.01)
+    worst = 0.0
+    for col, k in enumerate(sub):
+        cs = orc.ContinuousState(c.previous_theta["r_arm"], c.previous_sol["r_arm"])
+        Ms = np.tile(np.eye(4), (n_steps, 1, 1))
+        Ms[:, :3, :3] = M12[:, :9, col].reshape(n_steps, 3, 3)
+        Ms[:, :3, 3] = M12[:, 9:, col]
+        for i in range(n_steps):
+            j, ok, code = orc.control_continuous_step(a, cs, Ms[i], timed_out=(i == 0), preferred_theta_arg=-4 * np.pi / 6,
+                                                      preferred_theta_self=c.preferred_theta["r_arm"], constrained_mode=0,
+                                                      current_joints=cs.previous_sol, current_pose=Ms[0])
+            assert ok == bool(F[i, k]) and code == S[i, k], (k, i)
+            worst = max(worst, float(np.max(np.abs(j - J[i, k]))))
+        assert abs(cs.previous_theta - float(st[0, k])) < 1e-9
+    assert worst < 1e-7, worst
 
 
 # ------------------------------------------------------------------------------------------ oracle-free properties
@@ -902,10 +938,9 @@ def test_solve_is_hipgraph_capturable(torch_mod, orc):
     torch_mod.cuda.synchronize()
     g = torch_mod.cuda.CUDAGraph()
     with torch_mod.cuda.graph(g, capture_error_mode="thread_local"):
-        solver._bind_stream()
-        plan["launch"]()
-        plan["launch"]()
-    solver._bind_stream()
+        cs = torch_mod.cuda.current_stream().cuda_stream  # a planned launch goes to its planning stream unless told otherwise
+        plan["launch"](cs)
+        plan["launch"](cs)
     for _ in range(2):
         pos, eul = batch()
         buf.copy_(soa(pos, eul, torch_mod))
