@@ -51,6 +51,13 @@ extern "C" {
 #define RSIK_STATE_EMPTY 7               /* ""  (continuous mode, reachable)    control_ik.py:297 */
 #define RSIK_STATE_EMERGENCY 8           /* emergency stop latched              control_ik.py:205-210 */
 
+/* ---- why an emergency stop tripped: one bit per message the reference appends to ControlIK.emergency_state
+ * (utils.multiturn_safety_check utils.py:544-566, utils.continuity_check utils.py:584-586) ---- */
+#define RSIK_EMERGENCY_SHOULDER_PITCH 1  /* "EMERGENCY STOP: shoulder pitch limit reached"  joint 0 beyond +-6 pi */
+#define RSIK_EMERGENCY_ELBOW_YAW 2       /* "EMERGENCY STOP: elbow yaw limit reached"       joint 2 */
+#define RSIK_EMERGENCY_WRIST_YAW 4       /* "EMERGENCY STOP: wrist yaw limit reached"       joint 6 */
+#define RSIK_EMERGENCY_CONTINUITY 8      /* " EMERGENCY STOP: joints are not continuous ..." continuous mode only */
+
 /* ---- arms ---- */
 #define RSIK_ARM_R 0
 #define RSIK_ARM_L 1
@@ -144,19 +151,17 @@ int rsik_set_arm(rsik_ctx *ctx, int arm, const double *consts_host, int count);
  *                           exhaustive wave-cooperative sweep, 2 = always the per-lane search
  *   RSIK_OPT_NO_TIPZ        non-zero: never use the goal stage specialised for tip_x = tip_y = 0
  *   RSIK_OPT_NO_MIRROR      non-zero: mixed r/l launches read every constant per lane (no mirror-image shortcut)
- *   RSIK_OPT_CONT_RUN_MODE  rsik_control_continuous_run: 0 = by batch size, 1 = always one launch walking all steps,
- *                           2 = always one launch per step
- *   RSIK_OPT_CONT_GROUP     rsik_control_continuous_*: 0 = by batch size, 1 = one trajectory per lane, 2 = one trajectory
- *                           per 16-lane group (small batches: 16x more waves, grid points evaluated in parallel) */
+ *   RSIK_OPT_CONT_RUN_MODE  rsik_control_continuous_run: 0 / 1 = the phased trajectory pipeline (see there), 2 = one launch
+ *                           of the step kernel per control step, exactly what n_steps calls of
+ *                           rsik_control_continuous_step issue */
 #define RSIK_OPT_SWEEP_MODE 1
 #define RSIK_OPT_NO_TIPZ 2
 #define RSIK_OPT_NO_MIRROR 3
 #define RSIK_OPT_CONT_RUN_MODE 4
 #define RSIK_CONT_RUN_AUTO 0
-#define RSIK_CONT_RUN_LOOP 1
+#define RSIK_CONT_RUN_PHASED 1
 #define RSIK_CONT_RUN_STEPS 2
-#define RSIK_OPT_CONT_GROUP 5
-#define RSIK_OPT_COUNT 6
+#define RSIK_OPT_COUNT 5
 int rsik_set_option(rsik_ctx *ctx, int option, int value);
 int rsik_get_option(const rsik_ctx *ctx, int option, int *value);
 
@@ -203,8 +208,8 @@ int rsik_solve(rsik_ctx *ctx, int64_t n, const double *const pose_soa[6], const 
  *   previous_sol_host 14 doubles: ControlIK.previous_sol["r_arm"], ["l_arm"] (control_ik.py:136,140)
  *   current_joints   [n,7] device or NULL (=> previous_sol of the pose's arm, control_ik.py:237-238)
  *   orbita3d_max_angle  wrist cone half-angle in radians (control_ik.py:84)
- *   joints [n,7], reachable [n], state [n] as above; emergency [n] uint8 or NULL: 1 where
- *   multiturn_safety_check tripped (utils.py:535-568).
+ *   joints [n,7], reachable [n], state [n] as above; emergency [n] uint8 or NULL: non-zero where
+ *   multiturn_safety_check tripped (utils.py:535-568), as RSIK_EMERGENCY_* cause bits.
  */
 int rsik_control_discrete(rsik_ctx *ctx, int64_t n, const double *const m12_soa[12], const uint8_t *arm,
                           int arm_uniform, int nb_search_points, double preferred_theta, int constrained_mode,
@@ -217,7 +222,9 @@ int rsik_control_discrete(rsik_ctx *ctx, int64_t n, const double *const m12_soa[
  * one control step per call.  The reference keeps previous_theta / previous_sol / init / emergency_stop on the
  * ControlIK object (control_ik.py:60-83); here they live in a caller-owned device array
  * cont_state[RSIK_CONT_STATE_ROWS][n] (SoA): row 0 previous_theta, rows 1-7 previous_sol, row 8 init (0/1),
- * row 9 emergency_stop (0/1), row 10 has_previous_sol (0/1).
+ * row 9 emergency_stop (0/1), row 10 has_previous_sol (0/1); written only by the step that trips an emergency stop:
+ * row 11 its RSIK_EMERGENCY_* cause bits and rows 12-18 the joints that failed the continuity check (the "joints" of
+ * the reference's message, utils.py:584-586; its "previous_joints" are rows 1-7).
  *
  *   m12_soa               goal matrices of this step (layout as rsik_control_discrete)
  *   current_pose_m12_soa  current_pose of trajectories that (re)initialise this step, or NULL (=> the goal matrix)
@@ -230,7 +237,7 @@ int rsik_control_discrete(rsik_ctx *ctx, int64_t n, const double *const m12_soa[
  *   state codes           RSIK_STATE_EMPTY when reachable, RSIK_STATE_LIMITED_BY_SHOULDER, the is_reachable state when
  *                         unreachable, RSIK_STATE_EMERGENCY while the emergency stop is latched.
  */
-#define RSIK_CONT_STATE_ROWS 11
+#define RSIK_CONT_STATE_ROWS 19
 int rsik_control_continuous_step(rsik_ctx *ctx, int64_t n, const double *const m12_soa[12],
                                  const double *const current_pose_m12_soa[12], const uint8_t *arm, int arm_uniform,
                                  const uint8_t *timed_out, double preferred_theta, const double *preferred_theta_self_host,
@@ -240,10 +247,20 @@ int rsik_control_continuous_step(rsik_ctx *ctx, int64_t n, const double *const m
 
 /*
  * rsik_control_continuous_run — n_steps consecutive control steps of n trajectories from one host call (the whole
- * trajectory batch resident in HBM).  Batches that do not fill the GPU are solved by ONE launch whose kernel walks the
- * steps itself, the per-trajectory state in registers and the next step's goal matrices in flight (4096 trajectories:
- * 9.7 us per step against 13.4 us for one launch per step); chip-filling batches (>= 2^19 trajectories) get one launch
- * per step.  Either way the result equals n_steps calls of rsik_control_continuous_step.
+ * trajectory batch resident in HBM).  The result equals n_steps calls of rsik_control_continuous_step, but the work is
+ * not done step by step: most of a control step does not depend on the previous one — the goal conversion,
+ * is_reachable / is_reachable_no_limits and the 10-point search for the target theta (control_ik.py:327-388 up to the
+ * rate limiter) are functions of the pose alone — so the batch is solved in four phases per block of steps:
+ *   1. prepare   one thread per (step, trajectory), chip-filling: geometry + target theta -> workspace
+ *   2. theta     one thread per trajectory, sequential over steps: the d_theta_max rate limiter and
+ *                limit_theta_to_interval (the only recurrence on previous_theta)
+ *   3. joints    one thread per (step, trajectory): get_joints at the limited theta + the Orbita3D cone clamp
+ *   4. chain     eight lanes per trajectory (one per joint), sequential over steps: allow_multiturn, the +-6 pi clamp,
+ *                continuity_check and the emergency latch (the recurrence on previous_sol); steps whose get_joints
+ *                hit an exact singularity (fallback to previous_sol[0] / [2]) are recomputed here
+ * The workspace (23 doubles per step and trajectory of a block, at most 256 MB) belongs to the context and is
+ * allocated on first use (not capturable into a hipGraph for that reason).  4096 trajectories x 1000 steps: see
+ * DESIGN.md section 4.
  *   m12_steps        device [n_steps][12][n]: the goal matrices of every step
  *   current_pose_m12_soa / current_joints   used by the first step only (see rsik_control_continuous_step)
  *   first_step_timed_out  non-zero: every trajectory (re)initialises on the first step (the reference's behaviour for

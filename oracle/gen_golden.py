@@ -719,6 +719,119 @@ def gen_custom_urdf_control(out, n=512, n_traj=4, n_steps=200):
     np.savez_compressed(os.path.join(out, "g10_custom_urdf_control.npz"), **data)
 
 
+# ----------------------------------------------------------------------------------------
+# G11: emergency stops and the diagnostics the reference reports for them
+# (utils.multiturn_safety_check utils.py:535-568, utils.continuity_check utils.py:571-589,
+#  ControlIK.symbolic_inverse_kinematics control_ik.py:196-210: the latched state returns emergency_state as `state`)
+# ----------------------------------------------------------------------------------------
+def _near_limit(jstar, sign, delta=0.1):
+    """previous value of a joint such that allow_multiturn(jstar, prev) = prev + sign * delta lands beyond +-6 pi."""
+    lim = 6 * np.pi
+    if sign > 0:
+        m = np.ceil((lim - jstar) / (2 * np.pi))
+        return jstar + 2 * np.pi * m - delta
+    m = np.ceil((lim + jstar) / (2 * np.pi))
+    return jstar - 2 * np.pi * m + delta
+
+
+def gen_emergency(out):
+    rng = np.random.default_rng(11)
+    data = {}
+    real_time = ref_control_mod.time
+    cases = [((0, +1),), ((0, -1),), ((2, +1),), ((2, -1),), ((6, +1),), ((6, -1),), ((0, -1), (6, +1)), ((0, +1), (2, -1), (6, -1))]
+    for arm in ARMS:
+        ai = ARMS.index(arm)
+        # ---- discrete mode: previous_sol next to the +-6 pi multiturn limit
+        D = dict(M=[], current_joints=[], joints1=[], ok1=[], state1=[], emergency_state=[], joints2=[], ok2=[], state2=[], cause=[])
+        tries = 0
+        for case in cases * 2:
+            while True:
+                tries += 1
+                pos, eul = trajectory_pose(11.0 + rng.uniform(0, 40.0), arm)
+                M = pose_to_matrix(pos, eul)
+                c0 = quiet(ControlIK, urdf_path="../config_files/reachy2.urdf")
+                jstar, ok, _ = quiet(c0.symbolic_inverse_kinematics, arm, M, "discrete")
+                if ok:
+                    break
+            jstar = np.array(jstar, dtype=float)
+            cur = [list(ref_default_joints(0)), list(ref_default_joints(1))]
+            prev = jstar + rng.uniform(-0.05, 0.05, 7)
+            cause = 0
+            for (k, sign) in case:
+                prev[k] = _near_limit(jstar[k], sign)
+                cause |= {0: 1, 2: 2, 6: 4}[k]
+            cur[ai] = list(prev)
+            c = quiet(ControlIK, current_joints=cur, urdf_path="../config_files/reachy2.urdf")
+            j1, ok1, st1 = quiet(c.symbolic_inverse_kinematics, arm, M, "discrete")
+            assert c.emergency_stop, (arm, case)
+            es = c.emergency_state
+            j2, ok2, st2 = quiet(c.symbolic_inverse_kinematics, arm, M, "discrete")
+            assert st2 == es and not ok2
+            for key, val in (("M", M), ("current_joints", np.array(cur)), ("joints1", np.array(j1, dtype=float)), ("ok1", bool(ok1)),
+                             ("state1", st1), ("emergency_state", es), ("joints2", np.array(j2, dtype=float)), ("ok2", bool(ok2)),
+                             ("state2", st2), ("cause", cause)):
+                D[key].append(val)
+        for key, val in D.items():
+            data[f"{arm}_discrete_{key}"] = np.array(val)
+        # ---- continuous mode: a jump of the goal (continuity_check) and a start next to the multiturn limit
+        n_traj, n_steps, jump_at = 6, 12, 6
+        C = dict(M=np.zeros((n_traj, n_steps, 4, 4)), joints=np.zeros((n_traj, n_steps, 7)), ok=np.zeros((n_traj, n_steps), dtype=np.uint8),
+                 state=[], emergency_state=[], start_joints=np.full((n_traj, 7), np.nan), control_type=[], estop=np.zeros((n_traj, n_steps), dtype=np.uint8),
+                 previous_sol=np.zeros((n_traj, n_steps, 7)))
+        for k in range(n_traj):
+            for attempt in range(200):  # draw phases until the scenario really trips the emergency stop
+                clock = FakeClock()
+                ref_control_mod.time = clock
+                try:
+                    c = quiet(ControlIK, urdf_path="../config_files/reachy2.urdf")
+                    phase = rng.uniform(0.0, 40.0)
+                    states, ctypes, es_list = [], [], []
+                    multiturn_start = k >= 4
+                    if multiturn_start:
+                        pos, eul = trajectory_pose(11.0 + phase, arm)
+                        cprobe = quiet(ControlIK, urdf_path="../config_files/reachy2.urdf")
+                        jstar, _, _ = quiet(cprobe.symbolic_inverse_kinematics, arm, pose_to_matrix(pos, eul), "continuous", d_theta_max=0.01)
+                        start = np.array(jstar, dtype=float) + rng.uniform(-0.02, 0.02, 7)
+                        which = 0 if k == 4 else 6
+                        start[which] = _near_limit(float(jstar[which]), -1 if k == 4 else +1)
+                        C["start_joints"][k] = start
+                    for i in range(n_steps):
+                        t = i / 120.0 + 11.0 + phase
+                        if not multiturn_start and i >= jump_at:
+                            t += 2.5 + k  # the goal jumps: some joint moves by more than its continuity threshold
+                        pos, eul = trajectory_pose(t, arm)
+                        M = pose_to_matrix(pos, eul)
+                        clock.t += 1.0 / 120.0
+                        ctype = "unfreeze" if i == n_steps - 3 else "continuous"
+                        kw = dict(current_joints=list(C["start_joints"][k])) if (multiturn_start and i == 0) else {}
+                        j, ok, st = quiet(c.symbolic_inverse_kinematics, arm, M, ctype, d_theta_max=0.01, **kw)
+                        C["M"][k, i] = M
+                        C["joints"][k, i] = np.array(j, dtype=float)
+                        C["ok"][k, i] = bool(ok)
+                        C["estop"][k, i] = bool(c.emergency_stop)
+                        C["previous_sol"][k, i] = np.array(c.previous_sol[arm], dtype=float)
+                        states.append(st)
+                        ctypes.append(ctype)
+                        es_list.append(c.emergency_state)
+                finally:
+                    ref_control_mod.time = real_time
+                if C["estop"][k, : n_steps - 3].any():
+                    break
+            else:
+                raise AssertionError((arm, k, "no emergency stop in 200 draws"))
+            C["state"].append(states)
+            C["control_type"].append(ctypes)
+            C["emergency_state"].append(es_list)
+        for key, val in C.items():
+            data[f"{arm}_continuous_{key}"] = np.array(val)
+    np.savez_compressed(os.path.join(out, "g11_emergency.npz"), **data)
+
+
+def ref_default_joints(k):
+    return [[0.0, 0.2617993877991494, -0.17453292519943295, 0.0, 0.0, 0.0, 0.0],
+            [0.0, -0.2617993877991494, 0.17453292519943295, 0.0, 0.0, 0.0, 0.0]][k]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
@@ -729,7 +842,7 @@ def main():
     steps = [("g0", gen_constants), ("g1", gen_catalogue), ("g2", gen_sweep), ("g3", gen_reachable),
              ("g4", gen_control), ("g5", gen_helpers), ("g6", gen_continuous),
              ("g7", gen_continuous_start), ("g8", gen_matrix_edges),
-             ("g9", gen_custom_geometry), ("g10", gen_custom_urdf_control)]
+             ("g9", gen_custom_geometry), ("g10", gen_custom_urdf_control), ("g11", gen_emergency)]
     for name, fn in steps:
         if args.only and name not in args.only.split(","):
             continue

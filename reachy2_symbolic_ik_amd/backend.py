@@ -269,7 +269,7 @@ class HipSolver:
         orbita3d_max_angle: float = float(np.deg2rad(42.5)),
         out: Optional[Dict[str, torch.Tensor]] = None,
     ) -> Dict[str, torch.Tensor]:
-        """One control step for n trajectories; `cont_state` ([11, n], see include/rsik.h) is updated in place."""
+        """One control step for n trajectories; `cont_state` ([RSIK_CONT_STATE_ROWS, n], see include/rsik.h) is updated in place."""
         if m12_soa.dim() != 2 or m12_soa.shape[0] != 12:
             raise ValueError("m12_soa must have shape [12, n]")
         n = int(m12_soa.shape[1])

@@ -46,6 +46,19 @@ def matrices_to_m12_soa(M: Any, device: torch.device) -> torch.Tensor:
     return torch.cat([rot, tr], dim=1).t().contiguous()
 
 
+def emergency_messages(cause: int, previous_joints: Any = None, joints: Any = None) -> str:
+    """What the reference appends to ControlIK.emergency_state for the RSIK_EMERGENCY_* cause bits of one call:
+    utils.multiturn_safety_check (utils.py:544-566), then utils.continuity_check (utils.py:584-586), in that order."""
+    text = ""
+    for bit, joint in ((_abi.EMERGENCY_SHOULDER_PITCH, "shoulder pitch"), (_abi.EMERGENCY_ELBOW_YAW, "elbow yaw"),
+                       (_abi.EMERGENCY_WRIST_YAW, "wrist yaw")):
+        if cause & bit:
+            text += "\n" + f"EMERGENCY STOP: {joint} limit reached"
+    if cause & _abi.EMERGENCY_CONTINUITY:
+        text += f"\n EMERGENCY STOP: joints are not continuous \n previous_joints: {np.asarray(previous_joints)} \n joints: {np.asarray(joints)}"
+    return text
+
+
 def angle_diff(a: float, b: float) -> float:
     """utils.py:486-490."""
     d = a - b
@@ -202,25 +215,27 @@ class ControlIK:
 
     # One scalar call = one pinned upload (goal matrix + whatever else the call reads), one launch, one download (joints,
     # flags and, in continuous mode, the trajectory state), one stream synchronisation.  Device layout of the packed
-    # buffer, in doubles: [0:11] continuous state, [11:23] goal matrix (12), [23:35] current pose (12), [35:42]
-    # current_joints, [42:49] joints out, then 8 bytes: reachable, state, emergency, timed_out.
+    # buffer, in doubles: [0:19] continuous state, [19:31] goal matrix (12), [31:43] current pose (12), [43:50]
+    # current_joints, [50:57] joints out, then 8 bytes: reachable, state, emergency, timed_out.
+    _IO_M, _IO_CP, _IO_CJ, _IO_J, _IO_B = 19, 31, 43, 50, 57
+
     def _scalar_io(self):
         io = getattr(self, "_io", None)
         if io is None:
             import ctypes as C
 
             dev = self._solver.device
-            nd = 50
+            nd = self._IO_B + 1
             h = torch.empty(nd, dtype=torch.float64).pin_memory()
             d = torch.empty(nd, dtype=torch.float64, device=dev)
             base = d.data_ptr()
             io = self._io = {
                 "h": h, "h_np": h.numpy(), "h_bytes": h.numpy().view(np.uint8), "d": d,
-                "state": C.c_void_p(base), "m_cols": (C.c_void_p * 12)(*[base + 8 * (11 + k) for k in range(12)]),
-                "cp_cols": (C.c_void_p * 12)(*[base + 8 * (23 + k) for k in range(12)]),
-                "cj": C.c_void_p(base + 8 * 35), "joints": C.c_void_p(base + 8 * 42),
-                "reachable": C.c_void_p(base + 8 * 49), "code": C.c_void_p(base + 8 * 49 + 1),
-                "emergency": C.c_void_p(base + 8 * 49 + 2), "timed_out": C.c_void_p(base + 8 * 49 + 3),
+                "state": C.c_void_p(base), "m_cols": (C.c_void_p * 12)(*[base + 8 * (self._IO_M + k) for k in range(12)]),
+                "cp_cols": (C.c_void_p * 12)(*[base + 8 * (self._IO_CP + k) for k in range(12)]),
+                "cj": C.c_void_p(base + 8 * self._IO_CJ), "joints": C.c_void_p(base + 8 * self._IO_J),
+                "reachable": C.c_void_p(base + 8 * self._IO_B), "code": C.c_void_p(base + 8 * self._IO_B + 1),
+                "emergency": C.c_void_p(base + 8 * self._IO_B + 2), "timed_out": C.c_void_p(base + 8 * self._IO_B + 3),
                 "pts": np.zeros(2), "ps": np.zeros((2, 7)),
             }
         return io
@@ -235,8 +250,8 @@ class ControlIK:
 
         io = self._scalar_io()
         hn = io["h_np"]
-        self._pack_m12(hn[11:23], M)
-        hn[35:42] = current_joints
+        self._pack_m12(hn[self._IO_M: self._IO_M + 12], M)
+        hn[self._IO_CJ: self._IO_CJ + 7] = current_joints
         sv = self._solver
         io["ps"][:] = self._previous_sol_2x7()
         self._upload_arms()
@@ -249,8 +264,8 @@ class ControlIK:
                 float(self.orbita3D_max_angle), io["joints"], io["reachable"], io["code"], io["emergency"]))
             io["h"].copy_(io["d"], non_blocking=True)
             torch.cuda.current_stream(sv.device).synchronize()
-        flags = io["h_bytes"][8 * 49: 8 * 49 + 4]
-        return hn[42:49].tolist(), bool(flags[0]), STATE_STRINGS[int(flags[1])], bool(flags[2])
+        flags = io["h_bytes"][8 * self._IO_B: 8 * self._IO_B + 4]
+        return hn[self._IO_J: self._IO_J + 7].tolist(), bool(flags[0]), STATE_STRINGS[int(flags[1])], int(flags[2])
 
     # ------------------------------------------------------------------ reference API
     def symbolic_inverse_kinematics(
@@ -286,11 +301,11 @@ class ControlIK:
             M = np.asarray(M, dtype=np.float64)
             if name not in self.symbolic_ik_solver:
                 raise KeyError(name)
-            ik_joints, is_reachable, state, emergency = self._discrete_scalar(
+            ik_joints, is_reachable, state, cause = self._discrete_scalar(
                 name, M, np.asarray(current_joints, dtype=np.float64).reshape(7), constrained_mode, preferred_theta)
-            if emergency:
+            if cause:  # control_ik.py:486-495: multiturn_safety_check's messages, one per joint that hit +-6 pi
                 self.emergency_stop = True
-                self.emergency_state += "\nEMERGENCY STOP: multiturn limit reached"
+                self.emergency_state += emergency_messages(cause)
         else:
             raise ValueError(f"Unknown type {control_type}")
         self.previous_pose[name] = M
@@ -309,17 +324,19 @@ class ControlIK:
         hn = io["h_np"]
         hn[0] = self.previous_theta[name]
         has_prev = len(self.previous_sol[name]) == 7
-        hn[1:8] = self.previous_sol[name] if has_prev else 0.0
+        previous_sol = np.array(self.previous_sol[name], dtype=np.float64) if has_prev else np.zeros(7)
+        hn[1:8] = previous_sol
         hn[8] = 1.0 if self.init else 0.0
         hn[9] = 0.0
         hn[10] = 1.0 if has_prev else 0.0
-        self._pack_m12(hn[11:23], M)
-        self._pack_m12(hn[23:35], current_pose)
+        hn[11:19] = 0.0
+        self._pack_m12(hn[self._IO_M: self._IO_M + 12], M)
+        self._pack_m12(hn[self._IO_CP: self._IO_CP + 12], current_pose)
         cj = np.asarray(current_joints, dtype=np.float64)
         has_cj = cj.size == 7
         if has_cj:
-            hn[35:42] = cj.reshape(7)
-        io["h_bytes"][8 * 49 + 3] = 1 if timed_out else 0
+            hn[self._IO_CJ: self._IO_CJ + 7] = cj.reshape(7)
+        io["h_bytes"][8 * self._IO_B + 3] = 1 if timed_out else 0
         io["pts"][:] = [self.preferred_theta.get("r_arm", -4 * np.pi / 6), self.preferred_theta.get("l_arm", -np.pi + 4 * np.pi / 6)]
         sv = self._solver
         self._upload_arms()
@@ -333,23 +350,34 @@ class ControlIK:
                 io["code"]))
             io["h"].copy_(io["d"], non_blocking=True)
             torch.cuda.current_stream(sv.device).synchronize()
-        back = hn[0:11]
-        ik_joints = hn[42:49].copy()
-        flags = io["h_bytes"][8 * 49: 8 * 49 + 2]
+        back = hn[0:19]
+        ik_joints = hn[self._IO_J: self._IO_J + 7].copy()
+        flags = io["h_bytes"][8 * self._IO_B: 8 * self._IO_B + 2]
         self.previous_theta[name] = float(back[0])
         self.init = bool(back[8])
-        if back[9] != 0.0:
+        if back[9] != 0.0:  # control_ik.py:486-495, 396-401: the reference's own diagnostics for what tripped
             self.emergency_stop = True
-            self.emergency_state += f"\n EMERGENCY STOP: joints are not continuous or multiturn limit reached ({name})"
+            # continuity_check prints the previous_sol the step was checked against: after a (re)initialisation that is
+            # current_joints (control_ik.py:312), i.e. the state rows the kernel hands back
+            self.emergency_state += emergency_messages(int(back[11]), previous_joints=back[1:8].copy(), joints=back[12:19].copy())
         if not self.emergency_stop:
             self.previous_sol[name] = copy.deepcopy(ik_joints)
         else:
             self.previous_sol[name] = back[1:8].copy()
         return ik_joints, bool(flags[0]), STATE_STRINGS[int(flags[1])]
 
+    def emergency_report(self, cont_state: torch.Tensor) -> Dict[int, str]:
+        """For a batch state (new_continuous_state): trajectory index -> the text the reference would have put in
+        emergency_state when that trajectory's emergency stop tripped (cause bits + rejected joints, state rows 11-18)."""
+        st = cont_state.detach().cpu().numpy()
+        out: Dict[int, str] = {}
+        for i in np.nonzero(st[9] != 0.0)[0]:
+            out[int(i)] = emergency_messages(int(st[11, i]), previous_joints=st[1:8, i], joints=st[12:19, i])
+        return out
+
     # ------------------------------------------------------------------ MI355X-native batch API
     def new_continuous_state(self, name: Any, n: int) -> torch.Tensor:
-        """Per-trajectory state [11, n] initialised like a freshly constructed ControlIK (control_ik.py:133-160):
+        """Per-trajectory state [RSIK_CONT_STATE_ROWS, n] initialised like a freshly constructed ControlIK (control_ik.py:133-160):
         previous_theta / previous_sol of the arm(s), init = True, no emergency stop."""
         st = self._solver.new_continuous_state(n)
         if isinstance(name, str):

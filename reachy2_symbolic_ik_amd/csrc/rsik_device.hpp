@@ -608,6 +608,7 @@ struct JointsOut {
     double j[7];
     V3 elbow;
     bool projected;
+    bool sing;  // an exact singularity fell back to previous_joints[0] / [2] (S:751-753, 782-784)
     // unit vectors of the wrist angles, for ControlIK.safety_checks without re-evaluating sin/cos
     double c4, s4, c5, s5, c6, s6;
 };
@@ -760,6 +761,7 @@ __device__ JointsOut joints_from_theta_g(const Acc& A, Reach& r, const Goal& G, 
         if (sing_ey) o.j[2] = prev[2];
         if (tau_zero) o.j[4] = wr_zero > kPi ? wr_zero - kTwoPi : wr_zero;
     }
+    o.sing = sing_sp || sing_ey;
     o.c4 = cw; o.s4 = sw; o.c5 = cp; o.s5 = -spp;
     o.c6 = c6; o.s6 = s6;
     return o;
@@ -845,22 +847,23 @@ __device__ __forceinline__ double limit_theta_to_interval(double theta, double l
     return l0;
 }
 
-// ControlIK.safety_checks (C:464-497):
-//   utils.limit_orbita3d_joints (U:508-519): wrist triple as intrinsic XYZ -> ZYZ (alpha, beta, gamma), clamp
-//   beta to the Orbita3D cone, back to XYZ (scipy gimbal conventions: beta within 1e-7 of 0 or pi => gamma := 0);
-//   utils.allow_multiturn (U:493-505); utils.multiturn_safety_check (U:535-568).
+// ControlIK.safety_checks (C:464-497), in two halves:
+//   limit_wrist_cone — utils.limit_orbita3d_joints_wrist (U:508-532): wrist triple as intrinsic XYZ -> ZYZ (alpha, beta,
+//     gamma), clamp beta to the Orbita3D cone, back to XYZ (scipy gimbal conventions: beta within 1e-7 of 0 or pi =>
+//     gamma := 0).  A function of this step's joints only.
+//   multiturn_checks — utils.allow_multiturn (U:493-505) + utils.multiturn_safety_check (U:535-568): needs
+//     previous_sol, i.e. the previous step's result.  Returns the cause bits RSIK_EMERGENCY_* of the limits that tripped
+//     (the reference appends one message per tripped joint to ControlIK.emergency_state).
 // The wrist angles enter as unit vectors (c, s) so no sin/cos is evaluated for joints that came out of atan2.
-__device__ __forceinline__ bool safety_checks(UnitAtanTab utab, double (&j)[7], double ca, double sa, double cb, double sb,
-                                              double cc, double sc, const double* prev, double max_angle, double cos_max,
-                                              double sin_max) {
+__device__ __forceinline__ void limit_wrist_cone(UnitAtanTab utab, double (&j)[7], double ca, double sa, double cb, double sb,
+                                                 double cc, double sc, double cos_max, double sin_max) {
     // W = Rx(a) Ry(b) Rz(c); its third column (W02, W12, W22) = (sin beta cos alpha, sin beta sin alpha, cos beta) is
     // the wrist axis, so everything about beta in [0, pi] is decided on its cosine / sine, no angle is formed:
     //   beta <= 1e-7 or pi - beta <= 1e-7 (SciPy's gimbal cases)  <=>  sin beta <= sin(1e-7), sign of cos beta
     //   beta > max_angle (the only clamp that can act, beta >= 0)   <=>  cos beta < cos(max_angle)
-    double W00 = cb * cc, W01 = -cb * sc, W02 = sb;
+    double W00 = cb * cc, W02 = sb;
     double W10 = ca * sc + sa * sb * cc, W12 = -sa * cb;
     double W20 = sa * sc - ca * sb * cc, W21 = sa * cc + ca * sb * sc, W22 = ca * cb;
-    (void)W01; (void)max_angle;
     const double sb2 = W02 * W02 + W12 * W12;
     double cal, sal, cga, sga;  // cos/sin of alpha, gamma
     double cbe = W22, sbe;
@@ -882,32 +885,43 @@ __device__ __forceinline__ bool safety_checks(UnitAtanTab utab, double (&j)[7], 
     // square root makes all three direction vectors unit and the table atan2 applies.
     double V02 = cal * sbe, V12 = sal * sbe, V22 = cbe;
     double V01 = -cal * cbe * sga - sal * cga, V00 = cal * cbe * cga - sal * sga;
-    {
-        const double cp2 = fma(-V02, V02, 1.0);
-        const double icp = rsqrt_fast(cp2);
-        const double ss[3] = {-V12 * icp, V02, -V01 * icp};
-        const double cs[3] = {V22 * icp, cp2 * icp, V00 * icp};
-        double aa[3];
-        unit_atan2_n<3>(utab, ss, cs, aa);
-        j[4] = aa[0]; j[5] = aa[1]; j[6] = aa[2];
-    }
-    bool emergency = false;
-    // utils.allow_multiturn (U:493-505): prev + angle_diff(j, prev); the wrap only acts when they are > pi apart
-#pragma unroll
-    for (int k = 0; k < 7; k++) {
-        double t = (j[k] - prev[k]) + kPi;
-        if (RSIK_RARE(!(t >= 0.0 && t < kTwoPi))) t = pymod_2pi(t);
-        j[k] = prev[k] + (t - kPi);
-    }
+    const double cp2 = fma(-V02, V02, 1.0);
+    const double icp = rsqrt_fast(cp2);
+    const double ss[3] = {-V12 * icp, V02, -V01 * icp};
+    const double cs[3] = {V22 * icp, cp2 * icp, V00 * icp};
+    double aa[3];
+    unit_atan2_n<3>(utab, ss, cs, aa);
+    j[4] = aa[0]; j[5] = aa[1]; j[6] = aa[2];
+}
+// one joint: utils.allow_multiturn (U:493-505): prev + angle_diff(j, prev); the wrap only acts when they are > pi apart
+__device__ __forceinline__ double allow_multiturn_one(double j, double prev) {
+    double t = (j - prev) + kPi;
+    if (RSIK_RARE(!(t >= 0.0 && t < kTwoPi))) t = pymod_2pi(t);
+    return prev + (t - kPi);
+}
+// one joint of utils.multiturn_safety_check (U:535-568): joints 0, 2, 6 are clamped to +-6 pi; true if it tripped
+__device__ __forceinline__ bool multiturn_limit_one(double& j) {
     const double lim = 6 * kPi;
+    bool hit = false;
+    if (j > lim) { j = lim; hit = true; }
+    if (j < -lim) { j = -lim; hit = true; }
+    return hit;
+}
+__device__ __forceinline__ int multiturn_checks(double (&j)[7], const double* prev) {
 #pragma unroll
-    for (int k = 0; k < 7; k++) {
-        if (k == 0 || k == 2 || k == 6) {
-            if (j[k] > lim) { j[k] = lim; emergency = true; }
-            if (j[k] < -lim) { j[k] = -lim; emergency = true; }
-        }
-    }
-    return emergency;
+    for (int k = 0; k < 7; k++) j[k] = allow_multiturn_one(j[k], prev[k]);
+    int cause = 0;
+    if (multiturn_limit_one(j[0])) cause |= RSIK_EMERGENCY_SHOULDER_PITCH;
+    if (multiturn_limit_one(j[2])) cause |= RSIK_EMERGENCY_ELBOW_YAW;
+    if (multiturn_limit_one(j[6])) cause |= RSIK_EMERGENCY_WRIST_YAW;
+    return cause;
+}
+__device__ __forceinline__ int safety_checks(UnitAtanTab utab, double (&j)[7], double ca, double sa, double cb, double sb,
+                                             double cc, double sc, const double* prev, double max_angle, double cos_max,
+                                             double sin_max) {
+    (void)max_angle;
+    limit_wrist_cone(utab, j, ca, sa, cb, sb, cc, sc, cos_max, sin_max);
+    return multiturn_checks(j, prev);
 }
 
 // The grid part of utils.get_best_discrete_theta (U:372-396), one pose per lane, walking every grid point.

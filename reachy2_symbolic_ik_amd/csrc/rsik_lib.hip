@@ -630,19 +630,20 @@ __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR void co
         fast_sincos(jv[5], &s5, &c5);
         fast_sincos(jv[6], &s6, &c6);
     }
-    bool em = safety_checks(A.utab, jv, c4, s4, c5, s5, c6, s6, prev, K.max_angle, K.cos_max, K.sin_max);
+    const int em = safety_checks(A.utab, jv, c4, s4, c5, s5, c6, s6, prev, K.max_angle, K.cos_max, K.sin_max);
     store_rows<7>(K.joints, wave_base, K.n, lane, &lds_slab[wave][0][0], jv);
     if (live) {
         if (K.reachable) K.reachable[i] = found ? 1 : 0;
         if (K.state) K.state[i] = (uint8_t)st_code;
-        if (K.emergency) K.emergency[i] = em ? 1 : 0;
+        if (K.emergency) K.emergency[i] = (uint8_t)em;  // RSIK_EMERGENCY_* cause bits
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// ControlIK continuous mode (C:276-407), one launch = one control step of n independent trajectories.
+// ControlIK continuous mode (C:276-407).
 // Per-trajectory state lives in a caller-owned SoA array state[RSIK_CONT_STATE_ROWS][n]:
-//   row 0 previous_theta, rows 1-7 previous_sol, row 8 init, row 9 emergency_stop, row 10 has_previous_sol.
+//   row 0 previous_theta, rows 1-7 previous_sol, row 8 init, row 9 emergency_stop, row 10 has_previous_sol,
+//   row 11 cause bits and rows 12-18 rejected joints of the step that tripped the emergency stop.
 // The reference's wall-clock timeout (C:296-304) becomes the per-trajectory `timed_out` byte.
 // ------------------------------------------------------------------------------------------
 struct ContinuousArgs {
@@ -652,10 +653,7 @@ struct ContinuousArgs {
     const uint8_t* arm;
     const uint8_t* timed_out;     // NULL => nobody timed out
     int euler_roundtrip;          // RSIK_OPT_EULER_ROUNDTRIP
-    // trajectory mode (rsik_control_continuous_run): the kernel itself walks n_steps control steps with the trajectory
-    // state in registers; step s reads in[c] + s * 12 n and writes joints + s * 7 n, reachable / state + s * n
-    int64_t n_steps;              // 1 for rsik_control_continuous_step
-    int first_timed_out;          // non-zero: every trajectory (re)initialises on step 0
+    int first_timed_out;          // non-zero: every trajectory (re)initialises
     double pref_arg[2];           // preferred_theta argument per arm slot (mirrored for l)
     double pref_self[2];          // ControlIK.preferred_theta[name] per arm slot
     double lim[2][2];
@@ -669,9 +667,78 @@ struct ContinuousArgs {
     ArmC arms[2];
 };
 
-// LOOP = false: the single-step kernel (n_steps == 1; no prefetch registers, 2 waves/SIMD for large batches);
-// LOOP = true: trajectory mode, 1 wave/SIMD with the next step's goal matrix in flight.
-template <bool MIXED, bool LOOP>
+// C:296-325: (re)initialisation of a trajectory whose caller timed out: previous_sol := current_joints and
+// previous_theta := the theta of the current pose closest to them (utils.get_best_theta_to_current_joints).
+// `only_init`: the launch does nothing else (rsik_control_continuous_run's first phase).
+template <class Acc>
+__device__ __forceinline__ void continuous_reinit(const Acc& A, const ContinuousArgs& K, int64_t ii, double pref,
+                                                  double& prev_theta, double (&prev_sol)[7]) {
+    if (K.current_joints) {
+#pragma unroll
+        for (int k = 0; k < 7; k++) prev_sol[k] = K.current_joints[ii * 7 + k];
+    }
+    Rot Rc;
+    V3 cpos;
+    load_m12(K.cur_pose[0] ? K.cur_pose : K.in, ii, Rc, cpos, K.euler_roundtrip);
+    Reach rc = reach<true>(A, cpos, Rc);
+    prev_theta = best_theta_to_current_joints(A, rc, Rc, prev_sol, pref);
+}
+
+// U:571-589 continuity_check with the thresholds of C:398
+__device__ __forceinline__ bool joints_discontinuous(const double (&jv)[7], const double (&prev)[7]) {
+    bool disc = false;
+#pragma unroll
+    for (int k = 0; k < 7; k++) disc = disc || (fabs(angle_diff(jv[k], prev[k])) > (k < 4 ? 0.5 : 1.0));
+    return disc;
+}
+
+// The state-independent front half of a control step (C:327-388 up to the rate limiter): is_reachable, and then
+// either the 10-point search for the target theta (get_best_continuous_theta2 -> get_best_discrete_theta, U:220-264)
+// or, for an unreachable goal, is_reachable_no_limits.  `r` is left holding the geometry get_joints will use.
+struct ThetaTarget {
+    bool ok_limits;   // is_reachable succeeded
+    bool found;       // ... and the grid search found an elbow-ok theta
+    double theta;     // the search's theta (found only)
+    int code;         // state code the step reports
+};
+template <class Acc>
+__device__ __forceinline__ ThetaTarget continuous_target(const Acc& A, V3 pos, const V3 woff, double pref_self, Reach& r) {
+    ThetaTarget T;
+    r = reach_g<false, false>(A, pos, woff);
+    T.ok_limits = r.ok;
+    T.found = false;
+    T.theta = 0.0;
+    T.code = RSIK_STATE_EMPTY;
+    if (r.ok) {
+        T.found = best_discrete_theta_serial(A, r, 10, pref_self, T.theta);
+        if (!T.found) T.code = RSIK_STATE_LIMITED_BY_SHOULDER;
+    } else {
+        T.code = r.state;
+        r = reach_g<true>(A, pos, woff);
+    }
+    return T;
+}
+// The recurrence on previous_theta: rate limiter of get_best_continuous_theta2 (U:252-264) / tend_to_preferred_theta
+// (U:115-127), then limit_theta_to_interval (U:93-112).
+__device__ __forceinline__ double continuous_next_theta(bool ok_limits, bool found, double target, double pref_arg,
+                                                        double prev_theta, double d_theta_max, double l0, double l1) {
+    double theta;
+    if (ok_limits) {
+        theta = found ? target : prev_theta;
+        if (found && !(fabs(angle_diff(theta, prev_theta)) < d_theta_max)) {
+            const double ad = angle_diff(theta, prev_theta);
+            theta = prev_theta + (ad / fabs(ad)) * d_theta_max;
+        }
+    } else {
+        const double ad = angle_diff(pref_arg, prev_theta);
+        theta = (fabs(ad) < d_theta_max) ? pref_arg : (prev_theta + (ad / fabs(ad)) * d_theta_max);
+    }
+    return limit_theta_to_interval(theta, l0, l1);
+}
+
+// One launch = one control step of n independent trajectories (rsik_control_continuous_step): everything fused, the
+// trajectory state makes one round trip through HBM.
+template <bool MIXED>
 __global__ __launch_bounds__(kBlock) void control_continuous_kernel(const ContinuousArgs K) {
     __shared__ double lds_out[kBlock / 64][64 * 7];
     const int lane = threadIdx.x & 63;
@@ -695,143 +762,320 @@ __global__ __launch_bounds__(kBlock) void control_continuous_kernel(const Contin
     bool emergency = K.st[9 * n + ii] != 0.0;
     bool has_prev = K.st[10 * n + ii] != 0.0;
 
-    // One launch = K.n_steps control steps (1 for the step entry point).  With 4096 trajectories a launch is one wave
-    // on 64 of the 1024 SIMDs and its time is that wave's latency; walking the steps inside the kernel keeps tables,
-    // constants and the trajectory state on chip and asks for the next step's goal matrix while the current step is
-    // being solved, instead of paying launch + kernarg + staging + state round trip on every step.
-    double m_next[LOOP ? 12 : 1];
-    if constexpr (LOOP) {
+    double jv[7], rejected[7];
+    int st_code = RSIK_STATE_EMPTY;
+    int cause = 0;
+    bool ok = false;
+    if (emergency) {  // C:205-210
 #pragma unroll
-        for (int k = 0; k < 12; k++) m_next[k] = K.in[k][ii];
-    }
-    const int64_t n_steps = LOOP ? K.n_steps : 1;
-#ifdef RSIK_CONT_PROBE
-    // diagnostic build only: core-clock ticks per phase of a control step, summed over the steps (lane 0 of each wave
-    // writes them over its trajectory's state rows 1-6 at the end)
-    uint64_t pc[6] = {0, 0, 0, 0, 0, 0};
-#define RSIK_CP(k) { const uint64_t now_ = __builtin_readcyclecounter(); pc[k] += now_ - pt; pt = now_; }
-#else
-#define RSIK_CP(k)
-#endif
-    auto one_step = [&](const int64_t step) {
-#ifdef RSIK_CONT_PROBE
-        uint64_t pt = __builtin_readcyclecounter();
-#endif
-        double m_cur[12];
-        if constexpr (LOOP) {
-#pragma unroll
-            for (int k = 0; k < 12; k++) m_cur[k] = m_next[k];
-            if (step + 1 < n_steps) {
-#pragma unroll
-                for (int k = 0; k < 12; k++) m_next[k] = K.in[k][(step + 1) * 12 * n + ii];
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 12; k++) m_cur[k] = K.in[k][ii];
-        }
-        double jv[7];
-        int st_code = RSIK_STATE_EMPTY;
-        bool ok = false;
-        if (emergency) {  // C:205-210
-#pragma unroll
-            for (int k = 0; k < 7; k++) jv[k] = prev_sol[k];
-            st_code = RSIK_STATE_EMERGENCY;
-        } else {
-            Rot Rg;
-            V3 pos;
-            goal_from_m12(m_cur, Rg, pos, K.euler_roundtrip);
-            const double pref = K.pref_arg[slot];
-            if (step == 0 && (K.first_timed_out || (K.timed_out && K.timed_out[ii]))) { has_prev = false; init = true; }  // C:298-304
-            if (!has_prev) {  // C:306-325
-                if (K.current_joints) {
-#pragma unroll
-                    for (int k = 0; k < 7; k++) prev_sol[k] = K.current_joints[ii * 7 + k];
-                }
-                has_prev = true;
-                Rot Rc;
-                V3 cpos;
-                load_m12(K.cur_pose[0] ? K.cur_pose : K.in, ii, Rc, cpos, K.euler_roundtrip);
-                Reach rc = reach<true>(A, cpos, Rc);
-                prev_theta = best_theta_to_current_joints(A, rc, Rc, prev_sol, pref);
-            }
-            RSIK_CP(0);  // goal matrix, start-up branch
-            Reach r = reach<false, false>(A, pos, Rg);
-            RSIK_CP(1);  // reach with limits
-            double theta;
-            ok = r.ok;
-            if (r.ok) {  // C:338-366
-                ok = best_discrete_theta_serial(A, r, 10, K.pref_self[slot], theta);  // U:220-264 get_best_continuous_theta2
-                if (!ok) {
-                    theta = prev_theta;
-                    st_code = RSIK_STATE_LIMITED_BY_SHOULDER;
-                } else if (!(fabs(angle_diff(theta, prev_theta)) < K.d_theta_max)) {
-                    double ad = angle_diff(theta, prev_theta);
-                    theta = prev_theta + (ad / fabs(ad)) * K.d_theta_max;
-                }
-            } else {  // C:368-388
-                const int st_reach = r.state;
-                r = reach<true>(A, pos, Rg);
-                double ad = angle_diff(pref, prev_theta);  // U:115-127 tend_to_preferred_theta
-                theta = (fabs(ad) < K.d_theta_max) ? pref : (prev_theta + (ad / fabs(ad)) * K.d_theta_max);
-                st_code = st_reach;
-            }
-            RSIK_CP(2);  // 10-point grid (reachable lanes) + no-limits reach (the others)
-            theta = limit_theta_to_interval(theta, K.lim[slot][0], K.lim[slot][1]);
-            prev_theta = theta;
-            double sn, cs;
-            fast_sincos(theta, &sn, &cs);
-            JointsOut o = joints_from_theta<true>(A, r, Rg, cs, sn, prev_sol);
-            RSIK_CP(3);  // theta limit + joints
-#pragma unroll
-            for (int k = 0; k < 7; k++) jv[k] = o.j[k];
-            bool em = safety_checks(A.utab, jv, o.c4, o.s4, o.c5, o.s5, o.c6, o.s6, prev_sol, K.max_angle, K.cos_max, K.sin_max);
-            emergency = emergency || em;
-            if (!init) {  // U:571-589 continuity_check, thresholds C:398
-                bool disc = false;
-#pragma unroll
-                for (int k = 0; k < 7; k++) disc = disc || (fabs(angle_diff(jv[k], prev_sol[k])) > (k < 4 ? 0.5 : 1.0));
-                if (disc) {
-                    emergency = true;
-#pragma unroll
-                    for (int k = 0; k < 7; k++) jv[k] = prev_sol[k];
-                }
-            }
-            init = false;
-            if (!emergency) {
-#pragma unroll
-                for (int k = 0; k < 7; k++) prev_sol[k] = jv[k];
-            }
-            RSIK_CP(4);  // safety checks + continuity
-        }
-        store_rows<7>(K.joints + step * 7 * n, wave_base, K.n, lane, lds_out[wave], jv);
-        if (live) {
-            if (K.reachable) K.reachable[step * n + i] = ok ? 1 : 0;
-            if (K.state) K.state[step * n + i] = (uint8_t)st_code;
-        }
-        RSIK_CP(5);  // stores
-    };
-    if constexpr (LOOP) {
-#pragma unroll 1
-        for (int64_t step = 0; step < n_steps; ++step) one_step(step);
+        for (int k = 0; k < 7; k++) jv[k] = prev_sol[k];
+        st_code = RSIK_STATE_EMERGENCY;
     } else {
-        one_step(0);
+        Rot Rg;
+        V3 pos;
+        load_m12(K.in, ii, Rg, pos, K.euler_roundtrip);
+        if (K.first_timed_out || (K.timed_out && K.timed_out[ii])) { has_prev = false; init = true; }  // C:298-304
+        if (!has_prev) {  // C:306-325
+            has_prev = true;
+            continuous_reinit(A, K, ii, K.pref_arg[slot], prev_theta, prev_sol);
+        }
+        const Goal G = make_goal(A, Rg);
+        Reach r;
+        const ThetaTarget T = continuous_target(A, pos, G.woff, K.pref_self[slot], r);
+        ok = T.ok_limits && T.found;
+        st_code = T.code;
+        const double theta = continuous_next_theta(T.ok_limits, T.found, T.theta, K.pref_arg[slot], prev_theta, K.d_theta_max,
+                                                   K.lim[slot][0], K.lim[slot][1]);
+        prev_theta = theta;
+        double sn, cs;
+        fast_sincos(theta, &sn, &cs);
+        JointsOut o = joints_from_theta_g<true>(A, r, G, cs, sn, prev_sol);
+#pragma unroll
+        for (int k = 0; k < 7; k++) jv[k] = o.j[k];
+        cause = safety_checks(A.utab, jv, o.c4, o.s4, o.c5, o.s5, o.c6, o.s6, prev_sol, K.max_angle, K.cos_max, K.sin_max);
+        emergency = cause != 0;
+        if (!init && joints_discontinuous(jv, prev_sol)) {  // U:571-589 continuity_check, thresholds C:398
+            cause |= RSIK_EMERGENCY_CONTINUITY;
+            emergency = true;
+#pragma unroll
+            for (int k = 0; k < 7; k++) { rejected[k] = jv[k]; jv[k] = prev_sol[k]; }
+        }
+        init = false;
+        if (!emergency) {
+#pragma unroll
+            for (int k = 0; k < 7; k++) prev_sol[k] = jv[k];
+        }
     }
+    store_rows<7>(K.joints, wave_base, K.n, lane, lds_out[wave], jv);
     if (live) {
+        if (K.reachable) K.reachable[i] = ok ? 1 : 0;
+        if (K.state) K.state[i] = (uint8_t)st_code;
         K.st[0 * n + i] = prev_theta;
 #pragma unroll
         for (int k = 0; k < 7; k++) K.st[(1 + k) * n + i] = prev_sol[k];
         K.st[8 * n + i] = init ? 1.0 : 0.0;
         K.st[9 * n + i] = emergency ? 1.0 : 0.0;
         K.st[10 * n + i] = has_prev ? 1.0 : 0.0;
-#ifdef RSIK_CONT_PROBE
-        if (lane == 0) {
+        if (cause != 0) {
+            K.st[11 * n + i] = (double)cause;
+            if (cause & RSIK_EMERGENCY_CONTINUITY) {
 #pragma unroll
-            for (int k = 0; k < 6; k++) K.st[(1 + k) * n + i] = (double)pc[k];
+                for (int k = 0; k < 7; k++) K.st[(12 + k) * n + i] = rejected[k];
+            }
         }
-#endif
     }
 }
-#undef RSIK_CP
+
+// ------------------------------------------------------------------------------------------
+// rsik_control_continuous_run: the phased trajectory pipeline (include/rsik.h).  Workspace of one block of T steps,
+// SoA ws[field][t][n] doubles + two byte planes [t][n]:
+//   field 0      target theta (phase 1) -> the step's theta (phase 2)
+//   fields 1-16  geometry get_joints reads: goal position (3), wrist (3), circle centre (3), radius, axes a1, a2 (3 + 3)
+//   fields 17-22 the goal vectors of the joint stage: tip offset (3), goal x axis (3)
+//   flags        bit 0 is_reachable succeeded, bit 1 the grid search found a theta; (phase 3) bit 2: get_joints hit an
+//                exact singularity and needs previous_sol (recomputed in phase 4)
+// ------------------------------------------------------------------------------------------
+constexpr int kWsFields = 23;
+struct ContRunArgs {
+    int64_t n;
+    int64_t t0;                   // first step of this block
+    int64_t T;                    // steps in this block
+    const double* m12_steps;      // [n_steps][12][n]
+    const uint8_t* arm;
+    int euler_roundtrip;
+    double pref_arg[2], pref_self[2];
+    double lim[2][2];
+    double d_theta_max;
+    double max_angle, cos_max, sin_max;
+    double* ws;                   // [kWsFields][T][n]
+    uint8_t* flags;               // [T][n]
+    double* st;                   // cont_state
+    double* joints;               // [n_steps][n][7]
+    uint8_t* reachable;           // [n_steps][n] or NULL
+    uint8_t* state;               // [n_steps][n] or NULL
+    ArmC arms[2];
+};
+#define RSIK_WS(K, f, t, i) (K).ws[((int64_t)(f) * (K).T + (t)) * (K).n + (i)]
+
+// phase 1: one thread per (trajectory, step of the block)
+template <bool MIXED>
+__global__ __launch_bounds__(kBlock) void cont_prepare_kernel(const ContRunArgs K) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t t = blockIdx.y;
+    const bool live = i < K.n;
+    const int64_t ii = live ? i : (K.n - 1);
+    __shared__ SharedTables lds_tab;
+    stage_tables<MIXED>(lds_tab, K.arms);
+    const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[ii] != 0) : false, lds_tab);
+    const int slot = MIXED ? (A.isl ? 1 : 0) : 0;
+    double m[12];
+    const double* src = K.m12_steps + (K.t0 + t) * 12 * K.n + ii;
+#pragma unroll
+    for (int k = 0; k < 12; k++) m[k] = src[k * K.n];
+    Rot Rg;
+    V3 pos;
+    goal_from_m12(m, Rg, pos, K.euler_roundtrip);
+    const Goal G = make_goal(A, Rg);
+    Reach r;
+    const ThetaTarget T = continuous_target(A, pos, G.woff, K.pref_self[slot], r);
+    if (!live) return;
+    const double v[kWsFields] = {T.theta, r.pos.x, r.pos.y, r.pos.z, r.w.x, r.w.y, r.w.z, r.c2.x, r.c2.y, r.c2.z, r.r2,
+                                 r.a1.x, r.a1.y, r.a1.z, r.a2.x, r.a2.y, r.a2.z, G.toff.x, G.toff.y, G.toff.z, G.xg.x, G.xg.y, G.xg.z};
+#pragma unroll
+    for (int f = 0; f < kWsFields; f++) RSIK_WS(K, f, t, i) = v[f];
+    K.flags[t * K.n + i] = (uint8_t)((T.ok_limits ? 1 : 0) | (T.found ? 2 : 0));
+    if (K.state) K.state[(K.t0 + t) * K.n + i] = (uint8_t)T.code;
+    if (K.reachable) K.reachable[(K.t0 + t) * K.n + i] = (T.ok_limits && T.found) ? 1 : 0;
+}
+
+// phase 2: one thread per trajectory walks the block's steps: the recurrence on previous_theta
+template <bool MIXED>
+__global__ __launch_bounds__(kBlock) void cont_theta_kernel(const ContRunArgs K) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= K.n) return;
+    const int slot = MIXED ? (K.arm[i] != 0 ? 1 : 0) : 0;
+    if (K.st[9 * K.n + i] != 0.0) return;  // emergency stop latched: previous_theta stays (C:205-210)
+    double prev_theta = K.st[0 * K.n + i];
+    const double pref_arg = K.pref_arg[slot], l0 = K.lim[slot][0], l1 = K.lim[slot][1];
+    double target = RSIK_WS(K, 0, 0, i);
+    int fl = K.flags[i];
+#pragma unroll 1
+    for (int64_t t = 0; t < K.T; ++t) {
+        const double tg = target;
+        const int f = fl;
+        if (t + 1 < K.T) { target = RSIK_WS(K, 0, t + 1, i); fl = K.flags[(t + 1) * K.n + i]; }  // next step's operands in flight
+        prev_theta = continuous_next_theta((f & 1) != 0, (f & 2) != 0, tg, pref_arg, prev_theta, K.d_theta_max, l0, l1);
+        RSIK_WS(K, 0, t, i) = prev_theta;
+    }
+    K.st[0 * K.n + i] = prev_theta;
+}
+
+__device__ __forceinline__ void ws_load_geometry(const ContRunArgs& K, int64_t t, int64_t i, Reach& r, Goal& G) {
+    double v[kWsFields];
+#pragma unroll
+    for (int f = 1; f < kWsFields; f++) v[f] = RSIK_WS(K, f, t, i);
+    r.ok = true; r.state = RSIK_STATE_REACHABLE; r.stage = 2; r.i0 = -kPi; r.i1 = kPi; r.ct0 = 1.0; r.st0 = 0.0;
+    r.pos = {v[1], v[2], v[3]}; r.w = {v[4], v[5], v[6]}; r.c2 = {v[7], v[8], v[9]}; r.r2 = v[10];
+    r.a1 = {v[11], v[12], v[13]}; r.a2 = {v[14], v[15], v[16]};
+    r.n2 = r.a1;  // not read by get_joints
+    G.woff = {0.0, 0.0, 0.0};  // only read when the geometry is not fresh
+    G.toff = {v[17], v[18], v[19]}; G.xg = {v[20], v[21], v[22]};
+}
+
+// get_joints at theta (S:697-863) + the Orbita3D cone clamp (U:508-532): everything of a step's joints that does not
+// need previous_sol.  `sing`: an exact singularity fell back to prev (S:751-753, 782-784).
+template <class Acc>
+__device__ __forceinline__ void step_joints(const Acc& A, const ContRunArgs& K, Reach& r, const Goal& G, double theta,
+                                            const double* prev, double (&jv)[7], bool& sing) {
+    double sn, cs;
+    fast_sincos(theta, &sn, &cs);
+    JointsOut o = joints_from_theta_g<true>(A, r, G, cs, sn, prev);
+#pragma unroll
+    for (int k = 0; k < 7; k++) jv[k] = o.j[k];
+    sing = o.sing;
+    limit_wrist_cone(A.utab, jv, o.c4, o.s4, o.c5, o.s5, o.c6, o.s6, K.cos_max, K.sin_max);
+}
+
+// phase 3: one thread per (trajectory, step of the block)
+template <bool MIXED>
+__global__ __launch_bounds__(kBlock) void cont_joints_kernel(const ContRunArgs K) {
+    __shared__ double lds_out[kBlock / 64][64 * 7];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t wave_base = (int64_t)blockIdx.x * kBlock + wave * 64;
+    const int64_t t = blockIdx.y;
+    const bool live = i < K.n;
+    const int64_t ii = live ? i : (K.n - 1);
+    __shared__ SharedTables lds_tab;
+    stage_tables<MIXED>(lds_tab, K.arms);
+    const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[ii] != 0) : false, lds_tab);
+    Reach r;
+    Goal G;
+    ws_load_geometry(K, t, ii, r, G);
+    const double zeros[7] = {0, 0, 0, 0, 0, 0, 0};
+    double jv[7];
+    bool sing;
+    step_joints(A, K, r, G, RSIK_WS(K, 0, t, ii), zeros, jv, sing);
+    store_rows<7>(K.joints + (K.t0 + t) * K.n * 7, wave_base, K.n, lane, lds_out[wave], jv);
+    if (live && sing) K.flags[t * K.n + i] |= 4;
+}
+
+// phase 4: eight lanes per trajectory, lane j < 7 owns joint j; sequential over the block's steps: the recurrence on
+// previous_sol (allow_multiturn U:493-505, multiturn_safety_check U:535-568, continuity_check U:571-589, the emergency
+// latch C:205-210, C:398-405).
+template <bool MIXED>
+__global__ __launch_bounds__(kBlock) void cont_chain_kernel(const ContRunArgs K) {
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t i = gid >> 3;
+    const int j = (int)(gid & 7);
+    const int lane = threadIdx.x & 63;
+    const int gshift = lane & ~7;
+    const bool live = i < K.n;
+    const int64_t ii = live ? i : (K.n - 1);
+    const int jj = j < 7 ? j : 6;
+    const bool owner = live && j < 7;
+    __shared__ SharedTables lds_tab;
+    stage_tables<MIXED>(lds_tab, K.arms);
+    const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[ii] != 0) : false, lds_tab);
+    const int64_t n = K.n;
+    double prev = K.st[(1 + jj) * n + ii];
+    bool init = K.st[8 * n + ii] != 0.0;
+    bool emergency = K.st[9 * n + ii] != 0.0;
+    const double thr = jj < 4 ? 0.5 : 1.0;
+    auto group_bits = [&](bool p) -> unsigned { return (unsigned)((__ballot(p) >> gshift) & 0xffu); };
+    double* jp = K.joints + (K.t0 * n + ii) * 7 + jj;
+    double raw = *jp;
+    int fl = K.flags[ii];
+#pragma unroll 1
+    for (int64_t t = 0; t < K.T; ++t) {
+        double cur = raw;
+        const int f = fl;
+        double* const out = jp;
+        if (t + 1 < K.T) {  // next step's operands in flight while this one is chained
+            jp += n * 7;
+            raw = *jp;
+            fl = K.flags[(t + 1) * n + ii];
+        }
+        if (emergency) {  // latched (C:205-210): previous_sol, state "emergency"
+            if (owner) *out = prev;
+            if (live && j == 7) {
+                if (K.state) K.state[(K.t0 + t) * n + i] = (uint8_t)RSIK_STATE_EMERGENCY;
+                if (K.reachable) K.reachable[(K.t0 + t) * n + i] = 0;
+            }
+            continue;
+        }
+        if (RSIK_RARE(group_bits((f & 4) != 0) != 0)) {
+            // exact singularity in get_joints: the step is recomputed with the real previous_sol (every lane of the
+            // group computes all seven joints and keeps its own)
+            double pv[7];
+#pragma unroll
+            for (int k = 0; k < 7; k++) pv[k] = __shfl(prev, gshift + k);
+            if (f & 4) {
+                Reach r;
+                Goal G;
+                ws_load_geometry(K, t, ii, r, G);
+                double jv[7];
+                bool sing;
+                step_joints(A, K, r, G, RSIK_WS(K, 0, t, ii), pv, jv, sing);
+                cur = jv[0];
+#pragma unroll
+                for (int k = 1; k < 7; k++) cur = (jj == k) ? jv[k] : cur;
+            }
+        }
+        cur = allow_multiturn_one(cur, prev);
+        bool hit = false;
+        if (jj == 0 || jj == 2 || jj == 6) hit = multiturn_limit_one(cur);
+        const unsigned hits = group_bits(hit && j < 7);
+        int cause = (int)((hits & 1u) | ((hits >> 1) & 2u) | ((hits >> 4) & 4u));
+        const bool disc = !init && group_bits(j < 7 && fabs(angle_diff(cur, prev)) > thr) != 0;
+        const double rejected = cur;
+        if (disc) { cause |= RSIK_EMERGENCY_CONTINUITY; cur = prev; }
+        emergency = cause != 0;
+        init = false;
+        if (!emergency) prev = cur;
+        if (owner) *out = cur;
+        if (RSIK_RARE(emergency) && live) {
+            if (j == 7) {
+                K.st[11 * n + i] = (double)cause;
+                K.st[0 * n + i] = RSIK_WS(K, 0, t, i);  // previous_theta of the step that tripped (phase 2 ran ahead)
+            } else if (disc) {
+                K.st[(12 + j) * n + i] = rejected;
+            }
+        }
+    }
+    if (owner) K.st[(1 + j) * n + i] = prev;
+    if (live && j == 7) {
+        K.st[8 * n + i] = init ? 1.0 : 0.0;
+        K.st[9 * n + i] = emergency ? 1.0 : 0.0;
+    }
+}
+
+// C:296-325 for the trajectories of a batch that (re)initialise: previous_sol, previous_theta, init
+template <bool MIXED>
+__global__ __launch_bounds__(kBlock) void cont_init_kernel(const ContinuousArgs K) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool live = i < K.n;
+    const int64_t ii = live ? i : (K.n - 1);
+    __shared__ SharedTables lds_tab;
+    stage_tables<MIXED>(lds_tab, K.arms);
+    const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[ii] != 0) : false, lds_tab);
+    const int slot = MIXED ? (A.isl ? 1 : 0) : 0;
+    const int64_t n = K.n;
+    if (!live || K.st[9 * n + i] != 0.0) return;  // emergency latched: nothing is touched (C:205-210)
+    const bool timed_out = K.first_timed_out || (K.timed_out && K.timed_out[i]);
+    if (!timed_out && K.st[10 * n + i] != 0.0) return;
+    double prev_theta = K.st[0 * n + i];
+    double prev_sol[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) prev_sol[k] = K.st[(1 + k) * n + i];
+    continuous_reinit(A, K, i, K.pref_arg[slot], prev_theta, prev_sol);
+    K.st[0 * n + i] = prev_theta;
+#pragma unroll
+    for (int k = 0; k < 7; k++) K.st[(1 + k) * n + i] = prev_sol[k];
+    K.st[8 * n + i] = 1.0;
+    K.st[10 * n + i] = 1.0;
+}
 
 // ------------------------------------------------------------------------------------------
 // Solver-state kernels: the scalar drop-in API (SymbolicIK objects keep `self.goal_pose`,
@@ -1068,6 +1312,8 @@ struct rsik_ctx {
     bool have_arm[2];
     rsik::ArmC arms[2];
     int options[RSIK_OPT_COUNT];
+    void* ws;          // workspace of rsik_control_continuous_run's phased pipeline (device), grown on demand
+    size_t ws_bytes;
     std::string err;
 };
 
@@ -1115,11 +1361,14 @@ int rsik_create(int device_id, rsik_ctx** out) {
     c->stream = nullptr;
     c->have_arm[0] = c->have_arm[1] = false;
     for (int k = 0; k < RSIK_OPT_COUNT; k++) c->options[k] = 0;
+    c->ws = nullptr;
+    c->ws_bytes = 0;
     *out = c;
     return RSIK_OK;
 }
 
 int rsik_destroy(rsik_ctx* ctx) {
+    if (ctx && ctx->ws && hipSetDevice(ctx->device) == hipSuccess) (void)hipFree(ctx->ws);
     delete ctx;
     return RSIK_OK;
 }
@@ -1152,7 +1401,7 @@ int rsik_set_arm(rsik_ctx* ctx, int arm, const double* consts_host, int count) {
 int rsik_set_option(rsik_ctx* ctx, int option, int value) {
     if (!ctx) return RSIK_E_INVALID;
     if (option < 0 || option >= RSIK_OPT_COUNT) return fail(ctx, RSIK_E_INVALID, "rsik_set_option: unknown option");
-    static const int max_value[RSIK_OPT_COUNT] = {RSIK_EULER_NEVER, 2, 1, 1, RSIK_CONT_RUN_STEPS, 2};
+    static const int max_value[RSIK_OPT_COUNT] = {RSIK_EULER_NEVER, 2, 1, 1, RSIK_CONT_RUN_STEPS};
     if (value < 0 || value > max_value[option]) return fail(ctx, RSIK_E_INVALID, "rsik_set_option: value out of range");
     ctx->options[option] = value;
     return RSIK_OK;
@@ -1342,24 +1591,21 @@ int rsik_control_discrete(rsik_ctx* ctx, int64_t n, const double* const m12_soa[
     return RSIK_OK;
 }
 
-// One launch of the continuous-mode kernel covering n_steps control steps (1 for the step entry point).
-static int launch_continuous(rsik_ctx* ctx, const char* who, int64_t n, int64_t n_steps, const double* const m12_soa[12],
-                             const double* const current_pose_m12_soa[12], const uint8_t* arm, int arm_uniform,
-                             const uint8_t* timed_out, int first_timed_out, double preferred_theta,
-                             const double* preferred_theta_self_host, int constrained_mode, double d_theta_max,
-                             const double* current_joints, double orbita3d_max_angle, double* cont_state, double* joints,
-                             uint8_t* reachable, uint8_t* state) {
+// Arguments shared by the continuous-mode launches (validated once).
+static int fill_continuous(rsik_ctx* ctx, const char* who, rsik::ContinuousArgs& K, int64_t n, const double* const m12_soa[12],
+                           const double* const current_pose_m12_soa[12], const uint8_t* arm, int arm_uniform,
+                           const uint8_t* timed_out, int first_timed_out, double preferred_theta,
+                           const double* preferred_theta_self_host, int constrained_mode, double d_theta_max,
+                           const double* current_joints, double orbita3d_max_angle, double* cont_state, double* joints,
+                           uint8_t* reachable, uint8_t* state) {
     if (constrained_mode != RSIK_MODE_UNCONSTRAINED && constrained_mode != RSIK_MODE_LOW_ELBOW)
         return fail(ctx, RSIK_E_INVALID, std::string(who) + ": unknown constrained_mode");
     if (!preferred_theta_self_host) return fail(ctx, RSIK_E_INVALID, std::string(who) + ": preferred_theta_self_host is NULL");
     int rc = check_arms(ctx, arm, arm_uniform, who);
     if (rc != RSIK_OK) return rc;
-    if (n == 0 || n_steps == 0) return RSIK_OK;
     if (!m12_soa || !cont_state || !joints) return fail(ctx, RSIK_E_INVALID, std::string(who) + ": m12_soa / cont_state / joints is NULL");
-    rsik::ContinuousArgs K;
     std::memset(&K, 0, sizeof K);
     K.n = n;
-    K.n_steps = n_steps;
     K.first_timed_out = first_timed_out;
     for (int k = 0; k < 12; k++) {
         if (!m12_soa[k]) return fail(ctx, RSIK_E_INVALID, std::string(who) + ": an m12_soa column is NULL");
@@ -1383,18 +1629,6 @@ static int launch_continuous(rsik_ctx* ctx, const char* who, int64_t n, int64_t 
     K.cos_max = std::cos(orbita3d_max_angle);
     K.sin_max = std::sin(orbita3d_max_angle);
     K.st = cont_state; K.joints = joints; K.reachable = reachable; K.state = state;
-    RSIK_HIP(ctx, hipSetDevice(ctx->device));
-    dim3 grid, block(rsik::kBlock);
-    rc = launch_dims(ctx, n, &grid, who);
-    if (rc != RSIK_OK) return rc;
-    if (n_steps > 1) {
-        if (arm) hipLaunchKernelGGL((rsik::control_continuous_kernel<true, true>), grid, block, 0, ctx->stream, K);
-        else hipLaunchKernelGGL((rsik::control_continuous_kernel<false, true>), grid, block, 0, ctx->stream, K);
-    } else {
-        if (arm) hipLaunchKernelGGL((rsik::control_continuous_kernel<true, false>), grid, block, 0, ctx->stream, K);
-        else hipLaunchKernelGGL((rsik::control_continuous_kernel<false, false>), grid, block, 0, ctx->stream, K);
-    }
-    RSIK_HIP(ctx, hipGetLastError());
     return RSIK_OK;
 }
 
@@ -1406,44 +1640,119 @@ int rsik_control_continuous_step(rsik_ctx* ctx, int64_t n, const double* const m
                                  uint8_t* state) {
     if (!ctx) return RSIK_E_INVALID;
     if (n < 0) return fail(ctx, RSIK_E_INVALID, "rsik_control_continuous_step: n < 0");
-    return launch_continuous(ctx, "rsik_control_continuous_step", n, 1, m12_soa, current_pose_m12_soa, arm, arm_uniform,
-                             timed_out, 0, preferred_theta, preferred_theta_self_host, constrained_mode, d_theta_max,
-                             current_joints, orbita3d_max_angle, cont_state, joints, reachable, state);
+    if (n == 0) {
+        int rc0 = check_arms(ctx, arm, arm_uniform, "rsik_control_continuous_step");
+        return rc0;
+    }
+    rsik::ContinuousArgs K;
+    int rc = fill_continuous(ctx, "rsik_control_continuous_step", K, n, m12_soa, current_pose_m12_soa, arm, arm_uniform, timed_out,
+                             0, preferred_theta, preferred_theta_self_host, constrained_mode, d_theta_max, current_joints,
+                             orbita3d_max_angle, cont_state, joints, reachable, state);
+    if (rc != RSIK_OK) return rc;
+    RSIK_HIP(ctx, hipSetDevice(ctx->device));
+    dim3 grid, block(rsik::kBlock);
+    rc = launch_dims(ctx, n, &grid, "rsik_control_continuous_step");
+    if (rc != RSIK_OK) return rc;
+    if (arm) hipLaunchKernelGGL(rsik::control_continuous_kernel<true>, grid, block, 0, ctx->stream, K);
+    else hipLaunchKernelGGL(rsik::control_continuous_kernel<false>, grid, block, 0, ctx->stream, K);
+    RSIK_HIP(ctx, hipGetLastError());
+    return RSIK_OK;
 }
 
-// The whole trajectory batch in ONE launch: the kernel walks the n_steps control steps itself (control_continuous_kernel).
+// The whole trajectory batch: the phased pipeline (include/rsik.h), or — RSIK_CONT_RUN_STEPS — one launch of the step
+// kernel per control step.
 int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const double* m12_steps,
                                 const double* const current_pose_m12_soa[12], const uint8_t* arm, int arm_uniform,
                                 int first_step_timed_out, double preferred_theta, const double* preferred_theta_self_host,
                                 int constrained_mode, double d_theta_max, const double* current_joints,
                                 double orbita3d_max_angle, double* cont_state, double* joints_steps,
                                 uint8_t* reachable_steps, uint8_t* state_steps) {
+    const char* who = "rsik_control_continuous_run";
     if (!ctx) return RSIK_E_INVALID;
     if (n < 0 || n_steps < 0) return fail(ctx, RSIK_E_INVALID, "rsik_control_continuous_run: negative size");
-    if (n == 0 || n_steps == 0) return RSIK_OK;
+    if (n == 0 || n_steps == 0) return check_arms(ctx, arm, arm_uniform, who);
     if (!m12_steps || !joints_steps) return fail(ctx, RSIK_E_INVALID, "rsik_control_continuous_run: NULL buffer");
     const double* cols[12];
     for (int c = 0; c < 12; c++) cols[c] = m12_steps + (size_t)c * (size_t)n;  // step 0; step s is 12 n doubles further
-    // Batches that fill the chip many times over gain nothing from the in-kernel time loop and lose its 1 wave/SIMD
-    // occupancy: they go step by step (one launch per step, state through HBM), like a streaming caller would.
-    const int force = ctx->options[RSIK_OPT_CONT_RUN_MODE];
-    const bool stepwise = force != RSIK_CONT_RUN_AUTO ? (force == RSIK_CONT_RUN_STEPS) : (n >= (int64_t)1 << 19);
-    if (!stepwise)
-        return launch_continuous(ctx, "rsik_control_continuous_run", n, n_steps, cols, current_pose_m12_soa, arm, arm_uniform,
-                                 nullptr, first_step_timed_out ? 1 : 0, preferred_theta, preferred_theta_self_host,
-                                 constrained_mode, d_theta_max, current_joints, orbita3d_max_angle, cont_state,
-                                 joints_steps, reachable_steps, state_steps);
-    int rc = RSIK_OK;
-    for (int64_t k = 0; k < n_steps && rc == RSIK_OK; k++) {
-        for (int c = 0; c < 12; c++) cols[c] = m12_steps + ((size_t)k * 12 + c) * (size_t)n;
-        rc = launch_continuous(ctx, "rsik_control_continuous_run", n, 1, cols, k == 0 ? current_pose_m12_soa : nullptr, arm,
-                               arm_uniform, nullptr, (k == 0 && first_step_timed_out) ? 1 : 0, preferred_theta,
-                               preferred_theta_self_host, constrained_mode, d_theta_max, k == 0 ? current_joints : nullptr,
-                               orbita3d_max_angle, cont_state, joints_steps + (size_t)k * n * 7,
-                               reachable_steps ? reachable_steps + (size_t)k * n : nullptr,
-                               state_steps ? state_steps + (size_t)k * n : nullptr);
+    rsik::ContinuousArgs K0;
+    int rc = fill_continuous(ctx, who, K0, n, cols, current_pose_m12_soa, arm, arm_uniform, nullptr, first_step_timed_out ? 1 : 0,
+                             preferred_theta, preferred_theta_self_host, constrained_mode, d_theta_max, current_joints,
+                             orbita3d_max_angle, cont_state, joints_steps, reachable_steps, state_steps);
+    if (rc != RSIK_OK) return rc;
+    RSIK_HIP(ctx, hipSetDevice(ctx->device));
+    dim3 grid, block(rsik::kBlock);
+    rc = launch_dims(ctx, n, &grid, who);
+    if (rc != RSIK_OK) return rc;
+    if (ctx->options[RSIK_OPT_CONT_RUN_MODE] == RSIK_CONT_RUN_STEPS) {
+        for (int64_t k = 0; k < n_steps; k++) {
+            rsik::ContinuousArgs K = K0;
+            for (int c = 0; c < 12; c++) K.in[c] = m12_steps + ((size_t)k * 12 + c) * (size_t)n;
+            if (k > 0) {
+                K.first_timed_out = 0;
+                K.current_joints = nullptr;
+                for (int c = 0; c < 12; c++) K.cur_pose[c] = nullptr;
+            }
+            K.joints = joints_steps + (size_t)k * n * 7;
+            K.reachable = reachable_steps ? reachable_steps + (size_t)k * n : nullptr;
+            K.state = state_steps ? state_steps + (size_t)k * n : nullptr;
+            if (arm) hipLaunchKernelGGL(rsik::control_continuous_kernel<true>, grid, block, 0, ctx->stream, K);
+            else hipLaunchKernelGGL(rsik::control_continuous_kernel<false>, grid, block, 0, ctx->stream, K);
+        }
+        RSIK_HIP(ctx, hipGetLastError());
+        return RSIK_OK;
     }
-    return rc;
+    // ---- phased pipeline.  Block length: the workspace stays within 256 MB (the Infinity Cache holds it between phases)
+    const size_t per_step = (size_t)n * (rsik::kWsFields * sizeof(double) + 1);
+    int64_t T = (int64_t)((size_t)256 << 20) / (int64_t)per_step;
+    if (T < 1) T = 1;
+    if (T > n_steps) T = n_steps;
+    if (T > 65535) T = 65535;  // gridDim.y
+    const size_t need = (size_t)T * per_step + 256;
+    if (ctx->ws_bytes < need) {
+        if (ctx->ws) { RSIK_HIP(ctx, hipStreamSynchronize(ctx->stream)); RSIK_HIP(ctx, hipFree(ctx->ws)); ctx->ws = nullptr; ctx->ws_bytes = 0; }
+        RSIK_HIP(ctx, hipMalloc(&ctx->ws, need));
+        ctx->ws_bytes = need;
+    }
+    // (re)initialisation of the trajectories that start here (C:296-325)
+    if (arm) hipLaunchKernelGGL(rsik::cont_init_kernel<true>, grid, block, 0, ctx->stream, K0);
+    else hipLaunchKernelGGL(rsik::cont_init_kernel<false>, grid, block, 0, ctx->stream, K0);
+    rsik::ContRunArgs R;
+    std::memset(&R, 0, sizeof R);
+    R.n = n;
+    R.m12_steps = m12_steps;
+    R.arm = arm;
+    R.euler_roundtrip = K0.euler_roundtrip;
+    for (int slot = 0; slot < 2; slot++) {
+        R.pref_arg[slot] = K0.pref_arg[slot]; R.pref_self[slot] = K0.pref_self[slot];
+        R.lim[slot][0] = K0.lim[slot][0]; R.lim[slot][1] = K0.lim[slot][1];
+        R.arms[slot] = K0.arms[slot];
+    }
+    R.d_theta_max = d_theta_max;
+    R.max_angle = K0.max_angle; R.cos_max = K0.cos_max; R.sin_max = K0.sin_max;
+    R.st = cont_state; R.joints = joints_steps; R.reachable = reachable_steps; R.state = state_steps;
+    dim3 grid8;
+    rc = launch_dims(ctx, n * 8, &grid8, who);
+    if (rc != RSIK_OK) return rc;
+    for (int64_t t0 = 0; t0 < n_steps; t0 += T) {
+        R.t0 = t0;
+        R.T = (n_steps - t0 < T) ? (n_steps - t0) : T;
+        R.ws = static_cast<double*>(ctx->ws);
+        R.flags = reinterpret_cast<uint8_t*>(R.ws + (size_t)rsik::kWsFields * (size_t)R.T * (size_t)n);
+        const dim3 grid2(grid.x, (unsigned)R.T);
+        if (arm) {
+            hipLaunchKernelGGL(rsik::cont_prepare_kernel<true>, grid2, block, 0, ctx->stream, R);
+            hipLaunchKernelGGL(rsik::cont_theta_kernel<true>, grid, block, 0, ctx->stream, R);
+            hipLaunchKernelGGL(rsik::cont_joints_kernel<true>, grid2, block, 0, ctx->stream, R);
+            hipLaunchKernelGGL(rsik::cont_chain_kernel<true>, grid8, block, 0, ctx->stream, R);
+        } else {
+            hipLaunchKernelGGL(rsik::cont_prepare_kernel<false>, grid2, block, 0, ctx->stream, R);
+            hipLaunchKernelGGL(rsik::cont_theta_kernel<false>, grid, block, 0, ctx->stream, R);
+            hipLaunchKernelGGL(rsik::cont_joints_kernel<false>, grid2, block, 0, ctx->stream, R);
+            hipLaunchKernelGGL(rsik::cont_chain_kernel<false>, grid8, block, 0, ctx->stream, R);
+        }
+    }
+    RSIK_HIP(ctx, hipGetLastError());
+    return RSIK_OK;
 }
 
 int rsik_matrix_to_pose(rsik_ctx* ctx, int64_t n, const double* const m12_soa[12], int identity_shortcut,
