@@ -839,12 +839,14 @@ __device__ FkOut forward_kinematics(const Acc& A, const double (&j)[7]) {
 // U:93-112 limit_theta_to_interval (previous_theta is normalised by the reference but never used, Q12)
 __device__ __forceinline__ double limit_theta_to_interval(double theta, double l0, double l1) {
     theta = pymod_2pi(theta);
-    if (theta > kPi) theta -= kTwoPi;
-    if (is_valid_angle(theta, l0, l1)) return theta;
-    double posDiff = angle_diff(theta, l1);
-    double negDiff = angle_diff(theta, l0);
-    if (fabs(posDiff) < fabs(negDiff)) return l1;
-    return l0;
+    theta = (theta > kPi) ? theta - kTwoPi : theta;
+    // straight-line: both distances are formed whether or not they are needed (the callers are latency-bound or
+    // mix both outcomes in every wave)
+    const bool valid = is_valid_angle(theta, l0, l1);
+    const double posDiff = angle_diff(theta, l1);
+    const double negDiff = angle_diff(theta, l0);
+    const double snapped = (fabs(posDiff) < fabs(negDiff)) ? l1 : l0;
+    return valid ? theta : snapped;
 }
 
 // ControlIK.safety_checks (C:464-497), in two halves:

@@ -550,7 +550,9 @@ __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR void co
 #pragma unroll
         for (int k = 0; k < 6; k++) lds_slab[wave][k][lane] = pk[k];
     }
+    RSIK_MARK("disc_reach");
     Reach r = reach_g<false, false>(A, pos, G.woff);
+    RSIK_MARK("disc_shortcut");
     const double pref = K.pref[slot];
     bool found = false;
     double theta = 0.0;
@@ -576,6 +578,7 @@ __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR void co
     // Two ways to search the grid, chosen per wave (wave-uniform): when only a few lanes need it, the exhaustive
     // wave-cooperative sweep (cost ~ number of such poses); when most lanes need it, every lane searches its own
     // pose serially — the whole grid if it is short, else the 12 bracketing candidates (grid_theta_candidates).
+    RSIK_MARK("disc_grid");
     const uint64_t need_mask = __ballot(need);
     const int cnt = __popcll(need_mask);
     const int serial_evals = (K.nb <= 16) ? K.nb : 12;
@@ -598,6 +601,7 @@ __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR void co
             coop = !fast_ok;
         }
     }
+    RSIK_MARK("disc_sweep");
     wave_lds_sync();
     const uint64_t mask = __ballot(coop);
     sweep_theta_grid<MIXED>(K, mask, lane, A.isl, lds_tab, &lds_slab[wave][kGeoRow0], &lds_slab[wave][kGeoRow0 + 9][0]);
@@ -609,6 +613,7 @@ __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR void co
         else st_code = RSIK_STATE_LIMITED_BY_SHOULDER;  // C:451-452
     }
 
+    RSIK_MARK("disc_joints");
     const double* prev = K.prev_sol[slot];
     double jv[7];
     double c4, s4, c5, s5, c6, s6;
@@ -630,7 +635,9 @@ __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR void co
         fast_sincos(jv[5], &s5, &c5);
         fast_sincos(jv[6], &s6, &c6);
     }
+    RSIK_MARK("disc_safety");
     const int em = safety_checks(A.utab, jv, c4, s4, c5, s5, c6, s6, prev, K.max_angle, K.cos_max, K.sin_max);
+    RSIK_MARK("disc_store");
     store_rows<7>(K.joints, wave_base, K.n, lane, &lds_slab[wave][0][0], jv);
     if (live) {
         if (K.reachable) K.reachable[i] = found ? 1 : 0;
@@ -722,17 +729,14 @@ __device__ __forceinline__ ThetaTarget continuous_target(const Acc& A, V3 pos, c
 // (U:115-127), then limit_theta_to_interval (U:93-112).
 __device__ __forceinline__ double continuous_next_theta(bool ok_limits, bool found, double target, double pref_arg,
                                                         double prev_theta, double d_theta_max, double l0, double l1) {
-    double theta;
-    if (ok_limits) {
-        theta = found ? target : prev_theta;
-        if (found && !(fabs(angle_diff(theta, prev_theta)) < d_theta_max)) {
-            const double ad = angle_diff(theta, prev_theta);
-            theta = prev_theta + (ad / fabs(ad)) * d_theta_max;
-        }
-    } else {
-        const double ad = angle_diff(pref_arg, prev_theta);
-        theta = (fabs(ad) < d_theta_max) ? pref_arg : (prev_theta + (ad / fabs(ad)) * d_theta_max);
-    }
+    // One straight line for the three cases (this is the serial part of a trajectory: a lone wave pays every dependent
+    // instruction in full).  Reachable and found: tend to the search's theta (U:252-264); reachable, nothing found:
+    // stay (goal = previous_theta, whose angle_diff is 0); unreachable: tend to the preferred theta (U:115-127).
+    // sign * d_theta_max with sign = ad / |ad| (U:260, U:126) is copysign(d_theta_max, ad), bit for bit: the quotient
+    // of a non-zero finite number by its own magnitude is exactly +-1.
+    const double goal = ok_limits ? (found ? target : prev_theta) : pref_arg;
+    const double ad = angle_diff(goal, prev_theta);
+    const double theta = (fabs(ad) < d_theta_max) ? goal : (prev_theta + copysign(d_theta_max, ad));
     return limit_theta_to_interval(theta, l0, l1);
 }
 
@@ -836,6 +840,7 @@ __global__ __launch_bounds__(kBlock) void control_continuous_kernel(const Contin
 //                exact singularity and needs previous_sol (recomputed in phase 4)
 // ------------------------------------------------------------------------------------------
 constexpr int kWsFields = 23;
+constexpr int kSeqBatch = 8;  // steps whose operands the sequential phases fetch at once
 struct ContRunArgs {
     int64_t n;
     int64_t t0;                   // first step of this block
@@ -897,15 +902,44 @@ __global__ __launch_bounds__(kBlock) void cont_theta_kernel(const ContRunArgs K)
     if (K.st[9 * K.n + i] != 0.0) return;  // emergency stop latched: previous_theta stays (C:205-210)
     double prev_theta = K.st[0 * K.n + i];
     const double pref_arg = K.pref_arg[slot], l0 = K.lim[slot][0], l1 = K.lim[slot][1];
-    double target = RSIK_WS(K, 0, 0, i);
-    int fl = K.flags[i];
-#pragma unroll 1
-    for (int64_t t = 0; t < K.T; ++t) {
-        const double tg = target;
-        const int f = fl;
-        if (t + 1 < K.T) { target = RSIK_WS(K, 0, t + 1, i); fl = K.flags[(t + 1) * K.n + i]; }  // next step's operands in flight
+    // The recurrence itself is ~50 dependent instructions per step; the memory round trip of a step's operands would
+    // double that (a lone wave per SIMD, nothing to switch to), so they are fetched kSeqBatch steps at a time, one batch
+    // ahead of the one being computed; the last T mod kSeqBatch steps go one by one.
+    const int64_t n = K.n;
+    double* wp = &RSIK_WS(K, 0, 0, i);          // this trajectory's theta column, step 0; step t is t * n further
+    const uint8_t* fp = K.flags + i;
+    auto one = [&](double tg, int f, double* dst) {
         prev_theta = continuous_next_theta((f & 1) != 0, (f & 2) != 0, tg, pref_arg, prev_theta, K.d_theta_max, l0, l1);
-        RSIK_WS(K, 0, t, i) = prev_theta;
+        *dst = prev_theta;
+    };
+    const int64_t full = K.T - (K.T % kSeqBatch);
+    double target[kSeqBatch];
+    int fl[kSeqBatch];
+    if (full > 0) {
+#pragma unroll
+        for (int u = 0; u < kSeqBatch; u++) { target[u] = wp[u * n]; fl[u] = fp[u * n]; }
+    }
+#pragma unroll 1
+    for (int64_t t0 = 0; t0 < full; t0 += kSeqBatch) {
+        double tg[kSeqBatch];
+        int f[kSeqBatch];
+#pragma unroll
+        for (int u = 0; u < kSeqBatch; u++) { tg[u] = target[u]; f[u] = fl[u]; }
+        double* const w0 = wp;
+        wp += kSeqBatch * n;
+        fp += kSeqBatch * n;
+        if (t0 + kSeqBatch < full) {
+#pragma unroll
+            for (int u = 0; u < kSeqBatch; u++) { target[u] = wp[u * n]; fl[u] = fp[u * n]; }
+        }
+#pragma unroll
+        for (int u = 0; u < kSeqBatch; u++) one(tg[u], f[u], w0 + u * n);
+    }
+#pragma unroll 1
+    for (int64_t t = full; t < K.T; ++t) {
+        one(*wp, *fp, wp);
+        wp += n;
+        fp += n;
     }
     K.st[0 * K.n + i] = prev_theta;
 }
@@ -982,67 +1016,97 @@ __global__ __launch_bounds__(kBlock) void cont_chain_kernel(const ContRunArgs K)
     double prev = K.st[(1 + jj) * n + ii];
     bool init = K.st[8 * n + ii] != 0.0;
     bool emergency = K.st[9 * n + ii] != 0.0;
-    const double thr = jj < 4 ? 0.5 : 1.0;
-    auto group_bits = [&](bool p) -> unsigned { return (unsigned)((__ballot(p) >> gshift) & 0xffu); };
-    double* jp = K.joints + (K.t0 * n + ii) * 7 + jj;
-    double raw = *jp;
-    int fl = K.flags[ii];
-#pragma unroll 1
-    for (int64_t t = 0; t < K.T; ++t) {
-        double cur = raw;
-        const int f = fl;
-        double* const out = jp;
-        if (t + 1 < K.T) {  // next step's operands in flight while this one is chained
-            jp += n * 7;
-            raw = *jp;
-            fl = K.flags[(t + 1) * n + ii];
-        }
-        if (emergency) {  // latched (C:205-210): previous_sol, state "emergency"
-            if (owner) *out = prev;
-            if (live && j == 7) {
-                if (K.state) K.state[(K.t0 + t) * n + i] = (uint8_t)RSIK_STATE_EMERGENCY;
-                if (K.reachable) K.reachable[(K.t0 + t) * n + i] = 0;
-            }
-            continue;
-        }
-        if (RSIK_RARE(group_bits((f & 4) != 0) != 0)) {
+    const double thr = jj < 4 ? 0.5 : 1.0;                                       // continuity thresholds, C:398
+    const double lim = (jj == 0 || jj == 2 || jj == 6) ? 6 * kPi : __builtin_inf();  // multiturn limit of this lane's joint (U:535-568)
+    const int hit_bit = jj == 0 ? RSIK_EMERGENCY_SHOULDER_PITCH : (jj == 2 ? RSIK_EMERGENCY_ELBOW_YAW : RSIK_EMERGENCY_WRIST_YAW);
+    // OR over the 8 lanes of a trajectory, left in every one of them: two quad permutes and a half-row mirror (DPP)
+    auto group_or = [](int v) -> int {
+        v |= __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+        v |= __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+        v |= __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);  // row_half_mirror
+        return v;
+    };
+    // Operands of kSeqBatch steps are fetched together, one batch ahead (see cont_theta_kernel).  A step is straight-line
+    // code: a latched trajectory (rare) goes through the same arithmetic and only its selects differ.
+    double* jp = K.joints + (K.t0 * n + ii) * 7 + jj;   // this lane's joint, step 0 of the block; step t is t * 7 n further
+    const uint8_t* fp = K.flags + ii;
+    int64_t t_abs = K.t0;
+    const int64_t step_stride = n * 7;
+    auto one = [&](double cur, int f, double* out, int64_t t) {
+        if (RSIK_RARE((f & 4) != 0 && !emergency)) {  // the same byte in all 8 lanes of the trajectory
             // exact singularity in get_joints: the step is recomputed with the real previous_sol (every lane of the
             // group computes all seven joints and keeps its own)
             double pv[7];
 #pragma unroll
             for (int k = 0; k < 7; k++) pv[k] = __shfl(prev, gshift + k);
-            if (f & 4) {
-                Reach r;
-                Goal G;
-                ws_load_geometry(K, t, ii, r, G);
-                double jv[7];
-                bool sing;
-                step_joints(A, K, r, G, RSIK_WS(K, 0, t, ii), pv, jv, sing);
-                cur = jv[0];
+            Reach r;
+            Goal G;
+            ws_load_geometry(K, t, ii, r, G);
+            double jv[7];
+            bool sing;
+            step_joints(A, K, r, G, RSIK_WS(K, 0, t, ii), pv, jv, sing);
+            cur = jv[0];
 #pragma unroll
-                for (int k = 1; k < 7; k++) cur = (jj == k) ? jv[k] : cur;
-            }
+            for (int k = 1; k < 7; k++) cur = (jj == k) ? jv[k] : cur;
         }
-        cur = allow_multiturn_one(cur, prev);
-        bool hit = false;
-        if (jj == 0 || jj == 2 || jj == 6) hit = multiturn_limit_one(cur);
-        const unsigned hits = group_bits(hit && j < 7);
-        int cause = (int)((hits & 1u) | ((hits >> 1) & 2u) | ((hits >> 4) & 4u));
-        const bool disc = !init && group_bits(j < 7 && fabs(angle_diff(cur, prev)) > thr) != 0;
-        const double rejected = cur;
-        if (disc) { cause |= RSIK_EMERGENCY_CONTINUITY; cur = prev; }
-        emergency = cause != 0;
-        init = false;
-        if (!emergency) prev = cur;
-        if (owner) *out = cur;
-        if (RSIK_RARE(emergency) && live) {
-            if (j == 7) {
+        const double turned = allow_multiturn_one(cur, prev);                 // U:493-505
+        const double clamped = fmin(fmax(turned, -lim), lim);                 // U:535-568 (lim = inf for joints 1, 3, 4, 5)
+        int code = (clamped != turned && j < 7) ? hit_bit : 0;
+        // U:571-589: |angle_diff(joint, previous)| against the joint's threshold, on the limited value like the reference
+        code |= (j < 7 && fabs(angle_diff(clamped, prev)) > thr) ? 16 : 0;
+        code = group_or(code);
+        const bool disc = !init && (code & 16) != 0;
+        const int cause = (code & 7) | (disc ? RSIK_EMERGENCY_CONTINUITY : 0);
+        const double accepted = disc ? prev : clamped;
+        const bool trips = cause != 0 && !emergency;
+        const double result = emergency ? prev : accepted;                    // latched (C:205-210): previous_sol
+        if (owner) *out = result;
+        if (RSIK_RARE(emergency || trips) && live) {
+            if (emergency) {
+                if (j == 7) {
+                    if (K.state) K.state[t_abs * n + i] = (uint8_t)RSIK_STATE_EMERGENCY;
+                    if (K.reachable) K.reachable[t_abs * n + i] = 0;
+                }
+            } else if (j == 7) {
                 K.st[11 * n + i] = (double)cause;
                 K.st[0 * n + i] = RSIK_WS(K, 0, t, i);  // previous_theta of the step that tripped (phase 2 ran ahead)
             } else if (disc) {
-                K.st[(12 + j) * n + i] = rejected;
+                K.st[(12 + j) * n + i] = clamped;       // the joints that failed the check
             }
         }
+        prev = (emergency || trips) ? prev : accepted;
+        init = emergency ? init : false;
+        emergency = emergency || trips;
+        t_abs += 1;
+    };
+    const int64_t full = K.T - (K.T % kSeqBatch);
+    double raw[kSeqBatch];
+    int fl[kSeqBatch];
+    if (full > 0) {
+#pragma unroll
+        for (int u = 0; u < kSeqBatch; u++) { raw[u] = jp[u * step_stride]; fl[u] = fp[u * n]; }
+    }
+#pragma unroll 1
+    for (int64_t t0 = 0; t0 < full; t0 += kSeqBatch) {
+        double rw[kSeqBatch];
+        int fb[kSeqBatch];
+#pragma unroll
+        for (int u = 0; u < kSeqBatch; u++) { rw[u] = raw[u]; fb[u] = fl[u]; }
+        double* const j0 = jp;
+        jp += kSeqBatch * step_stride;
+        fp += kSeqBatch * n;
+        if (t0 + kSeqBatch < full) {
+#pragma unroll
+            for (int u = 0; u < kSeqBatch; u++) { raw[u] = jp[u * step_stride]; fl[u] = fp[u * n]; }
+        }
+#pragma unroll
+        for (int u = 0; u < kSeqBatch; u++) one(rw[u], fb[u], j0 + u * step_stride, t0 + u);
+    }
+#pragma unroll 1
+    for (int64_t t = full; t < K.T; ++t) {
+        one(*jp, *fp, jp, t);
+        jp += step_stride;
+        fp += n;
     }
     if (owner) K.st[(1 + j) * n + i] = prev;
     if (live && j == 7) {
