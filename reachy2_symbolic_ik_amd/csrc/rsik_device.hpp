@@ -84,6 +84,19 @@ __device__ __forceinline__ double pymod_2pi(double a) {
     }
     return m;
 }
+// The same value without a branch, for the serial phases of the continuous mode: there a lone wave pays the
+// compare -> exec mask -> branch round trip of every RSIK_RARE test in full, and four selects are cheaper.
+__device__ __forceinline__ double pymod_2pi_straight(double a) {
+    double q = floor(a * 0.15915494309189535);
+    double m = fma(-q, kTwoPi, a);
+    m = (m < 0) ? m + kTwoPi : m;
+    m = (m >= kTwoPi) ? m - kTwoPi : m;
+    return m;
+}
+__device__ __forceinline__ double angle_diff_straight(double a, double b) {
+    double d = a - b;
+    return pymod_2pi_straight(d + kPi) - kPi;
+}
 // U:486-490
 __device__ __forceinline__ double angle_diff(double a, double b) {
     double d = a - b;
@@ -137,16 +150,13 @@ __device__ __forceinline__ Rot rot_from_euler(double roll, double pitch, double 
 // the third angle is set to 0 and the first takes the whole rotation.  Not on the hot path.
 // np.isclose(M M^T, I, atol=1e-12) with the default rtol = 1e-5: SciPy's test for "already a rotation"
 __device__ __forceinline__ bool gram_is_identity(const double (&m)[9]) {
-    bool orth = true;
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = i; j < 3; j++) {
-            const double g = m[3 * i] * m[3 * j] + m[3 * i + 1] * m[3 * j + 1] + m[3 * i + 2] * m[3 * j + 2];
-            const double e = (i == j) ? 1.0 : 0.0;
-            orth = orth && (fabs(g - e) <= 1e-12 + 1e-5 * e);
-        }
-    return orth;
+    // the six distinct entries of M M^T - I; the tolerance of np.isclose is 1e-12 + 1e-5 |I_ij|, i.e. 1e-12 off the
+    // diagonal and 1e-5 (+1e-12) on it, four orders of magnitude above any rounding of the products, so the dot
+    // products are fused and the two groups are reduced to one comparison each
+    auto g = [&](int i, int j) { return fma(m[3 * i], m[3 * j], fma(m[3 * i + 1], m[3 * j + 1], m[3 * i + 2] * m[3 * j + 2])); };
+    const double off = fmax(fmax(fabs(g(0, 1)), fabs(g(0, 2))), fabs(g(1, 2)));
+    const double dia = fmax(fmax(fabs(g(0, 0) - 1.0), fabs(g(1, 1) - 1.0)), fabs(g(2, 2) - 1.0));
+    return off <= 1e-12 && dia <= 1e-12 + 1e-5;
 }
 __device__ inline void nearest_rotation(double (&m)[9]) {
     for (int it = 0; it < 24; it++) {
@@ -247,6 +257,7 @@ struct Reach {
     bool ok;
     double i0, i1; // theta interval
     double ct0, st0; // cos / sin of i0 (from the intersection point itself, no trigonometric call)
+    double ct1, st1; // cos / sin of i1
     V3 pos;        // self.goal_pose[0]
     V3 w;          // self.wrist_position
     V3 c2;         // intersection circle centre
@@ -332,7 +343,7 @@ __device__ Reach reach_g(const Acc& A, V3 pos_in, const V3 woff) {
     }
     r.state = st;
     r.stage = 0;
-    if (KEEP) { r.pos = gp; r.w = gp; r.c2 = gp; r.n2 = gp; r.a1 = gp; r.a2 = gp; r.r2 = 0.0; r.ct0 = 1.0; r.st0 = 0.0; }
+    if (KEEP) { r.pos = gp; r.w = gp; r.c2 = gp; r.n2 = gp; r.a1 = gp; r.a2 = gp; r.r2 = 0.0; r.ct0 = 1.0; r.st0 = 0.0; r.ct1 = 1.0; r.st1 = 0.0; }
     if (!NO_LIMITS && st != RSIK_STATE_REACHABLE) return r;
     r.stage = 1;
 
@@ -408,6 +419,7 @@ __device__ Reach reach_g(const Acc& A, V3 pos_in, const V3 woff) {
     if (NO_LIMITS) {
         r.ok = true; r.state = RSIK_STATE_REACHABLE; r.i0 = -kPi; r.i1 = kPi;
         r.ct0 = -1.0; r.st0 = -1.2246467991473532e-16;  // cos(-pi), sin(-pi) as np.cos/np.sin return them
+        r.ct1 = -1.0; r.st1 = 1.2246467991473532e-16;
         return r;
     }
 
@@ -433,6 +445,7 @@ __device__ Reach reach_g(const Acc& A, V3 pos_in, const V3 woff) {
         r.i0 = side_ok ? -kPi : __builtin_nan("");
         r.i1 = side_ok ? kPi : __builtin_nan("");
         r.ct0 = -1.0; r.st0 = -1.2246467991473532e-16;  // cos(-pi), sin(-pi) as np.cos/np.sin return them
+        r.ct1 = -1.0; r.st1 = 1.2246467991473532e-16;
     };
 
     RSIK_MARK("reach_line");
@@ -470,6 +483,7 @@ __device__ Reach reach_g(const Acc& A, V3 pos_in, const V3 woff) {
             unit_atan2_n<2>(A.utab, ss, cc, aa);
             r.i0 = aa[0]; r.i1 = aa[1];
             r.ct0 = c0; r.st0 = s0;
+            r.ct1 = c1; r.st1 = s1;
             return r;
         }
     }
@@ -523,7 +537,7 @@ __device__ Reach reach_g(const Acc& A, V3 pos_in, const V3 woff) {
             double ly = dot(a1, p) + oy, lz = dot(a2, p) + oz;
             double ang = fast_atan2(lz, ly);
             double il = rsqrt_fast(ly * ly + lz * lz);
-            r.i0 = ang; r.i1 = ang; r.ct0 = ly * il; r.st0 = lz * il;
+            r.i0 = ang; r.i1 = ang; r.ct0 = ly * il; r.st0 = lz * il; r.ct1 = r.ct0; r.st1 = r.st0;
             return r;
         }
         double sq = sqrt_cr(disc);
@@ -578,6 +592,8 @@ __device__ Reach reach_g(const Acc& A, V3 pos_in, const V3 woff) {
     r.i1 = first ? ang2 : ang1;
     r.ct0 = first ? ly1 : ly2;
     r.st0 = first ? lz1 : lz2;
+    r.ct1 = first ? ly2 : ly1;
+    r.st1 = first ? lz2 : lz1;
     return r;
 }
 
@@ -597,11 +613,14 @@ template <class Acc>
 __device__ __forceinline__ bool above_singularity_plane(const Acc& A, V3 e) {
     return e.z > (e.x - A(RSIK_C_ES)) * A(RSIK_C_SING_COEFF) + A(RSIK_C_ES + 2) - A(RSIK_C_SING_OFFSET);
 }
-// U:443-465 (effective predicate, Q10)
-template <class Acc>
+// U:443-465 (effective predicate, Q10).  PLANE = false: the launch's host code has shown that the singularity-plane half
+// holds for every point a shoulder-centred sphere of radius u can reach (the non-DVT offset, Q18), so only the
+// elbow-side half is evaluated.
+template <bool PLANE = true, class Acc>
 __device__ __forceinline__ bool is_elbow_ok(const Acc& A, V3 e) {
     bool ok = e.y * A(RSIK_C_SIDE) < -0.2;
-    return ok && (e.z < (e.x - A(RSIK_C_ES)) * A(RSIK_C_SING_COEFF) + A(RSIK_C_ES + 2) - A(RSIK_C_SING_OFFSET));
+    if constexpr (PLANE) ok = ok && (e.z < (e.x - A(RSIK_C_ES)) * A(RSIK_C_SING_COEFF) + A(RSIK_C_ES + 2) - A(RSIK_C_SING_OFFSET));
+    return ok;
 }
 
 struct JointsOut {
@@ -849,6 +868,17 @@ __device__ __forceinline__ double limit_theta_to_interval(double theta, double l
     return valid ? theta : snapped;
 }
 
+// limit_theta_to_interval for the serial theta phase (no branches, see pymod_2pi_straight)
+__device__ __forceinline__ double limit_theta_to_interval_straight(double theta, double l0, double l1) {
+    theta = pymod_2pi_straight(theta);
+    theta = (theta > kPi) ? theta - kTwoPi : theta;
+    const bool valid = is_valid_angle(theta, l0, l1);
+    const double posDiff = angle_diff_straight(theta, l1);
+    const double negDiff = angle_diff_straight(theta, l0);
+    const double snapped = (fabs(posDiff) < fabs(negDiff)) ? l1 : l0;
+    return valid ? theta : snapped;
+}
+
 // ControlIK.safety_checks (C:464-497), in two halves:
 //   limit_wrist_cone — utils.limit_orbita3d_joints_wrist (U:508-532): wrist triple as intrinsic XYZ -> ZYZ (alpha, beta,
 //     gamma), clamp beta to the Orbita3D cone, back to XYZ (scipy gimbal conventions: beta within 1e-7 of 0 or pi =>
@@ -901,6 +931,9 @@ __device__ __forceinline__ double allow_multiturn_one(double j, double prev) {
     if (RSIK_RARE(!(t >= 0.0 && t < kTwoPi))) t = pymod_2pi(t);
     return prev + (t - kPi);
 }
+__device__ __forceinline__ double allow_multiturn_one_straight(double j, double prev) {
+    return prev + (pymod_2pi_straight((j - prev) + kPi) - kPi);
+}
 // one joint of utils.multiturn_safety_check (U:535-568): joints 0, 2, 6 are clamped to +-6 pi; true if it tripped
 __device__ __forceinline__ bool multiturn_limit_one(double& j) {
     const double lim = 6 * kPi;
@@ -927,7 +960,7 @@ __device__ __forceinline__ int safety_checks(UnitAtanTab utab, double (&j)[7], d
 }
 
 // The grid part of utils.get_best_discrete_theta (U:372-396), one pose per lane, walking every grid point.
-template <class Acc>
+template <bool PLANE = true, class Acc>
 __device__ bool best_discrete_theta_grid(const Acc& A, const Reach& r, double a, double step, double b, int nb, double pref,
                                          double& theta_out) {
     bool found = false;
@@ -936,7 +969,7 @@ __device__ bool best_discrete_theta_grid(const Acc& A, const Reach& r, double a,
         double th = (k == nb - 1) ? b : ((double)k * step + a);
         double st, ct;
         fast_sincos(th, &st, &ct);
-        if (is_elbow_ok(A, elbow_on_circle(r, ct, st))) {
+        if (is_elbow_ok<PLANE>(A, elbow_on_circle(r, ct, st))) {
             double dist = fabs(angle_diff(th, pref));
             if (dist < best_d) { best_d = dist; best = th; found = true; }
         }
@@ -1003,35 +1036,54 @@ __device__ double best_theta_to_current_joints(const Acc& A, Reach& r, const Rot
 // then judged with the reference's own predicate and distance (same theta_k = linspace value, same is_elbow_ok), so the
 // analytic arcs only propose candidates, they never decide.  `fast_ok` = false (degenerate step) asks the caller to
 // fall back to the exhaustive wave-cooperative sweep.
-template <class Acc>
+// ends_cs = cos/sin of the two grid ends (known from the interval's intersection points, or constants for the whole
+// circle): they are not evaluated again.  The second point of every bracket is the first one turned by one grid step.
+template <bool PLANE = true, class Acc>
 __device__ bool grid_theta_candidates(const Acc& A, const Reach& r, double a, double step, double b, int nb, double pref,
-                                      double& theta_out, bool& fast_ok) {
+                                      double ca, double sa, double cb, double sb, double& theta_out, bool& fast_ok) {
     fast_ok = step > 1e-9;
     const double side = A(RSIK_C_SIDE), sc = A(RSIK_C_SING_COEFF);
     // constraint 1: side * e_y < -0.2;  constraint 2: e_z - sc * e_x < es_z - so - sc * es_x
     const double A1 = side * r.r2 * r.a1.y, B1 = side * r.r2 * r.a2.y, D1 = -0.2 - side * r.c2.y;
-    const double A2 = r.r2 * fma(-sc, r.a1.x, r.a1.z), B2 = r.r2 * fma(-sc, r.a2.x, r.a2.z);
-    const double D2 = (A(RSIK_C_ES + 2) - A(RSIK_C_SING_OFFSET) - sc * A(RSIK_C_ES)) - fma(-sc, r.c2.x, r.c2.z);
-    const double R1s = fma(A1, A1, B1 * B1), R2s = fma(A2, A2, B2 * B2);
-    const bool v1 = R1s > D1 * D1, v2 = R2s > D2 * D2;  // the constraint really changes sign on the circle
-    double ang[5];
+    const double R1s = fma(A1, A1, B1 * B1);
+    const bool v1 = R1s > D1 * D1;  // the constraint really changes sign on the circle
+    constexpr int NA = PLANE ? 5 : 3;
+    double ang[NA];
+    bool v2 = false;
     {
         // phi = direction of (A, B), alpha = acos(D / R) = direction of (D, sqrt(R^2 - D^2)): both vectors have length R,
         // so one reciprocal square root per constraint makes them unit and the table atan2 applies.  A constraint that
         // does not change sign on the circle (v false) gets harmless stand-ins; its angles are not used.
-        const double Rs1 = v1 ? R1s : 1.0, Rs2 = v2 ? R2s : 1.0;
-        const double i1 = rsqrt_fast(Rs1), i2 = rsqrt_fast(Rs2);
-        const double q1 = v1 ? R1s - D1 * D1 : 1.0, q2 = v2 ? R2s - D2 * D2 : 1.0;  // > 0 where the constraint binds
-        const double h1 = v1 ? q1 * rsqrt_fast(q1) : 0.0, h2 = v2 ? q2 * rsqrt_fast(q2) : 0.0;
-        const double yy[4] = {(v1 ? B1 : 0.0) * i1, h1 * i1, (v2 ? B2 : 0.0) * i2, h2 * i2};
-        const double xx[4] = {(v1 ? A1 : 1.0) * i1, (v1 ? D1 : 1.0) * i1, (v2 ? A2 : 1.0) * i2, (v2 ? D2 : 1.0) * i2};
-        double at[4];
-        unit_atan2_n<4>(A.utab, yy, xx, at);  // phi_1, alpha_1, phi_2, alpha_2
+        const double Rs1 = v1 ? R1s : 1.0;
+        const double i1 = rsqrt_fast(Rs1);
+        const double q1 = v1 ? R1s - D1 * D1 : 1.0;
+        const double h1 = v1 ? q1 * rsqrt_fast(q1) : 0.0;
         ang[0] = pref;
-        ang[1] = v1 ? at[0] + at[1] : a;
-        ang[2] = v1 ? at[0] - at[1] : a;
-        ang[3] = v2 ? at[2] + at[3] : a;
-        ang[4] = v2 ? at[2] - at[3] : a;
+        if constexpr (PLANE) {
+            const double A2 = r.r2 * fma(-sc, r.a1.x, r.a1.z), B2 = r.r2 * fma(-sc, r.a2.x, r.a2.z);
+            const double D2 = (A(RSIK_C_ES + 2) - A(RSIK_C_SING_OFFSET) - sc * A(RSIK_C_ES)) - fma(-sc, r.c2.x, r.c2.z);
+            const double R2s = fma(A2, A2, B2 * B2);
+            v2 = R2s > D2 * D2;
+            const double Rs2 = v2 ? R2s : 1.0;
+            const double i2 = rsqrt_fast(Rs2);
+            const double q2 = v2 ? R2s - D2 * D2 : 1.0;
+            const double h2 = v2 ? q2 * rsqrt_fast(q2) : 0.0;
+            const double yy[4] = {(v1 ? B1 : 0.0) * i1, h1 * i1, (v2 ? B2 : 0.0) * i2, h2 * i2};
+            const double xx[4] = {(v1 ? A1 : 1.0) * i1, (v1 ? D1 : 1.0) * i1, (v2 ? A2 : 1.0) * i2, (v2 ? D2 : 1.0) * i2};
+            double at[4];
+            unit_atan2_n<4>(A.utab, yy, xx, at);  // phi_1, alpha_1, phi_2, alpha_2
+            ang[1] = v1 ? at[0] + at[1] : a;
+            ang[2] = v1 ? at[0] - at[1] : a;
+            ang[NA - 2] = v2 ? at[2] + at[3] : a;
+            ang[NA - 1] = v2 ? at[2] - at[3] : a;
+        } else {
+            const double yy[2] = {(v1 ? B1 : 0.0) * i1, h1 * i1};
+            const double xx[2] = {(v1 ? A1 : 1.0) * i1, (v1 ? D1 : 1.0) * i1};
+            double at[2];
+            unit_atan2_n<2>(A.utab, yy, xx, at);
+            ang[1] = v1 ? at[0] + at[1] : a;
+            ang[2] = v1 ? at[0] - at[1] : a;
+        }
     }
     const double inv_step = fast_rcp(step);
     const int last = nb - 1;
@@ -1039,23 +1091,20 @@ __device__ bool grid_theta_candidates(const Acc& A, const Reach& r, double a, do
     int best_k = 0x7fffffff;
     double best_th = 0.0;
     auto judge = [&](int k, double th, double sn, double cs) {
-        if (is_elbow_ok(A, elbow_on_circle(r, cs, sn))) {
+        if (is_elbow_ok<PLANE>(A, elbow_on_circle(r, cs, sn))) {
             double dist = fabs(angle_diff(th, pref));
             if (dist < best_d || (dist == best_d && k < best_k)) { best_d = dist; best_k = k; best_th = th; }
         }
     };
     auto theta_of = [&](int k) -> double { return (k == last) ? b : ((double)k * step + a); };  // np.linspace (Q11)
-    {   // the two grid ends
-        const double th[2] = {theta_of(0), theta_of(last)};
-        double sn[2], cs[2];
-        fast_sincos_n<2>(th, sn, cs);
-        judge(0, th[0], sn[0], cs[0]);
-        judge(last, th[1], sn[1], cs[1]);
-    }
+    judge(0, a, sa, ca);      // the two grid ends
+    judge(last, b, sb, cb);
+    double sstep, cstep;
+    fast_sincos(step, &sstep, &cstep);
 #pragma unroll
-    for (int j = 0; j < 5; j++) {
+    for (int j = 0; j < NA; j++) {
         // an arc that never ends on the circle has no end points to look around: skip the pair when that holds for the
-        // whole wave (wave-uniform branch; e.g. the singularity-plane half never binds with the non-DVT offset, Q18)
+        // whole wave (wave-uniform branch)
         const bool anchor_valid = (j == 0) ? true : ((j <= 2) ? v1 : v2);
         if (!__any(anchor_valid)) continue;
         double pos = pymod_2pi(ang[j] - a) * inv_step;   // real-valued grid index of the anchor angle, >= 0
@@ -1065,18 +1114,16 @@ __device__ bool grid_theta_candidates(const Acc& A, const Reach& r, double a, do
         const int k0 = (int)pos;
         const double frac = pos - (double)k0;
         if (anchor_valid && (frac < 1e-6 || frac > 1.0 - 1e-6)) fast_ok = false;
-        int kk[2];
-        double th[2], sn[2], cs[2];
-#pragma unroll
-        for (int t = 0; t < 2; t++) {
-            int k = k0 + t;
-            k = k > last ? last : k;
-            kk[t] = k;
-            th[t] = theta_of(k);
-        }
-        fast_sincos_n<2>(th, sn, cs);
-#pragma unroll
-        for (int t = 0; t < 2; t++) judge(kk[t], th[t], sn[t], cs[t]);
+        const int ka = k0 > last ? last : k0, kb = k0 + 1 > last ? last : k0 + 1;
+        const double tha = theta_of(ka), thb = theta_of(kb);
+        double sna, csa;
+        fast_sincos(tha, &sna, &csa);
+        // theta_b = theta_a + step, or the grid's end point: one rotation instead of a second sincos
+        const bool b_is_end = kb == last;
+        const double csb = b_is_end ? cb : fma(csa, cstep, -(sna * sstep));
+        const double snb = b_is_end ? sb : fma(sna, cstep, csa * sstep);
+        judge(ka, tha, sna, csa);
+        judge(kb, thb, snb, csb);
     }
     theta_out = best_th;
     return best_k != 0x7fffffff;

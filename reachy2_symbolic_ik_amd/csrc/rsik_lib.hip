@@ -14,6 +14,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "rsik_device.hpp"
 
@@ -423,6 +424,7 @@ struct DiscreteArgs {
     double pref_cs[2], pref_sn[2];  // its cosine / sine (host libm, once per launch)
     double lim[2][2];     // interval_limit per arm slot (C:225-250)
     double prev_sol[2][7];
+    double prev_cs[2][3], prev_sn[2][3];  // cos / sin of previous_sol[4..6] (host libm): the wrist of a pose that falls back to it
     const double* current_joints;
     double max_angle, cos_max, sin_max;
     double* joints;
@@ -455,7 +457,7 @@ constexpr int kGeoRow0 = 6;
 // (U:443-465) and |angle_diff(theta_k, preferred)|, a segmented xor-butterfly keeps the lexicographic
 // minimum of (distance, k) = the reference's "first strict minimum" (U:381-388), the sub-group leader
 // posts the winner.  nb > 64 is handled by extra rounds of the same lanes.
-template <bool MIXED>
+template <bool MIXED, bool PLANE>
 __device__ __forceinline__ void sweep_theta_grid(const DiscreteArgs& K, uint64_t mask, int lane, bool my_isl,
                                                  SharedTables& lds_tab, const double (*geo)[64], double* res) {
     const int P = 1 << K.log2p;
@@ -496,7 +498,7 @@ __device__ __forceinline__ void sweep_theta_grid(const DiscreteArgs& K, uint64_t
                     double st, ct;
                     fast_sincos(th, &st, &ct);
                     V3 e = {a1.x * ct + a2.x * st + c2.x, a1.y * ct + a2.y * st + c2.y, a1.z * ct + a2.z * st + c2.z};
-                    if (is_elbow_ok(A, e)) {
+                    if (is_elbow_ok<PLANE>(A, e)) {
                         double dist = fabs(angle_diff(th, pref));
                         if (dist < best_d) { best_d = dist; best_k = k; }
                     }
@@ -522,7 +524,8 @@ __device__ __forceinline__ void sweep_theta_grid(const DiscreteArgs& K, uint64_t
 #ifndef RSIK_DISC_MIN_WAVES
 #define RSIK_DISC_MIN_WAVES 3  // 168 VGPR (28 B scratch) beats 182 VGPR at 2 waves/SIMD: 37.6 vs 39.0 us on config 3
 #endif
-template <bool MIXED>
+// PLANE = false: the singularity-plane half of is_elbow_ok can never fail for these arms (decided on the host).
+template <bool MIXED, bool PLANE>
 __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR void control_discrete_kernel(const DiscreteArgs K) {
     __shared__ double lds_slab[kBlock / 64][kDiscRows][64];
     const int lane = threadIdx.x & 63;
@@ -532,15 +535,20 @@ __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR void co
     const bool live = i < K.n;
     const int64_t ii = live ? i : (K.n - 1);
 
+    // the twelve goal-matrix loads (and the arm byte) are issued before the table staging so that their latency overlaps it
+    double m12[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) m12[k] = K.in[k][ii];
+    const bool lane_isl = MIXED ? (K.arm[ii] != 0) : false;
     __shared__ SharedTables lds_tab;
     stage_tables<MIXED>(lds_tab, K.arms);
-    const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[ii] != 0) : false, lds_tab);
+    const Acc<MIXED> A = make_acc<MIXED>(K.arms, lane_isl, lds_tab);
     const int slot = MIXED ? (A.isl ? 1 : 0) : 0;
 
-    // C:212-217: M -> pose (see load_m12)
+    // C:212-217: M -> pose (see goal_from_m12)
     Rot Rg;
     V3 pos;
-    load_m12(K.in, ii, Rg, pos, K.euler_roundtrip);
+    goal_from_m12(m12, Rg, pos, K.euler_roundtrip);
 
     // Of the goal orientation the solver only needs three vectors (Goal); the two that are read again by the joint
     // stage wait in the output staging slab while the theta search runs (registers are the scarce resource here)
@@ -560,15 +568,20 @@ __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR void co
     if (r.ok) {  // U:357-364 preferred-theta shortcut
         if (is_valid_angle(pref, r.i0, r.i1)) {
             const double st = K.pref_sn[slot], ct = K.pref_cs[slot];  // launch-uniform: not evaluated per lane
-            if (is_elbow_ok(A, elbow_on_circle(r, ct, st))) { found = true; theta = pref; }
+            if (is_elbow_ok<PLANE>(A, elbow_on_circle(r, ct, st))) { found = true; theta = pref; }
         }
         need = !found;
     }
+    double ca = 1.0, sa = 0.0, cb = 1.0, sb = 0.0;  // cos / sin of the grid's end points
     if (need) {  // U:366-375 grid end points
         double a, b;
-        if (fabs(fabs(r.i0) + fabs(r.i1) - kTwoPi) < 0.00001) { a = kPi / 2; b = kPi / 2 + kTwoPi; }
-        else if (r.i0 < r.i1) { a = r.i0; b = r.i1; }
-        else { a = r.i0; b = r.i1 + kTwoPi; }
+        if (fabs(fabs(r.i0) + fabs(r.i1) - kTwoPi) < 0.00001) {
+            a = kPi / 2; b = kPi / 2 + kTwoPi;
+            ca = 6.123233995736766e-17; sa = 1.0; cb = 3.061616997868383e-16; sb = 1.0;  // np.cos / np.sin of pi/2, 5pi/2
+        } else {
+            a = r.i0; b = (r.i0 < r.i1) ? r.i1 : r.i1 + kTwoPi;
+            ca = r.ct0; sa = r.st0; cb = r.ct1; sb = r.st1;  // the interval's own intersection points (reach_g)
+        }
         double (*g)[64] = &lds_slab[wave][kGeoRow0];
         g[0][lane] = r.c2.x; g[1][lane] = r.c2.y; g[2][lane] = r.c2.z;
         g[3][lane] = r.r2 * r.a1.x; g[4][lane] = r.r2 * r.a1.y; g[5][lane] = r.r2 * r.a1.z;
@@ -593,19 +606,21 @@ __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR void co
         const double ga = lds_slab[wave][kGeoRow0 + 9][lane], gb = lds_slab[wave][kGeoRow0 + 10][lane];
         const double gstep = (gb - ga) / (double)(K.nb - 1);
         if (K.nb <= 16) {
-            found_serial = best_discrete_theta_grid(A, r, ga, gstep, gb, K.nb, pref, th_serial);
+            found_serial = best_discrete_theta_grid<PLANE>(A, r, ga, gstep, gb, K.nb, pref, th_serial);
             coop = false;
         } else {
             bool fast_ok;
-            found_serial = grid_theta_candidates(A, r, ga, gstep, gb, K.nb, pref, th_serial, fast_ok);
+            found_serial = grid_theta_candidates<PLANE>(A, r, ga, gstep, gb, K.nb, pref, ca, sa, cb, sb, th_serial, fast_ok);
             coop = !fast_ok;
         }
     }
     RSIK_MARK("disc_sweep");
-    wave_lds_sync();
     const uint64_t mask = __ballot(coop);
-    sweep_theta_grid<MIXED>(K, mask, lane, A.isl, lds_tab, &lds_slab[wave][kGeoRow0], &lds_slab[wave][kGeoRow0 + 9][0]);
-    wave_lds_sync();
+    if (mask) {  // wave-uniform: most waves of a dense launch have nothing for the cooperative sweep
+        wave_lds_sync();
+        sweep_theta_grid<MIXED, PLANE>(K, mask, lane, A.isl, lds_tab, &lds_slab[wave][kGeoRow0], &lds_slab[wave][kGeoRow0 + 9][0]);
+        wave_lds_sync();
+    }
     int st_code = r.state;
     if (need) {
         double th = coop ? lds_slab[wave][kGeoRow0 + 9][lane] : (found_serial ? th_serial : __builtin_nan(""));
@@ -628,12 +643,18 @@ __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR void co
 #pragma unroll
         for (int k = 0; k < 7; k++) jv[k] = o.j[k];
         c4 = o.c4; s4 = o.s4; c5 = o.c5; s5 = o.s5; c6 = o.c6; s6 = o.s6;
-    } else {  // C:457-458
+    } else if (K.current_joints) {  // C:457-458
 #pragma unroll
-        for (int k = 0; k < 7; k++) jv[k] = K.current_joints ? K.current_joints[ii * 7 + k] : prev[k];
-        fast_sincos(jv[4], &s4, &c4);
-        fast_sincos(jv[5], &s5, &c5);
-        fast_sincos(jv[6], &s6, &c6);
+        for (int k = 0; k < 7; k++) jv[k] = K.current_joints[ii * 7 + k];
+        const double w3[3] = {jv[4], jv[5], jv[6]};
+        double sn3[3], cs3[3];
+        fast_sincos_n<3>(w3, sn3, cs3);
+        c4 = cs3[0]; s4 = sn3[0]; c5 = cs3[1]; s5 = sn3[1]; c6 = cs3[2]; s6 = sn3[2];
+    } else {  // current_joints defaults to previous_sol (C:237-238): launch constants, their sin / cos come with the launch
+#pragma unroll
+        for (int k = 0; k < 7; k++) jv[k] = prev[k];
+        c4 = K.prev_cs[slot][0]; s4 = K.prev_sn[slot][0]; c5 = K.prev_cs[slot][1]; s5 = K.prev_sn[slot][1];
+        c6 = K.prev_cs[slot][2]; s6 = K.prev_sn[slot][2];
     }
     RSIK_MARK("disc_safety");
     const int em = safety_checks(A.utab, jv, c4, s4, c5, s5, c6, s6, prev, K.max_angle, K.cos_max, K.sin_max);
@@ -735,9 +756,9 @@ __device__ __forceinline__ double continuous_next_theta(bool ok_limits, bool fou
     // sign * d_theta_max with sign = ad / |ad| (U:260, U:126) is copysign(d_theta_max, ad), bit for bit: the quotient
     // of a non-zero finite number by its own magnitude is exactly +-1.
     const double goal = ok_limits ? (found ? target : prev_theta) : pref_arg;
-    const double ad = angle_diff(goal, prev_theta);
+    const double ad = angle_diff_straight(goal, prev_theta);
     const double theta = (fabs(ad) < d_theta_max) ? goal : (prev_theta + copysign(d_theta_max, ad));
-    return limit_theta_to_interval(theta, l0, l1);
+    return limit_theta_to_interval_straight(theta, l0, l1);
 }
 
 // One launch = one control step of n independent trajectories (rsik_control_continuous_step): everything fused, the
@@ -854,6 +875,8 @@ struct ContRunArgs {
     double max_angle, cos_max, sin_max;
     double* ws;                   // [kWsFields][T][n]
     uint8_t* flags;               // [T][n]
+    double* theta_carry;          // [n]: previous_theta between the blocks of one run (phase 2's own state)
+    int first_block, last_block;
     double* st;                   // cont_state
     double* joints;               // [n_steps][n][7]
     uint8_t* reachable;           // [n_steps][n] or NULL
@@ -869,14 +892,15 @@ __global__ __launch_bounds__(kBlock) void cont_prepare_kernel(const ContRunArgs 
     const int64_t t = blockIdx.y;
     const bool live = i < K.n;
     const int64_t ii = live ? i : (K.n - 1);
-    __shared__ SharedTables lds_tab;
-    stage_tables<MIXED>(lds_tab, K.arms);
-    const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[ii] != 0) : false, lds_tab);
-    const int slot = MIXED ? (A.isl ? 1 : 0) : 0;
-    double m[12];
+    double m[12];  // loads first: their latency overlaps the table staging
     const double* src = K.m12_steps + (K.t0 + t) * 12 * K.n + ii;
 #pragma unroll
     for (int k = 0; k < 12; k++) m[k] = src[k * K.n];
+    const bool lane_isl = MIXED ? (K.arm[ii] != 0) : false;
+    __shared__ SharedTables lds_tab;
+    stage_tables<MIXED>(lds_tab, K.arms);
+    const Acc<MIXED> A = make_acc<MIXED>(K.arms, lane_isl, lds_tab);
+    const int slot = MIXED ? (A.isl ? 1 : 0) : 0;
     Rot Rg;
     V3 pos;
     goal_from_m12(m, Rg, pos, K.euler_roundtrip);
@@ -896,11 +920,16 @@ __global__ __launch_bounds__(kBlock) void cont_prepare_kernel(const ContRunArgs 
 // phase 2: one thread per trajectory walks the block's steps: the recurrence on previous_theta
 template <bool MIXED>
 __global__ __launch_bounds__(kBlock) void cont_theta_kernel(const ContRunArgs K) {
+    // a serial phase: its few waves share their SIMDs with the chip-filling phases of the neighbouring blocks (other
+    // streams) and must win the issue arbitration, or every dependent instruction waits behind throughput work
+    __builtin_amdgcn_s_setprio(3);
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= K.n) return;
     const int slot = MIXED ? (K.arm[i] != 0 ? 1 : 0) : 0;
-    if (K.st[9 * K.n + i] != 0.0) return;  // emergency stop latched: previous_theta stays (C:205-210)
-    double prev_theta = K.st[0 * K.n + i];
+    // previous_theta travels from block to block in theta_carry: this phase runs ahead of phase 4 (other streams), which
+    // alone decides what ends up in the state's row 0 — the theta of the last step, or of the step that latched the
+    // emergency stop (C:205-210; what this phase computes for a latched trajectory is never looked at).
+    double prev_theta = K.first_block ? K.st[0 * K.n + i] : K.theta_carry[i];
     const double pref_arg = K.pref_arg[slot], l0 = K.lim[slot][0], l1 = K.lim[slot][1];
     // The recurrence itself is ~50 dependent instructions per step; the memory round trip of a step's operands would
     // double that (a lone wave per SIMD, nothing to switch to), so they are fetched kSeqBatch steps at a time, one batch
@@ -941,7 +970,7 @@ __global__ __launch_bounds__(kBlock) void cont_theta_kernel(const ContRunArgs K)
         wp += n;
         fp += n;
     }
-    K.st[0 * K.n + i] = prev_theta;
+    K.theta_carry[i] = prev_theta;
 }
 
 __device__ __forceinline__ void ws_load_geometry(const ContRunArgs& K, int64_t t, int64_t i, Reach& r, Goal& G) {
@@ -981,16 +1010,18 @@ __global__ __launch_bounds__(kBlock) void cont_joints_kernel(const ContRunArgs K
     const int64_t t = blockIdx.y;
     const bool live = i < K.n;
     const int64_t ii = live ? i : (K.n - 1);
-    __shared__ SharedTables lds_tab;
-    stage_tables<MIXED>(lds_tab, K.arms);
-    const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[ii] != 0) : false, lds_tab);
-    Reach r;
+    Reach r;  // loads first: their latency overlaps the table staging
     Goal G;
     ws_load_geometry(K, t, ii, r, G);
+    const double theta = RSIK_WS(K, 0, t, ii);
+    const bool lane_isl = MIXED ? (K.arm[ii] != 0) : false;
+    __shared__ SharedTables lds_tab;
+    stage_tables<MIXED>(lds_tab, K.arms);
+    const Acc<MIXED> A = make_acc<MIXED>(K.arms, lane_isl, lds_tab);
     const double zeros[7] = {0, 0, 0, 0, 0, 0, 0};
     double jv[7];
     bool sing;
-    step_joints(A, K, r, G, RSIK_WS(K, 0, t, ii), zeros, jv, sing);
+    step_joints(A, K, r, G, theta, zeros, jv, sing);
     store_rows<7>(K.joints + (K.t0 + t) * K.n * 7, wave_base, K.n, lane, lds_out[wave], jv);
     if (live && sing) K.flags[t * K.n + i] |= 4;
 }
@@ -1000,6 +1031,7 @@ __global__ __launch_bounds__(kBlock) void cont_joints_kernel(const ContRunArgs K
 // latch C:205-210, C:398-405).
 template <bool MIXED>
 __global__ __launch_bounds__(kBlock) void cont_chain_kernel(const ContRunArgs K) {
+    __builtin_amdgcn_s_setprio(3);  // serial phase beside throughput phases (see cont_theta_kernel)
     const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t i = gid >> 3;
     const int j = (int)(gid & 7);
@@ -1049,11 +1081,11 @@ __global__ __launch_bounds__(kBlock) void cont_chain_kernel(const ContRunArgs K)
 #pragma unroll
             for (int k = 1; k < 7; k++) cur = (jj == k) ? jv[k] : cur;
         }
-        const double turned = allow_multiturn_one(cur, prev);                 // U:493-505
+        const double turned = allow_multiturn_one_straight(cur, prev);        // U:493-505
         const double clamped = fmin(fmax(turned, -lim), lim);                 // U:535-568 (lim = inf for joints 1, 3, 4, 5)
         int code = (clamped != turned && j < 7) ? hit_bit : 0;
         // U:571-589: |angle_diff(joint, previous)| against the joint's threshold, on the limited value like the reference
-        code |= (j < 7 && fabs(angle_diff(clamped, prev)) > thr) ? 16 : 0;
+        code |= (j < 7 && fabs(angle_diff_straight(clamped, prev)) > thr) ? 16 : 0;
         code = group_or(code);
         const bool disc = !init && (code & 16) != 0;
         const int cause = (code & 7) | (disc ? RSIK_EMERGENCY_CONTINUITY : 0);
@@ -1112,6 +1144,7 @@ __global__ __launch_bounds__(kBlock) void cont_chain_kernel(const ContRunArgs K)
     if (live && j == 7) {
         K.st[8 * n + i] = init ? 1.0 : 0.0;
         K.st[9 * n + i] = emergency ? 1.0 : 0.0;
+        if (K.last_block && !emergency) K.st[0 * n + i] = RSIK_WS(K, 0, K.T - 1, i);  // previous_theta after the last step
     }
 }
 
@@ -1378,6 +1411,9 @@ struct rsik_ctx {
     int options[RSIK_OPT_COUNT];
     void* ws;          // workspace of rsik_control_continuous_run's phased pipeline (device), grown on demand
     size_t ws_bytes;
+    hipStream_t side[3];             // the pipeline's own streams (prepare / joints / chain), created on first use
+    std::vector<hipEvent_t> events;  // reusable, timing disabled
+    bool have_side;
     std::string err;
 };
 
@@ -1427,12 +1463,19 @@ int rsik_create(int device_id, rsik_ctx** out) {
     for (int k = 0; k < RSIK_OPT_COUNT; k++) c->options[k] = 0;
     c->ws = nullptr;
     c->ws_bytes = 0;
+    c->have_side = false;
+    for (auto& st : c->side) st = nullptr;
     *out = c;
     return RSIK_OK;
 }
 
 int rsik_destroy(rsik_ctx* ctx) {
-    if (ctx && ctx->ws && hipSetDevice(ctx->device) == hipSuccess) (void)hipFree(ctx->ws);
+    if (ctx && hipSetDevice(ctx->device) == hipSuccess) {
+        if (ctx->ws) (void)hipFree(ctx->ws);
+        for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
+        if (ctx->have_side)
+            for (hipStream_t st : ctx->side) (void)hipStreamDestroy(st);
+    }
     delete ctx;
     return RSIK_OK;
 }
@@ -1638,7 +1681,22 @@ int rsik_control_discrete(rsik_ctx* ctx, int64_t n, const double* const m12_soa[
         K.pref_cs[slot] = std::cos(K.pref[slot]);  // np.cos / np.sin of the reference (U:359-360), once per launch
         K.pref_sn[slot] = std::sin(K.pref[slot]);
         for (int k = 0; k < 7; k++) K.prev_sol[slot][k] = previous_sol_host[7 * a + k];
+        for (int k = 0; k < 3; k++) {
+            K.prev_cs[slot][k] = std::cos(K.prev_sol[slot][4 + k]);
+            K.prev_sn[slot][k] = std::sin(K.prev_sol[slot][4 + k]);
+        }
         K.arms[slot] = ctx->arms[a];
+    }
+    // Can the singularity-plane half of is_elbow_ok (utils.py:459-464) fail at all?  The elbow lies on the sphere of
+    // radius u around the shoulder, so e_z - c e_x <= s_z - c s_x + u sqrt(1 + c^2); when that bound stays below the
+    // plane's right-hand side (the non-DVT offset -1.01: by a metre) the test is compiled out of the launch.
+    bool plane_binds = false;
+    for (int slot = 0; slot < 2; slot++) {
+        const double* c = K.arms[slot].v;
+        const double sc = c[RSIK_C_SING_COEFF];
+        const double rhs = c[RSIK_C_ES + 2] - c[RSIK_C_SING_OFFSET] - sc * c[RSIK_C_ES];
+        const double reach_max = c[RSIK_C_SHOULDER + 2] - sc * c[RSIK_C_SHOULDER] + c[RSIK_C_UPPER_ARM] * std::sqrt(1.0 + sc * sc);
+        if (!(rhs > reach_max + 1e-6)) plane_binds = true;
     }
     K.current_joints = current_joints;
     K.max_angle = orbita3d_max_angle;
@@ -1649,8 +1707,13 @@ int rsik_control_discrete(rsik_ctx* ctx, int64_t n, const double* const m12_soa[
     dim3 grid, block(rsik::kBlock);
     rc = launch_dims(ctx, n, &grid, "rsik_control_discrete");
     if (rc != RSIK_OK) return rc;
-    if (arm) hipLaunchKernelGGL(rsik::control_discrete_kernel<true>, grid, block, 0, ctx->stream, K);
-    else hipLaunchKernelGGL(rsik::control_discrete_kernel<false>, grid, block, 0, ctx->stream, K);
+    if (arm) {
+        if (plane_binds) hipLaunchKernelGGL((rsik::control_discrete_kernel<true, true>), grid, block, 0, ctx->stream, K);
+        else hipLaunchKernelGGL((rsik::control_discrete_kernel<true, false>), grid, block, 0, ctx->stream, K);
+    } else {
+        if (plane_binds) hipLaunchKernelGGL((rsik::control_discrete_kernel<false, true>), grid, block, 0, ctx->stream, K);
+        else hipLaunchKernelGGL((rsik::control_discrete_kernel<false, false>), grid, block, 0, ctx->stream, K);
+    }
     RSIK_HIP(ctx, hipGetLastError());
     return RSIK_OK;
 }
@@ -1765,21 +1828,46 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         RSIK_HIP(ctx, hipGetLastError());
         return RSIK_OK;
     }
-    // ---- phased pipeline.  Block length: the workspace stays within 256 MB (the Infinity Cache holds it between phases)
+    // ---- phased pipeline.  The four phases of a block run on four streams (theta on the caller's, the others on the
+    // context's own), ordered by events: prepare(b) -> theta(b) -> joints(b) -> chain(b), theta(b) after theta(b-1),
+    // chain(b) after chain(b-1).  The two sequential phases (a lone wave per SIMD on a few CUs) then run beside each other
+    // and beside the chip-filling ones of the neighbouring blocks.  Four workspace slots are in flight (block b + 4
+    // reuses the slot of block b once chain(b) has finished); a block's slot is at most 64 MB.
+    constexpr int kSlots = 4;
     const size_t per_step = (size_t)n * (rsik::kWsFields * sizeof(double) + 1);
-    int64_t T = (int64_t)((size_t)256 << 20) / (int64_t)per_step;
+    int64_t T = (int64_t)((size_t)128 << 20) / (int64_t)per_step;
     if (T < 1) T = 1;
     if (T > n_steps) T = n_steps;
     if (T > 65535) T = 65535;  // gridDim.y
-    const size_t need = (size_t)T * per_step + 256;
+    const int64_t n_blocks = (n_steps + T - 1) / T;
+    const size_t slot_bytes = (((size_t)T * per_step + 255) / 256) * 256;
+    const int slots = n_blocks < kSlots ? (int)n_blocks : kSlots;
+    const size_t carry_bytes = (((size_t)n * sizeof(double) + 255) / 256) * 256;
+    const size_t need = slot_bytes * slots + carry_bytes;
     if (ctx->ws_bytes < need) {
-        if (ctx->ws) { RSIK_HIP(ctx, hipStreamSynchronize(ctx->stream)); RSIK_HIP(ctx, hipFree(ctx->ws)); ctx->ws = nullptr; ctx->ws_bytes = 0; }
+        if (ctx->ws) { RSIK_HIP(ctx, hipDeviceSynchronize()); RSIK_HIP(ctx, hipFree(ctx->ws)); ctx->ws = nullptr; ctx->ws_bytes = 0; }
         RSIK_HIP(ctx, hipMalloc(&ctx->ws, need));
         ctx->ws_bytes = need;
     }
-    // (re)initialisation of the trajectories that start here (C:296-325)
-    if (arm) hipLaunchKernelGGL(rsik::cont_init_kernel<true>, grid, block, 0, ctx->stream, K0);
-    else hipLaunchKernelGGL(rsik::cont_init_kernel<false>, grid, block, 0, ctx->stream, K0);
+    if (!ctx->have_side) {
+        for (auto& st : ctx->side) RSIK_HIP(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        ctx->have_side = true;
+    }
+    const size_t n_events = 2 + 4 * (size_t)n_blocks;
+    while (ctx->events.size() < n_events) {
+        hipEvent_t e;
+        RSIK_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->events.push_back(e);
+    }
+    hipStream_t s_theta = ctx->stream, s_prep = ctx->side[0], s_joints = ctx->side[1], s_chain = ctx->side[2];
+    auto ev = [&](int kind, int64_t b) { return ctx->events[2 + 4 * (size_t)b + kind]; };  // 0 prepared, 1 theta, 2 joints, 3 chain
+    // (re)initialisation of the trajectories that start here (C:296-325), then the side streams join in
+    if (arm) hipLaunchKernelGGL(rsik::cont_init_kernel<true>, grid, block, 0, s_theta, K0);
+    else hipLaunchKernelGGL(rsik::cont_init_kernel<false>, grid, block, 0, s_theta, K0);
+    RSIK_HIP(ctx, hipEventRecord(ctx->events[0], s_theta));
+    RSIK_HIP(ctx, hipStreamWaitEvent(s_prep, ctx->events[0], 0));
+    RSIK_HIP(ctx, hipStreamWaitEvent(s_joints, ctx->events[0], 0));
+    RSIK_HIP(ctx, hipStreamWaitEvent(s_chain, ctx->events[0], 0));
     rsik::ContRunArgs R;
     std::memset(&R, 0, sizeof R);
     R.n = n;
@@ -1794,27 +1882,38 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     R.d_theta_max = d_theta_max;
     R.max_angle = K0.max_angle; R.cos_max = K0.cos_max; R.sin_max = K0.sin_max;
     R.st = cont_state; R.joints = joints_steps; R.reachable = reachable_steps; R.state = state_steps;
+    R.theta_carry = reinterpret_cast<double*>(static_cast<char*>(ctx->ws) + slot_bytes * slots);
     dim3 grid8;
     rc = launch_dims(ctx, n * 8, &grid8, who);
     if (rc != RSIK_OK) return rc;
-    for (int64_t t0 = 0; t0 < n_steps; t0 += T) {
+    for (int64_t b = 0; b < n_blocks; b++) {
+        const int64_t t0 = b * T;
         R.t0 = t0;
         R.T = (n_steps - t0 < T) ? (n_steps - t0) : T;
-        R.ws = static_cast<double*>(ctx->ws);
+        R.first_block = b == 0;
+        R.last_block = b == n_blocks - 1;
+        R.ws = reinterpret_cast<double*>(static_cast<char*>(ctx->ws) + slot_bytes * (size_t)(b % slots));
         R.flags = reinterpret_cast<uint8_t*>(R.ws + (size_t)rsik::kWsFields * (size_t)R.T * (size_t)n);
         const dim3 grid2(grid.x, (unsigned)R.T);
-        if (arm) {
-            hipLaunchKernelGGL(rsik::cont_prepare_kernel<true>, grid2, block, 0, ctx->stream, R);
-            hipLaunchKernelGGL(rsik::cont_theta_kernel<true>, grid, block, 0, ctx->stream, R);
-            hipLaunchKernelGGL(rsik::cont_joints_kernel<true>, grid2, block, 0, ctx->stream, R);
-            hipLaunchKernelGGL(rsik::cont_chain_kernel<true>, grid8, block, 0, ctx->stream, R);
-        } else {
-            hipLaunchKernelGGL(rsik::cont_prepare_kernel<false>, grid2, block, 0, ctx->stream, R);
-            hipLaunchKernelGGL(rsik::cont_theta_kernel<false>, grid, block, 0, ctx->stream, R);
-            hipLaunchKernelGGL(rsik::cont_joints_kernel<false>, grid2, block, 0, ctx->stream, R);
-            hipLaunchKernelGGL(rsik::cont_chain_kernel<false>, grid8, block, 0, ctx->stream, R);
-        }
+        if (b >= slots) RSIK_HIP(ctx, hipStreamWaitEvent(s_prep, ev(3, b - slots), 0));  // the slot's previous block is done
+        if (arm) hipLaunchKernelGGL(rsik::cont_prepare_kernel<true>, grid2, block, 0, s_prep, R);
+        else hipLaunchKernelGGL(rsik::cont_prepare_kernel<false>, grid2, block, 0, s_prep, R);
+        RSIK_HIP(ctx, hipEventRecord(ev(0, b), s_prep));
+        RSIK_HIP(ctx, hipStreamWaitEvent(s_theta, ev(0, b), 0));
+        if (arm) hipLaunchKernelGGL(rsik::cont_theta_kernel<true>, grid, block, 0, s_theta, R);
+        else hipLaunchKernelGGL(rsik::cont_theta_kernel<false>, grid, block, 0, s_theta, R);
+        RSIK_HIP(ctx, hipEventRecord(ev(1, b), s_theta));
+        RSIK_HIP(ctx, hipStreamWaitEvent(s_joints, ev(1, b), 0));
+        if (arm) hipLaunchKernelGGL(rsik::cont_joints_kernel<true>, grid2, block, 0, s_joints, R);
+        else hipLaunchKernelGGL(rsik::cont_joints_kernel<false>, grid2, block, 0, s_joints, R);
+        RSIK_HIP(ctx, hipEventRecord(ev(2, b), s_joints));
+        RSIK_HIP(ctx, hipStreamWaitEvent(s_chain, ev(2, b), 0));
+        if (arm) hipLaunchKernelGGL(rsik::cont_chain_kernel<true>, grid8, block, 0, s_chain, R);
+        else hipLaunchKernelGGL(rsik::cont_chain_kernel<false>, grid8, block, 0, s_chain, R);
+        RSIK_HIP(ctx, hipEventRecord(ev(3, b), s_chain));
     }
+    // the caller's stream continues once the last chain (hence every phase of every block) is done
+    RSIK_HIP(ctx, hipStreamWaitEvent(s_theta, ev(3, n_blocks - 1), 0));
     RSIK_HIP(ctx, hipGetLastError());
     return RSIK_OK;
 }
