@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Copies the judged artefacts of scripts/profile.sh runs (gpurun_out/<prefix>_c{2,3,4}) into profiles/r01/ and
-rebuilds profiles/r01/traffic.json (HBM bytes per launch and executed VALU instructions per wave from the PMC passes).
+"""Copies the judged artefacts of scripts/profile.sh runs (gpurun_out/<prefix>_c{2,3,4,5}) into profiles/<round>/ and
+rebuilds profiles/<round>/counters.json: HBM bytes per launch and executed VALU instructions per wave from the PMC
+passes, together with the build id of the library they were collected with (bench.py only quotes them for that build).
 
-    python scripts/collect_profiles.py r01_s2c s2
+    python scripts/collect_profiles.py r02_c s1 [r02]
 """
 import glob
 import json
@@ -13,7 +14,9 @@ import sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prefix, suffix = sys.argv[1], sys.argv[2]
-dest = os.path.join(root, "profiles", "r01")
+rnd = sys.argv[3] if len(sys.argv) > 3 else "r02"
+dest = os.path.join(root, "profiles", rnd)
+os.makedirs(dest, exist_ok=True)
 
 
 def parse(path):
@@ -34,16 +37,30 @@ out = {"_comment": "HBM bytes per launch and executed vector instructions per wa
                    "gfx950 correction + WRITE_SIZE, KiB units; SQ_INSTS_VALU / SQ_WAVES), scripts/profile.sh; see "
                    f"config*_{suffix}_summary.txt"}
 want = {2: ("solve_kernel<0,", 1048576, "solve_kernel"), 3: ("control_discrete_kernel<false", 262144, "control_discrete_kernel"),
-        4: ("solve_kernel<2,", 1048576, "solve_kernel<mixed>")}
+        4: ("solve_kernel<2,", 1048576, "solve_kernel<mixed>"), 5: (None, 4096, "cont_*_kernel pipeline")}
+builds = set()
 for c, (kn, grid, label) in want.items():
-    src = os.path.join(root, "gpurun_out", f"{prefix}_c{c}")
+    src = os.path.join(root, "gpurun_out", f"{prefix}{c}")
+    if not os.path.isdir(src):
+        continue
     shutil.copy(os.path.join(src, "summary.txt"), os.path.join(dest, f"config{c}_{suffix}_summary.txt"))
     shutil.copy(os.path.join(src, "bench.json"), os.path.join(dest, f"bench_config{c}_{suffix}.json"))
+    try:
+        builds.add(json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])["library_build"])
+    except (ValueError, KeyError, IndexError):
+        pass
     for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
         shutil.copy(f, os.path.join(dest, f"config{c}_{suffix}_kernel_stats.csv"))
+    if kn is None:
+        continue
     for (name, g), v in parse(os.path.join(src, "summary.txt")).items():
         if kn in name and g == grid and "FETCH_SIZE" in v:
             out[str(c)] = {"poses_per_gpu": grid, "kernel": label, "bytes": int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024),
-                           "valu_per_wave": round(v["SQ_INSTS_VALU"] / v["SQ_WAVES"], 1)}
+                           "valu_per_wave": round(v["SQ_INSTS_VALU"] / v["SQ_WAVES"], 1),
+                           "lds_instr_per_wave": round(v.get("SQ_INSTS_LDS", 0.0) / v["SQ_WAVES"], 1),
+                           "lds_bank_conflict_cycles_per_wave": round(v.get("SQ_LDS_BANK_CONFLICT", 0.0) / v["SQ_WAVES"], 1)}
             print(c, out[str(c)])
-json.dump(out, open(os.path.join(dest, "traffic.json"), "w"), indent=2)
+assert len(builds) == 1, f"the runs were made with different library builds: {builds}"
+out["build_id"] = builds.pop()
+json.dump(out, open(os.path.join(dest, "counters.json"), "w"), indent=2)
+print("build", out["build_id"])
