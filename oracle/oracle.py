@@ -66,6 +66,8 @@ def _bind(L):
     L.orc_limit_orbita3d_joints.argtypes = [_dp, C.c_double, _dp]
     L.orc_rotation_matrix_from_vector.argtypes = [_dp, _dp]
     L.orc_euler_from_matrix_xyz.argtypes = [_dp, _dp]
+    L.orc_get_best_discrete_theta.restype = C.c_int
+    L.orc_get_best_discrete_theta.argtypes = [_dp, _dp, C.c_double, _dp, C.c_int, C.c_double, _dp]
     L.orc_control_discrete.restype = C.c_int
     L.orc_control_discrete.argtypes = [_dp, _dp, C.c_int, C.c_double, C.c_int, _dp, _dp, C.c_double, C.c_double, _dp, _ip, _ip]
     L.orc_control_continuous_step.restype = C.c_int
@@ -187,6 +189,13 @@ class Solver:
         pj = _f64(previous_joints)
         proj = lib().orc_get_joints(_d(self.arm.buf), _d(self.buf), float(theta), _d(pj), _d(j), _d(e))
         return j, e, bool(proj)
+
+    def best_discrete_theta(self, interval, nb_search_points, preferred_theta, previous_theta=0.0):
+        """utils.get_best_discrete_theta (utils.py:334-396) on the circle of the last is_reachable: (found, theta)."""
+        itv, th = _f64(interval), np.zeros(1)
+        ok = lib().orc_get_best_discrete_theta(_d(self.arm.buf), _d(self.buf), float(previous_theta), _d(itv),
+                                               int(nb_search_points), float(preferred_theta), _d(th))
+        return bool(ok), float(th[0])
 
     def best_theta_to_current_joints(self, current_joints, preferred_theta):
         cj = _f64(current_joints).ravel()

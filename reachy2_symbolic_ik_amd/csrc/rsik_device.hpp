@@ -1028,27 +1028,39 @@ __device__ double best_theta_to_current_joints(const Acc& A, Reach& r, const Rot
 // utils.get_best_discrete_theta's grid search (U:366-396) without walking the whole grid.
 //
 // Both halves of is_elbow_ok (U:443-465) are of the form  A cos(theta) + B sin(theta) < D  on the elbow circle, i.e.
-// each is satisfied on one open arc whose two end angles are phi +- acos(D / R) (R = |(A, B)|, phi = atan2(B, A)).
-// The grid points that pass are therefore at most a few index runs delimited by those four angles and the grid ends,
-// and inside a run |angle_diff(theta_k, preferred)| is smallest either next to the preferred angle or at a run end.
-// So the first-strict-minimum of the reference is among: the two grid ends, the 2 grid points that bracket the preferred
-// angle and the 2 that bracket each arc end (12 evaluations, independent of nb_search_points).  Each candidate is
-// then judged with the reference's own predicate and distance (same theta_k = linspace value, same is_elbow_ok), so the
-// analytic arcs only propose candidates, they never decide.  `fast_ok` = false (degenerate step) asks the caller to
-// fall back to the exhaustive wave-cooperative sweep.
+// each FAILS on one closed arc [phi - alpha, phi + alpha] (R = |(A, B)|, phi = atan2(B, A), alpha = acos(D / R)).
+// The grid points that pass are therefore a few index runs delimited by those arc ends and the grid ends, and the
+// first-strict-minimum of |angle_diff(theta_k, preferred)| (U:381-388) over a run sits at a run end or next to the
+// preferred angle.  This search only runs after the preferred-theta shortcut (U:357-364) has failed, i.e. the
+// preferred angle is either outside the interval (no grid point around it: the nearest ones are the grid ends) or inside
+// one of the failing arcs (the nearest passing points are the ones just outside that arc's ends).  So the minimum is
+// among: the two grid ends and, per arc, the first grid point above its upper end and the last one below its lower end
+// — 4 (PLANE = false) or 6 candidates, independent of nb_search_points.  (The grid points just INSIDE an arc end fail by
+// construction; if an arc holds no grid point at all, the outside neighbour of one end is the inside neighbour of the
+// other.)  Each candidate is then judged with the reference's own predicate and distance (same theta_k = linspace value,
+// same is_elbow_ok), so the arcs only propose.  `fast_ok` = false hands the pose to the exhaustive wave-cooperative sweep:
+// a degenerate step, an anchor within 1e-10 rad / 1e-6 steps of a grid point (its rounding could move it across), an arc
+// that nearly vanishes (its ends are ill-conditioned).  `pref_free`: the caller saw one of the two situations in which
+// the shortcut fails although the preferred angle can have passing grid points around it — the whole-circle grid of
+// U:366-368 chosen for an interval that does not contain the preferred angle, or a preferred angle outside [-pi, pi]
+// (U:468-474 compares it unwrapped; the left arm's mirrored -pi - preferred_theta, C:252) — and the two grid points that
+// bracket the preferred angle are judged as well (a wave-uniform branch no wave of a typical launch takes).
 // ends_cs = cos/sin of the two grid ends (known from the interval's intersection points, or constants for the whole
-// circle): they are not evaluated again.  The second point of every bracket is the first one turned by one grid step.
+// circle): they are not evaluated again.
 template <bool PLANE = true, class Acc>
 __device__ bool grid_theta_candidates(const Acc& A, const Reach& r, double a, double step, double b, int nb, double pref,
-                                      double ca, double sa, double cb, double sb, double& theta_out, bool& fast_ok) {
+                                      double ca, double sa, double cb, double sb, bool pref_free, double& theta_out,
+                                      bool& fast_ok) {
     fast_ok = step > 1e-9;
     const double side = A(RSIK_C_SIDE), sc = A(RSIK_C_SING_COEFF);
     // constraint 1: side * e_y < -0.2;  constraint 2: e_z - sc * e_x < es_z - so - sc * es_x
     const double A1 = side * r.r2 * r.a1.y, B1 = side * r.r2 * r.a2.y, D1 = -0.2 - side * r.c2.y;
     const double R1s = fma(A1, A1, B1 * B1);
-    const bool v1 = R1s > D1 * D1;  // the constraint really changes sign on the circle
-    constexpr int NA = PLANE ? 5 : 3;
-    double ang[NA];
+    const double q1r = fma(-D1, D1, R1s);
+    const bool v1 = q1r > 0.0;  // the constraint really changes sign on the circle
+    if (fabs(q1r) < 1e-6 * R1s) fast_ok = false;
+    constexpr int NC = PLANE ? 4 : 2;  // candidates besides the grid ends
+    double ang[NC];
     bool v2 = false;
     {
         // phi = direction of (A, B), alpha = acos(D / R) = direction of (D, sqrt(R^2 - D^2)): both vectors have length R,
@@ -1056,36 +1068,35 @@ __device__ bool grid_theta_candidates(const Acc& A, const Reach& r, double a, do
         // does not change sign on the circle (v false) gets harmless stand-ins; its angles are not used.
         const double Rs1 = v1 ? R1s : 1.0;
         const double i1 = rsqrt_fast(Rs1);
-        const double q1 = v1 ? R1s - D1 * D1 : 1.0;
+        const double q1 = v1 ? q1r : 1.0;
         const double h1 = v1 ? q1 * rsqrt_fast(q1) : 0.0;
-        ang[0] = pref;
         if constexpr (PLANE) {
             const double A2 = r.r2 * fma(-sc, r.a1.x, r.a1.z), B2 = r.r2 * fma(-sc, r.a2.x, r.a2.z);
             const double D2 = (A(RSIK_C_ES + 2) - A(RSIK_C_SING_OFFSET) - sc * A(RSIK_C_ES)) - fma(-sc, r.c2.x, r.c2.z);
             const double R2s = fma(A2, A2, B2 * B2);
-            v2 = R2s > D2 * D2;
+            const double q2r = fma(-D2, D2, R2s);
+            v2 = q2r > 0.0;
+            if (fabs(q2r) < 1e-6 * R2s) fast_ok = false;
             const double Rs2 = v2 ? R2s : 1.0;
             const double i2 = rsqrt_fast(Rs2);
-            const double q2 = v2 ? R2s - D2 * D2 : 1.0;
+            const double q2 = v2 ? q2r : 1.0;
             const double h2 = v2 ? q2 * rsqrt_fast(q2) : 0.0;
             const double yy[4] = {(v1 ? B1 : 0.0) * i1, h1 * i1, (v2 ? B2 : 0.0) * i2, h2 * i2};
             const double xx[4] = {(v1 ? A1 : 1.0) * i1, (v1 ? D1 : 1.0) * i1, (v2 ? A2 : 1.0) * i2, (v2 ? D2 : 1.0) * i2};
             double at[4];
             unit_atan2_n<4>(A.utab, yy, xx, at);  // phi_1, alpha_1, phi_2, alpha_2
-            ang[1] = v1 ? at[0] + at[1] : a;
-            ang[2] = v1 ? at[0] - at[1] : a;
-            ang[NA - 2] = v2 ? at[2] + at[3] : a;
-            ang[NA - 1] = v2 ? at[2] - at[3] : a;
+            ang[0] = at[0] + at[1]; ang[1] = at[0] - at[1];
+            ang[2] = at[2] + at[3]; ang[3] = at[2] - at[3];
         } else {
             const double yy[2] = {(v1 ? B1 : 0.0) * i1, h1 * i1};
             const double xx[2] = {(v1 ? A1 : 1.0) * i1, (v1 ? D1 : 1.0) * i1};
             double at[2];
             unit_atan2_n<2>(A.utab, yy, xx, at);
-            ang[1] = v1 ? at[0] + at[1] : a;
-            ang[2] = v1 ? at[0] - at[1] : a;
+            ang[0] = at[0] + at[1]; ang[1] = at[0] - at[1];
         }
     }
     const double inv_step = fast_rcp(step);
+    const double eps = fmax(1e-6, 1e-10 * inv_step);  // in grid steps
     const int last = nb - 1;
     double best_d = __builtin_inf();
     int best_k = 0x7fffffff;
@@ -1096,34 +1107,41 @@ __device__ bool grid_theta_candidates(const Acc& A, const Reach& r, double a, do
             if (dist < best_d || (dist == best_d && k < best_k)) { best_d = dist; best_k = k; best_th = th; }
         }
     };
-    auto theta_of = [&](int k) -> double { return (k == last) ? b : ((double)k * step + a); };  // np.linspace (Q11)
     judge(0, a, sa, ca);      // the two grid ends
     judge(last, b, sb, cb);
-    double sstep, cstep;
-    fast_sincos(step, &sstep, &cstep);
+    // arc j: ang[2 j] = its upper end (candidate: the first grid point above), ang[2 j + 1] = its lower end (the last
+    // grid point below).  An end beyond the grid clamps to the last point, i.e. to a candidate that is already there.
+    int kc[NC];
+    double thc[NC];
 #pragma unroll
-    for (int j = 0; j < NA; j++) {
-        // an arc that never ends on the circle has no end points to look around: skip the pair when that holds for the
-        // whole wave (wave-uniform branch)
-        const bool anchor_valid = (j == 0) ? true : ((j <= 2) ? v1 : v2);
-        if (!__any(anchor_valid)) continue;
-        double pos = pymod_2pi(ang[j] - a) * inv_step;   // real-valued grid index of the anchor angle, >= 0
+    for (int j = 0; j < NC; j++) {
+        const bool arc_valid = (j < 2) ? v1 : v2;
+        double pos = pymod_2pi(ang[j] - a) * inv_step;   // real-valued grid index of the arc end, >= 0
         pos = (pos < 2.0e9) ? pos : 0.0;                 // also catches NaN
-        // the two grid points that bracket the anchor.  When the anchor sits within 1e-6 of a grid point its own
-        // rounding could move it across: such a pose goes to the exhaustive sweep instead (fast_ok = false).
         const int k0 = (int)pos;
         const double frac = pos - (double)k0;
-        if (anchor_valid && (frac < 1e-6 || frac > 1.0 - 1e-6)) fast_ok = false;
-        const int ka = k0 > last ? last : k0, kb = k0 + 1 > last ? last : k0 + 1;
-        const double tha = theta_of(ka), thb = theta_of(kb);
-        double sna, csa;
-        fast_sincos(tha, &sna, &csa);
-        // theta_b = theta_a + step, or the grid's end point: one rotation instead of a second sincos
-        const bool b_is_end = kb == last;
-        const double csb = b_is_end ? cb : fma(csa, cstep, -(sna * sstep));
-        const double snb = b_is_end ? sb : fma(sna, cstep, csa * sstep);
-        judge(ka, tha, sna, csa);
-        judge(kb, thb, snb, csb);
+        if (arc_valid && (frac < eps || frac > 1.0 - eps)) fast_ok = false;
+        const int kk = k0 + ((j & 1) ? 0 : 1);
+        kc[j] = arc_valid ? (kk > last ? last : kk) : 0;  // an arc without ends proposes the grid's first point again
+        thc[j] = (kc[j] == last) ? b : ((double)kc[j] * step + a);  // np.linspace (Q11)
+    }
+    {
+        double sn[NC], cs[NC];
+        fast_sincos_n<NC>(thc, sn, cs);
+#pragma unroll
+        for (int j = 0; j < NC; j++) judge(kc[j], thc[j], sn[j], cs[j]);
+    }
+    if (RSIK_RARE(__any(pref_free))) {
+        double pos = pymod_2pi(pref - a) * inv_step;
+        pos = (pos < 2.0e9) ? pos : 0.0;
+        const int k0 = (int)pos;
+        const double frac = pos - (double)k0;
+        if (pref_free && (frac < eps || frac > 1.0 - eps)) fast_ok = false;
+        const int kb[2] = {k0 > last ? last : k0, k0 + 1 > last ? last : k0 + 1};
+        const double thb[2] = {(kb[0] == last) ? b : ((double)kb[0] * step + a), (kb[1] == last) ? b : ((double)kb[1] * step + a)};
+        double sn[2], cs[2];
+        fast_sincos_n<2>(thb, sn, cs);
+        if (pref_free) { judge(kb[0], thb[0], sn[0], cs[0]); judge(kb[1], thb[1], sn[1], cs[1]); }
     }
     theta_out = best_th;
     return best_k != 0x7fffffff;

@@ -565,19 +565,24 @@ __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR void co
     bool found = false;
     double theta = 0.0;
     bool need = false;
+    bool pref_valid = false;
     if (r.ok) {  // U:357-364 preferred-theta shortcut
-        if (is_valid_angle(pref, r.i0, r.i1)) {
+        pref_valid = is_valid_angle(pref, r.i0, r.i1);
+        if (pref_valid) {
             const double st = K.pref_sn[slot], ct = K.pref_cs[slot];  // launch-uniform: not evaluated per lane
             if (is_elbow_ok<PLANE>(A, elbow_on_circle(r, ct, st))) { found = true; theta = pref; }
         }
         need = !found;
     }
     double ca = 1.0, sa = 0.0, cb = 1.0, sb = 0.0;  // cos / sin of the grid's end points
+    // grid points may pass on both sides of the preferred angle although the shortcut failed (see grid_theta_candidates)
+    bool pref_free = need && !pref_valid && fabs(pref) > kPi;
     if (need) {  // U:366-375 grid end points
         double a, b;
         if (fabs(fabs(r.i0) + fabs(r.i1) - kTwoPi) < 0.00001) {
             a = kPi / 2; b = kPi / 2 + kTwoPi;
             ca = 6.123233995736766e-17; sa = 1.0; cb = 3.061616997868383e-16; sb = 1.0;  // np.cos / np.sin of pi/2, 5pi/2
+            pref_free = pref_free || !pref_valid;
         } else {
             a = r.i0; b = (r.i0 < r.i1) ? r.i1 : r.i1 + kTwoPi;
             ca = r.ct0; sa = r.st0; cb = r.ct1; sb = r.st1;  // the interval's own intersection points (reach_g)
@@ -590,13 +595,14 @@ __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR void co
     }
     // Two ways to search the grid, chosen per wave (wave-uniform): when only a few lanes need it, the exhaustive
     // wave-cooperative sweep (cost ~ number of such poses); when most lanes need it, every lane searches its own
-    // pose serially — the whole grid if it is short, else the 12 bracketing candidates (grid_theta_candidates).
+    // pose serially — the whole grid if it is short, else the 4 / 6 arc-end candidates (grid_theta_candidates).
     RSIK_MARK("disc_grid");
     const uint64_t need_mask = __ballot(need);
     const int cnt = __popcll(need_mask);
-    const int serial_evals = (K.nb <= 16) ? K.nb : 12;
+    const bool walk = K.nb <= 4;  // a grid this short is cheaper to walk than to analyse
+    const int serial_cost = walk ? K.nb * 60 : (PLANE ? 340 : 230);
     const int coop_rounds = ((cnt + (64 >> K.log2p) - 1) >> (6 - K.log2p)) * ((K.nb + 63) >> 6);
-    bool dense = serial_evals * 70 + (K.nb <= 16 ? 0 : 350) < coop_rounds * 150;
+    bool dense = serial_cost < coop_rounds * 150;
     if (K.sweep_mode == 1) dense = false;
     if (K.sweep_mode == 2) dense = true;
     bool coop = need;
@@ -605,12 +611,12 @@ __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR void co
     if (dense && need) {
         const double ga = lds_slab[wave][kGeoRow0 + 9][lane], gb = lds_slab[wave][kGeoRow0 + 10][lane];
         const double gstep = (gb - ga) / (double)(K.nb - 1);
-        if (K.nb <= 16) {
+        if (walk) {
             found_serial = best_discrete_theta_grid<PLANE>(A, r, ga, gstep, gb, K.nb, pref, th_serial);
             coop = false;
         } else {
             bool fast_ok;
-            found_serial = grid_theta_candidates<PLANE>(A, r, ga, gstep, gb, K.nb, pref, ca, sa, cb, sb, th_serial, fast_ok);
+            found_serial = grid_theta_candidates<PLANE>(A, r, ga, gstep, gb, K.nb, pref, ca, sa, cb, sb, pref_free, th_serial, fast_ok);
             coop = !fast_ok;
         }
     }
