@@ -161,7 +161,11 @@ int rsik_set_arm(rsik_ctx *ctx, int arm, const double *consts_host, int count);
 #define RSIK_CONT_RUN_AUTO 0
 #define RSIK_CONT_RUN_PHASED 1
 #define RSIK_CONT_RUN_STEPS 2
-#define RSIK_OPT_COUNT 5
+/* Tuning of rsik_control_continuous_run's phased pipeline (results do not depend on it):
+ *   RSIK_OPT_CONT_BLOCK_STEPS  0 (default) = equal blocks of as many control steps as a 128 MB workspace slot holds;
+ *                              n > 0 = the run's first block has n steps and the following ones double up to that limit */
+#define RSIK_OPT_CONT_BLOCK_STEPS 5
+#define RSIK_OPT_COUNT 6
 int rsik_set_option(rsik_ctx *ctx, int option, int value);
 int rsik_get_option(const rsik_ctx *ctx, int option, int *value);
 

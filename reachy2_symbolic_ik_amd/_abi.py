@@ -75,6 +75,7 @@ PROTOTYPES = {
 
 GOAL_POSE6, GOAL_M12 = 0, 1
 OPT_EULER_ROUNDTRIP, OPT_SWEEP_MODE, OPT_NO_TIPZ, OPT_NO_MIRROR, OPT_CONT_RUN_MODE = 0, 1, 2, 3, 4
+OPT_CONT_BLOCK_STEPS = 5
 CONT_RUN_AUTO, CONT_RUN_PHASED, CONT_RUN_STEPS = 0, 1, 2
 EMERGENCY_SHOULDER_PITCH, EMERGENCY_ELBOW_YAW, EMERGENCY_WRIST_YAW, EMERGENCY_CONTINUITY = 1, 2, 4, 8
 EULER_AUTO, EULER_ALWAYS, EULER_NEVER = 0, 1, 2

@@ -1147,4 +1147,32 @@ __device__ bool grid_theta_candidates(const Acc& A, const Reach& r, double a, do
     return best_k != 0x7fffffff;
 }
 
+// utils.get_best_discrete_theta (U:334-396), one pose per lane, as the continuous mode calls it for every control step
+// (10 points, C:350-361): the preferred-theta shortcut, then the arc-end candidates of grid_theta_candidates instead of
+// a walk over the grid; the few poses that search hands back (fast_ok false) walk it.
+// pref_cs / pref_sn: cos / sin of the (launch-constant) preferred angle, host libm.
+template <bool PLANE, class Acc>
+__device__ bool best_discrete_theta_lane(const Acc& A, const Reach& r, int nb, double pref, double pref_cs, double pref_sn,
+                                         double& theta_out) {
+    const bool valid = is_valid_angle(pref, r.i0, r.i1);
+    if (valid && is_elbow_ok<PLANE>(A, elbow_on_circle(r, pref_cs, pref_sn))) { theta_out = pref; return true; }  // U:357-364
+    double a, b, ca, sa, cb, sb;
+    bool pref_free = !valid && fabs(pref) > kPi;
+    if (fabs(fabs(r.i0) + fabs(r.i1) - kTwoPi) < 0.00001) {  // U:366-368
+        a = kPi / 2; b = kPi / 2 + kTwoPi;
+        ca = 6.123233995736766e-17; sa = 1.0; cb = 3.061616997868383e-16; sb = 1.0;  // np.cos / np.sin of pi/2, 5pi/2
+        pref_free = pref_free || !valid;
+    } else {
+        a = r.i0; b = (r.i0 < r.i1) ? r.i1 : r.i1 + kTwoPi;
+        ca = r.ct0; sa = r.st0; cb = r.ct1; sb = r.st1;
+    }
+    const double step = (b - a) / (double)(nb - 1);
+    bool fast_ok;
+    double th;
+    bool found = grid_theta_candidates<PLANE>(A, r, a, step, b, nb, pref, ca, sa, cb, sb, pref_free, th, fast_ok);
+    if (RSIK_RARE(!fast_ok)) found = best_discrete_theta_grid<PLANE>(A, r, a, step, b, nb, pref, th);
+    theta_out = th;
+    return found;
+}
+
 }  // namespace rsik

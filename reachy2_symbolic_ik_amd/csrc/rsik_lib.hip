@@ -690,6 +690,7 @@ struct ContinuousArgs {
     int first_timed_out;          // non-zero: every trajectory (re)initialises
     double pref_arg[2];           // preferred_theta argument per arm slot (mirrored for l)
     double pref_self[2];          // ControlIK.preferred_theta[name] per arm slot
+    double pref_self_cs[2], pref_self_sn[2];  // its cosine / sine (host libm, once per launch)
     double lim[2][2];
     double d_theta_max;
     const double* current_joints; // [n,7] or NULL => previous_sol
@@ -735,8 +736,9 @@ struct ThetaTarget {
     double theta;     // the search's theta (found only)
     int code;         // state code the step reports
 };
-template <class Acc>
-__device__ __forceinline__ ThetaTarget continuous_target(const Acc& A, V3 pos, const V3 woff, double pref_self, Reach& r) {
+template <bool PLANE, class Acc>
+__device__ __forceinline__ ThetaTarget continuous_target(const Acc& A, V3 pos, const V3 woff, double pref_self, double pref_cs,
+                                                         double pref_sn, Reach& r) {
     ThetaTarget T;
     r = reach_g<false, false>(A, pos, woff);
     T.ok_limits = r.ok;
@@ -744,7 +746,7 @@ __device__ __forceinline__ ThetaTarget continuous_target(const Acc& A, V3 pos, c
     T.theta = 0.0;
     T.code = RSIK_STATE_EMPTY;
     if (r.ok) {
-        T.found = best_discrete_theta_serial(A, r, 10, pref_self, T.theta);
+        T.found = best_discrete_theta_lane<PLANE>(A, r, 10, pref_self, pref_cs, pref_sn, T.theta);
         if (!T.found) T.code = RSIK_STATE_LIMITED_BY_SHOULDER;
     } else {
         T.code = r.state;
@@ -769,7 +771,7 @@ __device__ __forceinline__ double continuous_next_theta(bool ok_limits, bool fou
 
 // One launch = one control step of n independent trajectories (rsik_control_continuous_step): everything fused, the
 // trajectory state makes one round trip through HBM.
-template <bool MIXED>
+template <bool MIXED, bool PLANE>
 __global__ __launch_bounds__(kBlock) void control_continuous_kernel(const ContinuousArgs K) {
     __shared__ double lds_out[kBlock / 64][64 * 7];
     const int lane = threadIdx.x & 63;
@@ -812,7 +814,7 @@ __global__ __launch_bounds__(kBlock) void control_continuous_kernel(const Contin
         }
         const Goal G = make_goal(A, Rg);
         Reach r;
-        const ThetaTarget T = continuous_target(A, pos, G.woff, K.pref_self[slot], r);
+        const ThetaTarget T = continuous_target<PLANE>(A, pos, G.woff, K.pref_self[slot], K.pref_self_cs[slot], K.pref_self_sn[slot], r);
         ok = T.ok_limits && T.found;
         st_code = T.code;
         const double theta = continuous_next_theta(T.ok_limits, T.found, T.theta, K.pref_arg[slot], prev_theta, K.d_theta_max,
@@ -876,6 +878,7 @@ struct ContRunArgs {
     const uint8_t* arm;
     int euler_roundtrip;
     double pref_arg[2], pref_self[2];
+    double pref_self_cs[2], pref_self_sn[2];
     double lim[2][2];
     double d_theta_max;
     double max_angle, cos_max, sin_max;
@@ -892,7 +895,7 @@ struct ContRunArgs {
 #define RSIK_WS(K, f, t, i) (K).ws[((int64_t)(f) * (K).T + (t)) * (K).n + (i)]
 
 // phase 1: one thread per (trajectory, step of the block)
-template <bool MIXED>
+template <bool MIXED, bool PLANE>
 __global__ __launch_bounds__(kBlock) void cont_prepare_kernel(const ContRunArgs K) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t t = blockIdx.y;
@@ -912,7 +915,7 @@ __global__ __launch_bounds__(kBlock) void cont_prepare_kernel(const ContRunArgs 
     goal_from_m12(m, Rg, pos, K.euler_roundtrip);
     const Goal G = make_goal(A, Rg);
     Reach r;
-    const ThetaTarget T = continuous_target(A, pos, G.woff, K.pref_self[slot], r);
+    const ThetaTarget T = continuous_target<PLANE>(A, pos, G.woff, K.pref_self[slot], K.pref_self_cs[slot], K.pref_self_sn[slot], r);
     if (!live) return;
     const double v[kWsFields] = {T.theta, r.pos.x, r.pos.y, r.pos.z, r.w.x, r.w.y, r.w.z, r.c2.x, r.c2.y, r.c2.z, r.r2,
                                  r.a1.x, r.a1.y, r.a1.z, r.a2.x, r.a2.y, r.a2.z, G.toff.x, G.toff.y, G.toff.z, G.xg.x, G.xg.y, G.xg.z};
@@ -1514,7 +1517,7 @@ int rsik_set_arm(rsik_ctx* ctx, int arm, const double* consts_host, int count) {
 int rsik_set_option(rsik_ctx* ctx, int option, int value) {
     if (!ctx) return RSIK_E_INVALID;
     if (option < 0 || option >= RSIK_OPT_COUNT) return fail(ctx, RSIK_E_INVALID, "rsik_set_option: unknown option");
-    static const int max_value[RSIK_OPT_COUNT] = {RSIK_EULER_NEVER, 2, 1, 1, RSIK_CONT_RUN_STEPS};
+    static const int max_value[RSIK_OPT_COUNT] = {RSIK_EULER_NEVER, 2, 1, 1, RSIK_CONT_RUN_STEPS, 65535};
     if (value < 0 || value > max_value[option]) return fail(ctx, RSIK_E_INVALID, "rsik_set_option: value out of range");
     ctx->options[option] = value;
     return RSIK_OK;
@@ -1654,6 +1657,20 @@ static int launch_dims(rsik_ctx* ctx, int64_t n, dim3* grid, const char* who) {
     return RSIK_OK;
 }
 
+// Can the singularity-plane half of is_elbow_ok (utils.py:459-464) fail at all?  The elbow lies on the sphere of
+// radius u around the shoulder, so e_z - c e_x <= s_z - c s_x + u sqrt(1 + c^2); when that bound stays below the
+// plane's right-hand side (the non-DVT offset -1.01: by a metre) the test is compiled out of the launch.
+static bool singularity_plane_binds(const rsik::ArmC (&arms)[2]) {
+    for (int slot = 0; slot < 2; slot++) {
+        const double* c = arms[slot].v;
+        const double sc = c[RSIK_C_SING_COEFF];
+        const double rhs = c[RSIK_C_ES + 2] - c[RSIK_C_SING_OFFSET] - sc * c[RSIK_C_ES];
+        const double reach_max = c[RSIK_C_SHOULDER + 2] - sc * c[RSIK_C_SHOULDER] + c[RSIK_C_UPPER_ARM] * std::sqrt(1.0 + sc * sc);
+        if (!(rhs > reach_max + 1e-6)) return true;
+    }
+    return false;
+}
+
 int rsik_control_discrete(rsik_ctx* ctx, int64_t n, const double* const m12_soa[12], const uint8_t* arm,
                           int arm_uniform, int nb_search_points, double preferred_theta, int constrained_mode,
                           const double* previous_sol_host, const double* current_joints, double orbita3d_max_angle,
@@ -1693,17 +1710,7 @@ int rsik_control_discrete(rsik_ctx* ctx, int64_t n, const double* const m12_soa[
         }
         K.arms[slot] = ctx->arms[a];
     }
-    // Can the singularity-plane half of is_elbow_ok (utils.py:459-464) fail at all?  The elbow lies on the sphere of
-    // radius u around the shoulder, so e_z - c e_x <= s_z - c s_x + u sqrt(1 + c^2); when that bound stays below the
-    // plane's right-hand side (the non-DVT offset -1.01: by a metre) the test is compiled out of the launch.
-    bool plane_binds = false;
-    for (int slot = 0; slot < 2; slot++) {
-        const double* c = K.arms[slot].v;
-        const double sc = c[RSIK_C_SING_COEFF];
-        const double rhs = c[RSIK_C_ES + 2] - c[RSIK_C_SING_OFFSET] - sc * c[RSIK_C_ES];
-        const double reach_max = c[RSIK_C_SHOULDER + 2] - sc * c[RSIK_C_SHOULDER] + c[RSIK_C_UPPER_ARM] * std::sqrt(1.0 + sc * sc);
-        if (!(rhs > reach_max + 1e-6)) plane_binds = true;
-    }
+    const bool plane_binds = singularity_plane_binds(K.arms);
     K.current_joints = current_joints;
     K.max_angle = orbita3d_max_angle;
     K.cos_max = std::cos(orbita3d_max_angle);
@@ -1754,6 +1761,8 @@ static int fill_continuous(rsik_ctx* ctx, const char* who, rsik::ContinuousArgs&
         const int a = arm ? slot : arm_uniform;
         control_limits(a, constrained_mode, preferred_theta, K.lim[slot], &K.pref_arg[slot]);
         K.pref_self[slot] = preferred_theta_self_host[a];
+        K.pref_self_cs[slot] = std::cos(K.pref_self[slot]);  // np.cos / np.sin of the reference (U:359-360)
+        K.pref_self_sn[slot] = std::sin(K.pref_self[slot]);
         K.arms[slot] = ctx->arms[a];
     }
     K.d_theta_max = d_theta_max;
@@ -1786,8 +1795,11 @@ int rsik_control_continuous_step(rsik_ctx* ctx, int64_t n, const double* const m
     dim3 grid, block(rsik::kBlock);
     rc = launch_dims(ctx, n, &grid, "rsik_control_continuous_step");
     if (rc != RSIK_OK) return rc;
-    if (arm) hipLaunchKernelGGL(rsik::control_continuous_kernel<true>, grid, block, 0, ctx->stream, K);
-    else hipLaunchKernelGGL(rsik::control_continuous_kernel<false>, grid, block, 0, ctx->stream, K);
+    {
+        const bool pb = singularity_plane_binds(K.arms);
+        if (arm) { if (pb) hipLaunchKernelGGL((rsik::control_continuous_kernel<true, true>), grid, block, 0, ctx->stream, K); else hipLaunchKernelGGL((rsik::control_continuous_kernel<true, false>), grid, block, 0, ctx->stream, K); }
+        else { if (pb) hipLaunchKernelGGL((rsik::control_continuous_kernel<false, true>), grid, block, 0, ctx->stream, K); else hipLaunchKernelGGL((rsik::control_continuous_kernel<false, false>), grid, block, 0, ctx->stream, K); }
+    }
     RSIK_HIP(ctx, hipGetLastError());
     return RSIK_OK;
 }
@@ -1828,8 +1840,11 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
             K.joints = joints_steps + (size_t)k * n * 7;
             K.reachable = reachable_steps ? reachable_steps + (size_t)k * n : nullptr;
             K.state = state_steps ? state_steps + (size_t)k * n : nullptr;
-            if (arm) hipLaunchKernelGGL(rsik::control_continuous_kernel<true>, grid, block, 0, ctx->stream, K);
-            else hipLaunchKernelGGL(rsik::control_continuous_kernel<false>, grid, block, 0, ctx->stream, K);
+            {
+                const bool pb = singularity_plane_binds(K.arms);
+                if (arm) { if (pb) hipLaunchKernelGGL((rsik::control_continuous_kernel<true, true>), grid, block, 0, ctx->stream, K); else hipLaunchKernelGGL((rsik::control_continuous_kernel<true, false>), grid, block, 0, ctx->stream, K); }
+                else { if (pb) hipLaunchKernelGGL((rsik::control_continuous_kernel<false, true>), grid, block, 0, ctx->stream, K); else hipLaunchKernelGGL((rsik::control_continuous_kernel<false, false>), grid, block, 0, ctx->stream, K); }
+            }
         }
         RSIK_HIP(ctx, hipGetLastError());
         return RSIK_OK;
@@ -1837,15 +1852,35 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     // ---- phased pipeline.  The four phases of a block run on four streams (theta on the caller's, the others on the
     // context's own), ordered by events: prepare(b) -> theta(b) -> joints(b) -> chain(b), theta(b) after theta(b-1),
     // chain(b) after chain(b-1).  The two sequential phases (a lone wave per SIMD on a few CUs) then run beside each other
-    // and beside the chip-filling ones of the neighbouring blocks.  Four workspace slots are in flight (block b + 4
-    // reuses the slot of block b once chain(b) has finished); a block's slot is at most 64 MB.
+    // and beside the chip-filling ones of the neighbouring blocks.  Exactly four streams: the runtime multiplexes streams
+    // onto four hardware queues, and a fifth stream shares a queue with another one — measured with theta on a stream of
+    // its own: theta(b + 1) queued up behind chain(b)'s wait for joints(b), 0.85 -> 1.28 ms per 1000-step pass.  (Giving
+    // the sequential phases compute units of their own with hipExtStreamCreateWithCUMask was measured too: every kernel
+    // got slower, 2.4 ms per pass.)
+    // A run is cut into blocks of as many steps as a 128 MB workspace slot holds (177 for 4096 trajectories); four slots
+    // are in flight (block b + 4 reuses the slot of block b once chain(b) has finished).  RSIK_OPT_CONT_BLOCK_STEPS makes
+    // the first block smaller and lets the following ones double up to that limit, so that the first chain starts after
+    // a shorter fill: measured 0.85 - 0.91 ms per 4096 x 1000 pass for first blocks of 8 ... 128 steps against 0.84 ms
+    // with equal blocks (the pipeline is bound by the work of its kernels, not by its fill), hence off by default.
     constexpr int kSlots = 4;
     const size_t per_step = (size_t)n * (rsik::kWsFields * sizeof(double) + 1);
     int64_t T = (int64_t)((size_t)128 << 20) / (int64_t)per_step;
     if (T < 1) T = 1;
     if (T > n_steps) T = n_steps;
     if (T > 65535) T = 65535;  // gridDim.y
-    const int64_t n_blocks = (n_steps + T - 1) / T;
+    std::vector<int64_t> block_t0, block_T;
+    {
+        int64_t first = ctx->options[RSIK_OPT_CONT_BLOCK_STEPS] > 0 ? ctx->options[RSIK_OPT_CONT_BLOCK_STEPS] : T;
+        int64_t t0 = 0, cur = first < T ? first : T;
+        while (t0 < n_steps) {
+            const int64_t left = n_steps - t0, tb = left < cur ? left : cur;
+            block_t0.push_back(t0);
+            block_T.push_back(tb);
+            t0 += tb;
+            cur = cur * 2 > T ? T : cur * 2;
+        }
+    }
+    const int64_t n_blocks = (int64_t)block_t0.size();
     const size_t slot_bytes = (((size_t)T * per_step + 255) / 256) * 256;
     const int slots = n_blocks < kSlots ? (int)n_blocks : kSlots;
     const size_t carry_bytes = (((size_t)n * sizeof(double) + 255) / 256) * 256;
@@ -1865,15 +1900,13 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         RSIK_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->events.push_back(e);
     }
-    hipStream_t s_theta = ctx->stream, s_prep = ctx->side[0], s_joints = ctx->side[1], s_chain = ctx->side[2];
+    hipStream_t s_main = ctx->stream, s_theta = ctx->stream, s_prep = ctx->side[0], s_joints = ctx->side[1], s_chain = ctx->side[2];
     auto ev = [&](int kind, int64_t b) { return ctx->events[2 + 4 * (size_t)b + kind]; };  // 0 prepared, 1 theta, 2 joints, 3 chain
-    // (re)initialisation of the trajectories that start here (C:296-325), then the side streams join in
-    if (arm) hipLaunchKernelGGL(rsik::cont_init_kernel<true>, grid, block, 0, s_theta, K0);
-    else hipLaunchKernelGGL(rsik::cont_init_kernel<false>, grid, block, 0, s_theta, K0);
-    RSIK_HIP(ctx, hipEventRecord(ctx->events[0], s_theta));
-    RSIK_HIP(ctx, hipStreamWaitEvent(s_prep, ctx->events[0], 0));
-    RSIK_HIP(ctx, hipStreamWaitEvent(s_joints, ctx->events[0], 0));
-    RSIK_HIP(ctx, hipStreamWaitEvent(s_chain, ctx->events[0], 0));
+    // (re)initialisation of the trajectories that start here (C:296-325), then the pipeline's streams join in
+    if (arm) hipLaunchKernelGGL(rsik::cont_init_kernel<true>, grid, block, 0, s_main, K0);
+    else hipLaunchKernelGGL(rsik::cont_init_kernel<false>, grid, block, 0, s_main, K0);
+    RSIK_HIP(ctx, hipEventRecord(ctx->events[0], s_main));
+    for (hipStream_t st : ctx->side) RSIK_HIP(ctx, hipStreamWaitEvent(st, ctx->events[0], 0));
     rsik::ContRunArgs R;
     std::memset(&R, 0, sizeof R);
     R.n = n;
@@ -1882,6 +1915,7 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     R.euler_roundtrip = K0.euler_roundtrip;
     for (int slot = 0; slot < 2; slot++) {
         R.pref_arg[slot] = K0.pref_arg[slot]; R.pref_self[slot] = K0.pref_self[slot];
+        R.pref_self_cs[slot] = K0.pref_self_cs[slot]; R.pref_self_sn[slot] = K0.pref_self_sn[slot];
         R.lim[slot][0] = K0.lim[slot][0]; R.lim[slot][1] = K0.lim[slot][1];
         R.arms[slot] = K0.arms[slot];
     }
@@ -1893,17 +1927,19 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     rc = launch_dims(ctx, n * 8, &grid8, who);
     if (rc != RSIK_OK) return rc;
     for (int64_t b = 0; b < n_blocks; b++) {
-        const int64_t t0 = b * T;
-        R.t0 = t0;
-        R.T = (n_steps - t0 < T) ? (n_steps - t0) : T;
+        R.t0 = block_t0[b];
+        R.T = block_T[b];
         R.first_block = b == 0;
         R.last_block = b == n_blocks - 1;
         R.ws = reinterpret_cast<double*>(static_cast<char*>(ctx->ws) + slot_bytes * (size_t)(b % slots));
         R.flags = reinterpret_cast<uint8_t*>(R.ws + (size_t)rsik::kWsFields * (size_t)R.T * (size_t)n);
         const dim3 grid2(grid.x, (unsigned)R.T);
         if (b >= slots) RSIK_HIP(ctx, hipStreamWaitEvent(s_prep, ev(3, b - slots), 0));  // the slot's previous block is done
-        if (arm) hipLaunchKernelGGL(rsik::cont_prepare_kernel<true>, grid2, block, 0, s_prep, R);
-        else hipLaunchKernelGGL(rsik::cont_prepare_kernel<false>, grid2, block, 0, s_prep, R);
+        {
+            const bool pb = singularity_plane_binds(R.arms);
+            if (arm) { if (pb) hipLaunchKernelGGL((rsik::cont_prepare_kernel<true, true>), grid2, block, 0, s_prep, R); else hipLaunchKernelGGL((rsik::cont_prepare_kernel<true, false>), grid2, block, 0, s_prep, R); }
+            else { if (pb) hipLaunchKernelGGL((rsik::cont_prepare_kernel<false, true>), grid2, block, 0, s_prep, R); else hipLaunchKernelGGL((rsik::cont_prepare_kernel<false, false>), grid2, block, 0, s_prep, R); }
+        }
         RSIK_HIP(ctx, hipEventRecord(ev(0, b), s_prep));
         RSIK_HIP(ctx, hipStreamWaitEvent(s_theta, ev(0, b), 0));
         if (arm) hipLaunchKernelGGL(rsik::cont_theta_kernel<true>, grid, block, 0, s_theta, R);
@@ -1919,7 +1955,7 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         RSIK_HIP(ctx, hipEventRecord(ev(3, b), s_chain));
     }
     // the caller's stream continues once the last chain (hence every phase of every block) is done
-    RSIK_HIP(ctx, hipStreamWaitEvent(s_theta, ev(3, n_blocks - 1), 0));
+    RSIK_HIP(ctx, hipStreamWaitEvent(s_main, ev(3, n_blocks - 1), 0));
     RSIK_HIP(ctx, hipGetLastError());
     return RSIK_OK;
 }

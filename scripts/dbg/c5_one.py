@@ -1,0 +1,19 @@
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import bench
+from reachy2_symbolic_ik_amd import ControlIK, _abi
+cus, blk = int(sys.argv[1]), int(sys.argv[2])
+n, n_steps = 4096, 1000
+traj = bench.make_config5_trajectories(n, n_steps, seed=20250204, device=0)
+ctrl = bench._quiet(ControlIK, urdf_path=bench.URDF, device=0)
+cont0 = ctrl.new_continuous_state("r_arm", n)
+ctrl._solver.set_option(_abi.OPT_CONT_SERIAL_CUS, cus)
+ctrl._solver.set_option(_abi.OPT_CONT_BLOCK_STEPS, blk)
+out = {"joints": torch.empty((n_steps, n, 7), dtype=torch.float64, device="cuda"),
+       "reachable": torch.empty((n_steps, n), dtype=torch.uint8, device="cuda"),
+       "state": torch.empty((n_steps, n), dtype=torch.uint8, device="cuda")}
+cont = cont0.clone()
+for _ in range(6):
+    cont.copy_(cont0)
+    ctrl.run_continuous_trajectories("r_arm", traj, cont, first_step_timed_out=True, current_pose=traj[0], out=out)
+torch.cuda.synchronize()
