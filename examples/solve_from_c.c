@@ -4,7 +4,7 @@
  *
  *   gcc -std=c99 -I include examples/solve_from_c.c -L reachy2_symbolic_ik_amd/csrc -lrsik_hip \
  *       -Wl,-rpath,$PWD/reachy2_symbolic_ik_amd/csrc -o solve_from_c
- *   ./solve_from_c consts.bin            # 51 doubles written by ArmGeometry(...).pack().tofile(...)
+ *   ./solve_from_c consts.bin            # RSIK_ARM_CONSTS_COUNT doubles written by ArmGeometry(...).pack().tofile(...)
  *
  * Prints one line per pose: reachable, state code, interval, seven joints (what tests/test_gpu_parity.py compares with
  * the Python drop-in class).

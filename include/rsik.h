@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RSIK_ABI_VERSION 2
+#define RSIK_ABI_VERSION 3
 
 /* ---- status codes ---- */
 #define RSIK_OK 0
@@ -108,7 +108,10 @@ enum {
     RSIK_C_INV_TIPZ = 48,     /* 1 / |tip_position[2]|                                     */
     RSIK_C_INV_GRIP = 49,     /* 1 / gripper_size = 1 / |tip_position|                     */
     RSIK_C_MAX_LEN_SQ = 50,   /* largest double x with sqrt(x) <= max_arm_length: |v| > max_arm_length <=> v.v > x, bit for bit */
-    RSIK_ARM_CONSTS_COUNT = 51
+    RSIK_C_INV_MIN_DIST = 51, /* 1 / shoulder_wrist_min_distance                           */
+    RSIK_C_PLANE_K = 52,      /* es_z - singularity_offset - singularity_limit_coeff * es_x: the elbow is above the singularity
+                                 plane (symbolic_ik.py:708-713) iff e_z > coeff * e_x + this */
+    RSIK_ARM_CONSTS_COUNT = 53
 };
 
 typedef struct rsik_ctx rsik_ctx;
@@ -162,8 +165,8 @@ int rsik_set_arm(rsik_ctx *ctx, int arm, const double *consts_host, int count);
 #define RSIK_CONT_RUN_PHASED 1
 #define RSIK_CONT_RUN_STEPS 2
 /* Tuning of rsik_control_continuous_run's phased pipeline (results do not depend on it):
- *   RSIK_OPT_CONT_BLOCK_STEPS  0 (default) = equal blocks of as many control steps as a 128 MB workspace slot holds;
- *                              n > 0 = the run's first block has n steps and the following ones double up to that limit */
+ *   RSIK_OPT_CONT_BLOCK_STEPS  control steps per block of the pipeline: 0 (default) = a quarter of the run, at least 64;
+ *                              n > 0 = n (rounded up to the sequential phases' batch of steps) */
 #define RSIK_OPT_CONT_BLOCK_STEPS 5
 #define RSIK_OPT_COUNT 6
 int rsik_set_option(rsik_ctx *ctx, int option, int value);

@@ -24,7 +24,7 @@ def use_library(path: str) -> None:
     LIB_PATH = os.path.abspath(path)
 
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 RSIK_OK = 0
 RSIK_E_INVALID, RSIK_E_NO_DEVICE, RSIK_E_HIP, RSIK_E_NOT_SET = -1, -2, -3, -4
 

@@ -20,7 +20,7 @@ C_SHOULDER, C_UPPER_ARM, C_FOREARM, C_TIPL, C_MAX_LEN, C_MIN_DIST, C_BACKWARD = 
 C_PROJ_MARGIN, C_NORMAL_MARGIN, C_UPF, C_WRIST_R, C_WRIST_AX, C_MST, C_TSH, C_ES = 11, 12, 13, 14, 15, 16, 25, 28
 C_SING_OFFSET, C_SING_COEFF, C_ELBOW_LIMIT, C_SIDE, C_PLANE_P, C_PLANE_N = 31, 32, 33, 34, 35, 38
 C_PROJ_CENTER, C_PROJ_RADIUS, C_TIP_Z = 41, 44, 45
-C_INV_U, C_INV_F, C_INV_TIPZ, C_INV_GRIP, C_MAX_LEN_SQ, ARM_CONSTS_COUNT = 46, 47, 48, 49, 50, 51
+C_INV_U, C_INV_F, C_INV_TIPZ, C_INV_GRIP, C_MAX_LEN_SQ, C_INV_MIN_DIST, C_PLANE_K, ARM_CONSTS_COUNT = 46, 47, 48, 49, 50, 51, 52, 53
 
 ARM_IDS = {"r_arm": 0, "l_arm": 1}
 
@@ -162,7 +162,10 @@ class ArmGeometry:
             c[C_INV_F] = 1.0 / self.forearm_size
             c[C_INV_TIPZ] = 1.0 / abs(self.tip_position[2])
             c[C_INV_GRIP] = 1.0 / self.gripper_size
+            c[C_INV_MIN_DIST] = 1.0 / self.shoulder_wrist_min_distance
         c[C_MAX_LEN_SQ] = sqrt_threshold(self.max_arm_length)
+        es = self.elbow_singularity_position
+        c[C_PLANE_K] = es[2] - self.singularity_offset - self.singularity_limit_coeff * es[0]
         return c
 
 

@@ -278,6 +278,7 @@ __device__ __forceinline__ V3 cvec(const Acc& A, int off) {
 // LDS while the reachability stage runs).
 struct Goal {
     V3 woff, toff, xg;
+    V3 tw;  // toff - woff = R.(0, 0, -tip_z): the "tip" point of S:808-812 seen from the wrist
 };
 template <class Acc>
 __device__ __forceinline__ Goal make_goal(const Acc& A, const Rot& Rg) {
@@ -288,6 +289,7 @@ __device__ __forceinline__ Goal make_goal(const Acc& A, const Rot& Rg) {
               Rg.m[6] * tl.x + Rg.m[7] * tl.y + Rg.m[8] * tl.z};
     g.toff = {fma(Rg.m[0], tl.x, Rg.m[1] * tl.y), fma(Rg.m[3], tl.x, Rg.m[4] * tl.y), fma(Rg.m[6], tl.x, Rg.m[7] * tl.y)};
     g.xg = Rg.col0();
+    g.tw = {-(Rg.m[2] * tl.z), -(Rg.m[5] * tl.z), -(Rg.m[8] * tl.z)};
     return g;
 }
 // The same three vectors straight from the Euler angles for a tip offset along the goal z axis only (tip_x = tip_y = 0:
@@ -305,6 +307,7 @@ __device__ __forceinline__ Goal goal_from_euler_tipz(const Acc& A, double roll, 
     g.woff = {fma(cc * sb, ca, sc * sa) * tz, fma(sc * sb, ca, -(cc * sa)) * tz, (cb * ca) * tz};
     g.toff = {0.0, 0.0, 0.0};
     g.xg = {cc * cb, sc * cb, -sb};
+    g.tw = {-g.woff.x, -g.woff.y, -g.woff.z};
     return g;
 }
 // S:418-425 — wrist = T_torso_goal . (-tip_x, tip_y, tip_z, 1)
@@ -316,8 +319,17 @@ __device__ __forceinline__ V3 wrist_position(const V3& woff, V3 pos) { return wo
 // NO_LIMITS = true gives SymbolicIK.is_reachable_no_limits (S:85-119): never fails on reach, interval [-pi, pi].
 // KEEP = false (fused kernels that only go on when r.ok): the geometry fields of a failed pose are left unwritten
 // instead of being filled with what the reference leaves on `self` (saves the register copies at every early exit).
-template <bool NO_LIMITS, bool KEEP = true, class Acc>
-__device__ Reach reach_g(const Acc& A, V3 pos_in, const V3 woff) {
+// reach_impl takes the NO_LIMITS choice as a value: a compile-time constant (BoolC, folded away) for the fused kernels,
+// or a per-lane bool for the joint phase of the continuous-mode pipeline, which re-derives the circle of whichever
+// variant the step's get_joints follows.  GEOM_ONLY: stop once the intersection circle is known (stage 2) — what
+// get_joints needs — for a pose that is known to pass the reach tests before it.
+template <bool V>
+struct BoolC {
+    __device__ __forceinline__ constexpr operator bool() const { return V; }
+};
+template <bool KEEP, bool GEOM_ONLY, class NL, class Acc>
+__device__ Reach reach_impl(const Acc& A, V3 pos_in, const V3 woff, const NL no_limits_v) {
+    const bool NO_LIMITS = no_limits_v;
     Reach r;
     r.ok = false;
     r.i0 = r.i1 = __builtin_nan("");
@@ -379,15 +391,19 @@ __device__ Reach reach_g(const Acc& A, V3 pos_in, const V3 woff) {
     }
     if (RSIK_RARE(dsw < A(RSIK_C_MIN_DIST))) {  // [D] S:166-171 / S:107-112
         // the wrist is pushed out radially to the minimum distance: new wrist = s + P k, k = d_min / (|P| + margin)
-        const double k = A(RSIK_C_MIN_DIST) * fast_rcp(fabs(dsw) + pm);
-        gp = gp + (madd(P, k, s) - w);
-        w = wrist_position(woff, gp);  // recomputed from the moved goal like the reference does (S:170)
+        // (this branch runs in nearly every wave: 8 % of the reachable poses of a random batch sit at the elbow limit.
+        // The reference moves the goal by new_wrist - wrist and recomputes the wrist from it (S:168-170): goal and wrist
+        // both move by P (k - 1), the new P is P k and |P| = |P_old| k up to rounding — no second square root, one
+        // reciprocal: 1 / k = (|P| + margin) / d_min.)
+        const double t = fabs(dsw) + pm;
+        const double k = A(RSIK_C_MIN_DIST) * fast_rcp(t);
+        const double km1 = k - 1.0;
+        gp = madd(P, km1, gp);
+        w = madd(P, km1, w);
         self_pos = gp;
-        P = w - s;
-        // |P| = |P_old| k up to rounding: no second square root (this branch runs in nearly every wave: 8 % of the
-        // reachable poses of a random batch sit at the elbow limit)
+        P = P * k;
         d = dsw * k;
-        inv_d = inv_d * fast_rcp(k);
+        inv_d = inv_d * (t * A(RSIK_C_INV_MIN_DIST));
     }
 
     RSIK_MARK("reach_circle");
@@ -401,22 +417,26 @@ __device__ Reach reach_g(const Acc& A, V3 pos_in, const V3 woff) {
     r.w = w;
     V3 n2 = P * inv_d;
     double r2, ir2;  // radius and its reciprocal (0 for the degenerate circle)
+    double kk;
     V3 c2;
     {
         double d2 = d * d, k = d2 - f * f + u * u;
         // [D] the radicand is exactly 0 for a fully extended arm (Q23) and must not become -1e-18 through an fma
         double rad = 4 * d2 * (u * u) - k * k;
-        double srad = 0.0, irad = 0.0;
-        if (rad != 0.0) sqrt_rsqrt(rad, srad, irad);
-        r2 = (0.5 * inv_d) * srad;
+        // radius = sqrt(rad) / (2 d) and its reciprocal from ONE reciprocal square root (sqrt(rad) = rad / sqrt(rad) to
+        // 1 - 2 ulp; the radius is not a decision value)
+        const double irad = (rad != 0.0) ? rsqrt_fast(rad) : 0.0;
+        const double hid = 0.5 * inv_d;
+        r2 = hid * (rad * irad);
         ir2 = (d + d) * irad;
-        c2 = s + n2 * (k * (0.5 * inv_d));
+        kk = k * hid;  // distance of the circle's centre from the shoulder along n2
+        c2 = s + n2 * kk;
     }
     RSIK_MARK("reach_frame");
     Frame F2 = frame_from_unit(n2);
     r.c2 = c2; r.r2 = r2; r.n2 = n2; r.a1 = F2.c1; r.a2 = F2.c2;
     r.stage = 2;
-    if (NO_LIMITS) {
+    if (NO_LIMITS || GEOM_ONLY) {
         r.ok = true; r.state = RSIK_STATE_REACHABLE; r.i0 = -kPi; r.i1 = kPi;
         r.ct0 = -1.0; r.st0 = -1.2246467991473532e-16;  // cos(-pi), sin(-pi) as np.cos/np.sin return them
         r.ct1 = -1.0; r.st1 = 1.2246467991473532e-16;
@@ -466,7 +486,8 @@ __device__ Reach reach_g(const Acc& A, V3 pos_in, const V3 woff) {
         const double R2 = fma(Ap, Ap, Bp * Bp);
         const double Dp = -side_val * ir2;
         const double disc = fma(-Dp, Dp, R2);
-        const double n2b = dot(N2, p2) - A(RSIK_C_WRIST_AX) * dot(N1, N2);
+        // N2.p2 = N2.(c2 - w) = kk - d  (c2 - s = kk n2, w - s = d n2); this value only feeds the guard below
+        const double n2b = (kk - d) - A(RSIK_C_WRIST_AX) * dot(N1, N2);
         const bool exact = (ir2 == 0.0) || (R2 < 1e-12) || (fabs(disc) < 1e-8) ||
                            (fabs(side_val - n2b) <= 2e-8 + 2e-5 * fabs(n2b));
         if (!RSIK_RARE(exact)) {
@@ -598,6 +619,11 @@ __device__ Reach reach_g(const Acc& A, V3 pos_in, const V3 woff) {
 }
 
 template <bool NO_LIMITS, bool KEEP = true, class Acc>
+__device__ __forceinline__ Reach reach_g(const Acc& A, V3 pos_in, const V3 woff) {
+    return reach_impl<KEEP, false>(A, pos_in, woff, BoolC<NO_LIMITS>{});
+}
+
+template <bool NO_LIMITS, bool KEEP = true, class Acc>
 __device__ __forceinline__ Reach reach(const Acc& A, V3 pos_in, const Rot& Rg) {
     return reach_g<NO_LIMITS, KEEP>(A, pos_in, make_goal(A, Rg).woff);
 }
@@ -609,9 +635,13 @@ __device__ __forceinline__ V3 elbow_on_circle(const Reach& r, double ct, double 
 }
 
 // [D] S:708-713 / U:459-464: elbow above the singularity plane
-template <class Acc>
+// EXACT = false (the fused kernels): one fused multiply-add against the host-side constant RSIK_C_PLANE_K.  The
+// projection this test triggers is continuous across the plane (a point on the plane is its own projection), so the
+// rounding of the test is immaterial there; the stored-state path keeps the reference's operation order.
+template <bool EXACT = true, class Acc>
 __device__ __forceinline__ bool above_singularity_plane(const Acc& A, V3 e) {
-    return e.z > (e.x - A(RSIK_C_ES)) * A(RSIK_C_SING_COEFF) + A(RSIK_C_ES + 2) - A(RSIK_C_SING_OFFSET);
+    if constexpr (EXACT) return e.z > (e.x - A(RSIK_C_ES)) * A(RSIK_C_SING_COEFF) + A(RSIK_C_ES + 2) - A(RSIK_C_SING_OFFSET);
+    else return e.z > fma(e.x, A(RSIK_C_SING_COEFF), A(RSIK_C_PLANE_K));
 }
 // U:443-465 (effective predicate, Q10).  PLANE = false: the launch's host code has shown that the singularity-plane half
 // holds for every point a shoulder-centred sphere of radius u can reach (the non-DVT offset, Q18), so only the
@@ -647,7 +677,7 @@ __device__ JointsOut joints_from_theta_g(const Acc& A, Reach& r, const Goal& G, 
     JointsOut o;
     V3 e = elbow_on_circle(r, ct, st);
     o.projected = false;
-    if (RSIK_RARE(above_singularity_plane(A, e))) {  // S:708-718 -> make_elbow_projection S:647-682
+    if (RSIK_RARE(above_singularity_plane<!FRESH>(A, e))) {  // S:708-718 -> make_elbow_projection S:647-682
         // project the elbow onto the plane and snap it to the circle (centre pc, in the plane) cut out of the shoulder sphere:
         // the in-plane vector from pc is measured directly (the plane point of S:657 is only needed for the distance, and
         // pc - P_limits is orthogonal to the normal)
@@ -656,10 +686,15 @@ __device__ JointsOut joints_from_theta_g(const Acc& A, Reach& r, const Goal& G, 
         const V3 V = madd(v3, -dot(d1, v3), d1);
         const V3 ne = madd(V, A(RSIK_C_PROJ_RADIUS) * rsqrt_fast(dot(V, V)), pc);
         const V3 shift = ne - e;
-        r.pos = r.pos + shift;
         e = ne;
-        // S:718 recomputes the wrist from the moved goal; it is the old wrist moved by the same vector (to rounding)
-        r.w = FRESH ? (r.w + shift) : wrist_position(G.woff, r.pos);
+        // S:718 recomputes the wrist from the moved goal; it is the old wrist moved by the same vector (to rounding).
+        // FRESH: the moved goal position itself is not consumed again (the tip is taken relative to the wrist)
+        if constexpr (FRESH) {
+            r.w = r.w + shift;
+        } else {
+            r.pos = r.pos + shift;
+            r.w = wrist_position(G.woff, r.pos);
+        }
         o.projected = true;
     }
     RSIK_MARK("joints_shoulder");
@@ -693,9 +728,12 @@ __device__ JointsOut joints_from_theta_g(const Acc& A, Reach& r, const Goal& G, 
     V3 g0 = {cr * cphi, srs, cr * sphi};
     V3 g1 = {-srs * cphi, cr, -srs * sphi};
     V3 g2 = {-sphi, 0.0, cphi};
+    // (g2 and h1 have a structural zero: their products are written out, a literal 0.0 operand is not folded away)
+    auto rot_g = [&](V3 a) -> V3 { return {dot(g0, a), dot(g1, a), fma(g2.x, a.x, g2.z * a.z)}; };
     auto to_elbow = [&](V3 p) -> V3 {  // T_elbow_torso (S:776-777)
-        V3 a = to_shoulder(p);
-        return {dot(g0, a) - u, dot(g1, a), dot(g2, a)};
+        V3 a = rot_g(to_shoulder(p));
+        a.x -= u;
+        return a;
     };
     RSIK_MARK("joints_elbow_angles");
     // elbow yaw / pitch (S:780-797)
@@ -717,15 +755,20 @@ __device__ JointsOut joints_from_theta_g(const Acc& A, Reach& r, const Goal& G, 
     V3 h0 = {cchi, schi * sa, schi * ca};
     V3 h1 = {0.0, ca, -sa};
     V3 h2 = {-schi, cchi * sa, cchi * ca};
-    auto to_wrist = [&](V3 p) -> V3 {  // T_wrist_torso (S:805-806)
-        V3 a = to_elbow(p);
-        return {dot(h0, a) - f, dot(h1, a), dot(h2, a)};
-    };
+    auto rot_h = [&](V3 a) -> V3 { return {dot(h0, a), fma(h1.y, a.y, h1.z * a.z), dot(h2, a)}; };
     RSIK_MARK("joints_wrist");
-    // wrist roll / pitch (S:808-826)
-    V3 tl = cvec(A, RSIK_C_TIPL);
-    V3 ptip = TIPZ ? r.pos : (G.toff + r.pos);  // TIPZ: the tip offset has no x / y part (goal_from_euler_tipz)
-    V3 t = to_wrist(ptip);
+    // wrist roll / pitch (S:808-826): the "tip" point of S:808-812 in the wrist frame
+    V3 t;
+    if constexpr (FRESH) {
+        // the wrist is the origin of the wrist frame (T_wrist_torso . wrist = 0 by construction of G and H), so only the
+        // three rotations act on tip' - wrist = R.(0, 0, -tip_z) (Goal::tw; a projection above moved both points alike)
+        const V3 vs = {dot(cvec(A, RSIK_C_MST + 0), G.tw), dot(cvec(A, RSIK_C_MST + 3), G.tw), dot(cvec(A, RSIK_C_MST + 6), G.tw)};
+        t = rot_h(rot_g(vs));
+    } else {
+        V3 a = to_elbow(TIPZ ? r.pos : (G.toff + r.pos));  // T_wrist_torso (S:805-806)
+        t = rot_h(a);
+        t.x -= f;
+    }
     double tau, cw, sw, wr_zero = 0.0;
     const bool tau_zero = RSIK_RARE(t.x == 0 && t.y == 0);
     if (tau_zero) {
@@ -748,9 +791,8 @@ __device__ JointsOut joints_from_theta_g(const Acc& A, Reach& r, const Goal& G, 
     // wrist yaw (S:839-848): direction of the goal frame's x axis seen from the tip frame
     V3 xg = G.xg;
     V3 xs = {dot(cvec(A, RSIK_C_MST + 0), xg), dot(cvec(A, RSIK_C_MST + 3), xg), dot(cvec(A, RSIK_C_MST + 6), xg)};
-    V3 xe = {dot(g0, xs), dot(g1, xs), dot(g2, xs)};
-    V3 xw = {dot(h0, xe), dot(h1, xe), dot(h2, xe)};
-    double gy = dot(k1, xw), gz = dot(k2, xw);
+    V3 xw = rot_h(rot_g(xs));
+    double gy = fma(k1.x, xw.x, k1.y * xw.y), gz = dot(k2, xw);
     RSIK_MARK("joints_atan2x7");
     // All seven angles are directions of normalised vectors: unit_atan2_n (no division), seven in lock step.
     // (gy, gz) is the goal x axis seen in the plane normal to the tip axis.  With a tip offset along the goal z axis

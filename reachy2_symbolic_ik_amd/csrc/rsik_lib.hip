@@ -554,7 +554,7 @@ __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR void co
     // stage wait in the output staging slab while the theta search runs (registers are the scarce resource here)
     Goal G = make_goal(A, Rg);
     {
-        const double pk[6] = {G.toff.x, G.toff.y, G.toff.z, G.xg.x, G.xg.y, G.xg.z};
+        const double pk[6] = {G.tw.x, G.tw.y, G.tw.z, G.xg.x, G.xg.y, G.xg.z};
 #pragma unroll
         for (int k = 0; k < 6; k++) lds_slab[wave][k][lane] = pk[k];
     }
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR void co
         double st, ct;
         fast_sincos(theta, &st, &ct);
         const double* pk = &lds_slab[wave][0][0];
-        G.toff = {pk[0 * 64 + lane], pk[1 * 64 + lane], pk[2 * 64 + lane]};
+        G.tw = {pk[0 * 64 + lane], pk[1 * 64 + lane], pk[2 * 64 + lane]};
         G.xg = {pk[3 * 64 + lane], pk[4 * 64 + lane], pk[5 * 64 + lane]};
         JointsOut o = joints_from_theta_g<true>(A, r, G, ct, st, prev);
 #pragma unroll
@@ -736,7 +736,9 @@ struct ThetaTarget {
     double theta;     // the search's theta (found only)
     int code;         // state code the step reports
 };
-template <bool PLANE, class Acc>
+// FALLBACK_GEOMETRY = false (the pipeline's prepare phase): the unreachable side's is_reachable_no_limits is left to
+// the phase that needs its circle.
+template <bool PLANE, bool FALLBACK_GEOMETRY = true, class Acc>
 __device__ __forceinline__ ThetaTarget continuous_target(const Acc& A, V3 pos, const V3 woff, double pref_self, double pref_cs,
                                                          double pref_sn, Reach& r) {
     ThetaTarget T;
@@ -750,25 +752,28 @@ __device__ __forceinline__ ThetaTarget continuous_target(const Acc& A, V3 pos, c
         if (!T.found) T.code = RSIK_STATE_LIMITED_BY_SHOULDER;
     } else {
         T.code = r.state;
-        r = reach_g<true>(A, pos, woff);
+        if constexpr (FALLBACK_GEOMETRY) r = reach_g<true>(A, pos, woff);
     }
     return T;
 }
 // The recurrence on previous_theta: rate limiter of get_best_continuous_theta2 (U:252-264) / tend_to_preferred_theta
 // (U:115-127), then limit_theta_to_interval (U:93-112).
+__device__ __forceinline__ double continuous_next_theta_goal(double goal, double prev_theta, double d_theta_max, double l0,
+                                                            double l1) {
+    // sign * d_theta_max with sign = ad / |ad| (U:260, U:126) is copysign(d_theta_max, ad), bit for bit: the quotient
+    // of a non-zero finite number by its own magnitude is exactly +-1.
+    const double ad = angle_diff_straight(goal, prev_theta);
+    const double theta = (fabs(ad) < d_theta_max) ? goal : (prev_theta + copysign(d_theta_max, ad));
+    return limit_theta_to_interval_straight(theta, l0, l1);
+}
 __device__ __forceinline__ double continuous_next_theta(bool ok_limits, bool found, double target, double pref_arg,
                                                         double prev_theta, double d_theta_max, double l0, double l1) {
     // One straight line for the three cases (this is the serial part of a trajectory: a lone wave pays every dependent
     // instruction in full).  Reachable and found: tend to the search's theta (U:252-264); reachable, nothing found:
     // stay (goal = previous_theta, whose angle_diff is 0); unreachable: tend to the preferred theta (U:115-127).
-    // sign * d_theta_max with sign = ad / |ad| (U:260, U:126) is copysign(d_theta_max, ad), bit for bit: the quotient
-    // of a non-zero finite number by its own magnitude is exactly +-1.
     const double goal = ok_limits ? (found ? target : prev_theta) : pref_arg;
-    const double ad = angle_diff_straight(goal, prev_theta);
-    const double theta = (fabs(ad) < d_theta_max) ? goal : (prev_theta + copysign(d_theta_max, ad));
-    return limit_theta_to_interval_straight(theta, l0, l1);
+    return continuous_next_theta_goal(goal, prev_theta, d_theta_max, l0, l1);
 }
-
 // One launch = one control step of n independent trajectories (rsik_control_continuous_step): everything fused, the
 // trajectory state makes one round trip through HBM.
 template <bool MIXED, bool PLANE>
@@ -860,16 +865,15 @@ __global__ __launch_bounds__(kBlock) void control_continuous_kernel(const Contin
 }
 
 // ------------------------------------------------------------------------------------------
-// rsik_control_continuous_run: the phased trajectory pipeline (include/rsik.h).  Workspace of one block of T steps,
-// SoA ws[field][t][n] doubles + two byte planes [t][n]:
-//   field 0      target theta (phase 1) -> the step's theta (phase 2)
-//   fields 1-16  geometry get_joints reads: goal position (3), wrist (3), circle centre (3), radius, axes a1, a2 (3 + 3)
-//   fields 17-22 the goal vectors of the joint stage: tip offset (3), goal x axis (3)
-//   flags        bit 0 is_reachable succeeded, bit 1 the grid search found a theta; (phase 3) bit 2: get_joints hit an
-//                exact singularity and needs previous_sol (recomputed in phase 4)
+// rsik_control_continuous_run: the phased trajectory pipeline (include/rsik.h).  Workspace of one block of T steps:
+//   ws[t][n] doubles  the step's goal for the theta recurrence (phase 1) -> the step's theta (phase 2)
+//   flags[t][n] bytes bit 0 is_reachable succeeded, bit 1 the grid search found a theta; (phase 3) bit 2: get_joints hit an
+//                     exact singularity and needs previous_sol (recomputed in phase 4)
+// Nothing else travels between the phases: the pipeline is bound by HBM traffic, not by arithmetic, so the joint phase
+// re-derives the circle it needs from the goal matrix (the geometric half of is_reachable, ~150 instructions) instead
+// of reading 22 doubles per trajectory-step that the prepare phase would have to write (652 -> 400 B per step).
 // ------------------------------------------------------------------------------------------
-constexpr int kWsFields = 23;
-constexpr int kSeqBatch = 8;  // steps whose operands the sequential phases fetch at once
+constexpr int kSeqBatch = 8;  // steps whose operands the sequential phases fetch at once (blocks are multiples of it)
 struct ContRunArgs {
     int64_t n;
     int64_t t0;                   // first step of this block
@@ -882,7 +886,7 @@ struct ContRunArgs {
     double lim[2][2];
     double d_theta_max;
     double max_angle, cos_max, sin_max;
-    double* ws;                   // [kWsFields][T][n]
+    double* ws;                   // [T][n]
     uint8_t* flags;               // [T][n]
     double* theta_carry;          // [n]: previous_theta between the blocks of one run (phase 2's own state)
     int first_block, last_block;
@@ -892,7 +896,7 @@ struct ContRunArgs {
     uint8_t* state;               // [n_steps][n] or NULL
     ArmC arms[2];
 };
-#define RSIK_WS(K, f, t, i) (K).ws[((int64_t)(f) * (K).T + (t)) * (K).n + (i)]
+#define RSIK_WS(K, t, i) (K).ws[(int64_t)(t) * (K).n + (i)]
 
 // phase 1: one thread per (trajectory, step of the block)
 template <bool MIXED, bool PLANE>
@@ -915,12 +919,11 @@ __global__ __launch_bounds__(kBlock) void cont_prepare_kernel(const ContRunArgs 
     goal_from_m12(m, Rg, pos, K.euler_roundtrip);
     const Goal G = make_goal(A, Rg);
     Reach r;
-    const ThetaTarget T = continuous_target<PLANE>(A, pos, G.woff, K.pref_self[slot], K.pref_self_cs[slot], K.pref_self_sn[slot], r);
+    const ThetaTarget T = continuous_target<PLANE, false>(A, pos, G.woff, K.pref_self[slot], K.pref_self_cs[slot], K.pref_self_sn[slot], r);
     if (!live) return;
-    const double v[kWsFields] = {T.theta, r.pos.x, r.pos.y, r.pos.z, r.w.x, r.w.y, r.w.z, r.c2.x, r.c2.y, r.c2.z, r.r2,
-                                 r.a1.x, r.a1.y, r.a1.z, r.a2.x, r.a2.y, r.a2.z, G.toff.x, G.toff.y, G.toff.z, G.xg.x, G.xg.y, G.xg.z};
-#pragma unroll
-    for (int f = 0; f < kWsFields; f++) RSIK_WS(K, f, t, i) = v[f];
+    // the step's goal for the theta phase: the search's theta, NaN = nothing found, stay (U:252-264 with goal =
+    // previous_theta), or the preferred theta of an unreachable pose (U:115-127)
+    RSIK_WS(K, t, i) = T.ok_limits ? (T.found ? T.theta : __builtin_nan("")) : K.pref_arg[slot];
     K.flags[t * K.n + i] = (uint8_t)((T.ok_limits ? 1 : 0) | (T.found ? 2 : 0));
     if (K.state) K.state[(K.t0 + t) * K.n + i] = (uint8_t)T.code;
     if (K.reachable) K.reachable[(K.t0 + t) * K.n + i] = (T.ok_limits && T.found) ? 1 : 0;
@@ -939,59 +942,64 @@ __global__ __launch_bounds__(kBlock) void cont_theta_kernel(const ContRunArgs K)
     // alone decides what ends up in the state's row 0 — the theta of the last step, or of the step that latched the
     // emergency stop (C:205-210; what this phase computes for a latched trajectory is never looked at).
     double prev_theta = K.first_block ? K.st[0 * K.n + i] : K.theta_carry[i];
-    const double pref_arg = K.pref_arg[slot], l0 = K.lim[slot][0], l1 = K.lim[slot][1];
+    const double l0 = K.lim[slot][0], l1 = K.lim[slot][1];
     // The recurrence itself is ~50 dependent instructions per step; the memory round trip of a step's operands would
     // double that (a lone wave per SIMD, nothing to switch to), so they are fetched kSeqBatch steps at a time, one batch
     // ahead of the one being computed; the last T mod kSeqBatch steps go one by one.
     const int64_t n = K.n;
-    double* wp = &RSIK_WS(K, 0, 0, i);          // this trajectory's theta column, step 0; step t is t * n further
-    const uint8_t* fp = K.flags + i;
-    auto one = [&](double tg, int f, double* dst) {
-        prev_theta = continuous_next_theta((f & 1) != 0, (f & 2) != 0, tg, pref_arg, prev_theta, K.d_theta_max, l0, l1);
+    double* wp = &RSIK_WS(K, 0, i);             // this trajectory's theta column, step 0; step t is t * n further
+    // `target` is the step's goal as the prepare phase encoded it: the search's theta, the preferred theta for an
+    // unreachable pose, NaN = "stay".  Straight-line arithmetic only: a lone wave pays the compare -> scalar branch round
+    // trip of every test in full.  (Measured and not kept: a speculative short form of the step for goal - previous
+    // within one turn, checked once per batch — half the waves hold a trajectory that is snapped to the interval
+    // limits or has unwound past +-pi, and then pay both forms.)
+    auto one = [&](double tg, double* dst) {
+        prev_theta = continuous_next_theta_goal((tg != tg) ? prev_theta : tg, prev_theta, K.d_theta_max, l0, l1);
         *dst = prev_theta;
     };
     const int64_t full = K.T - (K.T % kSeqBatch);
     double target[kSeqBatch];
-    int fl[kSeqBatch];
     if (full > 0) {
 #pragma unroll
-        for (int u = 0; u < kSeqBatch; u++) { target[u] = wp[u * n]; fl[u] = fp[u * n]; }
+        for (int u = 0; u < kSeqBatch; u++) target[u] = wp[u * n];
     }
 #pragma unroll 1
     for (int64_t t0 = 0; t0 < full; t0 += kSeqBatch) {
         double tg[kSeqBatch];
-        int f[kSeqBatch];
 #pragma unroll
-        for (int u = 0; u < kSeqBatch; u++) { tg[u] = target[u]; f[u] = fl[u]; }
+        for (int u = 0; u < kSeqBatch; u++) tg[u] = target[u];
         double* const w0 = wp;
         wp += kSeqBatch * n;
-        fp += kSeqBatch * n;
         if (t0 + kSeqBatch < full) {
 #pragma unroll
-            for (int u = 0; u < kSeqBatch; u++) { target[u] = wp[u * n]; fl[u] = fp[u * n]; }
+            for (int u = 0; u < kSeqBatch; u++) target[u] = wp[u * n];
         }
 #pragma unroll
-        for (int u = 0; u < kSeqBatch; u++) one(tg[u], f[u], w0 + u * n);
+        for (int u = 0; u < kSeqBatch; u++) one(tg[u], w0 + u * n);
     }
 #pragma unroll 1
     for (int64_t t = full; t < K.T; ++t) {
-        one(*wp, *fp, wp);
+        one(*wp, wp);
         wp += n;
-        fp += n;
     }
     K.theta_carry[i] = prev_theta;
 }
 
-__device__ __forceinline__ void ws_load_geometry(const ContRunArgs& K, int64_t t, int64_t i, Reach& r, Goal& G) {
-    double v[kWsFields];
+// What get_joints reads of a step (S:697-863), re-derived from the step's goal matrix: the goal vectors and the circle
+// is_reachable (flag bit 0 set) or is_reachable_no_limits (clear; C:371) left on the solver — the same device code the
+// step kernel runs, so the joints are the same to the last bit.  `m`: the step's twelve matrix entries.
+template <class Acc>
+__device__ __forceinline__ void step_geometry(const Acc& A, const double (&m)[12], int euler_roundtrip, bool no_limits, Reach& r, Goal& G) {
+    Rot Rg;
+    V3 pos;
+    goal_from_m12(m, Rg, pos, euler_roundtrip);
+    G = make_goal(A, Rg);
+    r = reach_impl<false, true>(A, pos, G.woff, no_limits);
+}
+__device__ __forceinline__ void load_step_m12(const ContRunArgs& K, int64_t t, int64_t i, double (&m)[12]) {
+    const double* src = K.m12_steps + (K.t0 + t) * 12 * K.n + i;
 #pragma unroll
-    for (int f = 1; f < kWsFields; f++) v[f] = RSIK_WS(K, f, t, i);
-    r.ok = true; r.state = RSIK_STATE_REACHABLE; r.stage = 2; r.i0 = -kPi; r.i1 = kPi; r.ct0 = 1.0; r.st0 = 0.0;
-    r.pos = {v[1], v[2], v[3]}; r.w = {v[4], v[5], v[6]}; r.c2 = {v[7], v[8], v[9]}; r.r2 = v[10];
-    r.a1 = {v[11], v[12], v[13]}; r.a2 = {v[14], v[15], v[16]};
-    r.n2 = r.a1;  // not read by get_joints
-    G.woff = {0.0, 0.0, 0.0};  // only read when the geometry is not fresh
-    G.toff = {v[17], v[18], v[19]}; G.xg = {v[20], v[21], v[22]};
+    for (int k = 0; k < 12; k++) m[k] = src[k * K.n];
 }
 
 // get_joints at theta (S:697-863) + the Orbita3D cone clamp (U:508-532): everything of a step's joints that does not
@@ -1019,14 +1027,17 @@ __global__ __launch_bounds__(kBlock) void cont_joints_kernel(const ContRunArgs K
     const int64_t t = blockIdx.y;
     const bool live = i < K.n;
     const int64_t ii = live ? i : (K.n - 1);
-    Reach r;  // loads first: their latency overlaps the table staging
-    Goal G;
-    ws_load_geometry(K, t, ii, r, G);
-    const double theta = RSIK_WS(K, 0, t, ii);
+    double m[12];  // loads first: their latency overlaps the table staging
+    load_step_m12(K, t, ii, m);
+    const double theta = RSIK_WS(K, t, ii);
+    const int flag = K.flags[t * K.n + ii];
     const bool lane_isl = MIXED ? (K.arm[ii] != 0) : false;
     __shared__ SharedTables lds_tab;
     stage_tables<MIXED>(lds_tab, K.arms);
     const Acc<MIXED> A = make_acc<MIXED>(K.arms, lane_isl, lds_tab);
+    Reach r;
+    Goal G;
+    step_geometry(A, m, K.euler_roundtrip, (flag & 1) == 0, r, G);
     const double zeros[7] = {0, 0, 0, 0, 0, 0, 0};
     double jv[7];
     bool sing;
@@ -1082,10 +1093,12 @@ __global__ __launch_bounds__(kBlock) void cont_chain_kernel(const ContRunArgs K)
             for (int k = 0; k < 7; k++) pv[k] = __shfl(prev, gshift + k);
             Reach r;
             Goal G;
-            ws_load_geometry(K, t, ii, r, G);
+            double m[12];
+            load_step_m12(K, t, ii, m);
+            step_geometry(A, m, K.euler_roundtrip, (f & 1) == 0, r, G);
             double jv[7];
             bool sing;
-            step_joints(A, K, r, G, RSIK_WS(K, 0, t, ii), pv, jv, sing);
+            step_joints(A, K, r, G, RSIK_WS(K, t, ii), pv, jv, sing);
             cur = jv[0];
 #pragma unroll
             for (int k = 1; k < 7; k++) cur = (jj == k) ? jv[k] : cur;
@@ -1110,7 +1123,7 @@ __global__ __launch_bounds__(kBlock) void cont_chain_kernel(const ContRunArgs K)
                 }
             } else if (j == 7) {
                 K.st[11 * n + i] = (double)cause;
-                K.st[0 * n + i] = RSIK_WS(K, 0, t, i);  // previous_theta of the step that tripped (phase 2 ran ahead)
+                K.st[0 * n + i] = RSIK_WS(K, t, i);  // previous_theta of the step that tripped (phase 2 ran ahead)
             } else if (disc) {
                 K.st[(12 + j) * n + i] = clamped;       // the joints that failed the check
             }
@@ -1153,7 +1166,7 @@ __global__ __launch_bounds__(kBlock) void cont_chain_kernel(const ContRunArgs K)
     if (live && j == 7) {
         K.st[8 * n + i] = init ? 1.0 : 0.0;
         K.st[9 * n + i] = emergency ? 1.0 : 0.0;
-        if (K.last_block && !emergency) K.st[0 * n + i] = RSIK_WS(K, 0, K.T - 1, i);  // previous_theta after the last step
+        if (K.last_block && !emergency) K.st[0 * n + i] = RSIK_WS(K, K.T - 1, i);  // previous_theta after the last step
     }
 }
 
@@ -1857,28 +1870,26 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     // its own: theta(b + 1) queued up behind chain(b)'s wait for joints(b), 0.85 -> 1.28 ms per 1000-step pass.  (Giving
     // the sequential phases compute units of their own with hipExtStreamCreateWithCUMask was measured too: every kernel
     // got slower, 2.4 ms per pass.)
-    // A run is cut into blocks of as many steps as a 128 MB workspace slot holds (177 for 4096 trajectories); four slots
-    // are in flight (block b + 4 reuses the slot of block b once chain(b) has finished).  RSIK_OPT_CONT_BLOCK_STEPS makes
-    // the first block smaller and lets the following ones double up to that limit, so that the first chain starts after
-    // a shorter fill: measured 0.85 - 0.91 ms per 4096 x 1000 pass for first blocks of 8 ... 128 steps against 0.84 ms
-    // with equal blocks (the pipeline is bound by the work of its kernels, not by its fill), hence off by default.
+    // A run is cut into blocks of steps; four workspace slots are in flight (block b + 4 reuses the slot of block b once
+    // chain(b) has finished).
     constexpr int kSlots = 4;
-    const size_t per_step = (size_t)n * (rsik::kWsFields * sizeof(double) + 1);
-    int64_t T = (int64_t)((size_t)128 << 20) / (int64_t)per_step;
-    if (T < 1) T = 1;
+    const size_t per_step = (size_t)n * (sizeof(double) + 1);
+    int64_t T_max = (int64_t)((size_t)128 << 20) / (int64_t)per_step;
+    if (T_max < 1) T_max = 1;
+    if (T_max > 65535) T_max = 65535;  // gridDim.y
+    // block size: a quarter of the run (the phases of neighbouring blocks overlap: more blocks, shorter fill and drain;
+    // fewer blocks, fewer of the ~12 us hand-overs between dependent launches on the critical chain -> chain -> chain
+    // path: 4096 x 1000 steps take 0.77 / 0.70 / 0.66 / 0.63 / 0.69 ms with blocks of 64 / 96 / 128 / 256 / 504 steps), a
+    // multiple of the sequential phases' batch; RSIK_OPT_CONT_BLOCK_STEPS overrides
+    int64_t T = ctx->options[RSIK_OPT_CONT_BLOCK_STEPS] > 0 ? ctx->options[RSIK_OPT_CONT_BLOCK_STEPS] : (n_steps + 3) / 4;
+    if (T < 64 && ctx->options[RSIK_OPT_CONT_BLOCK_STEPS] == 0) T = 64;
+    T = (T + rsik::kSeqBatch - 1) / rsik::kSeqBatch * rsik::kSeqBatch;
+    if (T > T_max) T = T_max;
     if (T > n_steps) T = n_steps;
-    if (T > 65535) T = 65535;  // gridDim.y
     std::vector<int64_t> block_t0, block_T;
-    {
-        int64_t first = ctx->options[RSIK_OPT_CONT_BLOCK_STEPS] > 0 ? ctx->options[RSIK_OPT_CONT_BLOCK_STEPS] : T;
-        int64_t t0 = 0, cur = first < T ? first : T;
-        while (t0 < n_steps) {
-            const int64_t left = n_steps - t0, tb = left < cur ? left : cur;
-            block_t0.push_back(t0);
-            block_T.push_back(tb);
-            t0 += tb;
-            cur = cur * 2 > T ? T : cur * 2;
-        }
+    for (int64_t t0 = 0; t0 < n_steps; t0 += T) {
+        block_t0.push_back(t0);
+        block_T.push_back(n_steps - t0 < T ? n_steps - t0 : T);
     }
     const int64_t n_blocks = (int64_t)block_t0.size();
     const size_t slot_bytes = (((size_t)T * per_step + 255) / 256) * 256;
@@ -1932,7 +1943,7 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         R.first_block = b == 0;
         R.last_block = b == n_blocks - 1;
         R.ws = reinterpret_cast<double*>(static_cast<char*>(ctx->ws) + slot_bytes * (size_t)(b % slots));
-        R.flags = reinterpret_cast<uint8_t*>(R.ws + (size_t)rsik::kWsFields * (size_t)R.T * (size_t)n);
+        R.flags = reinterpret_cast<uint8_t*>(R.ws + (size_t)R.T * (size_t)n);
         const dim3 grid2(grid.x, (unsigned)R.T);
         if (b >= slots) RSIK_HIP(ctx, hipStreamWaitEvent(s_prep, ev(3, b - slots), 0));  // the slot's previous block is done
         {

@@ -2,12 +2,13 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from reachy2_symbolic_ik_amd import ControlIK, _abi
-cus, blk = int(sys.argv[1]), int(sys.argv[2])
+blk = 0
+if len(sys.argv) > 1:
+    _abi.use_library(os.path.abspath(sys.argv[1]))
 n, n_steps = 4096, 1000
 traj = bench.make_config5_trajectories(n, n_steps, seed=20250204, device=0)
 ctrl = bench._quiet(ControlIK, urdf_path=bench.URDF, device=0)
 cont0 = ctrl.new_continuous_state("r_arm", n)
-ctrl._solver.set_option(_abi.OPT_CONT_SERIAL_CUS, cus)
 ctrl._solver.set_option(_abi.OPT_CONT_BLOCK_STEPS, blk)
 out = {"joints": torch.empty((n_steps, n, 7), dtype=torch.float64, device="cuda"),
        "reachable": torch.empty((n_steps, n), dtype=torch.uint8, device="cuda"),
