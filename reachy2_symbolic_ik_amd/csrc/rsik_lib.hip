@@ -230,8 +230,8 @@ __device__ __forceinline__ void flush_rows(double* __restrict__ out, int64_t wav
 // TIPZ: every arm of the launch has tip_x = tip_y = 0 (goal_from_euler_tipz: -24 fp64 operations per pose).
 template <int MIXED, bool TIPZ>
 __global__ __launch_bounds__(kBlock, RSIK_SOLVE_MIN_WAVES) void solve_kernel(const SolveArgs K) {
-    __shared__ double lds[kBlock / 64][64 * 10];
     __shared__ SharedTables lds_tab;
+    __shared__ double lds[kBlock / 64][64 * 10];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: wave-level tests stay on the SALU
     const int64_t tile0 = (int64_t)blockIdx.x * kBlock;
