@@ -873,7 +873,17 @@ __global__ __launch_bounds__(kBlock) void control_continuous_kernel(const Contin
 // re-derives the circle it needs from the goal matrix (the geometric half of is_reachable, ~150 instructions) instead
 // of reading 22 doubles per trajectory-step that the prepare phase would have to write (652 -> 400 B per step).
 // ------------------------------------------------------------------------------------------
-constexpr int kSeqBatch = 8;  // steps whose operands the sequential phases fetch at once (blocks are multiples of it)
+// steps whose operands the sequential phases fetch at once, one batch ahead of the one being computed (blocks are multiples
+// of both): the theta step is ~50 dependent instructions, 8 of them outlast a memory round trip; the chain's short form is 16
+#ifndef RSIK_THETA_BATCH
+#define RSIK_THETA_BATCH 8
+#endif
+#ifndef RSIK_CHAIN_BATCH
+#define RSIK_CHAIN_BATCH 32
+#endif
+constexpr int kThetaBatch = RSIK_THETA_BATCH, kChainBatch = RSIK_CHAIN_BATCH;
+constexpr int kSeqBatch = kThetaBatch > kChainBatch ? kThetaBatch : kChainBatch;
+static_assert(kSeqBatch % kThetaBatch == 0 && kSeqBatch % kChainBatch == 0, "block sizes are multiples of both batches");
 struct ContRunArgs {
     int64_t n;
     int64_t t0;                   // first step of this block
@@ -944,8 +954,8 @@ __global__ __launch_bounds__(kBlock) void cont_theta_kernel(const ContRunArgs K)
     double prev_theta = K.first_block ? K.st[0 * K.n + i] : K.theta_carry[i];
     const double l0 = K.lim[slot][0], l1 = K.lim[slot][1];
     // The recurrence itself is ~50 dependent instructions per step; the memory round trip of a step's operands would
-    // double that (a lone wave per SIMD, nothing to switch to), so they are fetched kSeqBatch steps at a time, one batch
-    // ahead of the one being computed; the last T mod kSeqBatch steps go one by one.
+    // double that (a lone wave per SIMD, nothing to switch to), so they are fetched kThetaBatch steps at a time, one batch
+    // ahead of the one being computed; the last T mod kThetaBatch steps go one by one.
     const int64_t n = K.n;
     double* wp = &RSIK_WS(K, 0, i);             // this trajectory's theta column, step 0; step t is t * n further
     // `target` is the step's goal as the prepare phase encoded it: the search's theta, the preferred theta for an
@@ -957,25 +967,25 @@ __global__ __launch_bounds__(kBlock) void cont_theta_kernel(const ContRunArgs K)
         prev_theta = continuous_next_theta_goal((tg != tg) ? prev_theta : tg, prev_theta, K.d_theta_max, l0, l1);
         *dst = prev_theta;
     };
-    const int64_t full = K.T - (K.T % kSeqBatch);
-    double target[kSeqBatch];
+    const int64_t full = K.T - (K.T % kThetaBatch);
+    double target[kThetaBatch];
     if (full > 0) {
 #pragma unroll
-        for (int u = 0; u < kSeqBatch; u++) target[u] = wp[u * n];
+        for (int u = 0; u < kThetaBatch; u++) target[u] = wp[u * n];
     }
 #pragma unroll 1
-    for (int64_t t0 = 0; t0 < full; t0 += kSeqBatch) {
-        double tg[kSeqBatch];
+    for (int64_t t0 = 0; t0 < full; t0 += kThetaBatch) {
+        double tg[kThetaBatch];
 #pragma unroll
-        for (int u = 0; u < kSeqBatch; u++) tg[u] = target[u];
+        for (int u = 0; u < kThetaBatch; u++) tg[u] = target[u];
         double* const w0 = wp;
-        wp += kSeqBatch * n;
-        if (t0 + kSeqBatch < full) {
+        wp += kThetaBatch * n;
+        if (t0 + kThetaBatch < full) {
 #pragma unroll
-            for (int u = 0; u < kSeqBatch; u++) target[u] = wp[u * n];
+            for (int u = 0; u < kThetaBatch; u++) target[u] = wp[u * n];
         }
 #pragma unroll
-        for (int u = 0; u < kSeqBatch; u++) one(tg[u], w0 + u * n);
+        for (int u = 0; u < kThetaBatch; u++) one(tg[u], w0 + u * n);
     }
 #pragma unroll 1
     for (int64_t t = full; t < K.T; ++t) {
@@ -1078,7 +1088,7 @@ __global__ __launch_bounds__(kBlock) void cont_chain_kernel(const ContRunArgs K)
         v |= __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);  // row_half_mirror
         return v;
     };
-    // Operands of kSeqBatch steps are fetched together, one batch ahead (see cont_theta_kernel).  A step is straight-line
+    // Operands of kChainBatch steps are fetched together, one batch ahead (see cont_theta_kernel).  A step is straight-line
     // code: a latched trajectory (rare) goes through the same arithmetic and only its selects differ.
     double* jp = K.joints + (K.t0 * n + ii) * 7 + jj;   // this lane's joint, step 0 of the block; step t is t * 7 n further
     const uint8_t* fp = K.flags + ii;
@@ -1133,28 +1143,55 @@ __global__ __launch_bounds__(kBlock) void cont_chain_kernel(const ContRunArgs K)
         emergency = emergency || trips;
         t_abs += 1;
     };
-    const int64_t full = K.T - (K.T % kSeqBatch);
-    double raw[kSeqBatch];
-    int fl[kSeqBatch];
+    const int64_t full = K.T - (K.T % kChainBatch);
+    double raw[kChainBatch];
+    int fl[kChainBatch];
     if (full > 0) {
 #pragma unroll
-        for (int u = 0; u < kSeqBatch; u++) { raw[u] = jp[u * step_stride]; fl[u] = fp[u * n]; }
+        for (int u = 0; u < kChainBatch; u++) { raw[u] = jp[u * step_stride]; fl[u] = fp[u * n]; }
     }
 #pragma unroll 1
-    for (int64_t t0 = 0; t0 < full; t0 += kSeqBatch) {
-        double rw[kSeqBatch];
-        int fb[kSeqBatch];
+    for (int64_t t0 = 0; t0 < full; t0 += kChainBatch) {
+        double rw[kChainBatch];
+        int fb[kChainBatch];
 #pragma unroll
-        for (int u = 0; u < kSeqBatch; u++) { rw[u] = raw[u]; fb[u] = fl[u]; }
+        for (int u = 0; u < kChainBatch; u++) { rw[u] = raw[u]; fb[u] = fl[u]; }
         double* const j0 = jp;
-        jp += kSeqBatch * step_stride;
-        fp += kSeqBatch * n;
-        if (t0 + kSeqBatch < full) {
+        jp += kChainBatch * step_stride;
+        fp += kChainBatch * n;
+        if (t0 + kChainBatch < full) {
 #pragma unroll
-            for (int u = 0; u < kSeqBatch; u++) { raw[u] = jp[u * step_stride]; fl[u] = fp[u * n]; }
+            for (int u = 0; u < kChainBatch; u++) { raw[u] = jp[u * step_stride]; fl[u] = fp[u * n]; }
         }
+        // A step in which nothing happens — no +-6 pi limit, no discontinuity, no singular get_joints, no latch, not the
+        // first step after a (re)initialisation — is previous := clamp(previous + angle_diff(joint, previous)), and the
+        // tests that establish "nothing happens" do not feed the next step.  So the batch first runs in that short form
+        // (the same straight-line arithmetic as `one`, 16 dependent instructions per step instead of ~45: no group OR,
+        // no selects, no branches; the tests fill the issue slots the chain leaves free) and ONE wave-uniform test
+        // decides whether it stands; otherwise the batch is repeated step by step with `one`.  (Unlike the short form
+        // tried for the theta phase, this one only gives up on real events, which are rare.)
+        bool event = emergency | init;
+        double pv = prev, res[kChainBatch];
 #pragma unroll
-        for (int u = 0; u < kSeqBatch; u++) one(rw[u], fb[u], j0 + u * step_stride, t0 + u);
+        for (int u = 0; u < kChainBatch; u++) {
+            const double turned = allow_multiturn_one_straight(rw[u], pv);     // U:493-505
+            const double clamped = fmin(fmax(turned, -lim), lim);              // U:535-568
+            event = event | (clamped != turned) | (fabs(angle_diff_straight(clamped, pv)) > thr) | ((fb[u] & 4) != 0);
+            res[u] = clamped;
+            pv = clamped;
+        }
+        if (RSIK_RARE(__any(event))) {  // (rolled, operands re-read: rare, and 32 copies of `one` would be 5k instructions)
+            const uint8_t* const f0 = fp - kChainBatch * n;
+#pragma unroll 1
+            for (int u = 0; u < kChainBatch; u++) one(j0[u * step_stride], f0[u * n], j0 + u * step_stride, t0 + u);
+        } else {
+            if (owner) {
+#pragma unroll
+                for (int u = 0; u < kChainBatch; u++) j0[u * step_stride] = res[u];
+            }
+            prev = pv;
+            t_abs += kChainBatch;
+        }
     }
 #pragma unroll 1
     for (int64_t t = full; t < K.T; ++t) {
