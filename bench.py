@@ -170,8 +170,16 @@ def cpu_baseline(config, sample, seconds, gpu=None):
         m = len(M)
         ar, al = orc.Arm("r_arm", -1.01), orc.Arm("l_arm", -1.01)
         run = lambda nt, L=None: orc.control_discrete_batch(ar, al, M, nb_search_points=64, nthreads=nt, L=L)  # noqa: E731
-    else:
-        return None  # config 5: the checker's continuous step is a per-trajectory state machine driven from Python: not timed
+    else:  # config 5: a subsample of the trajectories walked by the checker's state machine (control_ik.py:276-407)
+        M = np.ascontiguousarray(sample["M"])                     # [n_steps, n_sub, 4, 4]
+        n_steps_s, n_sub = M.shape[:2]
+        m = n_steps_s * n_sub                                     # trajectory-steps per pass
+        ar = orc.Arm("r_arm", -1.01)
+        st0 = np.ascontiguousarray(sample["state0"])              # [n_sub, 11] checker state rows
+
+        def run(nt, L=None):
+            return orc.control_continuous_run_batch(ar, st0.copy(), M, first_step_timed_out=True, preferred_theta_self=sample["pref_self"],
+                                                    nthreads=nt, L=L)
 
     def rate(nt, budget, L=None):
         run(nt, L)
@@ -192,11 +200,11 @@ def cpu_baseline(config, sample, seconds, gpu=None):
     left = max(2.0, seconds - 0.5 * len(cands))
     value, passes, el = rate(best, left / 2)
     base = {
-        "value": value, "unit": "solves/s", "cores": best, "kind": "port", "single_thread": probe[1],
+        "value": value, "unit": "steps/s" if config == 5 else "solves/s", "cores": best, "kind": "port", "single_thread": probe[1],
         "portable_build": {"value": value, "flags": "gcc -O2 -ffp-contract=off (built in the build container, travels with the repo)",
                            "single_thread": probe[1]},
-        "sample": f"{m} poses of the workload x {passes} passes ({el:.1f} s) with OpenMP {best} threads "
-                  f"(best of {cands}; 1 thread: {probe[1]:.0f} solves/s)",
+        "sample": f"{m} {'trajectory-steps' if config == 5 else 'poses'} of the workload x {passes} passes ({el:.1f} s) with OpenMP {best} threads "
+                  f"(best of {cands}; 1 thread: {probe[1]:.0f} per s)",
     }
     try:
         Ln = orc.native_lib()
@@ -206,13 +214,13 @@ def cpu_baseline(config, sample, seconds, gpu=None):
                                 "single_thread": nat1, "passes": npass, "seconds": nel}
         if natv > value:
             base["value"], base["single_thread"] = natv, nat1
-            base["sample"] += f"; value = the native build ({natv:.0f} solves/s; portable build {value:.0f})"
+            base["sample"] += f"; value = the native build ({natv:.0f} per s; portable build {value:.0f})"
     except Exception as e:  # no gcc on the box: the portable figure stands
         base["native_build"] = {"error": f"{type(e).__name__}: {e}"}
     if gpu is not None:
         ref = run(best)
         np.testing.assert_array_equal(gpu["state"], ref["state"], err_msg="GPU state codes differ from the checker")
-        ok = ref["reachable"].astype(bool)
+        ok = ref["reachable"].astype(bool) if config != 5 else np.ones(ref["reachable"].shape, dtype=bool)  # config 5: every step has joints
         if "reachable" in gpu:
             np.testing.assert_array_equal(gpu["reachable"], ref["reachable"], err_msg="GPU flags differ from the checker")
         err = float(np.max(np.abs(gpu["joints"][ok] - ref["joints"][ok]), initial=0.0))
@@ -675,7 +683,19 @@ def main(argv=None):
 
     # ---- the rows the CPU-baseline leg re-solves, and the GPU's results for them
     sample, gpu_rows = None, None
-    if not args.no_cpu_baseline and cfg != 5:
+    if not args.no_cpu_baseline and cfg == 5 and world == 1:
+        # 64 of the trajectories (evenly spread), all their steps: what the CPU leg re-walks
+        sub = torch.arange(0, n, max(1, n // 64), device=dev)[:64]
+        m12 = traj[:, :, sub].cpu().numpy()                         # [n_steps, 12, n_sub]
+        Ms = np.tile(np.eye(4), (m12.shape[0], m12.shape[2], 1, 1))
+        Ms[:, :, :3, :3] = np.moveaxis(m12[:, :9, :], 1, 2).reshape(m12.shape[0], m12.shape[2], 3, 3)
+        Ms[:, :, :3, 3] = np.moveaxis(m12[:, 9:, :], 1, 2)
+        st0 = np.zeros((len(sub), 11))
+        c0 = cont0[:, sub].cpu().numpy()
+        st0[:, 0], st0[:, 1:8], st0[:, 8], st0[:, 9], st0[:, 10] = c0[0], c0[1:8].T, c0[8], c0[9], c0[10]
+        sample = {"M": Ms, "state0": st0, "pref_self": float(ctrl.preferred_theta["r_arm"])}
+        gpu_rows = {k: out[k][:, sub].cpu().numpy() for k in ("joints", "state", "reachable")}
+    elif not args.no_cpu_baseline and cfg != 5:
         m = min(n, 1 << 18 if cfg in (2, 4) else 1 << 17)
         if world == 1:
             sample = {k: (None if v is None else v[:m]) for k, v in sample_local.items()}

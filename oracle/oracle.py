@@ -76,6 +76,8 @@ def _bind(L):
     L.orc_solve_batch.argtypes = [_dp, _dp, C.c_long] + [_dp] * 6 + [_u8p, C.c_int, _dp, _dp, _dp, _dp, _dp, _u8p, _u8p, _u8p, C.c_int]
     L.orc_control_discrete_batch.argtypes = [_dp, _dp, C.c_long, _dp, _u8p, C.c_int, C.c_double, C.c_int, _dp, _dp,
                                              C.c_double, _dp, _u8p, _u8p, _u8p, C.c_int]
+    L.orc_control_continuous_run_batch.argtypes = [_dp, _dp, C.c_long, C.c_long, _dp, C.c_int, C.c_double, C.c_double, C.c_int,
+                                                   C.c_double, C.c_double, _dp, _u8p, _u8p, C.c_int]
     return L
 
 
@@ -270,6 +272,23 @@ def control_continuous_step(arm, cs, M, timed_out, preferred_theta_arg, preferre
                                            float(preferred_theta_self), int(constrained_mode), _d(cj), _d(cp),
                                            float(d_theta_max), float(orbita3d_max_angle), _d(j), C.byref(ok))
     return j, bool(ok.value), st
+
+
+def control_continuous_run_batch(arm, states, M, first_step_timed_out=True, preferred_theta_arg=-4 * np.pi / 6,
+                                 preferred_theta_self=-4 * np.pi / 6, constrained_mode=0, d_theta_max=0.01,
+                                 orbita3d_max_angle=float(np.deg2rad(42.5)), nthreads=1, L=None):
+    """M [n_steps, n_traj, 4, 4]; states [n_traj, 11] float64 (orc_cont_state_t rows: previous_theta, previous_sol[7], init,
+    emergency_stop, has_previous_sol), updated in place."""
+    M = np.ascontiguousarray(M, dtype=np.float64)
+    n_steps, n_traj = M.shape[:2]
+    assert states.shape == (n_traj, 11) and states.dtype == np.float64 and states.flags.c_contiguous
+    joints = np.empty((n_steps, n_traj, 7)); reach = np.empty((n_steps, n_traj), dtype=np.uint8)
+    state = np.empty((n_steps, n_traj), dtype=np.uint8)
+    (L or lib()).orc_control_continuous_run_batch(_d(arm.buf), _d(states), n_traj, n_steps, _d(M.reshape(-1)), int(bool(first_step_timed_out)),
+                                                  float(preferred_theta_arg), float(preferred_theta_self), int(constrained_mode),
+                                                  float(d_theta_max), float(orbita3d_max_angle), _d(joints), _u8(reach), _u8(state),
+                                                  int(nthreads))
+    return dict(joints=joints, reachable=reach, state=state)
 
 
 def euler_from_matrix_xyz(M):

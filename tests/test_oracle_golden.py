@@ -394,3 +394,25 @@ def test_custom_urdf_control(golden_dir):
                 prev_pose = Ms[k, s]
                 assert ok == bool(F[k, s]) and st == S[k, s], (arm, k, s)
                 assert np.max(np.abs(j - J[k, s])) < 1e-7, (arm, k, s)
+
+
+def test_continuous_batch_driver_equals_the_step_driver():
+    """orc_control_continuous_run_batch (what bench.py's config-5 CPU leg times) walks trajectories exactly like the
+    step-by-step driver the parity tests use."""
+    rng = np.random.default_rng(5)
+    a = orc.Arm("r_arm", -1.01)
+    n_steps, n_traj = 60, 5
+    M = np.tile(np.eye(4), (n_steps, n_traj, 1, 1))
+    M[:, :, :3, 3] = np.array([0.4, -0.3, -0.2]) + 0.01 * rng.standard_normal((n_steps, n_traj, 3)).cumsum(0)
+    start = [0.0, 0.26, -0.17, 0.0, 0.0, 0.0, 0.0]
+    st = np.zeros((n_traj, 11))
+    st[:, 0], st[:, 1:8], st[:, 8], st[:, 10] = -2.0, start, 1.0, 1.0
+    res = orc.control_continuous_run_batch(a, st, M, nthreads=2)
+    for k in range(n_traj):
+        cs = orc.ContinuousState(-2.0, start)
+        for i in range(n_steps):
+            j, ok, code = orc.control_continuous_step(a, cs, M[i, k], timed_out=(i == 0), preferred_theta_arg=-4 * np.pi / 6,
+                                                    preferred_theta_self=-4 * np.pi / 6, constrained_mode=0,
+                                                    current_joints=cs.previous_sol, current_pose=M[0, k])
+            assert np.array_equal(j, res["joints"][i, k]) and ok == bool(res["reachable"][i, k]) and code == res["state"][i, k]
+        assert np.array_equal(cs.buf, st[k])
