@@ -258,14 +258,17 @@ int rsik_control_continuous_step(rsik_ctx *ctx, int64_t n, const double *const m
  * not done step by step: most of a control step does not depend on the previous one — the goal conversion,
  * is_reachable / is_reachable_no_limits and the 10-point search for the target theta (control_ik.py:327-388 up to the
  * rate limiter) are functions of the pose alone — so the batch is solved in four phases per block of steps:
- *   1. prepare   one thread per (step, trajectory), chip-filling: geometry + target theta -> workspace
+ *   1. prepare   one thread per (step, trajectory), chip-filling: is_reachable + the search for the target theta; the
+ *                step's goal for the rate limiter (the search's theta / the preferred theta / "stay") -> workspace
  *   2. theta     one thread per trajectory, sequential over steps: the d_theta_max rate limiter and
  *                limit_theta_to_interval (the only recurrence on previous_theta)
- *   3. joints    one thread per (step, trajectory): get_joints at the limited theta + the Orbita3D cone clamp
+ *   3. joints    one thread per (step, trajectory): the circle of is_reachable / is_reachable_no_limits re-derived from
+ *                the goal matrix, get_joints at the limited theta + the Orbita3D cone clamp
  *   4. chain     eight lanes per trajectory (one per joint), sequential over steps: allow_multiturn, the +-6 pi clamp,
  *                continuity_check and the emergency latch (the recurrence on previous_sol); steps whose get_joints
  *                hit an exact singularity (fallback to previous_sol[0] / [2]) are recomputed here
- * The workspace (23 doubles per step and trajectory of a block, at most 256 MB) belongs to the context and is
+ * The phases of neighbouring blocks overlap on four streams (the caller's and three of the context's).  The workspace
+ * (one double + one byte per step and trajectory of the four blocks in flight) belongs to the context and is
  * allocated on first use (not capturable into a hipGraph for that reason).  4096 trajectories x 1000 steps: see
  * DESIGN.md section 4.
  *   m12_steps        device [n_steps][12][n]: the goal matrices of every step

@@ -86,12 +86,23 @@ __device__ __forceinline__ double pymod_2pi(double a) {
 }
 // The same value without a branch, for the serial phases of the continuous mode: there a lone wave pays the
 // compare -> exec mask -> branch round trip of every RSIK_RARE test in full, and four selects are cheaper.
+// (The two fix-ups are formed side by side and selected, not chained: two dependent instructions fewer per modulo on
+// the serial path.  They differ from the chained form in one corner only — a result that rounds up to 2 pi itself,
+// a = -1e-17, stays 2 pi — and that is what CPython returns there.)
 __device__ __forceinline__ double pymod_2pi_straight(double a) {
-    double q = floor(a * 0.15915494309189535);
-    double m = fma(-q, kTwoPi, a);
-    m = (m < 0) ? m + kTwoPi : m;
-    m = (m >= kTwoPi) ? m - kTwoPi : m;
-    return m;
+    const double q = floor(a * 0.15915494309189535);
+    const double m = fma(-q, kTwoPi, a);
+    const double lo = m + kTwoPi, hi = m - kTwoPi;
+    return (m < 0) ? lo : ((m >= kTwoPi) ? hi : m);
+}
+// angle_diff (U:486-490) for |a - b| <= 2 pi, i.e. two angles of [-pi, pi]: x = (a - b) + pi lies in [-pi, 3 pi], where
+// Python's `x % 2pi` is x, x + 2 pi (x < 0) or x - 2 pi (x >= 2 pi, exact) — no quotient, no floor: bit for bit the
+// general form's value, five dependent instructions instead of nine.
+__device__ __forceinline__ double angle_diff_near(double a, double b) {
+    const double x = (a - b) + kPi;
+    const double lo = x + kTwoPi, hi = x - kTwoPi;
+    const double m = (x < 0) ? lo : ((x >= kTwoPi) ? hi : x);
+    return m - kPi;
 }
 __device__ __forceinline__ double angle_diff_straight(double a, double b) {
     double d = a - b;
@@ -915,8 +926,9 @@ __device__ __forceinline__ double limit_theta_to_interval_straight(double theta,
     theta = pymod_2pi_straight(theta);
     theta = (theta > kPi) ? theta - kTwoPi : theta;
     const bool valid = is_valid_angle(theta, l0, l1);
-    const double posDiff = angle_diff_straight(theta, l1);
-    const double negDiff = angle_diff_straight(theta, l0);
+    // theta is in (-pi, pi] here and the interval limits are in [-pi, pi] (control_limits wraps them): the short form
+    const double posDiff = angle_diff_near(theta, l1);
+    const double negDiff = angle_diff_near(theta, l0);
     const double snapped = (fabs(posDiff) < fabs(negDiff)) ? l1 : l0;
     return valid ? theta : snapped;
 }
