@@ -1032,23 +1032,6 @@ __device__ bool best_discrete_theta_grid(const Acc& A, const Reach& r, double a,
     return found;
 }
 
-// utils.get_best_discrete_theta (U:334-396), one pose per lane: used by the continuous mode with its fixed 10-point
-// grid (C:350-361); the discrete mode picks between this, the arc-end candidates and the wave-cooperative sweep.
-template <class Acc>
-__device__ bool best_discrete_theta_serial(const Acc& A, const Reach& r, int nb, double pref, double& theta_out) {
-    if (is_valid_angle(pref, r.i0, r.i1)) {
-        double st, ct;
-        fast_sincos(pref, &st, &ct);
-        if (is_elbow_ok(A, elbow_on_circle(r, ct, st))) { theta_out = pref; return true; }
-    }
-    double a, b;
-    if (fabs(fabs(r.i0) + fabs(r.i1) - kTwoPi) < 0.00001) { a = kPi / 2; b = kPi / 2 + kTwoPi; }
-    else if (r.i0 < r.i1) { a = r.i0; b = r.i1; }
-    else { a = r.i0; b = r.i1 + kTwoPi; }
-    const double step = (b - a) / (double)(nb - 1);
-    return best_discrete_theta_grid(A, r, a, step, b, nb, pref, theta_out);
-}
-
 // utils.get_best_theta_to_current_joints (U:267-331) with a flat 7-joint target (C:322-324): ternary search over the
 // circle; every evaluation is a state-mutating get_joints call exactly like the reference (Q1).
 template <class Acc>

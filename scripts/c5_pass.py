@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""Six 4096 x 1000 passes of the continuous pipeline (config 5) and nothing else: the command rocprofv3 traces for
+scripts/c5_timeline.py.  usage: c5_pass.py [alternative librsik_hip.so]"""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from reachy2_symbolic_ik_amd import ControlIK, _abi
 blk = 0
