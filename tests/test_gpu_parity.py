@@ -367,8 +367,8 @@ def test_control_random(golden_dir, torch_mod, dvt_tag, is_dvt):
 @pytest.mark.parametrize("nb", [2, 3, 10, 20, 25, 33, 64, 65, 100, 200, 1000])
 def test_control_grid_sizes_match_checker(golden_dir, torch_mod, orc, nb, mode):
     """Grid search strategies (rsik_set_option RSIK_OPT_SWEEP_MODE: 0 = per-wave choice, 1 = exhaustive wave-cooperative sweep, which packs
-    64/pow2ceil(nb) poses per round and needs extra rounds above 64 points, 2 = per-lane search: whole grid up to 16
-    points, the 12 bracketing candidates above) must all reproduce the reference's first strict minimum."""
+    64/pow2ceil(nb) poses per round and needs extra rounds above 64 points, 2 = per-lane search: whole grid up to 4
+    points, the arc-end candidates above) must all reproduce the reference's first strict minimum."""
     g = load(golden_dir, "g4_control_discrete.npz")
     c = make_control()
     c._solver.set_option(_abi_mod().OPT_SWEEP_MODE, mode)
@@ -381,6 +381,38 @@ def test_control_grid_sizes_match_checker(golden_dir, torch_mod, orc, nb, mode):
     np.testing.assert_array_equal(res["reachable"], ref["reachable"])
     np.testing.assert_array_equal(res["state"], ref["state"])
     assert np.max(np.abs(res["joints"] - ref["joints"])) < TOL
+
+
+@pytest.mark.parametrize("dvt_tag,is_dvt,offset", [("std", False, -1.01), ("dvt", True, 0.03)])
+def test_control_candidate_search_any_preferred_theta(golden_dir, torch_mod, orc, dvt_tag, is_dvt, offset):
+    """The per-lane candidate search (grid_theta_candidates: 4 candidates, 6 with the DVT singularity plane) under
+    preferred angles other than the default: random ones, angles whose left-arm mirror image -pi - preferred_theta
+    falls outside [-pi, pi] (control_ik.py:252; utils.py:468-474 then compares it unwrapped and the shortcut fails on a
+    free angle: the brackets of the preferred angle join the candidates) and an angle at the edge of the range; mixed
+    r / l launches, three grid sizes, per-lane search forced and per-wave choice, against the checker's exhaustive walk."""
+    g = load(golden_dir, "g4_control_discrete.npz")
+    c = make_control(is_dvt)
+    ar, al = orc.Arm("r_arm", offset), orc.Arm("l_arm", offset)
+    Mr, Ml = g[f"{dvt_tag}_r_arm_M"][::2], g[f"{dvt_tag}_l_arm_M"][1::2]   # both halves of G4: uniform and wrist-reachable goals
+    M = np.concatenate([Mr, Ml])
+    arm = np.concatenate([np.zeros(len(Mr), np.uint8), np.ones(len(Ml), np.uint8)])
+    arm_t = torch_mod.as_tensor(arm).cuda()
+    rng = np.random.default_rng(77)
+    prefs = [float(x) for x in rng.uniform(-np.pi, np.pi, 4)] + [2.9, -3.1, 0.0]
+    searched = 0
+    for k, pref in enumerate(prefs):
+        nb = (10, 20, 64)[k % 3]
+        c.nb_search_points = nb
+        ref = orc.control_discrete_batch(ar, al, M, arm_id=arm, nb_search_points=nb, preferred_theta=pref)
+        for mode in (2, 0):
+            c._solver.set_option(_abi_mod().OPT_SWEEP_MODE, mode)
+            res = to_np(c.symbolic_inverse_kinematics_batch(arm_t, M, preferred_theta=pref))
+            np.testing.assert_array_equal(res["reachable"], ref["reachable"], err_msg=f"pref {pref} nb {nb} mode {mode}")
+            np.testing.assert_array_equal(res["state"], ref["state"], err_msg=f"pref {pref} nb {nb} mode {mode}")
+            assert np.max(np.abs(res["joints"] - ref["joints"])) < TOL, (pref, nb, mode)
+        searched += int(ref["reachable"].sum())
+    c._solver.set_option(_abi_mod().OPT_SWEEP_MODE, 0)
+    assert searched > 1000, searched
 
 
 @pytest.mark.parametrize("mode", [1, 2])
