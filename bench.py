@@ -371,7 +371,7 @@ def parse_args(argv):
                     help="N > 1 with --gather step: stripes per shard; stripe c's all-gather travels while stripe c + 1 is solved")
     ap.add_argument("--launch", choices=["auto", "eager", "graph"], default="auto",
                     help="N = 1: K pre-bound launches from Python (eager) or one replay of a hipGraph holding the K launches; "
-                         "auto = graph from 100 steps on (the replay has a fixed start-up cost but removes the launch gaps)")
+                         "auto = graph for K <= 32 and K >= 200, eager between (measured: graphs of 33 ... ~150 nodes replay slower than eager launches)")
     ap.add_argument("--graph", action="store_true", help="same as --launch graph")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--single-device", action="store_true", help="every rank uses GPU 0 (with --backend gloo: rehearsal on a 1-GPU box)")
@@ -600,7 +600,11 @@ def main(argv=None):
     fence()
 
     # ---- timed region: exactly K steps, bracketed by barrier + synchronize on both sides
-    use_graph = world == 1 and cfg != 5 and (args.launch == "graph" or (args.launch == "auto" and args.steps >= 100))
+    # auto: replay the K launches from a hipGraph where that is the faster way to issue them.  Measured per step on 1 M-pose
+    # batches (eager / graph, us): K = 10: 35.6 / 34.5, 20: 33.7 / 33.1, 32: 33.2 / 33.0, 33: 33.2 / 34.0, 50: 34.1 / 38.6,
+    # 64: 33.8 / 39.1, 100: 36.9 / 38.7, 200: 37.3 / 34.1, 1000: - / 31.1 — a graph of 33 ... ~150 kernel nodes replays
+    # slower than eager launches, shorter and longer ones faster.
+    use_graph = world == 1 and cfg != 5 and (args.launch == "graph" or (args.launch == "auto" and (args.steps <= 32 or args.steps >= 200)))
     graph = None
     if use_graph:
         try:
