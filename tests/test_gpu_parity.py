@@ -667,6 +667,37 @@ def test_continuous_run_equals_stepwise(golden_dir, torch_mod, run_mode):
     assert np.max(np.abs(res["joints"] - np.swapaxes(J, 0, 1))) < 1e-7
 
 
+def test_continuous_pipeline_block_sizes_are_bit_identical(torch_mod):
+    """The trajectory pipeline cuts a run into blocks (RSIK_OPT_CONT_BLOCK_STEPS) whose four phases overlap on four
+    streams; the operands of the two sequential phases are fetched 8 / 32 steps at a time.  Whatever the block size —
+    shorter than a batch, not a multiple of one, the whole run — results and carried state must be the same bits, and
+    equal to one launch of the step kernel per control step."""
+    from bench import make_config5_trajectories
+
+    A = _abi_mod()
+    n_traj, n_steps = 300, 131
+    traj = make_config5_trajectories(n_traj, n_steps, seed=99)
+    c = make_control()
+    ref = None
+    for mode, blk in ((A.CONT_RUN_STEPS, 0), (A.CONT_RUN_PHASED, 0), (A.CONT_RUN_PHASED, 5), (A.CONT_RUN_PHASED, 32),
+                      (A.CONT_RUN_PHASED, 40), (A.CONT_RUN_PHASED, 131), (A.CONT_RUN_PHASED, 4000)):
+        c._solver.set_option(A.OPT_CONT_RUN_MODE, mode)
+        c._solver.set_option(A.OPT_CONT_BLOCK_STEPS, blk)
+        st = c.new_continuous_state("r_arm", n_traj)
+        res = c.run_continuous_trajectories("r_arm", traj, st, first_step_timed_out=True, current_pose=traj[0])
+        torch_mod.cuda.synchronize()
+        got = {k: v.clone() for k, v in res.items()}
+        got["cont_state"] = st[:11].clone()
+        if ref is None:
+            ref = got
+            assert bool(torch_mod.isfinite(ref["joints"]).all()) and 0.05 < float(ref["reachable"].float().mean()) < 0.95
+        else:
+            for k in ref:
+                assert torch_mod.equal(ref[k].view(torch_mod.uint8), got[k].view(torch_mod.uint8)), (mode, blk, k)
+    c._solver.set_option(A.OPT_CONT_RUN_MODE, A.CONT_RUN_AUTO)
+    c._solver.set_option(A.OPT_CONT_BLOCK_STEPS, 0)
+
+
 def test_config5_full_size_against_checker(torch_mod, orc):
     """BASELINE config 5 at its stated size: 4096 trajectories x 1000 control steps in one rsik_control_continuous_run
     call (bench.py's generator and call), a 96-trajectory subsample re-walked step by step by the CPU checker's state
