@@ -153,6 +153,29 @@ __device__ __forceinline__ T ld_stream(const T* p) {
 #endif
 }
 
+// The kernels read their ~1 KB argument block (pointers, launch constants, the arm constants) with scalar loads that the
+// compiler places where the values are first needed — a dozen first touches of different 64-byte lines, spread over the
+// whole kernel, and the scalar cache starts every launch cold: every wave of a launch's first round stalls on each of them
+// (measured: RSIK_WARM_KERNARG 0 vs 1).  warm_kernarg<BYTES>() touches every line of the block once, right after the
+// wave has issued its input loads: the misses overlap each other and the input latency, later reads hit.
+// (The values are discarded: all loads target one clobbered scalar register and are waited for inside the block.)
+#ifndef RSIK_WARM_KERNARG
+#define RSIK_WARM_KERNARG 1
+#endif
+template <int BYTES>
+__device__ __forceinline__ void warm_kernarg() {
+#if RSIK_WARM_KERNARG
+    const unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+#define RSIK_TOUCH(off) if constexpr (BYTES > (off)) asm volatile("s_load_dword s90, %0, " #off ::"s"(ka) : "s90", "memory")
+    RSIK_TOUCH(0x40); RSIK_TOUCH(0x80); RSIK_TOUCH(0xc0); RSIK_TOUCH(0x100); RSIK_TOUCH(0x140); RSIK_TOUCH(0x180);
+    RSIK_TOUCH(0x1c0); RSIK_TOUCH(0x200); RSIK_TOUCH(0x240); RSIK_TOUCH(0x280); RSIK_TOUCH(0x2c0); RSIK_TOUCH(0x300);
+    RSIK_TOUCH(0x340); RSIK_TOUCH(0x380); RSIK_TOUCH(0x3c0); RSIK_TOUCH(0x400); RSIK_TOUCH(0x440); RSIK_TOUCH(0x480);
+    RSIK_TOUCH(0x4c0); RSIK_TOUCH(0x500); RSIK_TOUCH(0x540); RSIK_TOUCH(0x580); RSIK_TOUCH(0x5c0); RSIK_TOUCH(0x600);
+#undef RSIK_TOUCH
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "s90", "memory");
+#endif
+}
+
 // Writes ROWxW doubles per lane as a contiguous [64*W] slab per wave (row-major [n,W] output).
 template <int W>
 __device__ __forceinline__ void store_rows(double* __restrict__ out, int64_t wave_base, int64_t n, int lane,
@@ -251,6 +274,7 @@ __global__ __launch_bounds__(kBlock, RSIK_SOLVE_MIN_WAVES) void solve_kernel(con
     double in[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) in[k] = ld_stream(K.in[k] + tile0 + tt);
+    warm_kernarg<(MIXED == 1 ? 0 : (int)offsetof(SolveArgs, arms) + (int)sizeof(ArmC))>();  // (every constant from LDS: nothing to warm)
     stage_tables<(MIXED != 0)>(lds_tab, K.arms);
 #ifdef RSIK_TIMELINE_PROBE
     const uint64_t probe_t1 = __builtin_amdgcn_s_memrealtime();
@@ -540,6 +564,7 @@ __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR void co
 #pragma unroll
     for (int k = 0; k < 12; k++) m12[k] = K.in[k][ii];
     const bool lane_isl = MIXED ? (K.arm[ii] != 0) : false;
+    warm_kernarg<(int)offsetof(DiscreteArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>();
     __shared__ SharedTables lds_tab;
     stage_tables<MIXED>(lds_tab, K.arms);
     const Acc<MIXED> A = make_acc<MIXED>(K.arms, lane_isl, lds_tab);
@@ -788,6 +813,7 @@ __global__ __launch_bounds__(kBlock) void control_continuous_kernel(const Contin
     const int64_t n = K.n;
 
     __shared__ SharedTables lds_tab;
+    warm_kernarg<(int)offsetof(ContinuousArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>();
     stage_tables<MIXED>(lds_tab, K.arms);
     const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[ii] != 0) : false, lds_tab);
     const int slot = MIXED ? (A.isl ? 1 : 0) : 0;
@@ -921,6 +947,7 @@ __global__ __launch_bounds__(kBlock) void cont_prepare_kernel(const ContRunArgs 
     for (int k = 0; k < 12; k++) m[k] = src[k * K.n];
     const bool lane_isl = MIXED ? (K.arm[ii] != 0) : false;
     __shared__ SharedTables lds_tab;
+    warm_kernarg<(int)offsetof(ContRunArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>();
     stage_tables<MIXED>(lds_tab, K.arms);
     const Acc<MIXED> A = make_acc<MIXED>(K.arms, lane_isl, lds_tab);
     const int slot = MIXED ? (A.isl ? 1 : 0) : 0;
@@ -1043,6 +1070,7 @@ __global__ __launch_bounds__(kBlock) void cont_joints_kernel(const ContRunArgs K
     const int flag = K.flags[t * K.n + ii];
     const bool lane_isl = MIXED ? (K.arm[ii] != 0) : false;
     __shared__ SharedTables lds_tab;
+    warm_kernarg<(int)offsetof(ContRunArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>();
     stage_tables<MIXED>(lds_tab, K.arms);
     const Acc<MIXED> A = make_acc<MIXED>(K.arms, lane_isl, lds_tab);
     Reach r;
@@ -1072,6 +1100,7 @@ __global__ __launch_bounds__(kBlock) void cont_chain_kernel(const ContRunArgs K)
     const int jj = j < 7 ? j : 6;
     const bool owner = live && j < 7;
     __shared__ SharedTables lds_tab;
+    warm_kernarg<(int)offsetof(ContRunArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>();
     stage_tables<MIXED>(lds_tab, K.arms);
     const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[ii] != 0) : false, lds_tab);
     const int64_t n = K.n;
@@ -1214,6 +1243,7 @@ __global__ __launch_bounds__(kBlock) void cont_init_kernel(const ContinuousArgs 
     const bool live = i < K.n;
     const int64_t ii = live ? i : (K.n - 1);
     __shared__ SharedTables lds_tab;
+    warm_kernarg<(int)offsetof(ContinuousArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>();
     stage_tables<MIXED>(lds_tab, K.arms);
     const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[ii] != 0) : false, lds_tab);
     const int slot = MIXED ? (A.isl ? 1 : 0) : 0;
@@ -1261,6 +1291,7 @@ template <bool MIXED>
 __global__ __launch_bounds__(kBlock) void reach_state_kernel(const StateArgs K) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     __shared__ SharedTables lds_tab;
+    warm_kernarg<(int)offsetof(StateArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>();
     stage_tables<MIXED>(lds_tab, K.arms);
     if (i >= K.n) return;
     const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[i] != 0) : false, lds_tab);
@@ -1301,6 +1332,7 @@ template <bool MIXED>
 __global__ __launch_bounds__(kBlock) void joints_state_kernel(const StateArgs K) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     __shared__ SharedTables lds_tab;
+    warm_kernarg<(int)offsetof(StateArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>();
     stage_tables<MIXED>(lds_tab, K.arms);
     if (i >= K.n) return;
     const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[i] != 0) : false, lds_tab);
