@@ -83,9 +83,34 @@ struct SharedTables {
     double arm[2][RSIK_ARM_CONSTS_COUNT];
     double utab[3][kUnitAtanRows];  // column-major, see unit_atan2_n
 };
+// The kernels read their ~1 KB argument block (pointers, launch constants, the arm constants) with scalar loads that the
+// compiler places where the values are first needed — a dozen first touches of different 64-byte lines, spread over the
+// whole kernel, and the scalar cache starts every launch cold: every wave of a launch's first round stalls on each of them
+// (measured: RSIK_WARM_KERNARG 0 vs 1).  warm_kernarg<BYTES>() touches every line of the block once, after the wave
+// has issued its input loads and the table-staging loads (stage_tables): the misses overlap each other and those loads'
+// latency, later reads hit.
+// (The values are discarded: all loads target one clobbered scalar register and are waited for inside the block.)
+#ifndef RSIK_WARM_KERNARG
+#define RSIK_WARM_KERNARG 1
+#endif
+template <int BYTES>
+__device__ __forceinline__ void warm_kernarg() {
+#if RSIK_WARM_KERNARG
+    const unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+#define RSIK_TOUCH(off) if constexpr (BYTES > (off)) asm volatile("s_load_dword s90, %0, " #off ::"s"(ka) : "s90", "memory")
+    RSIK_TOUCH(0x40); RSIK_TOUCH(0x80); RSIK_TOUCH(0xc0); RSIK_TOUCH(0x100); RSIK_TOUCH(0x140); RSIK_TOUCH(0x180);
+    RSIK_TOUCH(0x1c0); RSIK_TOUCH(0x200); RSIK_TOUCH(0x240); RSIK_TOUCH(0x280); RSIK_TOUCH(0x2c0); RSIK_TOUCH(0x300);
+    RSIK_TOUCH(0x340); RSIK_TOUCH(0x380); RSIK_TOUCH(0x3c0); RSIK_TOUCH(0x400); RSIK_TOUCH(0x440); RSIK_TOUCH(0x480);
+    RSIK_TOUCH(0x4c0); RSIK_TOUCH(0x500); RSIK_TOUCH(0x540); RSIK_TOUCH(0x580); RSIK_TOUCH(0x5c0); RSIK_TOUCH(0x600);
+#undef RSIK_TOUCH
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "s90", "memory");
+#endif
+}
+
 // All global reads of the staging are issued first and the LDS writes follow, so a workgroup pays ONE memory round trip
 // before its barrier (a copy loop per table serialises one round trip per table: +0.6 us on every wave's start-up).
-template <bool MIXED>
+// WARM: bytes of the kernel's argument block to warm in the scalar cache (warm_kernarg) while the staging loads fly.
+template <bool MIXED, int WARM = 0>
 __device__ __forceinline__ void stage_tables(SharedTables& S, const ArmC* arms) {
     constexpr int NA = kUnitAtanRows * 3, NS = kSinCosRows * 2, NC = 2 * RSIK_ARM_CONSTS_COUNT;
     constexpr int RA = (NA + kBlock - 1) / kBlock, RS = (NS + kBlock - 1) / kBlock, RC = (NC + kBlock - 1) / kBlock;
@@ -105,7 +130,7 @@ __device__ __forceinline__ void stage_tables(SharedTables& S, const ArmC* arms) 
             vc[r] = ((r + 1) * kBlock <= NC || k < NC) ? arms[k / RSIK_ARM_CONSTS_COUNT].v[k % RSIK_ARM_CONSTS_COUNT] : 0.0;
         }
     }
-    double* la = &S.utab[0][0];
+        double* la = &S.utab[0][0];
     double* ls = &g_sincos_tab[0][0];
 #pragma unroll
     for (int r = 0; r < RA; r++)
@@ -150,29 +175,6 @@ __device__ __forceinline__ T ld_stream(const T* p) {
     return __builtin_nontemporal_load(p);
 #else
     return *p;
-#endif
-}
-
-// The kernels read their ~1 KB argument block (pointers, launch constants, the arm constants) with scalar loads that the
-// compiler places where the values are first needed — a dozen first touches of different 64-byte lines, spread over the
-// whole kernel, and the scalar cache starts every launch cold: every wave of a launch's first round stalls on each of them
-// (measured: RSIK_WARM_KERNARG 0 vs 1).  warm_kernarg<BYTES>() touches every line of the block once, right after the
-// wave has issued its input loads: the misses overlap each other and the input latency, later reads hit.
-// (The values are discarded: all loads target one clobbered scalar register and are waited for inside the block.)
-#ifndef RSIK_WARM_KERNARG
-#define RSIK_WARM_KERNARG 1
-#endif
-template <int BYTES>
-__device__ __forceinline__ void warm_kernarg() {
-#if RSIK_WARM_KERNARG
-    const unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
-#define RSIK_TOUCH(off) if constexpr (BYTES > (off)) asm volatile("s_load_dword s90, %0, " #off ::"s"(ka) : "s90", "memory")
-    RSIK_TOUCH(0x40); RSIK_TOUCH(0x80); RSIK_TOUCH(0xc0); RSIK_TOUCH(0x100); RSIK_TOUCH(0x140); RSIK_TOUCH(0x180);
-    RSIK_TOUCH(0x1c0); RSIK_TOUCH(0x200); RSIK_TOUCH(0x240); RSIK_TOUCH(0x280); RSIK_TOUCH(0x2c0); RSIK_TOUCH(0x300);
-    RSIK_TOUCH(0x340); RSIK_TOUCH(0x380); RSIK_TOUCH(0x3c0); RSIK_TOUCH(0x400); RSIK_TOUCH(0x440); RSIK_TOUCH(0x480);
-    RSIK_TOUCH(0x4c0); RSIK_TOUCH(0x500); RSIK_TOUCH(0x540); RSIK_TOUCH(0x580); RSIK_TOUCH(0x5c0); RSIK_TOUCH(0x600);
-#undef RSIK_TOUCH
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "s90", "memory");
 #endif
 }
 
@@ -274,7 +276,10 @@ __global__ __launch_bounds__(kBlock, RSIK_SOLVE_MIN_WAVES) void solve_kernel(con
     double in[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) in[k] = ld_stream(K.in[k] + tile0 + tt);
-    warm_kernarg<(MIXED == 1 ? 0 : (int)offsetof(SolveArgs, arms) + (int)sizeof(ArmC))>();  // (every constant from LDS: nothing to warm)
+    // (MIXED == 1 takes every constant from LDS: nothing to warm.  Here the warm-up goes BEFORE the staging loads are issued,
+    // in the other kernels between their issue and their use (stage_tables<., WARM>): measured both ways per kernel, config
+    // 2 31.1 vs 31.9 us, config 3 15.9 vs 15.7 us)
+    warm_kernarg<(MIXED == 1 ? 0 : (int)offsetof(SolveArgs, arms) + (int)sizeof(ArmC))>();
     stage_tables<(MIXED != 0)>(lds_tab, K.arms);
 #ifdef RSIK_TIMELINE_PROBE
     const uint64_t probe_t1 = __builtin_amdgcn_s_memrealtime();
@@ -564,9 +569,8 @@ __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR void co
 #pragma unroll
     for (int k = 0; k < 12; k++) m12[k] = K.in[k][ii];
     const bool lane_isl = MIXED ? (K.arm[ii] != 0) : false;
-    warm_kernarg<(int)offsetof(DiscreteArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>();
-    __shared__ SharedTables lds_tab;
-    stage_tables<MIXED>(lds_tab, K.arms);
+        __shared__ SharedTables lds_tab;
+    stage_tables<MIXED, (int)offsetof(DiscreteArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>(lds_tab, K.arms);
     const Acc<MIXED> A = make_acc<MIXED>(K.arms, lane_isl, lds_tab);
     const int slot = MIXED ? (A.isl ? 1 : 0) : 0;
 
@@ -813,8 +817,7 @@ __global__ __launch_bounds__(kBlock) void control_continuous_kernel(const Contin
     const int64_t n = K.n;
 
     __shared__ SharedTables lds_tab;
-    warm_kernarg<(int)offsetof(ContinuousArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>();
-    stage_tables<MIXED>(lds_tab, K.arms);
+        stage_tables<MIXED, (int)offsetof(ContinuousArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>(lds_tab, K.arms);
     const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[ii] != 0) : false, lds_tab);
     const int slot = MIXED ? (A.isl ? 1 : 0) : 0;
 
@@ -947,8 +950,7 @@ __global__ __launch_bounds__(kBlock) void cont_prepare_kernel(const ContRunArgs 
     for (int k = 0; k < 12; k++) m[k] = src[k * K.n];
     const bool lane_isl = MIXED ? (K.arm[ii] != 0) : false;
     __shared__ SharedTables lds_tab;
-    warm_kernarg<(int)offsetof(ContRunArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>();
-    stage_tables<MIXED>(lds_tab, K.arms);
+        stage_tables<MIXED, (int)offsetof(ContRunArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>(lds_tab, K.arms);
     const Acc<MIXED> A = make_acc<MIXED>(K.arms, lane_isl, lds_tab);
     const int slot = MIXED ? (A.isl ? 1 : 0) : 0;
     Rot Rg;
@@ -1070,8 +1072,7 @@ __global__ __launch_bounds__(kBlock) void cont_joints_kernel(const ContRunArgs K
     const int flag = K.flags[t * K.n + ii];
     const bool lane_isl = MIXED ? (K.arm[ii] != 0) : false;
     __shared__ SharedTables lds_tab;
-    warm_kernarg<(int)offsetof(ContRunArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>();
-    stage_tables<MIXED>(lds_tab, K.arms);
+        stage_tables<MIXED, (int)offsetof(ContRunArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>(lds_tab, K.arms);
     const Acc<MIXED> A = make_acc<MIXED>(K.arms, lane_isl, lds_tab);
     Reach r;
     Goal G;
@@ -1100,8 +1101,7 @@ __global__ __launch_bounds__(kBlock) void cont_chain_kernel(const ContRunArgs K)
     const int jj = j < 7 ? j : 6;
     const bool owner = live && j < 7;
     __shared__ SharedTables lds_tab;
-    warm_kernarg<(int)offsetof(ContRunArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>();
-    stage_tables<MIXED>(lds_tab, K.arms);
+        stage_tables<MIXED, (int)offsetof(ContRunArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>(lds_tab, K.arms);
     const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[ii] != 0) : false, lds_tab);
     const int64_t n = K.n;
     double prev = K.st[(1 + jj) * n + ii];
@@ -1243,8 +1243,7 @@ __global__ __launch_bounds__(kBlock) void cont_init_kernel(const ContinuousArgs 
     const bool live = i < K.n;
     const int64_t ii = live ? i : (K.n - 1);
     __shared__ SharedTables lds_tab;
-    warm_kernarg<(int)offsetof(ContinuousArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>();
-    stage_tables<MIXED>(lds_tab, K.arms);
+        stage_tables<MIXED, (int)offsetof(ContinuousArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>(lds_tab, K.arms);
     const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[ii] != 0) : false, lds_tab);
     const int slot = MIXED ? (A.isl ? 1 : 0) : 0;
     const int64_t n = K.n;
@@ -1291,8 +1290,7 @@ template <bool MIXED>
 __global__ __launch_bounds__(kBlock) void reach_state_kernel(const StateArgs K) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     __shared__ SharedTables lds_tab;
-    warm_kernarg<(int)offsetof(StateArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>();
-    stage_tables<MIXED>(lds_tab, K.arms);
+        stage_tables<MIXED, (int)offsetof(StateArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>(lds_tab, K.arms);
     if (i >= K.n) return;
     const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[i] != 0) : false, lds_tab);
     V3 pos = {K.in[0][i], K.in[1][i], K.in[2][i]};
@@ -1332,8 +1330,7 @@ template <bool MIXED>
 __global__ __launch_bounds__(kBlock) void joints_state_kernel(const StateArgs K) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     __shared__ SharedTables lds_tab;
-    warm_kernarg<(int)offsetof(StateArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>();
-    stage_tables<MIXED>(lds_tab, K.arms);
+        stage_tables<MIXED, (int)offsetof(StateArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>(lds_tab, K.arms);
     if (i >= K.n) return;
     const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[i] != 0) : false, lds_tab);
     double* S = K.solver_state + i * RSIK_SOLVER_STATE_STRIDE;
