@@ -1239,6 +1239,7 @@ __global__ __launch_bounds__(kBlock) void cont_chain_kernel(const ContRunArgs K)
 // C:296-325 for the trajectories of a batch that (re)initialise: previous_sol, previous_theta, init
 template <bool MIXED>
 __global__ __launch_bounds__(kBlock) void cont_init_kernel(const ContinuousArgs K) {
+    __builtin_amdgcn_s_setprio(3);  // a few lone waves on the critical path, beside the chip-filling prepare phase
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool live = i < K.n;
     const int64_t ii = live ? i : (K.n - 1);
@@ -1979,11 +1980,18 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     }
     hipStream_t s_main = ctx->stream, s_theta = ctx->stream, s_prep = ctx->side[0], s_joints = ctx->side[1], s_chain = ctx->side[2];
     auto ev = [&](int kind, int64_t b) { return ctx->events[2 + 4 * (size_t)b + kind]; };  // 0 prepared, 1 theta, 2 joints, 3 chain
-    // (re)initialisation of the trajectories that start here (C:296-325), then the pipeline's streams join in
+    // (Re)initialisation of the trajectories that start here (C:296-325: the start-up search for previous_theta, ~55 us
+    // of lone waves), then the pipeline's streams join in.  The prepare phase depends on the goal matrices alone, not on
+    // the trajectory state: its stream forks off BEFORE the initialisation (behind whatever the caller queued ahead of
+    // this call), so prepare(0) runs beside it and theta(0) starts when both are done; the joints and chain streams fork
+    // behind it.
+    RSIK_HIP(ctx, hipEventRecord(ctx->events[1], s_main));
+    RSIK_HIP(ctx, hipStreamWaitEvent(s_prep, ctx->events[1], 0));
     if (arm) hipLaunchKernelGGL(rsik::cont_init_kernel<true>, grid, block, 0, s_main, K0);
     else hipLaunchKernelGGL(rsik::cont_init_kernel<false>, grid, block, 0, s_main, K0);
     RSIK_HIP(ctx, hipEventRecord(ctx->events[0], s_main));
-    for (hipStream_t st : ctx->side) RSIK_HIP(ctx, hipStreamWaitEvent(st, ctx->events[0], 0));
+    RSIK_HIP(ctx, hipStreamWaitEvent(s_joints, ctx->events[0], 0));
+    RSIK_HIP(ctx, hipStreamWaitEvent(s_chain, ctx->events[0], 0));
     rsik::ContRunArgs R;
     std::memset(&R, 0, sizeof R);
     R.n = n;
@@ -2003,25 +2011,36 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     dim3 grid8;
     rc = launch_dims(ctx, n * 8, &grid8, who);
     if (rc != RSIK_OK) return rc;
-    for (int64_t b = 0; b < n_blocks; b++) {
+    // The order in which the host issues the launches matters: a launch + its event calls cost the host ~10 us, a block's
+    // four ~50 us, and a kernel that reaches its queue late starts late whatever its dependencies say.  The critical
+    // path is theta(0) -> theta(1) -> ... (and chain behind it), fed by prepare(b): so the blocks that have a workspace
+    // slot of their own get their prepare + theta launches first, then their joints + chain launches; a block that
+    // reuses a slot can only be issued once the chain that frees the slot has been (its event must have been recorded).
+    const bool plane_binds = singularity_plane_binds(R.arms);
+    auto set_block = [&](int64_t b) {
         R.t0 = block_t0[b];
         R.T = block_T[b];
         R.first_block = b == 0;
         R.last_block = b == n_blocks - 1;
         R.ws = reinterpret_cast<double*>(static_cast<char*>(ctx->ws) + slot_bytes * (size_t)(b % slots));
         R.flags = reinterpret_cast<uint8_t*>(R.ws + (size_t)R.T * (size_t)n);
+    };
+    auto issue_front = [&](int64_t b) -> int {  // prepare(b), theta(b)
+        set_block(b);
         const dim3 grid2(grid.x, (unsigned)R.T);
         if (b >= slots) RSIK_HIP(ctx, hipStreamWaitEvent(s_prep, ev(3, b - slots), 0));  // the slot's previous block is done
-        {
-            const bool pb = singularity_plane_binds(R.arms);
-            if (arm) { if (pb) hipLaunchKernelGGL((rsik::cont_prepare_kernel<true, true>), grid2, block, 0, s_prep, R); else hipLaunchKernelGGL((rsik::cont_prepare_kernel<true, false>), grid2, block, 0, s_prep, R); }
-            else { if (pb) hipLaunchKernelGGL((rsik::cont_prepare_kernel<false, true>), grid2, block, 0, s_prep, R); else hipLaunchKernelGGL((rsik::cont_prepare_kernel<false, false>), grid2, block, 0, s_prep, R); }
-        }
+        if (arm) { if (plane_binds) hipLaunchKernelGGL((rsik::cont_prepare_kernel<true, true>), grid2, block, 0, s_prep, R); else hipLaunchKernelGGL((rsik::cont_prepare_kernel<true, false>), grid2, block, 0, s_prep, R); }
+        else { if (plane_binds) hipLaunchKernelGGL((rsik::cont_prepare_kernel<false, true>), grid2, block, 0, s_prep, R); else hipLaunchKernelGGL((rsik::cont_prepare_kernel<false, false>), grid2, block, 0, s_prep, R); }
         RSIK_HIP(ctx, hipEventRecord(ev(0, b), s_prep));
         RSIK_HIP(ctx, hipStreamWaitEvent(s_theta, ev(0, b), 0));
         if (arm) hipLaunchKernelGGL(rsik::cont_theta_kernel<true>, grid, block, 0, s_theta, R);
         else hipLaunchKernelGGL(rsik::cont_theta_kernel<false>, grid, block, 0, s_theta, R);
         RSIK_HIP(ctx, hipEventRecord(ev(1, b), s_theta));
+        return RSIK_OK;
+    };
+    auto issue_back = [&](int64_t b) -> int {  // joints(b), chain(b)
+        set_block(b);
+        const dim3 grid2(grid.x, (unsigned)R.T);
         RSIK_HIP(ctx, hipStreamWaitEvent(s_joints, ev(1, b), 0));
         if (arm) hipLaunchKernelGGL(rsik::cont_joints_kernel<true>, grid2, block, 0, s_joints, R);
         else hipLaunchKernelGGL(rsik::cont_joints_kernel<false>, grid2, block, 0, s_joints, R);
@@ -2030,6 +2049,16 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         if (arm) hipLaunchKernelGGL(rsik::cont_chain_kernel<true>, grid8, block, 0, s_chain, R);
         else hipLaunchKernelGGL(rsik::cont_chain_kernel<false>, grid8, block, 0, s_chain, R);
         RSIK_HIP(ctx, hipEventRecord(ev(3, b), s_chain));
+        return RSIK_OK;
+    };
+    const int64_t head = n_blocks < slots ? n_blocks : slots;
+    for (int64_t b = 0; b < head; b++)
+        if ((rc = issue_front(b)) != RSIK_OK) return rc;
+    for (int64_t b = 0; b < head; b++)
+        if ((rc = issue_back(b)) != RSIK_OK) return rc;
+    for (int64_t b = head; b < n_blocks; b++) {
+        if ((rc = issue_front(b)) != RSIK_OK) return rc;
+        if ((rc = issue_back(b)) != RSIK_OK) return rc;
     }
     // the caller's stream continues once the last chain (hence every phase of every block) is done
     RSIK_HIP(ctx, hipStreamWaitEvent(s_main, ev(3, n_blocks - 1), 0));
