@@ -1034,8 +1034,12 @@ __device__ bool best_discrete_theta_grid(const Acc& A, const Reach& r, double a,
 
 // utils.get_best_theta_to_current_joints (U:267-331) with a flat 7-joint target (C:322-324): ternary search over the
 // circle; every evaluation is a state-mutating get_joints call exactly like the reference (Q1).
-template <class Acc>
-__device__ double best_theta_to_current_joints(const Acc& A, Reach& r, const Rot& Rg, const double* cur, double pref) {
+// PAIR: two lanes per trajectory (an even lane and its odd neighbour, `half` = 0 / 1) evaluate the two mid points of an
+// iteration side by side and swap the distances.  Only valid where get_joints cannot move the solver's state (no elbow
+// projection possible: the caller has checked that the singularity plane is out of the elbow's reach), so that the two
+// evaluations of the reference's sequential loop do not depend on each other; the numbers compared are the same.
+template <bool PAIR = false, class Acc>
+__device__ double best_theta_to_current_joints(const Acc& A, Reach& r, const Rot& Rg, const double* cur, double pref, int half = 0) {
     const double zeros[7] = {0, 0, 0, 0, 0, 0, 0};
     auto dist_at = [&](double th) -> double {
         double st, ct;
@@ -1053,12 +1057,23 @@ __device__ double best_theta_to_current_joints(const Acc& A, Reach& r, const Rot
     while ((high - low) > tolerance) {
         double mid1 = low + (high - low) / 3;
         double mid2 = high - (high - low) / 3;
-        double f1 = dist_at(mid1);
-        double f2 = dist_at(mid2);
+        double f1, f2;
+        if constexpr (PAIR) {
+            const double mine = dist_at(half ? mid2 : mid1);
+            const unsigned long long bits = __builtin_bit_cast(unsigned long long, mine);
+            const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)bits, 0xB1, 0xf, 0xf, true);          // quad_perm [1,0,3,2]
+            const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(bits >> 32), 0xB1, 0xf, 0xf, true);
+            const double other = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+            f1 = half ? other : mine;
+            f2 = half ? mine : other;
+        } else {
+            f1 = dist_at(mid1);
+            f2 = dist_at(mid2);
+        }
         if (f1 < f2) high = mid2; else low = mid1;
     }
     double best = (low + high) / 2;
-    (void)dist_at(best);  // U:324
+    if constexpr (!PAIR) (void)dist_at(best);  // U:324 (the call's side effect on the solver state; PAIR: there is none)
     return best;
 }
 

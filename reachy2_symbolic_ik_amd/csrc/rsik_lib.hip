@@ -734,9 +734,9 @@ struct ContinuousArgs {
 // C:296-325: (re)initialisation of a trajectory whose caller timed out: previous_sol := current_joints and
 // previous_theta := the theta of the current pose closest to them (utils.get_best_theta_to_current_joints).
 // `only_init`: the launch does nothing else (rsik_control_continuous_run's first phase).
-template <class Acc>
+template <bool PAIR = false, class Acc>
 __device__ __forceinline__ void continuous_reinit(const Acc& A, const ContinuousArgs& K, int64_t ii, double pref,
-                                                  double& prev_theta, double (&prev_sol)[7]) {
+                                                  double& prev_theta, double (&prev_sol)[7], int half = 0) {
     if (K.current_joints) {
 #pragma unroll
         for (int k = 0; k < 7; k++) prev_sol[k] = K.current_joints[ii * 7 + k];
@@ -745,7 +745,7 @@ __device__ __forceinline__ void continuous_reinit(const Acc& A, const Continuous
     V3 cpos;
     load_m12(K.cur_pose[0] ? K.cur_pose : K.in, ii, Rc, cpos, K.euler_roundtrip);
     Reach rc = reach<true>(A, cpos, Rc);
-    prev_theta = best_theta_to_current_joints(A, rc, Rc, prev_sol, pref);
+    prev_theta = best_theta_to_current_joints<PAIR>(A, rc, Rc, prev_sol, pref, half);
 }
 
 // U:571-589 continuity_check with the thresholds of C:398
@@ -1238,11 +1238,15 @@ __global__ __launch_bounds__(kBlock) void cont_chain_kernel(const ContRunArgs K)
     }
 }
 
-// C:296-325 for the trajectories of a batch that (re)initialise: previous_sol, previous_theta, init
-template <bool MIXED>
+// C:296-325 for the trajectories of a batch that (re)initialise: previous_sol, previous_theta, init.
+// PAIR: two lanes per trajectory share the start-up search (best_theta_to_current_joints<PAIR>): half its latency, which
+// is on the critical path of a run.
+template <bool MIXED, bool PAIR>
 __global__ __launch_bounds__(kBlock) void cont_init_kernel(const ContinuousArgs K) {
     __builtin_amdgcn_s_setprio(3);  // a few lone waves on the critical path, beside the chip-filling prepare phase
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t i = PAIR ? (gid >> 1) : gid;
+    const int half = PAIR ? (int)(gid & 1) : 0;
     const bool live = i < K.n;
     const int64_t ii = live ? i : (K.n - 1);
     __shared__ SharedTables lds_tab;
@@ -1257,7 +1261,8 @@ __global__ __launch_bounds__(kBlock) void cont_init_kernel(const ContinuousArgs 
     double prev_sol[7];
 #pragma unroll
     for (int k = 0; k < 7; k++) prev_sol[k] = K.st[(1 + k) * n + i];
-    continuous_reinit(A, K, i, K.pref_arg[slot], prev_theta, prev_sol);
+    continuous_reinit<PAIR>(A, K, i, K.pref_arg[slot], prev_theta, prev_sol, half);
+    if (half != 0) return;  // (both lanes of a pair hold the same result)
     K.st[0 * n + i] = prev_theta;
 #pragma unroll
     for (int k = 0; k < 7; k++) K.st[(1 + k) * n + i] = prev_sol[k];
@@ -1989,8 +1994,14 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     // behind it.
     RSIK_HIP(ctx, hipEventRecord(ctx->events[1], s_main));
     RSIK_HIP(ctx, hipStreamWaitEvent(s_prep, ctx->events[1], 0));
-    if (arm) hipLaunchKernelGGL(rsik::cont_init_kernel<true>, grid, block, 0, s_main, K0);
-    else hipLaunchKernelGGL(rsik::cont_init_kernel<false>, grid, block, 0, s_main, K0);
+    {
+        // two lanes per trajectory where get_joints cannot move the solver's state (no elbow projection possible)
+        const bool pair = !singularity_plane_binds(K0.arms);
+        dim3 grid_init = grid;
+        if (pair && (rc = launch_dims(ctx, n * 2, &grid_init, who)) != RSIK_OK) return rc;
+        if (arm) { if (pair) hipLaunchKernelGGL((rsik::cont_init_kernel<true, true>), grid_init, block, 0, s_main, K0); else hipLaunchKernelGGL((rsik::cont_init_kernel<true, false>), grid_init, block, 0, s_main, K0); }
+        else { if (pair) hipLaunchKernelGGL((rsik::cont_init_kernel<false, true>), grid_init, block, 0, s_main, K0); else hipLaunchKernelGGL((rsik::cont_init_kernel<false, false>), grid_init, block, 0, s_main, K0); }
+    }
     RSIK_HIP(ctx, hipEventRecord(ctx->events[0], s_main));
     RSIK_HIP(ctx, hipStreamWaitEvent(s_joints, ctx->events[0], 0));
     RSIK_HIP(ctx, hipStreamWaitEvent(s_chain, ctx->events[0], 0));
