@@ -86,23 +86,29 @@ __device__ __forceinline__ double pymod_2pi(double a) {
 }
 // The same value without a branch, for the serial phases of the continuous mode: there a lone wave pays the
 // compare -> exec mask -> branch round trip of every RSIK_RARE test in full, and four selects are cheaper.
-// (The two fix-ups are formed side by side and selected, not chained: two dependent instructions fewer per modulo on
-// the serial path.  They differ from the chained form in one corner only — a result that rounds up to 2 pi itself,
-// a = -1e-17, stays 2 pi — and that is what CPython returns there.)
+// The fix-up of a modulo result on the serial path: +2 pi below 0, -2 pi from 2 pi on, else +0.0 — selected as the two
+// words of the ADDEND (the low words of +-2 pi are the same, the high words differ in the sign bit), so that one addition
+// follows three 32-bit selects: six vector instructions where two candidate sums and two 64-bit selects take eight.  A
+// lone wave issues its instructions one at a time, so on that path the count is the latency.  (x + 0.0 is x; a result
+// that rounds up to 2 pi itself, a = -1e-17, stays 2 pi, as in CPython.)
+__device__ __forceinline__ double wrap_addend_2pi(double m) {
+    const bool neg = m < 0, big = m >= kTwoPi;
+    constexpr unsigned kLo = 0x54442d18u, kHi = 0x401921fbu;  // 2 pi = 0x401921fb54442d18
+    const unsigned lo = (neg | big) ? kLo : 0u;
+    const unsigned hi = neg ? kHi : (big ? (kHi | 0x80000000u) : 0u);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ double pymod_2pi_straight(double a) {
     const double q = floor(a * 0.15915494309189535);
     const double m = fma(-q, kTwoPi, a);
-    const double lo = m + kTwoPi, hi = m - kTwoPi;
-    return (m < 0) ? lo : ((m >= kTwoPi) ? hi : m);
+    return m + wrap_addend_2pi(m);
 }
 // angle_diff (U:486-490) for |a - b| <= 2 pi, i.e. two angles of [-pi, pi]: x = (a - b) + pi lies in [-pi, 3 pi], where
 // Python's `x % 2pi` is x, x + 2 pi (x < 0) or x - 2 pi (x >= 2 pi, exact) — no quotient, no floor: bit for bit the
-// general form's value, five dependent instructions instead of nine.
+// general form's value.
 __device__ __forceinline__ double angle_diff_near(double a, double b) {
     const double x = (a - b) + kPi;
-    const double lo = x + kTwoPi, hi = x - kTwoPi;
-    const double m = (x < 0) ? lo : ((x >= kTwoPi) ? hi : x);
-    return m - kPi;
+    return (x + wrap_addend_2pi(x)) - kPi;
 }
 __device__ __forceinline__ double angle_diff_straight(double a, double b) {
     double d = a - b;
@@ -922,15 +928,24 @@ __device__ __forceinline__ double limit_theta_to_interval(double theta, double l
 }
 
 // limit_theta_to_interval for the serial theta phase (no branches, see pymod_2pi_straight)
-__device__ __forceinline__ double limit_theta_to_interval_straight(double theta, double l0, double l1) {
+// l1v: l1 again, for the caller that keeps a copy in a vector register across its loop (a select needs one vector operand)
+__device__ __forceinline__ double limit_theta_to_interval_straight(double theta, double l0, double l1, double l1v) {
     theta = pymod_2pi_straight(theta);
     theta = (theta > kPi) ? theta - kTwoPi : theta;
-    const bool valid = is_valid_angle(theta, l0, l1);
+    // is_valid_angle without its short circuits: the limits are launch constants, so `whole` and `wrap` are scalar values
+    // and the test is three mask operations instead of three scalar branches per step
+    const bool whole = (l0 == l1) | ((fabs(l0) == kPi) & (fabs(l1) == kPi));
+    const bool wrap = !(l0 < l1);
+    const bool ge = l0 <= theta, le = theta <= l1;
+    const bool valid = whole | (wrap ? (ge | le) : (ge & le));
     // theta is in (-pi, pi] here and the interval limits are in [-pi, pi] (control_limits wraps them): the short form
     const double posDiff = angle_diff_near(theta, l1);
     const double negDiff = angle_diff_near(theta, l0);
-    const double snapped = (fabs(posDiff) < fabs(negDiff)) ? l1 : l0;
+    const double snapped = (fabs(posDiff) < fabs(negDiff)) ? l1v : l0;
     return valid ? theta : snapped;
+}
+__device__ __forceinline__ double limit_theta_to_interval_straight(double theta, double l0, double l1) {
+    return limit_theta_to_interval_straight(theta, l0, l1, l1);
 }
 
 // ControlIK.safety_checks (C:464-497), in two halves:

@@ -787,13 +787,18 @@ __device__ __forceinline__ ThetaTarget continuous_target(const Acc& A, V3 pos, c
 }
 // The recurrence on previous_theta: rate limiter of get_best_continuous_theta2 (U:252-264) / tend_to_preferred_theta
 // (U:115-127), then limit_theta_to_interval (U:93-112).
+// dmax_v / l1v: the same values again, for the caller that keeps copies in vector registers across its loop.
 __device__ __forceinline__ double continuous_next_theta_goal(double goal, double prev_theta, double d_theta_max, double l0,
-                                                            double l1) {
+                                                            double l1, double dmax_v, double l1v) {
     // sign * d_theta_max with sign = ad / |ad| (U:260, U:126) is copysign(d_theta_max, ad), bit for bit: the quotient
     // of a non-zero finite number by its own magnitude is exactly +-1.
     const double ad = angle_diff_straight(goal, prev_theta);
-    const double theta = (fabs(ad) < d_theta_max) ? goal : (prev_theta + copysign(d_theta_max, ad));
-    return limit_theta_to_interval_straight(theta, l0, l1);
+    const double theta = (fabs(ad) < d_theta_max) ? goal : (prev_theta + copysign(dmax_v, ad));
+    return limit_theta_to_interval_straight(theta, l0, l1, l1v);
+}
+__device__ __forceinline__ double continuous_next_theta_goal(double goal, double prev_theta, double d_theta_max, double l0,
+                                                            double l1) {
+    return continuous_next_theta_goal(goal, prev_theta, d_theta_max, l0, l1, d_theta_max, l1);
 }
 __device__ __forceinline__ double continuous_next_theta(bool ok_limits, bool found, double target, double pref_arg,
                                                         double prev_theta, double d_theta_max, double l0, double l1) {
@@ -903,9 +908,9 @@ __global__ __launch_bounds__(kBlock) void control_continuous_kernel(const Contin
 // of reading 22 doubles per trajectory-step that the prepare phase would have to write (652 -> 400 B per step).
 // ------------------------------------------------------------------------------------------
 // steps whose operands the sequential phases fetch at once, one batch ahead of the one being computed (blocks are multiples
-// of both): the theta step is ~50 dependent instructions, 8 of them outlast a memory round trip; the chain's short form is 16
+// of both; measured on 4096 x 1000 steps: theta batches of 8 / 16 / 32 steps 0.544 / 0.525 / 0.552 ms per pass)
 #ifndef RSIK_THETA_BATCH
-#define RSIK_THETA_BATCH 8
+#define RSIK_THETA_BATCH 16
 #endif
 #ifndef RSIK_CHAIN_BATCH
 #define RSIK_CHAIN_BATCH 32
@@ -992,8 +997,12 @@ __global__ __launch_bounds__(kBlock) void cont_theta_kernel(const ContRunArgs K)
     // trip of every test in full.  (Measured and not kept: a speculative short form of the step for goal - previous
     // within one turn, checked once per batch — half the waves hold a trajectory that is snapped to the interval
     // limits or has unwound past +-pi, and then pay both forms.)
+    // (launch constants that a select or a sign transfer needs as a vector operand: pinned in vector registers once,
+    // instead of two moves each per step)
+    double dmax_v = K.d_theta_max, l1v = l1;
+    asm volatile("" : "+v"(dmax_v), "+v"(l1v));
     auto one = [&](double tg, double* dst) {
-        prev_theta = continuous_next_theta_goal((tg != tg) ? prev_theta : tg, prev_theta, K.d_theta_max, l0, l1);
+        prev_theta = continuous_next_theta_goal((tg != tg) ? prev_theta : tg, prev_theta, K.d_theta_max, l0, l1, dmax_v, l1v);
         *dst = prev_theta;
     };
     const int64_t full = K.T - (K.T % kThetaBatch);
