@@ -84,18 +84,23 @@ __device__ __forceinline__ double pymod_2pi(double a) {
     }
     return m;
 }
-// The same value without a branch, for the serial phases of the continuous mode: there a lone wave pays the
-// compare -> exec mask -> branch round trip of every RSIK_RARE test in full, and four selects are cheaper.
-// The fix-up of a modulo result on the serial path: +2 pi below 0, -2 pi from 2 pi on, else +0.0 — selected as the two
-// words of the ADDEND (the low words of +-2 pi are the same, the high words differ in the sign bit), so that one addition
-// follows three 32-bit selects: six vector instructions where two candidate sums and two 64-bit selects take eight.  A
-// lone wave issues its instructions one at a time, so on that path the count is the latency.  (x + 0.0 is x; a result
-// that rounds up to 2 pi itself, a = -1e-17, stays 2 pi, as in CPython.)
+// The serial phases of the continuous mode (one wave alone on its SIMD) are written for that wave's issue rules, measured
+// with scripts/probes/issue_probe.hip: every vector instruction costs the wave ~4.5 cycles whether or not it depends on
+// the one before, a v_cmp feeding v_cndmask (through vcc or any SGPR pair) costs nothing extra — but a SCALAR instruction
+// that reads a mask a vector compare wrote (s_or_b64 / s_and_b64 of two compare results) stalls ~16 cycles, and a branch
+// on such a mask ~29.  So on those paths conditions are never combined as masks: selects are chained instead, and
+// `opaque` keeps the compiler from folding the chain back into mask algebra.
+__device__ __forceinline__ unsigned opaque(unsigned x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ double opaque(double x) { asm volatile("" : "+v"(x)); return x; }
+// The fix-up of a modulo result: +2 pi below 0, -2 pi from 2 pi on, else +0.0 — selected as the two words of the ADDEND
+// (the low words of +-2 pi are the same, the high words differ in the sign bit): two compares and four 32-bit selects
+// (the two conditions exclude each other), then one addition; x + 0.0 is x.
 __device__ __forceinline__ double wrap_addend_2pi(double m) {
-    const bool neg = m < 0, big = m >= kTwoPi;
     constexpr unsigned kLo = 0x54442d18u, kHi = 0x401921fbu;  // 2 pi = 0x401921fb54442d18
-    const unsigned lo = (neg | big) ? kLo : 0u;
-    const unsigned hi = neg ? kHi : (big ? (kHi | 0x80000000u) : 0u);
+    const bool neg = m < 0, big = m >= kTwoPi;
+    unsigned lo = opaque(neg ? kLo : 0u), hi = opaque(neg ? kHi : 0u);
+    lo = big ? kLo : lo;
+    hi = big ? (kHi | 0x80000000u) : hi;
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 __device__ __forceinline__ double pymod_2pi_straight(double a) {
@@ -946,6 +951,117 @@ __device__ __forceinline__ double limit_theta_to_interval_straight(double theta,
 }
 __device__ __forceinline__ double limit_theta_to_interval_straight(double theta, double l0, double l1) {
     return limit_theta_to_interval_straight(theta, l0, l1, l1);
+}
+
+// limit_theta_to_interval's wrap alone (U:93-97): `theta % 2pi`, then `- 2pi` above pi.  Its results are fixed points of
+// itself (m - 2 pi is exact for m in (pi, 2 pi], so adding 2 pi gives m back).
+__device__ __forceinline__ double wrap_theta_to_pi(double theta) {
+    theta = pymod_2pi_straight(theta);
+    return (theta > kPi) ? theta - kTwoPi : theta;
+}
+
+// The recurrence on previous_theta for the theta phase of the trajectory pipeline — rate limiter (U:252-264 / U:115-127),
+// then limit_theta_to_interval (U:93-112) — specialised by the KIND of the control interval [l0, l1] (theta_snap_plan on
+// the host decides it and finds `tdag`), ~40 vector instructions and no scalar one (see `opaque`):
+//   kSnapInner: l0 < l1, and of the gap's two ends l1 is the nearer one exactly for theta in (l1, tdag)
+//   kSnapWrap:  l0 > l1 (the interval contains +-pi), the gap is (l1, l0), l1 is the nearer end exactly below tdag
+// `tdag` replaces the reference's comparison |angle_diff(theta, l1)| < |angle_diff(theta, l0)| (U:105-111), which is
+// monotonic in theta across the gap: the host finds the one double at which it flips, by bisection with the reference's
+// own arithmetic, and checks the equivalence on a sample of the gap (else the generic form runs).
+//   g:  the step's goal as the prepare phase left it (NaN = "stay": goal = previous_theta), gw = wrap_theta_to_pi(g)
+//   prev in [-pi, pi] (any result of limit_theta_to_interval), 0 <= dmax < pi;  l0, l1, tdag, dmax in vector registers
+constexpr int kSnapGeneric = 0, kSnapInner = 1, kSnapWrap = 2;
+__device__ __forceinline__ unsigned hi_word(double x) { return (unsigned)(__builtin_bit_cast(unsigned long long, x) >> 32); }
+__device__ __forceinline__ unsigned lo_word(double x) { return (unsigned)__builtin_bit_cast(unsigned long long, x); }
+__device__ __forceinline__ double from_words(unsigned lo, unsigned hi) {
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// The compares and selects of the step are written as instructions: on gfx950 a vector instruction may read a mask
+// (vcc or a scalar register pair) two issue slots after the compare that wrote it at the earliest; the compiler keeps
+// every compare next to its select and pays an s_nop for each (9 of ~50 slots a step), while here the compares are
+// issued early and other work fills the slots.  Within a block, and from one block to the next, every mask is read at
+// least two instructions after its compare (the blocks are `volatile`: they keep their order, and the compiler can
+// only add instructions between them).  Everything else of the step is plain arithmetic and stays with the compiler.
+template <int KIND>
+__device__ __forceinline__ double continuous_next_theta_lean(double g, double gw, double prev, double dmax, double l0, double l1,
+                                                             double tdag) {
+    static_assert(KIND == kSnapInner || KIND == kSnapWrap, "the generic interval goes through continuous_next_theta_goal");
+    // angle_diff(goal, previous_theta) (U:486-490) enters the step through |ad| < d_theta_max and through its sign only.
+    // The modulo's fix-ups (pymod_2pi: +-2 pi when the quotient was rounded across an integer) move ad by a whole turn from
+    // below -pi or from pi on: they never change the first test (|ad| >= pi either way) and flip the sign — so the raw
+    // result is taken and the sign flipped where they would have acted.  NaN for "stay" (the unordered compare).
+    double adr, q;
+    unsigned long long m_stay, m_below, m_above, m_within;
+    asm volatile(
+        "v_add_f64 %[x], %[g], -%[prev]\n\t"
+        "v_cmp_u_f64 %[ms], %[g], %[g]\n\t"
+        "v_add_f64 %[x], %[x], %[pi]\n\t"
+        "v_mul_f64 %[q], %[x], %[inv]\n\t"
+        "v_floor_f64 %[q], %[q]\n\t"
+        "v_fma_f64 %[x], -%[q], %[two], %[x]\n\t"
+        "v_add_f64 %[x], %[x], -%[pi]\n\t"
+        "v_cmp_gt_f64 %[m1], -%[pi], %[x]\n\t"
+        "v_cmp_le_f64 %[m2], %[pi], %[x]\n\t"
+        "v_cmp_lt_f64 %[mw], |%[x]|, %[dmax]"
+        : [x] "=&v"(adr), [q] "=&v"(q), [ms] "=&s"(m_stay), [m1] "=&s"(m_below), [m2] "=&s"(m_above), [mw] "=&s"(m_within)
+        : [g] "v"(g), [prev] "v"(prev), [pi] "s"(kPi), [inv] "s"(0.15915494309189535), [two] "s"(kTwoPi), [dmax] "v"(dmax));
+    // previous_theta + sign * d_theta_max (sign = ad / |ad| is +-1 exactly), "stay" adds +0.0: then theta = previous_theta,
+    // which still goes through limit_theta_to_interval like any other
+    unsigned flip, ahi, alo;
+    asm volatile(
+        "v_cndmask_b32 %[f], 0, %[sign], %[m1]\n\t"
+        "v_cndmask_b32 %[f], %[f], %[sign], %[m2]\n\t"
+        "v_xor_b32 %[f], %[f], %[xhi]\n\t"
+        "v_bfi_b32 %[ahi], %[absmask], %[dhi], %[f]\n\t"
+        "v_cndmask_b32 %[ahi], %[ahi], 0, %[ms]\n\t"
+        "v_cndmask_b32 %[alo], %[dlo], 0, %[ms]"
+        : [f] "=&v"(flip), [ahi] "=&v"(ahi), [alo] "=&v"(alo)
+        : [sign] "v"(0x80000000u), [m1] "s"(m_below), [m2] "s"(m_above), [ms] "s"(m_stay), [xhi] "v"(hi_word(adr)),
+          [absmask] "s"(0x7fffffffu), [dhi] "v"(hi_word(dmax)), [dlo] "v"(lo_word(dmax)));
+    const double tr = prev + from_words(alo, ahi);
+    // U:93-97 for tr in (-2 pi, 2 pi): `% 2pi` is tr itself or tr + 2 pi (rounded, as Python does), then `- 2pi` above pi;
+    // both addends' words are masked with a sign (of tr, of pi - m; neither is ever -0.0)
+    constexpr unsigned kLo = 0x54442d18u, kHi = 0x401921fbu;  // 2 pi = 0x401921fb54442d18
+    const unsigned neg = (unsigned)((int)hi_word(tr) >> 31);
+    const double m = tr + from_words(neg & kLo, neg & kHi);
+    const unsigned over = (unsigned)((int)hi_word(kPi - m) >> 31);
+    const double r = m + from_words(over & kLo, over & (kHi | 0x80000000u));
+    // theta = goal where the rate limit allows it (its wrap was done by the prepare phase), then U:98-112: inside the
+    // interval theta stays, else the nearer end — below tdag that is l1 (or theta is inside)
+    unsigned tlo, thi;
+    asm volatile(
+        "v_cndmask_b32 %[tlo], %[rlo], %[glo], %[mw]\n\t"
+        "v_cndmask_b32 %[thi], %[rhi], %[ghi], %[mw]"
+        : [tlo] "=&v"(tlo), [thi] "=&v"(thi)
+        : [rlo] "v"(lo_word(r)), [rhi] "v"(hi_word(r)), [glo] "v"(lo_word(gw)), [ghi] "v"(hi_word(gw)), [mw] "s"(m_within));
+    const double t1 = from_words(tlo, thi);
+    double low, high;
+    unsigned long long m_low;
+    if constexpr (KIND == kSnapInner) {
+        // below tdag: [l0, l1] untouched, (l1, tdag) -> l1, below l0 -> l0; from tdag on: l0
+        asm volatile(
+            "v_cmp_lt_f64 %[mk], %[t], %[tdag]\n\t"
+            "v_max_f64 %[lo], %[t], %[l0]\n\t"
+            "v_min_f64 %[lo], %[lo], %[l1]"
+            : [mk] "=&s"(m_low), [lo] "=&v"(low)
+            : [t] "v"(t1), [tdag] "v"(tdag), [l0] "v"(l0), [l1] "v"(l1));
+        high = l0;
+    } else {
+        // the gap is (l1, l0): below tdag min(theta, l1), from tdag on max(theta, l0)
+        asm volatile(
+            "v_cmp_lt_f64 %[mk], %[t], %[tdag]\n\t"
+            "v_min_f64 %[lo], %[t], %[l1]\n\t"
+            "v_max_f64 %[hi], %[t], %[l0]"
+            : [mk] "=&s"(m_low), [lo] "=&v"(low), [hi] "=&v"(high)
+            : [t] "v"(t1), [tdag] "v"(tdag), [l0] "v"(l0), [l1] "v"(l1));
+    }
+    unsigned olo, ohi;
+    asm volatile(
+        "v_cndmask_b32 %[olo], %[hlo], %[llo], %[mk]\n\t"
+        "v_cndmask_b32 %[ohi], %[hhi], %[lhi], %[mk]"
+        : [olo] "=&v"(olo), [ohi] "=&v"(ohi)
+        : [hlo] "v"(lo_word(high)), [hhi] "v"(hi_word(high)), [llo] "v"(lo_word(low)), [lhi] "v"(hi_word(low)), [mk] "s"(m_low));
+    return from_words(olo, ohi);
 }
 
 // ControlIK.safety_checks (C:464-497), in two halves:

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "rsik_device.hpp"
@@ -930,8 +931,10 @@ struct ContRunArgs {
     double lim[2][2];
     double d_theta_max;
     double max_angle, cos_max, sin_max;
-    double* ws;                   // [T][n]
+    double* ws;                   // [T][n]: the step's theta goal (phase 1), overwritten by the step's theta (phase 2)
+    double* gw;                   // [T][n]: the goal after limit_theta_to_interval's wrap (phase 1 -> phase 2)
     uint8_t* flags;               // [T][n]
+    double snap_tdag;             // phase 2, single-arm launches: see continuous_next_theta_lean (the kind is a template argument)
     double* theta_carry;          // [n]: previous_theta between the blocks of one run (phase 2's own state)
     int first_block, last_block;
     double* st;                   // cont_state
@@ -967,17 +970,43 @@ __global__ __launch_bounds__(kBlock) void cont_prepare_kernel(const ContRunArgs 
     if (!live) return;
     // the step's goal for the theta phase: the search's theta, NaN = nothing found, stay (U:252-264 with goal =
     // previous_theta), or the preferred theta of an unreachable pose (U:115-127)
-    RSIK_WS(K, t, i) = T.ok_limits ? (T.found ? T.theta : __builtin_nan("")) : K.pref_arg[slot];
+    const double goal = T.ok_limits ? (T.found ? T.theta : __builtin_nan("")) : K.pref_arg[slot];
+    RSIK_WS(K, t, i) = goal;
+    // what limit_theta_to_interval makes of theta = goal before it looks at the interval (U:93-97): this phase has the
+    // issue slots for it, the theta phase (a lone wave per SIMD) has not
+    K.gw[t * K.n + i] = wrap_theta_to_pi(goal);
     K.flags[t * K.n + i] = (uint8_t)((T.ok_limits ? 1 : 0) | (T.found ? 2 : 0));
     if (K.state) K.state[(K.t0 + t) * K.n + i] = (uint8_t)T.code;
     if (K.reachable) K.reachable[(K.t0 + t) * K.n + i] = (T.ok_limits && T.found) ? 1 : 0;
 }
 
-// phase 2: one thread per trajectory walks the block's steps: the recurrence on previous_theta
-template <bool MIXED>
-__global__ __launch_bounds__(kBlock) void cont_theta_kernel(const ContRunArgs K) {
+// Row + lane addressing for the sequential phases: a step's row starts `row` bytes into the block's array (the same for
+// the whole wave: a scalar register), the lane's element `lane` bytes into the row — buffer instructions take exactly
+// these two, so an access costs one scalar addition and no 64-bit address arithmetic per lane (a batch of 32 steps would
+// otherwise hold 64 vector registers of addresses, or recompute them in the lone wave's instruction stream).
+// (raw buffer, 2 GB window: the host keeps a block's arrays below that)
+typedef unsigned RowWords2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_buffer(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ double ld_row_f64(__amdgpu_buffer_rsrc_t buf, unsigned lane, unsigned row) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(buf, lane, row, 0));
+}
+__device__ __forceinline__ void st_row_f64(__amdgpu_buffer_rsrc_t buf, unsigned lane, unsigned row, double v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(RowWords2, v), buf, lane, row, 0);
+}
+__device__ __forceinline__ int ld_row_u8(__amdgpu_buffer_rsrc_t buf, unsigned lane, unsigned row) {
+    return (int)__builtin_amdgcn_raw_buffer_load_b8(buf, lane, row, 0);
+}
+
+// phase 2: one thread per trajectory walks the block's steps: the recurrence on previous_theta.
+// KIND: kSnapInner / kSnapWrap = the step specialised for the launch's control interval (continuous_next_theta_lean;
+// single-arm launches), kSnapGeneric = the reference's own sequence of operations for any interval.
+template <bool MIXED, int KIND>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 1))) void cont_theta_kernel(const ContRunArgs K) {
+    static_assert(!MIXED || KIND == kSnapGeneric, "a mixed launch has an interval per lane");
     // a serial phase: its few waves share their SIMDs with the chip-filling phases of the neighbouring blocks (other
-    // streams) and must win the issue arbitration, or every dependent instruction waits behind throughput work
+    // streams) and must win the issue arbitration, or every instruction waits behind throughput work
     __builtin_amdgcn_s_setprio(3);
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= K.n) return;
@@ -987,48 +1016,76 @@ __global__ __launch_bounds__(kBlock) void cont_theta_kernel(const ContRunArgs K)
     // emergency stop (C:205-210; what this phase computes for a latched trajectory is never looked at).
     double prev_theta = K.first_block ? K.st[0 * K.n + i] : K.theta_carry[i];
     const double l0 = K.lim[slot][0], l1 = K.lim[slot][1];
-    // The recurrence itself is ~50 dependent instructions per step; the memory round trip of a step's operands would
-    // double that (a lone wave per SIMD, nothing to switch to), so they are fetched kThetaBatch steps at a time, one batch
-    // ahead of the one being computed; the last T mod kThetaBatch steps go one by one.
+    // A lone wave per SIMD: every instruction of a step is paid in full (~4.5 cycles each, rsik_device.hpp `opaque`), and
+    // the memory round trip of a step's operands would double a step, so they are fetched kThetaBatch steps at a time,
+    // one batch ahead of the one being computed, into two register sets that take turns (no copies); what is left of the
+    // block after the last full batch goes step by step.
     const int64_t n = K.n;
-    double* wp = &RSIK_WS(K, 0, i);             // this trajectory's theta column, step 0; step t is t * n further
-    // `target` is the step's goal as the prepare phase encoded it: the search's theta, the preferred theta for an
-    // unreachable pose, NaN = "stay".  Straight-line arithmetic only: a lone wave pays the compare -> scalar branch round
-    // trip of every test in full.  (Measured and not kept: a speculative short form of the step for goal - previous
-    // within one turn, checked once per batch — half the waves hold a trajectory that is snapped to the interval
-    // limits or has unwound past +-pi, and then pay both forms.)
-    // (launch constants that a select or a sign transfer needs as a vector operand: pinned in vector registers once,
-    // instead of two moves each per step)
-    double dmax_v = K.d_theta_max, l1v = l1;
-    asm volatile("" : "+v"(dmax_v), "+v"(l1v));
-    auto one = [&](double tg, double* dst) {
-        prev_theta = continuous_next_theta_goal((tg != tg) ? prev_theta : tg, prev_theta, K.d_theta_max, l0, l1, dmax_v, l1v);
-        *dst = prev_theta;
+    // this trajectory's goal / theta of the step the wave is at: (wbuf, off, row), its wrapped goal (gbuf, off, row); a step
+    // further is `stride` bytes further
+    const __amdgpu_buffer_rsrc_t wbuf = row_buffer(K.ws), gbuf = row_buffer(K.gw);
+    const unsigned off = (unsigned)(i * sizeof(double)), stride = (unsigned)(n * sizeof(double));
+    unsigned row = 0;
+    // launch constants that a select or a sign transfer needs as a vector operand: pinned in vector registers once
+    const double dmax_v = opaque(K.d_theta_max), l0v = opaque(l0), l1v = opaque(l1), tdag_v = opaque(K.snap_tdag);
+    // `g` is the step's goal as the prepare phase encoded it: the search's theta, the preferred theta for an unreachable
+    // pose, NaN = "stay".  Straight-line arithmetic only.
+    auto generic = [&](double g) {
+        return continuous_next_theta_goal((g != g) ? prev_theta : g, prev_theta, K.d_theta_max, l0, l1, dmax_v, l1v);
     };
-    const int64_t full = K.T - (K.T % kThetaBatch);
-    double target[kThetaBatch];
-    if (full > 0) {
-#pragma unroll
-        for (int u = 0; u < kThetaBatch; u++) target[u] = wp[u * n];
+    auto one = [&](double g, double gw, unsigned dst_row) {
+        if constexpr (KIND == kSnapGeneric) prev_theta = generic(g);
+        else prev_theta = continuous_next_theta_lean<KIND>(g, gw, prev_theta, dmax_v, l0v, l1v, tdag_v);
+        st_row_f64(wbuf, off, dst_row, prev_theta);
+    };
+    int64_t left = K.T;
+    if (KIND != kSnapGeneric && K.first_block && left > 0) {
+        // the state a run starts from is the caller's: only from the first result on is previous_theta known to lie in
+        // [-pi, pi], which the specialised step relies on
+        prev_theta = generic(ld_row_f64(wbuf, off, row));
+        st_row_f64(wbuf, off, row, prev_theta);
+        row += stride; left -= 1;
     }
-#pragma unroll 1
-    for (int64_t t0 = 0; t0 < full; t0 += kThetaBatch) {
-        double tg[kThetaBatch];
+    struct Operands { double g[kThetaBatch], gw[kThetaBatch]; };
+    // (`valid` < kThetaBatch: the block's last, partial batch — the steps past its end repeat the last one and are skipped)
+    auto fetch = [&](Operands& o, int ahead, int valid) {
 #pragma unroll
-        for (int u = 0; u < kThetaBatch; u++) tg[u] = target[u];
-        double* const w0 = wp;
-        wp += kThetaBatch * n;
-        if (t0 + kThetaBatch < full) {
-#pragma unroll
-            for (int u = 0; u < kThetaBatch; u++) target[u] = wp[u * n];
+        for (int u = 0; u < kThetaBatch; u++) {
+            const unsigned at = row + (unsigned)(ahead + (u < valid ? u : valid - 1)) * stride;
+            o.g[u] = ld_row_f64(wbuf, off, at);
+            if constexpr (KIND != kSnapGeneric) o.gw[u] = ld_row_f64(gbuf, off, at);
         }
+    };
+    auto compute = [&](const Operands& o, auto partial, int valid) {  // the batch at `row`; leaves `row` at the next one
+        constexpr bool kPartial = decltype(partial)::value;
+        const unsigned r0 = row;
+        row += (unsigned)(kPartial ? valid : kThetaBatch) * stride;
+        // one wait for the whole set (it was fetched a batch ago) instead of one per operand: a wait is an issue slot too
+        asm volatile("" : : "v"(o.g[kThetaBatch - 1]), "v"(o.gw[KIND != kSnapGeneric ? kThetaBatch - 1 : 0]));
 #pragma unroll
-        for (int u = 0; u < kThetaBatch; u++) one(tg[u], w0 + u * n);
-    }
+        for (int u = 0; u < kThetaBatch; u++) {
+            if (!kPartial || u < valid) one(o.g[u], o.gw[u], r0 + (unsigned)u * stride);  // (launch-uniform: a scalar branch)
+        }
+    };
+    int64_t batches = left / kThetaBatch;
+    left -= batches * kThetaBatch;
+    Operands a, b;
+    if (batches > 0) fetch(a, 0, kThetaBatch);
 #pragma unroll 1
-    for (int64_t t = full; t < K.T; ++t) {
-        one(*wp, wp);
-        wp += n;
+    while (batches >= 2) {
+        fetch(b, kThetaBatch, kThetaBatch);
+        compute(a, std::false_type{}, kThetaBatch);
+        if (batches > 2) fetch(a, kThetaBatch, kThetaBatch);
+        compute(b, std::false_type{}, kThetaBatch);
+        batches -= 2;
+    }
+    if (batches == 1) {
+        if (left > 0) fetch(b, kThetaBatch, (int)left);
+        compute(a, std::false_type{}, kThetaBatch);
+        if (left > 0) compute(b, std::true_type{}, (int)left);
+    } else if (left > 0) {
+        fetch(a, 0, (int)left);
+        compute(a, std::true_type{}, (int)left);
     }
     K.theta_carry[i] = prev_theta;
 }
@@ -1090,6 +1147,12 @@ __global__ __launch_bounds__(kBlock) void cont_joints_kernel(const ContRunArgs K
     double jv[7];
     bool sing;
     step_joints(A, K, r, G, theta, zeros, jv, sing);
+    // an exact singularity needs previous_sol (S:751-753, 782-784): phase 4 recomputes the step; the NaNs make its short
+    // form give up on the batch without reading the flag bytes
+    if (sing) {
+#pragma unroll
+        for (int k = 0; k < 7; k++) jv[k] = __builtin_nan("");
+    }
     store_rows<7>(K.joints + (K.t0 + t) * K.n * 7, wave_base, K.n, lane, lds_out[wave], jv);
     if (live && sing) K.flags[t * K.n + i] |= 4;
 }
@@ -1098,7 +1161,7 @@ __global__ __launch_bounds__(kBlock) void cont_joints_kernel(const ContRunArgs K
 // previous_sol (allow_multiturn U:493-505, multiturn_safety_check U:535-568, continuity_check U:571-589, the emergency
 // latch C:205-210, C:398-405).
 template <bool MIXED>
-__global__ __launch_bounds__(kBlock) void cont_chain_kernel(const ContRunArgs K) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 1))) void cont_chain_kernel(const ContRunArgs K) {
     // a serial phase beside throughput phases (see cont_theta_kernel), one step below the theta phase, which is the
     // critical path where the two share a SIMD (0.544 -> 0.536 ms per 4096 x 1000 pass)
     __builtin_amdgcn_s_setprio(2);
@@ -1130,11 +1193,14 @@ __global__ __launch_bounds__(kBlock) void cont_chain_kernel(const ContRunArgs K)
     };
     // Operands of kChainBatch steps are fetched together, one batch ahead (see cont_theta_kernel).  A step is straight-line
     // code: a latched trajectory (rare) goes through the same arithmetic and only its selects differ.
-    double* jp = K.joints + (K.t0 * n + ii) * 7 + jj;   // this lane's joint, step 0 of the block; step t is t * 7 n further
-    const uint8_t* fp = K.flags + ii;
+    // this lane's joint of the step the wave is at: jrow[joff]; its flag byte: frow[foff] (ld_row); a step further is
+    // step_stride doubles / n bytes further
+    const __amdgpu_buffer_rsrc_t jbuf = row_buffer(K.joints + K.t0 * n * 7), fbuf = row_buffer(K.flags);
+    const unsigned joff = (unsigned)((ii * 7 + jj) * sizeof(double)), foff = (unsigned)ii;
+    const unsigned jstride = (unsigned)(n * 7 * sizeof(double)), fstride = (unsigned)n;
+    unsigned jrow = 0, frow = 0;  // the step the wave is at: this lane's joint (jbuf, joff, jrow), its flag byte (fbuf, foff, frow)
     int64_t t_abs = K.t0;
-    const int64_t step_stride = n * 7;
-    auto one = [&](double cur, int f, double* out, int64_t t) {
+    auto one = [&](double cur, int f, int64_t t) {  // the step at jrow / frow
         if (RSIK_RARE((f & 4) != 0 && !emergency)) {  // the same byte in all 8 lanes of the trajectory
             // exact singularity in get_joints: the step is recomputed with the real previous_sol (every lane of the
             // group computes all seven joints and keeps its own)
@@ -1164,7 +1230,7 @@ __global__ __launch_bounds__(kBlock) void cont_chain_kernel(const ContRunArgs K)
         const double accepted = disc ? prev : clamped;
         const bool trips = cause != 0 && !emergency;
         const double result = emergency ? prev : accepted;                    // latched (C:205-210): previous_sol
-        if (owner) *out = result;
+        if (owner) st_row_f64(jbuf, joff, jrow, result);
         if (RSIK_RARE(emergency || trips) && live) {
             if (emergency) {
                 if (j == 7) {
@@ -1183,61 +1249,111 @@ __global__ __launch_bounds__(kBlock) void cont_chain_kernel(const ContRunArgs K)
         emergency = emergency || trips;
         t_abs += 1;
     };
-    const int64_t full = K.T - (K.T % kChainBatch);
-    double raw[kChainBatch];
-    int fl[kChainBatch];
-    if (full > 0) {
+    // A step in which nothing happens — no +-6 pi limit, no discontinuity, no singular get_joints, no latch, not the first
+    // step after a (re)initialisation — is previous := previous + angle_diff(joint, previous), and the tests that
+    // establish "nothing happens" do not feed the next step.  So a batch first runs in that short form: the modulo without
+    // its fix-ups (they act when the quotient was rounded across an integer; the result then lies outside [0, 2 pi) and
+    // the step fails the first test), seven arithmetic instructions, and two running values that stand for the tests:
+    // the largest |angle_diff| (against the continuity threshold less 1e-9: the reference tests angle_diff(result,
+    // previous), which is this one re-derived, U:571-589) and the largest |result| (against the multiturn limit,
+    // U:535-568).  A singular step arrives as NaN (phase 3) and, like any NaN, surfaces in the batch's last result.
+    // Nine vector instructions a step and no scalar one (rsik_device.hpp `opaque`: a lone wave pays ~16 cycles for every
+    // compare result that a scalar instruction combines); ONE wave-uniform test per batch decides whether the short
+    // form stands, otherwise the batch is done step by step with `one` (operands re-read: only real events get there).
+    // Operands are fetched a batch ahead into two register sets that take turns.
+    const double thr_short = thr - 1e-9;
+    struct Operands { double raw[kChainBatch]; };
+    // (`valid` < kChainBatch: the block's last, partial batch — the steps past its end repeat the last one and are skipped)
+    auto fetch = [&](Operands& o, int ahead, int valid) {
 #pragma unroll
-        for (int u = 0; u < kChainBatch; u++) { raw[u] = jp[u * step_stride]; fl[u] = fp[u * n]; }
-    }
-#pragma unroll 1
-    for (int64_t t0 = 0; t0 < full; t0 += kChainBatch) {
-        double rw[kChainBatch];
-        int fb[kChainBatch];
-#pragma unroll
-        for (int u = 0; u < kChainBatch; u++) { rw[u] = raw[u]; fb[u] = fl[u]; }
-        double* const j0 = jp;
-        jp += kChainBatch * step_stride;
-        fp += kChainBatch * n;
-        if (t0 + kChainBatch < full) {
-#pragma unroll
-            for (int u = 0; u < kChainBatch; u++) { raw[u] = jp[u * step_stride]; fl[u] = fp[u * n]; }
-        }
-        // A step in which nothing happens — no +-6 pi limit, no discontinuity, no singular get_joints, no latch, not the
-        // first step after a (re)initialisation — is previous := clamp(previous + angle_diff(joint, previous)), and the
-        // tests that establish "nothing happens" do not feed the next step.  So the batch first runs in that short form
-        // (the same straight-line arithmetic as `one`, 16 dependent instructions per step instead of ~45: no group OR,
-        // no selects, no branches; the tests fill the issue slots the chain leaves free) and ONE wave-uniform test
-        // decides whether it stands; otherwise the batch is repeated step by step with `one`.  (Unlike the short form
-        // tried for the theta phase, this one only gives up on real events, which are rare.)
-        bool event = emergency | init;
-        double pv = prev, res[kChainBatch];
+        for (int u = 0; u < kChainBatch; u++) o.raw[u] = ld_row_f64(jbuf, joff, jrow + (unsigned)(ahead + (u < valid ? u : valid - 1)) * jstride);
+    };
+    int64_t t_blk = 0;  // step of the block that jrow / frow point at
+    auto short_form = [&](const Operands& o, auto partial, int valid) -> bool {  // true: the batch at jrow is done
+        constexpr bool kPartial = decltype(partial)::value;
+        double pv = prev, res[kChainBatch], wmax = 0.0, tmax = 0.0;
+        asm volatile("" : : "v"(o.raw[kChainBatch - 1]));  // one wait for the whole set (see cont_theta_kernel)
 #pragma unroll
         for (int u = 0; u < kChainBatch; u++) {
-            const double turned = allow_multiturn_one_straight(rw[u], pv);     // U:493-505
-            const double clamped = fmin(fmax(turned, -lim), lim);              // U:535-568
-            event = event | (clamped != turned) | (fabs(angle_diff_straight(clamped, pv)) > thr) | ((fb[u] & 4) != 0);
-            res[u] = clamped;
-            pv = clamped;
-        }
-        if (RSIK_RARE(__any(event))) {  // (rolled, operands re-read: rare, and 32 copies of `one` would be 5k instructions)
-            const uint8_t* const f0 = fp - kChainBatch * n;
-#pragma unroll 1
-            for (int u = 0; u < kChainBatch; u++) one(j0[u * step_stride], f0[u * n], j0 + u * step_stride, t0 + u);
-        } else {
-            if (owner) {
-#pragma unroll
-                for (int u = 0; u < kChainBatch; u++) j0[u * step_stride] = res[u];
+            if (!kPartial || u < valid) {  // (launch-uniform: a scalar branch)
+                const double x0 = (o.raw[u] - pv) + kPi;
+                const double x = fma(-floor(x0 * 0.15915494309189535), kTwoPi, x0);  // pymod_2pi_straight less its fix-ups
+                const double w = x - kPi;
+                pv = pv + w;
+                wmax = __builtin_fmax(wmax, fabs(w));
+                tmax = __builtin_fmax(tmax, fabs(pv));
             }
-            prev = pv;
-            t_abs += kChainBatch;
+            res[u] = pv;
         }
-    }
+        const bool event = emergency | init | !(wmax <= thr_short) | !(tmax <= lim) | (pv != pv);
+        if (RSIK_RARE(__any(event))) return false;
+        if (owner) {
+#pragma unroll
+            for (int u = 0; u < kChainBatch; u++) {
+                if (!kPartial || u < valid) st_row_f64(jbuf, joff, jrow + (unsigned)u * jstride, res[u]);
+            }
+        }
+        const int done = kPartial ? valid : kChainBatch;
+        prev = pv;
+        jrow += (unsigned)done * jstride;
+        frow += (unsigned)done * fstride;
+        t_abs += done;
+        t_blk += done;
+        return true;
+    };
+    // step by step with `one` (the only copy of it), the operands of the next three steps in flight meanwhile
+    auto stepwise = [&](int64_t count) {
+        auto at = [&](int64_t k) { return k < count ? k : count - 1; };
+        auto raw_at = [&](int64_t k) { return ld_row_f64(jbuf, joff, jrow + (unsigned)k * jstride); };
+        auto flag_at = [&](int64_t k) { return ld_row_u8(fbuf, foff, frow + (unsigned)k * fstride); };
+        double r0 = raw_at(0), r1 = raw_at(at(1)), r2 = raw_at(at(2));
+        int f0 = flag_at(0), f1 = flag_at(at(1)), f2 = flag_at(at(2));
 #pragma unroll 1
-    for (int64_t t = full; t < K.T; ++t) {
-        one(*jp, *fp, jp, t);
-        jp += step_stride;
-        fp += n;
+        for (int64_t k = 0; k < count; ++k) {
+            const int64_t ahead = at(k + 3) - k;
+            const double rn = raw_at(ahead);
+            const int fn = flag_at(ahead);
+            one(r0, f0, t_blk);
+            r0 = r1; r1 = r2; r2 = rn;
+            f0 = f1; f1 = f2; f2 = fn;
+            jrow += jstride;
+            frow += fstride;
+            t_blk += 1;
+        }
+    };
+    constexpr int kStepwise = 8;  // steps done one by one after a batch gave up, before the short form is tried again
+    int64_t remaining = K.T;
+    bool latched = false;  // a latched trajectory in this wave: every batch is an event, the short form is not tried again
+#pragma unroll 1
+    while (remaining > 0) {
+        if (!latched) {
+            int64_t nb = remaining / kChainBatch;
+            Operands oa, ob;
+            if (nb > 0) {
+                fetch(oa, 0, kChainBatch);
+#pragma unroll 1
+                for (;;) {
+                    if (nb >= 2) fetch(ob, kChainBatch, kChainBatch);
+                    if (!short_form(oa, std::false_type{}, kChainBatch)) break;
+                    remaining -= kChainBatch;
+                    if (--nb == 0) break;
+                    if (nb >= 2) fetch(oa, kChainBatch, kChainBatch);
+                    if (!short_form(ob, std::false_type{}, kChainBatch)) break;
+                    remaining -= kChainBatch;
+                    if (--nb == 0) break;
+                }
+            }
+            if (nb == 0 && remaining > 0) {  // the partial batch at the end of the block
+                fetch(oa, 0, (int)remaining);
+                if (short_form(oa, std::true_type{}, (int)remaining)) remaining = 0;
+            }
+        }
+        if (remaining > 0) {
+            const int64_t count = latched || remaining < kStepwise ? remaining : kStepwise;
+            stepwise(count);
+            remaining -= count;
+            latched = __any(emergency);
+        }
     }
     if (owner) K.st[(1 + j) * n + i] = prev;
     if (live && j == 7) {
@@ -1746,6 +1862,50 @@ static void control_limits(int arm, int constrained_mode, double preferred_theta
     *pref = preferred_theta;
 }
 
+// The theta phase's specialised step (continuous_next_theta_lean) replaces limit_theta_to_interval's choice of the nearer
+// interval end — |angle_diff(theta, l1)| < |angle_diff(theta, l0)|, U:105-111 — by one comparison with a threshold.  Here
+// that threshold is found with the reference's own arithmetic (Python's float `%`), by bisection over the doubles of the
+// gap, and the equivalence is then checked on a sample of the gap and on the doubles around the threshold; an interval
+// for which it does not hold (or a rate limit the step's range analysis does not cover) keeps the generic step.
+static double host_angle_diff(double a, double b) { return host_pymod((a - b) + rsik::kPi, 2 * rsik::kPi) - rsik::kPi; }
+static int theta_snap_plan(double l0, double l1, double d_theta_max, double* tdag) {
+    const double pi = rsik::kPi;
+    *tdag = 0.0;
+    if (!(d_theta_max >= 0.0 && d_theta_max < 3.0)) return rsik::kSnapGeneric;
+    if (!(std::fabs(l0) <= pi && std::fabs(l1) <= pi)) return rsik::kSnapGeneric;
+    if (l0 == l1 || (std::fabs(l0) == pi && std::fabs(l1) == pi)) return rsik::kSnapGeneric;  // the whole circle (U:468-474)
+    auto nearer_is_l1 = [&](double t) { return std::fabs(host_angle_diff(t, l1)) < std::fabs(host_angle_diff(t, l0)); };
+    const bool wrap = !(l0 < l1);
+    // the stretch of the gap that starts at l1: up to l0 (wrap) or up to pi (the rest, (-pi, l0), must answer l0)
+    double lo = l1, hi = wrap ? l0 : pi;
+    if (!(lo < hi)) return rsik::kSnapGeneric;
+    if (!nearer_is_l1(std::nextafter(lo, hi)) || nearer_is_l1(hi)) return rsik::kSnapGeneric;
+    lo = std::nextafter(lo, hi);
+    while (std::nextafter(lo, hi) < hi) {
+        const double mid = lo + (hi - lo) / 2;
+        if (nearer_is_l1(mid)) lo = mid; else hi = mid;
+    }
+    const double t = hi;  // the smallest double of the stretch for which l1 is not the nearer end
+    auto agrees = [&](double x) {
+        const bool valid = wrap ? (l0 <= x || x <= l1) : (l0 <= x && x <= l1);
+        if (valid || !(x > -pi && x <= pi)) return true;
+        const bool want = nearer_is_l1(x);
+        const bool got = wrap ? (x < t) : (x >= l0 && x < t);  // (below l0 the specialised step answers l0)
+        return want == got;
+    };
+    double x = t;
+    for (int k = 0; k < 64; k++) { x = std::nextafter(x, -4.0); if (!agrees(x)) return rsik::kSnapGeneric; }
+    x = t;
+    for (int k = 0; k < 64; k++) { if (!agrees(x)) return rsik::kSnapGeneric; x = std::nextafter(x, 4.0); }
+    const int samples = 4096;
+    for (int k = 0; k <= samples; k++) {
+        if (!agrees(-pi + (2 * pi) * k / samples)) return rsik::kSnapGeneric;
+        if (!agrees(std::nextafter(l1, 4.0) + (t - l1) * k / samples)) return rsik::kSnapGeneric;
+    }
+    *tdag = t;
+    return wrap ? rsik::kSnapWrap : rsik::kSnapInner;
+}
+
 static int launch_dims(rsik_ctx* ctx, int64_t n, dim3* grid, const char* who) {
     const int64_t blocks = (n + rsik::kBlock - 1) / rsik::kBlock;
     if (blocks > 0x7fffffffLL) return fail(ctx, RSIK_E_INVALID, std::string(who) + ": n too large for one launch");
@@ -1956,7 +2116,10 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     // A run is cut into blocks of steps; four workspace slots are in flight (block b + 4 reuses the slot of block b once
     // chain(b) has finished).
     constexpr int kSlots = 4;
-    const size_t per_step = (size_t)n * (sizeof(double) + 1);
+    // (the sequential phases address a block's arrays through 2 GB buffer windows: rows of n * 56 bytes, blocks of <= 128 MB
+    // of workspace, i.e. <= 442 MB of joints)
+    if (n > (int64_t)30 << 20) return fail(ctx, RSIK_E_INVALID, std::string(who) + ": more than 30 Mi trajectories in one call");
+    const size_t per_step = (size_t)n * (2 * sizeof(double) + 1);
     int64_t T_max = (int64_t)((size_t)128 << 20) / (int64_t)per_step;
     if (T_max < 1) T_max = 1;
     if (T_max > 65535) T_max = 65535;  // gridDim.y
@@ -2039,13 +2202,17 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     // slot of their own get their prepare + theta launches first, then their joints + chain launches; a block that
     // reuses a slot can only be issued once the chain that frees the slot has been (its event must have been recorded).
     const bool plane_binds = singularity_plane_binds(R.arms);
+    // the theta phase's step, specialised for the control interval where that is proven equivalent (single-arm launches)
+    int snap_kind = rsik::kSnapGeneric;
+    if (!arm) snap_kind = theta_snap_plan(R.lim[0][0], R.lim[0][1], d_theta_max, &R.snap_tdag);
     auto set_block = [&](int64_t b) {
         R.t0 = block_t0[b];
         R.T = block_T[b];
         R.first_block = b == 0;
         R.last_block = b == n_blocks - 1;
         R.ws = reinterpret_cast<double*>(static_cast<char*>(ctx->ws) + slot_bytes * (size_t)(b % slots));
-        R.flags = reinterpret_cast<uint8_t*>(R.ws + (size_t)R.T * (size_t)n);
+        R.gw = R.ws + (size_t)R.T * (size_t)n;
+        R.flags = reinterpret_cast<uint8_t*>(R.gw + (size_t)R.T * (size_t)n);
     };
     auto issue_front = [&](int64_t b) -> int {  // prepare(b), theta(b)
         set_block(b);
@@ -2055,8 +2222,10 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         else { if (plane_binds) hipLaunchKernelGGL((rsik::cont_prepare_kernel<false, true>), grid2, block, 0, s_prep, R); else hipLaunchKernelGGL((rsik::cont_prepare_kernel<false, false>), grid2, block, 0, s_prep, R); }
         RSIK_HIP(ctx, hipEventRecord(ev(0, b), s_prep));
         RSIK_HIP(ctx, hipStreamWaitEvent(s_theta, ev(0, b), 0));
-        if (arm) hipLaunchKernelGGL(rsik::cont_theta_kernel<true>, grid, block, 0, s_theta, R);
-        else hipLaunchKernelGGL(rsik::cont_theta_kernel<false>, grid, block, 0, s_theta, R);
+        if (arm) hipLaunchKernelGGL((rsik::cont_theta_kernel<true, rsik::kSnapGeneric>), grid, block, 0, s_theta, R);
+        else if (snap_kind == rsik::kSnapInner) hipLaunchKernelGGL((rsik::cont_theta_kernel<false, rsik::kSnapInner>), grid, block, 0, s_theta, R);
+        else if (snap_kind == rsik::kSnapWrap) hipLaunchKernelGGL((rsik::cont_theta_kernel<false, rsik::kSnapWrap>), grid, block, 0, s_theta, R);
+        else hipLaunchKernelGGL((rsik::cont_theta_kernel<false, rsik::kSnapGeneric>), grid, block, 0, s_theta, R);
         RSIK_HIP(ctx, hipEventRecord(ev(1, b), s_theta));
         return RSIK_OK;
     };

@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """Six 4096 x 1000 passes of the continuous pipeline (config 5) and nothing else: the command rocprofv3 traces for
-scripts/c5_timeline.py.  usage: c5_pass.py [alternative librsik_hip.so]"""
+scripts/c5_timeline.py.  usage: c5_pass.py [alternative librsik_hip.so | -] [steps per block]
+(steps per block = 1000: one block, the four phases one after the other, i.e. each kernel's time with the chip to itself)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from reachy2_symbolic_ik_amd import ControlIK, _abi
-blk = 0
-if len(sys.argv) > 1:
+blk = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+if len(sys.argv) > 1 and sys.argv[1] != "-":
     _abi.use_library(os.path.abspath(sys.argv[1]))
 n, n_steps = 4096, 1000
 traj = bench.make_config5_trajectories(n, n_steps, seed=20250204, device=0)

@@ -633,6 +633,42 @@ def test_control_continuous_against_checker_dvt_and_emergency(torch_mod, orc):
         assert n_em == sum(s.emergency_stop for s in states) and n_em > 0
 
 
+@pytest.mark.parametrize("arm", ["r_arm", "l_arm"])
+@pytest.mark.parametrize("mode", ["unconstrained", "low_elbow"])
+@pytest.mark.parametrize("d_theta_max", [0.01, 0.4])
+def test_continuous_pipeline_theta_step_per_interval_kind(torch_mod, arm, mode, d_theta_max):
+    """The theta phase of the trajectory pipeline runs a step specialised for the launch's control interval (wrap-around
+    for the right arm unconstrained, inner intervals for the others — one of them starting at -pi), with the choice of
+    the nearer interval end reduced to one threshold the host derives (theta_snap_plan, rsik_lib.hip).  The step kernel
+    (one launch per control step) keeps limit_theta_to_interval's own arithmetic: both must give the same bits for every
+    arm x constrained mode, also with a rate limit large enough for theta to cross the gap's middle in one step."""
+    from bench import make_config5_trajectories
+
+    A = _abi_mod()
+    n_traj, n_steps = 520, 150
+    traj = make_config5_trajectories(n_traj, n_steps, seed=7 + len(arm) + len(mode))
+    if arm == "l_arm":  # the left arm's side of the workspace: y -> -y (rows 0-8 are the rotation, 9-11 x y z)
+        traj = traj.clone()
+        traj[:, 10] = -traj[:, 10]
+    c = make_control()
+    ref = None
+    for run_mode in (A.CONT_RUN_STEPS, A.CONT_RUN_PHASED):
+        c._solver.set_option(A.OPT_CONT_RUN_MODE, run_mode)
+        st = c.new_continuous_state(arm, n_traj)
+        res = c.run_continuous_trajectories(arm, traj, st, first_step_timed_out=True, current_pose=traj[0],
+                                            constrained_mode=mode, d_theta_max=d_theta_max)
+        torch_mod.cuda.synchronize()
+        got = {k: v.clone() for k, v in res.items()}
+        got["cont_state"] = st[:11].clone()
+        if ref is None:
+            ref = got
+            assert bool(torch_mod.isfinite(ref["joints"]).all())
+        else:
+            for k in ref:
+                assert torch_mod.equal(ref[k].view(torch_mod.uint8), got[k].view(torch_mod.uint8)), (arm, mode, k)
+    c._solver.set_option(A.OPT_CONT_RUN_MODE, A.CONT_RUN_AUTO)
+
+
 @pytest.mark.parametrize("run_mode", ["loop", "steps"])
 def test_continuous_run_equals_stepwise(golden_dir, torch_mod, run_mode):
     """rsik_control_continuous_run against G7 and against the step-by-step API, both ways it can issue the work: one
