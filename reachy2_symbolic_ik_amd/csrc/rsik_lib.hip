@@ -917,6 +917,15 @@ __global__ __launch_bounds__(kBlock) void control_continuous_kernel(const Contin
 #define RSIK_CHAIN_BATCH 32
 #endif
 constexpr int kThetaBatch = RSIK_THETA_BATCH, kChainBatch = RSIK_CHAIN_BATCH;
+// threads per workgroup of the theta phase: single waves — a workgroup of four has to find four wave slots on ONE compute
+// unit while the throughput phases of the neighbouring blocks keep the chip full (4096 x 1000 steps: 0.486 -> 0.448 ms
+// per pass).  Measured and not kept: a wave that claims its SIMD's whole register file (512 registers, nothing else
+// resident beside it) runs its block in 35-57 us instead of 60-80 us, but the SIMDs it takes from the throughput
+// phases cost as much (0.463 ms per pass).
+#ifndef RSIK_THETA_BLOCK
+#define RSIK_THETA_BLOCK 64
+#endif
+constexpr int kThetaBlock = RSIK_THETA_BLOCK;
 constexpr int kSeqBatch = kThetaBatch > kChainBatch ? kThetaBatch : kChainBatch;
 static_assert(kSeqBatch % kThetaBatch == 0 && kSeqBatch % kChainBatch == 0, "block sizes are multiples of both batches");
 struct ContRunArgs {
@@ -1003,12 +1012,12 @@ __device__ __forceinline__ int ld_row_u8(__amdgpu_buffer_rsrc_t buf, unsigned la
 // KIND: kSnapInner / kSnapWrap = the step specialised for the launch's control interval (continuous_next_theta_lean;
 // single-arm launches), kSnapGeneric = the reference's own sequence of operations for any interval.
 template <bool MIXED, int KIND>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 1))) void cont_theta_kernel(const ContRunArgs K) {
+__global__ __launch_bounds__(kThetaBlock) __attribute__((amdgpu_waves_per_eu(1, 1))) void cont_theta_kernel(const ContRunArgs K) {
     static_assert(!MIXED || KIND == kSnapGeneric, "a mixed launch has an interval per lane");
     // a serial phase: its few waves share their SIMDs with the chip-filling phases of the neighbouring blocks (other
     // streams) and must win the issue arbitration, or every instruction waits behind throughput work
     __builtin_amdgcn_s_setprio(3);
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * kThetaBlock + threadIdx.x;
     if (i >= K.n) return;
     const int slot = MIXED ? (K.arm[i] != 0 ? 1 : 0) : 0;
     // previous_theta travels from block to block in theta_carry: this phase runs ahead of phase 4 (other streams), which
@@ -2222,10 +2231,11 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         else { if (plane_binds) hipLaunchKernelGGL((rsik::cont_prepare_kernel<false, true>), grid2, block, 0, s_prep, R); else hipLaunchKernelGGL((rsik::cont_prepare_kernel<false, false>), grid2, block, 0, s_prep, R); }
         RSIK_HIP(ctx, hipEventRecord(ev(0, b), s_prep));
         RSIK_HIP(ctx, hipStreamWaitEvent(s_theta, ev(0, b), 0));
-        if (arm) hipLaunchKernelGGL((rsik::cont_theta_kernel<true, rsik::kSnapGeneric>), grid, block, 0, s_theta, R);
-        else if (snap_kind == rsik::kSnapInner) hipLaunchKernelGGL((rsik::cont_theta_kernel<false, rsik::kSnapInner>), grid, block, 0, s_theta, R);
-        else if (snap_kind == rsik::kSnapWrap) hipLaunchKernelGGL((rsik::cont_theta_kernel<false, rsik::kSnapWrap>), grid, block, 0, s_theta, R);
-        else hipLaunchKernelGGL((rsik::cont_theta_kernel<false, rsik::kSnapGeneric>), grid, block, 0, s_theta, R);
+        const dim3 grid_t((unsigned)((n + rsik::kThetaBlock - 1) / rsik::kThetaBlock)), block_t(rsik::kThetaBlock);
+        if (arm) hipLaunchKernelGGL((rsik::cont_theta_kernel<true, rsik::kSnapGeneric>), grid_t, block_t, 0, s_theta, R);
+        else if (snap_kind == rsik::kSnapInner) hipLaunchKernelGGL((rsik::cont_theta_kernel<false, rsik::kSnapInner>), grid_t, block_t, 0, s_theta, R);
+        else if (snap_kind == rsik::kSnapWrap) hipLaunchKernelGGL((rsik::cont_theta_kernel<false, rsik::kSnapWrap>), grid_t, block_t, 0, s_theta, R);
+        else hipLaunchKernelGGL((rsik::cont_theta_kernel<false, rsik::kSnapGeneric>), grid_t, block_t, 0, s_theta, R);
         RSIK_HIP(ctx, hipEventRecord(ev(1, b), s_theta));
         return RSIK_OK;
     };
