@@ -111,39 +111,40 @@ __device__ __forceinline__ void warm_kernarg() {
 // All global reads of the staging are issued first and the LDS writes follow, so a workgroup pays ONE memory round trip
 // before its barrier (a copy loop per table serialises one round trip per table: +0.6 us on every wave's start-up).
 // WARM: bytes of the kernel's argument block to warm in the scalar cache (warm_kernarg) while the staging loads fly.
-template <bool MIXED, int WARM = 0>
+// NB: threads of the workgroup (a power of two)
+template <bool MIXED, int WARM = 0, int NB = kBlock>
 __device__ __forceinline__ void stage_tables(SharedTables& S, const ArmC* arms) {
     constexpr int NA = kUnitAtanRows * 3, NS = kSinCosRows * 2, NC = 2 * RSIK_ARM_CONSTS_COUNT;
-    constexpr int RA = (NA + kBlock - 1) / kBlock, RS = (NS + kBlock - 1) / kBlock, RC = (NC + kBlock - 1) / kBlock;
-    const unsigned t = threadIdx.x & (kBlock - 1);  // the launch uses kBlock threads: tells the compiler t < kBlock
+    constexpr int RA = (NA + NB - 1) / NB, RS = (NS + NB - 1) / NB, RC = (NC + NB - 1) / NB;
+    const unsigned t = threadIdx.x & (NB - 1);  // the launch uses NB threads: tells the compiler t < NB
     const double* ga = &c_unit_atan_tab[0][0];
     const double* gs = &c_sincos_tab[0][0];
     double va[RA], vs[RS], vc[RC];
-    // chunk r of a table covers elements [r kBlock, (r+1) kBlock): only a table's last chunk can be partial
+    // chunk r of a table covers elements [r NB, (r+1) NB): only a table's last chunk can be partial
 #pragma unroll
-    for (int r = 0; r < RA; r++) va[r] = ((r + 1) * kBlock <= NA || t + r * kBlock < NA) ? ga[t + r * kBlock] : 0.0;
+    for (int r = 0; r < RA; r++) va[r] = ((r + 1) * NB <= NA || t + r * NB < NA) ? ga[t + r * NB] : 0.0;
 #pragma unroll
-    for (int r = 0; r < RS; r++) vs[r] = ((r + 1) * kBlock <= NS || t + r * kBlock < NS) ? gs[t + r * kBlock] : 0.0;
+    for (int r = 0; r < RS; r++) vs[r] = ((r + 1) * NB <= NS || t + r * NB < NS) ? gs[t + r * NB] : 0.0;
     if constexpr (MIXED) {
 #pragma unroll
         for (int r = 0; r < RC; r++) {
-            const unsigned k = t + r * kBlock;
-            vc[r] = ((r + 1) * kBlock <= NC || k < NC) ? arms[k / RSIK_ARM_CONSTS_COUNT].v[k % RSIK_ARM_CONSTS_COUNT] : 0.0;
+            const unsigned k = t + r * NB;
+            vc[r] = ((r + 1) * NB <= NC || k < NC) ? arms[k / RSIK_ARM_CONSTS_COUNT].v[k % RSIK_ARM_CONSTS_COUNT] : 0.0;
         }
     }
         double* la = &S.utab[0][0];
     double* ls = &g_sincos_tab[0][0];
 #pragma unroll
     for (int r = 0; r < RA; r++)
-        if ((r + 1) * kBlock <= NA || t + r * kBlock < NA) la[t + r * kBlock] = va[r];
+        if ((r + 1) * NB <= NA || t + r * NB < NA) la[t + r * NB] = va[r];
 #pragma unroll
     for (int r = 0; r < RS; r++)
-        if ((r + 1) * kBlock <= NS || t + r * kBlock < NS) ls[t + r * kBlock] = vs[r];
+        if ((r + 1) * NB <= NS || t + r * NB < NS) ls[t + r * NB] = vs[r];
     if constexpr (MIXED) {
         double* lc = &S.arm[0][0];
 #pragma unroll
         for (int r = 0; r < RC; r++)
-            if ((r + 1) * kBlock <= NC || t + r * kBlock < NC) lc[t + r * kBlock] = vc[r];
+            if ((r + 1) * NB <= NC || t + r * NB < NC) lc[t + r * NB] = vc[r];
     }
     __syncthreads();
 }
@@ -926,6 +927,10 @@ constexpr int kThetaBatch = RSIK_THETA_BATCH, kChainBatch = RSIK_CHAIN_BATCH;
 #define RSIK_THETA_BLOCK 64
 #endif
 constexpr int kThetaBlock = RSIK_THETA_BLOCK;
+#ifndef RSIK_CHAIN_BLOCK
+#define RSIK_CHAIN_BLOCK 256
+#endif
+constexpr int kChainBlock = RSIK_CHAIN_BLOCK;  // the chain phase: no such gain from single waves (0.447 / 0.452 ms with 256 / 64)
 constexpr int kSeqBatch = kThetaBatch > kChainBatch ? kThetaBatch : kChainBatch;
 static_assert(kSeqBatch % kThetaBatch == 0 && kSeqBatch % kChainBatch == 0, "block sizes are multiples of both batches");
 struct ContRunArgs {
@@ -1170,11 +1175,11 @@ __global__ __launch_bounds__(kBlock) void cont_joints_kernel(const ContRunArgs K
 // previous_sol (allow_multiturn U:493-505, multiturn_safety_check U:535-568, continuity_check U:571-589, the emergency
 // latch C:205-210, C:398-405).
 template <bool MIXED>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 1))) void cont_chain_kernel(const ContRunArgs K) {
+__global__ __launch_bounds__(kChainBlock) __attribute__((amdgpu_waves_per_eu(1, 1))) void cont_chain_kernel(const ContRunArgs K) {
     // a serial phase beside throughput phases (see cont_theta_kernel), one step below the theta phase, which is the
     // critical path where the two share a SIMD (0.544 -> 0.536 ms per 4096 x 1000 pass)
     __builtin_amdgcn_s_setprio(2);
-    const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t gid = (int64_t)blockIdx.x * kChainBlock + threadIdx.x;
     const int64_t i = gid >> 3;
     const int j = (int)(gid & 7);
     const int lane = threadIdx.x & 63;
@@ -1184,7 +1189,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     const int jj = j < 7 ? j : 6;
     const bool owner = live && j < 7;
     __shared__ SharedTables lds_tab;
-        stage_tables<MIXED, (int)offsetof(ContRunArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>(lds_tab, K.arms);
+        stage_tables<MIXED, (int)offsetof(ContRunArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC)), kChainBlock>(lds_tab, K.arms);
     const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[ii] != 0) : false, lds_tab);
     const int64_t n = K.n;
     double prev = K.st[(1 + jj) * n + ii];
@@ -2163,6 +2168,8 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     const size_t n_events = 2 + 4 * (size_t)n_blocks;
     while (ctx->events.size() < n_events) {
         hipEvent_t e;
+        // (hipEventReleaseToDevice / hipEventDisableSystemFence measured: 0.443 / 0.428 against 0.429-0.439 ms per pass — the
+        // ~12 us between dependent launches on different streams are not the cache write-back of the event's release)
         RSIK_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->events.push_back(e);
     }
@@ -2202,9 +2209,7 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     R.max_angle = K0.max_angle; R.cos_max = K0.cos_max; R.sin_max = K0.sin_max;
     R.st = cont_state; R.joints = joints_steps; R.reachable = reachable_steps; R.state = state_steps;
     R.theta_carry = reinterpret_cast<double*>(static_cast<char*>(ctx->ws) + slot_bytes * slots);
-    dim3 grid8;
-    rc = launch_dims(ctx, n * 8, &grid8, who);
-    if (rc != RSIK_OK) return rc;
+    const dim3 grid8((unsigned)((n * 8 + rsik::kChainBlock - 1) / rsik::kChainBlock));  // (n <= 30 Mi: fits)
     // The order in which the host issues the launches matters: a launch + its event calls cost the host ~10 us, a block's
     // four ~50 us, and a kernel that reaches its queue late starts late whatever its dependencies say.  The critical
     // path is theta(0) -> theta(1) -> ... (and chain behind it), fed by prepare(b): so the blocks that have a workspace
@@ -2247,8 +2252,8 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         else hipLaunchKernelGGL(rsik::cont_joints_kernel<false>, grid2, block, 0, s_joints, R);
         RSIK_HIP(ctx, hipEventRecord(ev(2, b), s_joints));
         RSIK_HIP(ctx, hipStreamWaitEvent(s_chain, ev(2, b), 0));
-        if (arm) hipLaunchKernelGGL(rsik::cont_chain_kernel<true>, grid8, block, 0, s_chain, R);
-        else hipLaunchKernelGGL(rsik::cont_chain_kernel<false>, grid8, block, 0, s_chain, R);
+        if (arm) hipLaunchKernelGGL(rsik::cont_chain_kernel<true>, grid8, dim3(rsik::kChainBlock), 0, s_chain, R);
+        else hipLaunchKernelGGL(rsik::cont_chain_kernel<false>, grid8, dim3(rsik::kChainBlock), 0, s_chain, R);
         RSIK_HIP(ctx, hipEventRecord(ev(3, b), s_chain));
         return RSIK_OK;
     };
