@@ -268,9 +268,10 @@ int rsik_control_continuous_step(rsik_ctx *ctx, int64_t n, const double *const m
  *                continuity_check and the emergency latch (the recurrence on previous_sol); steps whose get_joints
  *                hit an exact singularity (fallback to previous_sol[0] / [2]) are recomputed here
  * The phases of neighbouring blocks overlap on four streams (the caller's and three of the context's).  The workspace
- * (one double + one byte per step and trajectory of the four blocks in flight) belongs to the context and is
- * allocated on first use (not capturable into a hipGraph for that reason).  4096 trajectories x 1000 steps: see
- * DESIGN.md section 4.
+ * (two doubles + one byte per step and trajectory of the four blocks in flight), the side streams and the events
+ * belong to the context and are created on first use: a call can be captured into a hipGraph once a call of the same
+ * shape has run (the side streams join the capture through the events the call records).  At most 30 Mi trajectories
+ * per call.  4096 trajectories x 1000 steps: see DESIGN.md section 4.
  *   m12_steps        device [n_steps][12][n]: the goal matrices of every step
  *   current_pose_m12_soa / current_joints   used by the first step only (see rsik_control_continuous_step)
  *   first_step_timed_out  non-zero: every trajectory (re)initialises on the first step (the reference's behaviour for
