@@ -633,6 +633,32 @@ def test_control_continuous_against_checker_dvt_and_emergency(torch_mod, orc):
         assert n_em == sum(s.emergency_stop for s in states) and n_em > 0
 
 
+@pytest.mark.parametrize("n_traj,n_steps", [(1, 300), (2, 77), (7, 129), (65, 33), (4099, 40)])
+def test_continuous_pipeline_odd_batch_shapes(torch_mod, n_traj, n_steps):
+    """The pipeline's sequential phases address their arrays as (buffer, row, lane) and run single-wave workgroups: a
+    single trajectory (the reference's own use), a few, one more than a wave, one more than 64 waves — against the step
+    kernel, bit for bit."""
+    from bench import make_config5_trajectories
+
+    A = _abi_mod()
+    traj = make_config5_trajectories(n_traj, n_steps, seed=1000 + n_traj)
+    c = make_control()
+    ref = None
+    for run_mode in (A.CONT_RUN_STEPS, A.CONT_RUN_PHASED):
+        c._solver.set_option(A.OPT_CONT_RUN_MODE, run_mode)
+        st = c.new_continuous_state("r_arm", n_traj)
+        res = c.run_continuous_trajectories("r_arm", traj, st, first_step_timed_out=True, current_pose=traj[0])
+        torch_mod.cuda.synchronize()
+        got = {k: v.clone() for k, v in res.items()}
+        got["cont_state"] = st[:11].clone()
+        if ref is None:
+            ref = got
+        else:
+            for k in ref:
+                assert torch_mod.equal(ref[k].view(torch_mod.uint8), got[k].view(torch_mod.uint8)), (n_traj, n_steps, k)
+    c._solver.set_option(A.OPT_CONT_RUN_MODE, A.CONT_RUN_AUTO)
+
+
 @pytest.mark.parametrize("arm", ["r_arm", "l_arm"])
 @pytest.mark.parametrize("mode", ["unconstrained", "low_elbow"])
 @pytest.mark.parametrize("d_theta_max", [0.01, 0.4])
