@@ -731,7 +731,7 @@ def test_continuous_run_equals_stepwise(golden_dir, torch_mod, run_mode):
 
 def test_continuous_pipeline_block_sizes_are_bit_identical(torch_mod):
     """The trajectory pipeline cuts a run into blocks (RSIK_OPT_CONT_BLOCK_STEPS) whose four phases overlap on four
-    streams; the operands of the two sequential phases are fetched 8 / 32 steps at a time.  Whatever the block size —
+    streams; the operands of the two sequential phases are fetched 16 / 32 steps at a time.  Whatever the block size —
     shorter than a batch, not a multiple of one, the whole run — results and carried state must be the same bits, and
     equal to one launch of the step kernel per control step."""
     from bench import make_config5_trajectories
