@@ -801,6 +801,8 @@ def main(argv=None):
         if cnt and "bytes" in cnt:
             line["roofline"]["traffic"] = cnt["bytes"]
             line["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) / WRITE_SIZE of this build (profiles/r02/counters.json)"
+            if "bytes_per_pass_by_kernel" in cnt:  # config 5: `traffic` is per control step like `achieved`; the pass by kernel:
+                line["roofline"]["traffic_per_pass_by_kernel"] = cnt["bytes_per_pass_by_kernel"]
         elif cnt and "stale" in cnt:
             line["roofline"]["traffic_note"] = cnt["stale"]
         if not args.no_extras and world == 1 and cfg != 5:

@@ -27,9 +27,10 @@ def parse(path):
             cur = (m.group(1).strip(), int(m.group(2)))
             blocks[cur] = {}
             continue
-        m = re.match(r"\s+(\w+)\s+median=\s*([\d.]+)", line)
+        m = re.match(r"\s+(\w+)\s+median=\s*([\d.]+)\s+n=(\d+)", line)
         if m and cur:
             blocks[cur][m.group(1)] = float(m.group(2))
+            blocks[cur]["n_" + m.group(1)] = int(m.group(3))
     return blocks
 
 
@@ -52,6 +53,20 @@ for c, (kn, grid, label) in want.items():
     for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
         shutil.copy(f, os.path.join(dest, f"config{c}_{suffix}_kernel_stats.csv"))
     if kn is None:
+        # config 5: the pipeline's kernels of one 4096 x 1000 pass together (launches per pass = launches / passes seen, one
+        # start-up kernel per pass), per control step like the line's `achieved`
+        blocks = {k: v for k, v in parse(os.path.join(src, "summary.txt")).items() if "cont_" in k[0] and "FETCH_SIZE" in v}
+        passes = sum(v["n_FETCH_SIZE"] for (name, g), v in blocks.items() if "cont_init" in name)
+        if passes:
+            per_kernel, total = {}, 0.0
+            for (name, g), v in blocks.items():
+                b = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024 * v["n_FETCH_SIZE"] / passes
+                key = re.search(r"cont_\w+", name).group(0)
+                per_kernel[key] = per_kernel.get(key, 0) + int(b)
+                total += b
+            out[str(c)] = {"poses_per_gpu": grid, "kernel": label, "bytes": int(total / 1000), "bytes_per_pass": int(total),
+                           "bytes_per_pass_by_kernel": per_kernel, "steps_per_pass": 1000}
+            print(c, out[str(c)])
         continue
     for (name, g), v in parse(os.path.join(src, "summary.txt")).items():
         if kn in name and g == grid and "FETCH_SIZE" in v:
