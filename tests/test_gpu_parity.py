@@ -633,6 +633,51 @@ def test_control_continuous_against_checker_dvt_and_emergency(torch_mod, orc):
         assert n_em == sum(s.emergency_stop for s in states) and n_em > 0
 
 
+def test_continuous_run_replayed_from_a_graph(torch_mod):
+    """rsik_control_continuous_run issues its phases on four streams tied by the context's own events; once a call of the
+    same shape has run (workspace, side streams and events exist) the whole run can be captured into a hipGraph — the
+    side streams join the capture through those events — and replayed: same bits as the run issued launch by launch
+    (bench.py --config 5 times such replays)."""
+    from bench import make_config5_trajectories
+
+    n_traj, n_steps = 700, 150
+    traj = make_config5_trajectories(n_traj, n_steps, seed=4242)
+    c = make_control()
+    st0 = c.new_continuous_state("r_arm", n_traj)
+    st = st0.clone()
+    out = {"joints": torch_mod.empty((n_steps, n_traj, 7), dtype=torch_mod.float64, device="cuda"),
+           "reachable": torch_mod.empty((n_steps, n_traj), dtype=torch_mod.uint8, device="cuda"),
+           "state": torch_mod.empty((n_steps, n_traj), dtype=torch_mod.uint8, device="cuda")}
+
+    def one():
+        st.copy_(st0)
+        c.run_continuous_trajectories("r_arm", traj, st, first_step_timed_out=True, current_pose=traj[0], out=out)
+
+    one()
+    torch_mod.cuda.synchronize()
+    ref = {k: v.clone() for k, v in out.items()}
+    ref["cont_state"] = st.clone()
+    side = torch_mod.cuda.Stream()
+    with torch_mod.cuda.stream(side):
+        one()  # the capture stream has run a call of this shape
+        torch_mod.cuda.synchronize()
+        g = torch_mod.cuda.CUDAGraph()
+        try:
+            with torch_mod.cuda.graph(g, stream=side):
+                one()
+        except RuntimeError as e:  # (a runtime that refuses the capture: bench.py then issues the launches one by one)
+            pytest.skip(f"hipGraph capture refused: {e}")
+    for v in out.values():
+        v.zero_()
+    st.zero_()
+    for _ in range(2):
+        g.replay()
+    torch_mod.cuda.synchronize()
+    for k, v in out.items():
+        assert torch_mod.equal(ref[k].view(torch_mod.uint8), v.view(torch_mod.uint8)), k
+    assert torch_mod.equal(ref["cont_state"].view(torch_mod.uint8), st.view(torch_mod.uint8))
+
+
 @pytest.mark.parametrize("n_traj,n_steps", [(1, 300), (2, 77), (7, 129), (65, 33), (4099, 40)])
 def test_continuous_pipeline_odd_batch_shapes(torch_mod, n_traj, n_steps):
     """The pipeline's sequential phases address their arrays as (buffer, row, lane) and run single-wave workgroups: a
