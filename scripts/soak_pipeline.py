@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Soak of the trajectory pipeline's sequential phases: random jumpy trajectories (continuity trips, +-6 pi limits reached by
+winding joints, unreachable stretches, exact repeats = "stay" steps) through rsik_control_continuous_run as the phased
+pipeline and as one launch of the step kernel per control step — every output and the carried state must be the same
+bits, for both arms x both constrained modes x two rate limits.  usage: soak_pipeline.py [trajectories] [steps]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from reachy2_symbolic_ik_amd import ControlIK, _abi  # noqa: E402
+
+n_traj = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+n_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 203
+dev = torch.device("cuda", 0)
+
+
+def trajectories(seed, arm):
+    """[n_steps, 12, n_traj]: smooth sinusoids like config 5, plus per-trajectory events: a jump of the goal (a third of
+    them), a long winding of the wrist roll (a third), goals far out of reach for a stretch (a sixth)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    r = lambda *s: torch.rand(*s, generator=g, dtype=torch.float64).to(dev)  # noqa: E731
+    k = torch.arange(n_steps, dtype=torch.float64, device=dev)[:, None]
+    t = k / 60.0 + 11.0 + r(n_traj)[None, :] * 40.0
+    c0 = [0.45, -0.2 if arm == "r_arm" else 0.2, -0.1, 0.0, -np.pi / 2, 0.0]
+    amp = [0.3, 0.3, 0.3, np.pi / 4, np.pi / 4, np.pi / 4]
+    freq = [0.6, 0.34, 0.78, 0.18, 0.31, 0.47]
+    v = [c + a * torch.sin(f * t) for c, a, f in zip(c0, amp, freq)]
+    kind = (r(n_traj) * 6).floor()
+    at = (r(n_traj) * (n_steps - 20) + 10).floor()
+    after = (k >= at[None, :]).double()
+    v[0] = v[0] + after * (kind < 2).double()[None, :] * 0.25 * (r(n_traj)[None, :] - 0.5)       # a jump of the goal
+    v[5] = v[5] + (kind == 2).double()[None, :] * k * 0.12 + (kind == 3).double()[None, :] * k * -0.2  # winding wrist
+    far = ((k >= at[None, :]) & (k < at[None, :] + 25)).double() * (kind == 4).double()[None, :]
+    v[0] = v[0] + far * 2.0                                                                            # out of reach
+    hold = ((k >= at[None, :]) & (k < at[None, :] + 6)).double() * (kind == 5).double()[None, :]
+    idx = torch.where(hold.bool(), at[None, :].expand(n_steps, -1), k.expand(-1, n_traj)).long()
+    v = [torch.gather(x, 0, idx) for x in v]                                                           # exact repeats
+    ca, sa, cb, sb, cc, sc = torch.cos(v[3]), torch.sin(v[3]), torch.cos(v[4]), torch.sin(v[4]), torch.cos(v[5]), torch.sin(v[5])
+    rows = [cc * cb, cc * sb * sa - sc * ca, cc * sb * ca + sc * sa, sc * cb, sc * sb * sa + cc * ca, sc * sb * ca - cc * sa,
+            -sb, cb * sa, cb * ca, v[0], v[1], v[2]]
+    return torch.stack(rows, dim=1).contiguous()
+
+
+ctrl = bench._quiet(ControlIK, urdf_path=bench.URDF, device=0)
+A = _abi
+bad = 0
+for ai, arm in enumerate(("r_arm", "l_arm")):
+    for mode in ("unconstrained", "low_elbow"):
+        for dmax in (0.01, 0.3):
+            traj = trajectories(100 * ai + len(mode) + int(dmax * 100), arm)
+            res = {}
+            for name, run_mode in (("steps", A.CONT_RUN_STEPS), ("pipeline", A.CONT_RUN_PHASED)):
+                ctrl._solver.set_option(A.OPT_CONT_RUN_MODE, run_mode)
+                st = ctrl.new_continuous_state(arm, n_traj)
+                out = ctrl.run_continuous_trajectories(arm, traj, st, first_step_timed_out=True, current_pose=traj[0],
+                                                       constrained_mode=mode, d_theta_max=dmax)
+                torch.cuda.synchronize()
+                res[name] = {k: v.clone() for k, v in out.items()}
+                res[name]["cont_state"] = st.clone()
+            same = all(torch.equal(res["steps"][k].view(torch.uint8), res["pipeline"][k].view(torch.uint8)) for k in res["steps"])
+            st = res["steps"]["cont_state"]
+            j = res["steps"]["joints"]
+            print(f"{arm} {mode:13s} d_theta_max {dmax}: {n_traj} x {n_steps} steps, reachable {float(res['steps']['reachable'].float().mean()):.2f}, "
+                  f"latched {int((st[9] != 0).sum())}, joints beyond pi in {float((j.abs() > np.pi).any(dim=2).float().mean()):.3f} of the steps, "
+                  f"max |joint| {float(j[torch.isfinite(j)].abs().max()):.2f}: {'bit-identical' if same else 'MISMATCH'}")
+            bad += 0 if same else 1
+ctrl._solver.set_option(A.OPT_CONT_RUN_MODE, A.CONT_RUN_AUTO)
+print("TOTAL", "0 mismatches" if bad == 0 else f"{bad} configurations differ")
+sys.exit(1 if bad else 0)
