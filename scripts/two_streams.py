@@ -37,9 +37,7 @@ def capture(n_streams):
         for s in side:
             s.wait_stream(main)
         for k in range(K):
-            with torch.cuda.stream(side[k % n_streams]):
-                ik.solver._bind_stream()
-                plans[k % 2]["launch"]()
+            plans[k % 2]["launch"](side[k % n_streams].cuda_stream)  # (plans are stream-bound: name the capture's stream)
         for s in side:
             main.wait_stream(s)
     ik.solver._bind_stream()
