@@ -19,8 +19,3 @@ d = (j[1:] - j[:-1]).abs()
 print("max |dj| per joint:", d.amax(dim=(0, 1)).tolist())
 print("steps with |dj|>0.4:", int((d > 0.4).any(dim=2).sum()), "outside [-pi,pi]:", int((j.abs() > 3.141592653589793).any(dim=2).sum()), "nan:", int(torch.isnan(j).any(dim=2).sum()))
 print("reachable frac:", float(out["reachable"].float().mean()))
-em = (st == 6)
-first = torch.where(em.any(dim=0), em.float().argmax(dim=0), torch.full((n,), -1, device="cuda"))
-print("latched trajectories:", int((first >= 0).sum()), "first-latch step quantiles:", torch.quantile(first[first >= 0].float(), torch.tensor([0., .25, .5, .75, 1.], device="cuda")).tolist() if (first>=0).any() else None)
-w = (first >= 0).view(-1, 8).any(dim=1)
-print("groups of 8 trajectories (one chain wave) with a latched one:", int(w.sum()), "of", w.numel())
