@@ -827,6 +827,113 @@ def gen_emergency(out):
     np.savez_compressed(os.path.join(out, "g11_emergency.npz"), **data)
 
 
+# ----------------------------------------------------------------------------------------
+# G12: ControlIK continuous in EVERY mode: constrained_mode x d_theta_max x preferred_theta argument x DVT, both arms
+# (control_ik.py:225-252 interval_limit / l-arm mirror, :350-384 both branches, utils.py:93-112 limit_theta_to_interval,
+#  :115-127 tend_to_preferred_theta with the ARGUMENT as goal, :220-264 get_best_continuous_theta2 with self.preferred_theta).
+# The preferred_theta arguments 0.5 and 2.0 (r-arm convention; the reference mirrors them for the left arm) lie OUTSIDE
+# both control intervals, next to one end each, so the unreachable stretches of the trajectory (66 % of the steps) pull
+# theta out of the interval — limit_theta_to_interval snaps it to either end — and the reachable stretches pull it
+# back in towards self.preferred_theta.  Two trajectories per combination: default start and explicit generic start.
+# Also recorded: the RuntimeError of control_ik.py:385-387 (is_reachable_no_limits false), which needs a solver whose
+# projection_margin is negative (a public attribute swap: ControlIK itself always builds solvers with 1e-8).
+# ----------------------------------------------------------------------------------------
+G12_MODES = ("unconstrained", "low_elbow")
+G12_DTHETA = (0.01, 0.05, 0.4)
+G12_PREFERRED = (-4 * np.pi / 6, 0.5, 2.0)
+
+
+def gen_continuous_modes(out, n_steps=160):
+    rng = np.random.default_rng(12)
+    data = {}
+    real_time = ref_control_mod.time
+    for arm in ARMS:
+        rows = []
+        for mode_i, mode in enumerate(G12_MODES):
+            for dth in G12_DTHETA:
+                for pref in G12_PREFERRED:
+                    for is_dvt in (0, 1):
+                        for explicit in (0, 1):
+                            rows.append((mode_i, dth, pref, is_dvt, explicit))
+        n = len(rows)
+        M12 = np.zeros((n, n_steps, 12))
+        P0 = np.zeros((n, 4, 4))
+        CJ = np.zeros((n, 7))
+        J = np.zeros((n, n_steps, 7))
+        F = np.zeros((n, n_steps), dtype=np.uint8)
+        S = np.zeros((n, n_steps), dtype=np.uint8)
+        TH = np.zeros((n, n_steps))
+        ES = np.zeros((n, n_steps), dtype=np.uint8)
+        for k, (mode_i, dth, pref, is_dvt, explicit) in enumerate(rows):
+            clock = FakeClock()
+            ref_control_mod.time = clock
+            phase = rng.uniform(0.0, 40.0)
+            try:
+                ctrl = quiet(ControlIK, urdf_path="../config_files/reachy2.urdf", is_dvt=bool(is_dvt))
+                ai = ARMS.index(arm)
+                p0, e0 = trajectory_pose(11.0 + phase - 0.3, arm)
+                P0[k] = pose_to_matrix(p0 * np.array([0.8, 1.0, 1.0]) + rng.uniform(-0.02, 0.02, 3), e0 + rng.uniform(-0.1, 0.1, 3))
+                CJ[k] = rng.uniform(-0.6, 0.6, size=7)
+                if not explicit:
+                    P0[k] = np.asarray(ctrl.previous_pose[arm], dtype=float)
+                    CJ[k] = ref_default_joints(ai)
+                for i in range(n_steps):
+                    pos, eul = trajectory_pose(i / 120.0 + 11.0 + phase, arm)
+                    M = pose_to_matrix(pos, eul)
+                    M12[k, i, :9] = M[:3, :3].reshape(9)
+                    M12[k, i, 9:] = M[:3, 3]
+                    clock.t += 1.0 / 120.0
+                    kw = dict(current_joints=list(CJ[k]), current_pose=P0[k]) if (i == 0 and explicit) else {}
+                    j, ok, st = quiet(ctrl.symbolic_inverse_kinematics, arm, M, "continuous", constrained_mode=G12_MODES[mode_i],
+                                      d_theta_max=dth, preferred_theta=pref, **kw)
+                    J[k, i] = np.array(j, dtype=float)
+                    F[k, i] = bool(ok)
+                    S[k, i] = STATE_CODES.get(st, 255)
+                    TH[k, i] = ctrl.previous_theta[arm]
+                    ES[k, i] = bool(ctrl.emergency_stop)
+            finally:
+                ref_control_mod.time = real_time
+        rows = np.array(rows, dtype=float)
+        data[f"{arm}_mode"] = rows[:, 0].astype(np.uint8)
+        data[f"{arm}_d_theta_max"] = rows[:, 1]
+        data[f"{arm}_preferred_theta"] = rows[:, 2]
+        data[f"{arm}_is_dvt"] = rows[:, 3].astype(np.uint8)
+        data[f"{arm}_explicit_start"] = rows[:, 4].astype(np.uint8)
+        data[f"{arm}_M12"] = M12
+        data[f"{arm}_start_pose"] = P0
+        data[f"{arm}_start_joints"] = CJ
+        data[f"{arm}_joints"] = J
+        data[f"{arm}_reachable"] = F
+        data[f"{arm}_state"] = S
+        data[f"{arm}_previous_theta"] = TH
+        data[f"{arm}_emergency_stop"] = ES
+        # the deliberate crash of control_ik.py:385-387
+        ref_control_mod.time = FakeClock()
+        try:
+            ctrl = quiet(ControlIK, urdf_path="../config_files/reachy2.urdf")
+            ctrl.symbolic_ik_solver[arm] = quiet(SymbolicIK, arm=arm, projection_margin=-1e-3, singularity_offset=-1.01,
+                                                 wrist_limit=np.rad2deg(ctrl.orbita3D_max_angle))
+            far = np.array([0.9, SHOULDER[arm][1], 0.1])       # out of reach: pulled back with the negative margin
+            near = np.array([0.45, SHOULDER[arm][1], -0.1])    # reachable: no crash
+            raised, joints = [], []
+            start = pose_to_matrix(near, np.array([0.0, -np.pi / 2, 0.0]))  # (the default start pose is itself on the rim)
+            for p in (near, far, near):
+                try:
+                    j, ok, st = quiet(ctrl.symbolic_inverse_kinematics, arm, pose_to_matrix(p, np.array([0.0, -np.pi / 2, 0.0])),
+                                      "continuous", current_joints=list(ref_default_joints(ARMS.index(arm))), current_pose=start)
+                    raised.append(("", ""))
+                    joints.append(np.array(j, dtype=float))
+                except Exception as e:  # noqa: BLE001 - the type and text are the data
+                    raised.append((type(e).__name__, str(e)))
+                    joints.append(np.full(7, NAN))
+            data[f"{arm}_crash_positions"] = np.array([near, far, near])
+            data[f"{arm}_crash_raised"] = np.array(raised)
+            data[f"{arm}_crash_joints"] = np.array(joints)
+        finally:
+            ref_control_mod.time = real_time
+    np.savez_compressed(os.path.join(out, "g12_control_continuous_modes.npz"), **data)
+
+
 def ref_default_joints(k):
     return [[0.0, 0.2617993877991494, -0.17453292519943295, 0.0, 0.0, 0.0, 0.0],
             [0.0, -0.2617993877991494, 0.17453292519943295, 0.0, 0.0, 0.0, 0.0]][k]
@@ -842,9 +949,10 @@ def main():
     steps = [("g0", gen_constants), ("g1", gen_catalogue), ("g2", gen_sweep), ("g3", gen_reachable),
              ("g4", gen_control), ("g5", gen_helpers), ("g6", gen_continuous),
              ("g7", gen_continuous_start), ("g8", gen_matrix_edges),
-             ("g9", gen_custom_geometry), ("g10", gen_custom_urdf_control), ("g11", gen_emergency)]
+             ("g9", gen_custom_geometry), ("g10", gen_custom_urdf_control), ("g11", gen_emergency),
+             ("g12", gen_continuous_modes)]
     for name, fn in steps:
-        if args.only and name not in args.only.split(","):
+        if args.only and name not in args.only.split(","):  # exact names: "g1" does not select "g12"
             continue
         t0 = _time.time()
         fn(out)

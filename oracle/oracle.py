@@ -73,6 +73,7 @@ def _bind(L):
     L.orc_control_continuous_step.restype = C.c_int
     L.orc_control_continuous_step.argtypes = [_dp, _dp, _dp, C.c_int, C.c_double, C.c_double, C.c_int, _dp, _dp,
                                               C.c_double, C.c_double, _dp, _ip]
+    L.orc_interval_limit.argtypes = [_dp, C.c_int, C.c_double, _dp]
     L.orc_solve_batch.argtypes = [_dp, _dp, C.c_long] + [_dp] * 6 + [_u8p, C.c_int, _dp, _dp, _dp, _dp, _dp, _u8p, _u8p, _u8p, C.c_int]
     L.orc_control_discrete_batch.argtypes = [_dp, _dp, C.c_long, _dp, _u8p, C.c_int, C.c_double, C.c_int, _dp, _dp,
                                              C.c_double, _dp, _u8p, _u8p, _u8p, C.c_int]
@@ -258,6 +259,13 @@ class ContinuousState:
     @property
     def emergency_stop(self):
         return bool(self.buf[9])
+
+
+def interval_limit(arm, constrained_mode, preferred_theta=-4 * np.pi / 6):
+    """control_ik.py:225-252: (interval_limit[0], interval_limit[1], preferred_theta) as the arm's side sees them."""
+    out = np.zeros(3)
+    lib().orc_interval_limit(_d(arm.buf), int(constrained_mode), float(preferred_theta), _d(out))
+    return out
 
 
 def control_continuous_step(arm, cs, M, timed_out, preferred_theta_arg, preferred_theta_self, constrained_mode,

@@ -870,6 +870,12 @@ static void interval_limit_for(const orc_arm_t *arm, int constrained_mode, doubl
     }
 }
 
+/* C:225-252 exported for the tests: the control interval (and the mirrored preferred theta) of an arm / mode */
+void orc_interval_limit(const orc_arm_t *arm, int constrained_mode, double preferred_theta, double out[3]) {
+    interval_limit_for(arm, constrained_mode, out, &preferred_theta);
+    out[2] = preferred_theta;
+}
+
 /* C:464-497 safety_checks (+ U:493-505 allow_multiturn, U:535-568 multiturn_safety_check) */
 static void safety_checks(const double in[7], const double previous_sol[7], double max_angle, double out[7],
                           int *emergency_stop) {
@@ -988,7 +994,7 @@ int orc_control_continuous_step(const orc_arm_t *arm, orc_cont_state_t *cs, cons
     if (cs->emergency_stop != 0.0) { /* C:205-210 */
         memcpy(joints, cs->previous_sol, 7 * sizeof(double));
         *reachable = 0;
-        return 8;
+        return ORC_STATE_EMERGENCY;
     }
     double pos[3], eul[3], lim[2];
     matrix_to_pose(M, pos, eul);
@@ -1017,7 +1023,15 @@ int orc_control_continuous_step(const orc_arm_t *arm, orc_cont_state_t *cs, cons
         cs->previous_theta = theta;
         orc_get_joints(arm, &sv, theta, cs->previous_sol, raw, el);
     } else {
-        orc_is_reachable_no_limits(arm, &sv, pos, eul); /* C:371-373; "always True" */
+        /* C:371-373 "always True" with ControlIK's own solvers; false needs a solver whose projection_margin pushes the
+         * wrist beyond u + f (symbolic_ik.py:343-345): the reference then raises RuntimeError (C:385-387) before it
+         * touches previous_theta / previous_sol / init -> reported as ORC_STATE_NOT_REACHABLE_NO_LIMITS, state unchanged
+         * but for the start-up branch above (which has run, as in the reference). */
+        if (!orc_is_reachable_no_limits(arm, &sv, pos, eul)) {
+            for (int i = 0; i < 7; i++) joints[i] = NAN;
+            *reachable = 0;
+            return ORC_STATE_NOT_REACHABLE_NO_LIMITS;
+        }
         theta = tend_to_preferred_theta(cs->previous_theta, d_theta_max, pref);
         theta = orc_limit_theta_to_interval(theta, cs->previous_theta, lim);
         cs->previous_theta = theta;

@@ -259,6 +259,87 @@ def test_control_continuous_explicit_start(golden_dir):
                 assert abs(cs.previous_theta - TH[k, i]) < 1e-9
 
 
+def m12_to_matrices(M12):
+    """[..., 12] rows (R row-major, t) -> [..., 4, 4]."""
+    M = np.zeros(M12.shape[:-1] + (4, 4))
+    M[..., :3, :3] = M12[..., :9].reshape(M12.shape[:-1] + (3, 3))
+    M[..., :3, 3] = M12[..., 9:]
+    M[..., 3, 3] = 1.0
+    return M
+
+
+def test_control_continuous_every_mode(golden_dir):
+    """G12: continuous mode for constrained_mode x d_theta_max x preferred_theta ARGUMENT x DVT x start, both arms
+    (control_ik.py:225-252, 350-384; utils.py:93-127, 220-264).  The arguments 0.5 and 2.0 lie outside both control
+    intervals, so theta leaves and re-enters them and limit_theta_to_interval snaps to either end; one trajectory per
+    arm trips continuity_check with d_theta_max = 0.4 and stays latched (state 255 in the file = the emergency text)."""
+    g = load(golden_dir, "g12_control_continuous_modes.npz")
+    g0 = load(golden_dir, "g0_constants.npz")
+    snapped = {0: 0, 1: 0}
+    for arm in ("r_arm", "l_arm"):
+        Ms = m12_to_matrices(g[f"{arm}_M12"])
+        J, F, S, TH, ES = (g[f"{arm}_{k}"] for k in ("joints", "reachable", "state", "previous_theta", "emergency_stop"))
+        for k in range(Ms.shape[0]):
+            a = orc.Arm(arm, 0.03 if g[f"{arm}_is_dvt"][k] else -1.01)
+            mode, dth, pref = int(g[f"{arm}_mode"][k]), float(g[f"{arm}_d_theta_max"][k]), float(g[f"{arm}_preferred_theta"][k])
+            cs = orc.ContinuousState(g0[f"{arm}_urdf_previous_theta_init"], g0[f"{arm}_urdf_previous_sol"])
+            prev_pose = g[f"{arm}_start_pose"][k]
+            lim = orc.interval_limit(a, mode)
+            for i in range(Ms.shape[1]):
+                cur = g[f"{arm}_start_joints"][k] if i == 0 else cs.previous_sol
+                j, ok, st = orc.control_continuous_step(a, cs, Ms[k, i], timed_out=(i == 0), preferred_theta_arg=pref,
+                                                        preferred_theta_self=g0[f"{arm}_urdf_preferred_theta"],
+                                                        constrained_mode=mode, current_joints=cur, current_pose=prev_pose,
+                                                        d_theta_max=dth)
+                prev_pose = Ms[k, i]
+                want = 8 if S[k, i] == 255 else S[k, i]
+                assert ok == bool(F[k, i]) and st == want, (arm, k, i, st, S[k, i])
+                assert np.max(np.abs(j - J[k, i])) < 1e-7, (arm, k, i)
+                assert abs(cs.previous_theta - TH[k, i]) < 1e-9, (arm, k, i)
+                assert cs.emergency_stop == bool(ES[k, i]), (arm, k, i)
+                for e in (0, 1):
+                    snapped[e] += int(cs.previous_theta == lim[e])
+    assert snapped[0] > 1000 and snapped[1] > 1000  # both ends of the control intervals are exercised
+
+
+DEFAULT_IK_PARAMETERS = {  # symbolic_ik.py:40-51
+    "r_shoulder_position": [0.0, -0.2, 0.0], "r_shoulder_orientation": [-15, 0, 10], "r_upper_arm_size": 0.28,
+    "r_forearm_size": 0.28, "r_tip_position": [0.0, 0.0, 0.10],
+    "l_shoulder_position": [0.0, 0.2, 0.0], "l_shoulder_orientation": [15, 0, -10], "l_upper_arm_size": 0.28,
+    "l_forearm_size": 0.28, "l_tip_position": [0.0, 0.0, 0.10],
+}
+
+
+def test_control_continuous_deliberate_crash(golden_dir):
+    """G12, control_ik.py:385-387: with a solver whose projection_margin is negative is_reachable_no_limits comes back
+    false for a far goal and the reference raises RuntimeError; the call before and the call after it are ordinary."""
+    g = load(golden_dir, "g12_control_continuous_modes.npz")
+    g0 = load(golden_dir, "g0_constants.npz")
+    for arm in ("r_arm", "l_arm"):
+        a = orc.Arm(arm, -1.01, ik_parameters=DEFAULT_IK_PARAMETERS, projection_margin=-1e-3)
+        raised, J = g[f"{arm}_crash_raised"], g[f"{arm}_crash_joints"]
+        assert [r[0] for r in raised] == ["", "RuntimeError", ""]
+        cs = orc.ContinuousState(g0[f"{arm}_urdf_previous_theta_init"], g0[f"{arm}_urdf_previous_sol"])
+        eul = np.array([0.0, -np.pi / 2, 0.0])
+        from scipy.spatial.transform import Rotation as R
+
+        def mat(p):
+            M = np.eye(4)
+            M[:3, :3] = R.from_euler("xyz", eul).as_matrix()
+            M[:3, 3] = p
+            return M
+
+        start = mat(g[f"{arm}_crash_positions"][0])
+        for i, p in enumerate(g[f"{arm}_crash_positions"]):
+            j, ok, st = orc.control_continuous_step(a, cs, mat(p), timed_out=(i == 0), preferred_theta_arg=-4 * np.pi / 6,
+                                                    preferred_theta_self=g0[f"{arm}_urdf_preferred_theta"], constrained_mode=0,
+                                                    current_joints=g0[f"{arm}_urdf_previous_sol"], current_pose=start)
+            if raised[i][0]:
+                assert st == 9 and not ok and np.all(np.isnan(j))
+            else:
+                assert st != 9 and np.max(np.abs(j - J[i])) < 1e-7, (arm, i)
+
+
 def test_python_float_mod_semantics():
     L = orc.lib()
     rng = np.random.default_rng(7)
