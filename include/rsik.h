@@ -50,6 +50,9 @@ extern "C" {
 #define RSIK_STATE_LIMITED_BY_SHOULDER 6 /* "limited by shoulder"               control_ik.py:363,452 */
 #define RSIK_STATE_EMPTY 7               /* ""  (continuous mode, reachable)    control_ik.py:297 */
 #define RSIK_STATE_EMERGENCY 8           /* emergency stop latched              control_ik.py:205-210 */
+#define RSIK_STATE_NOT_REACHABLE_NO_LIMITS 9 /* continuous mode: is_reachable_no_limits failed, where the reference raises
+                                              * RuntimeError("Pose not reachable in symbolic IK. ...") control_ik.py:385-387.
+                                              * Joints NaN, trajectory state untouched.  Needs projection_margin <= 0. */
 
 /* ---- why an emergency stop tripped: one bit per message the reference appends to ControlIK.emergency_state
  * (utils.multiturn_safety_check utils.py:544-566, utils.continuity_check utils.py:584-586) ---- */

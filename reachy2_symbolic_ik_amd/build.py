@@ -56,12 +56,29 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    if force or needs_build():
-        cmd = [hipcc()] + HIPCC_FLAGS + [f'-DRSIK_SOURCE_HASH="{source_hash()}"'] + SOURCES + ["-o", OUT + ".tmp"]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd, cwd=CSRC)
-        os.replace(OUT + ".tmp", OUT)
+    """Compiles the library if it is missing or stale.  Safe when several ranks (bench.py --gpus N, torchrun, pytest-xdist)
+    find a stale library at once: they queue on a lock file, the first one compiles into a temporary file of its own and
+    renames it into place, the others re-check under the lock and load the result."""
+    if not (force or needs_build()):
+        return OUT
+    import fcntl
+
+    with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or needs_build():  # (another process may have built it while this one waited)
+                tmp = f"{OUT}.{os.getpid()}.tmp"
+                cmd = [hipcc()] + HIPCC_FLAGS + [f'-DRSIK_SOURCE_HASH="{source_hash()}"'] + SOURCES + ["-o", tmp]
+                if verbose:
+                    print(" ".join(cmd))
+                try:
+                    subprocess.check_call(cmd, cwd=CSRC)
+                    os.replace(tmp, OUT)
+                finally:
+                    if os.path.exists(tmp):
+                        os.remove(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return OUT
 
 

@@ -34,6 +34,7 @@ STATE_STRINGS = (
     "limited by shoulder",
     "",
     "emergency stop",
+    "not reachable without limits",  # RSIK_STATE_NOT_REACHABLE_NO_LIMITS: where the reference raises (control_ik.py:385-387)
 )
 
 

@@ -350,6 +350,12 @@ class ControlIK:
         flags = io["h_bytes"][8 * self._IO_B: 8 * self._IO_B + 2]
         self.previous_theta[name] = float(back[0])
         self.init = bool(back[8])
+        if int(flags[1]) == _abi.STATE_NOT_REACHABLE_NO_LIMITS:
+            # control_ik.py:385-387: is_reachable_no_limits failed (a solver with a non-positive projection_margin).  The
+            # reference has by now (re)initialised previous_sol / previous_theta if the call timed out, and nothing else.
+            self.previous_sol[name] = back[1:8].copy()
+            print(f"{name} Pose not reachable, this has to be fixed by projecting far poses to reachable sphere")
+            raise RuntimeError("Pose not reachable in symbolic IK. We crash on purpose while we are on the debug sessions.")
         if back[9] != 0.0:  # control_ik.py:486-495, 396-401: the reference's own diagnostics for what tripped
             self.emergency_stop = True
             # continuity_check prints the previous_sol the step was checked against: after a (re)initialisation that is

@@ -856,6 +856,14 @@ __global__ __launch_bounds__(kBlock) void control_continuous_kernel(const Contin
         const Goal G = make_goal(A, Rg);
         Reach r;
         const ThetaTarget T = continuous_target<PLANE>(A, pos, G.woff, K.pref_self[slot], K.pref_self_cs[slot], K.pref_self_sn[slot], r);
+        if (RSIK_RARE(!T.ok_limits && !r.ok)) {
+            // C:385-387: is_reachable_no_limits came back false (only a solver whose projection_margin lets the pulled-back
+            // wrist land beyond u + f can do that, S:343-345) and the reference raises RuntimeError — before it touches
+            // previous_theta, previous_sol or init.  Reported as data: NaN joints, RSIK_STATE_NOT_REACHABLE_NO_LIMITS.
+#pragma unroll
+            for (int k = 0; k < 7; k++) jv[k] = __builtin_nan("");
+            st_code = RSIK_STATE_NOT_REACHABLE_NO_LIMITS;
+        } else {
         ok = T.ok_limits && T.found;
         st_code = T.code;
         const double theta = continuous_next_theta(T.ok_limits, T.found, T.theta, K.pref_arg[slot], prev_theta, K.d_theta_max,
@@ -878,6 +886,7 @@ __global__ __launch_bounds__(kBlock) void control_continuous_kernel(const Contin
         if (!emergency) {
 #pragma unroll
             for (int k = 0; k < 7; k++) prev_sol[k] = jv[k];
+        }
         }
     }
     store_rows<7>(K.joints, wave_base, K.n, lane, lds_out[wave], jv);
@@ -915,9 +924,16 @@ __global__ __launch_bounds__(kBlock) void control_continuous_kernel(const Contin
 #define RSIK_THETA_BATCH 16
 #endif
 #ifndef RSIK_CHAIN_BATCH
-#define RSIK_CHAIN_BATCH 32
+#define RSIK_CHAIN_BATCH 8   // chunks of the joints phase whose first / last rows the chain phase fetches at once
 #endif
 constexpr int kThetaBatch = RSIK_THETA_BATCH, kChainBatch = RSIK_CHAIN_BATCH;
+// consecutive steps of a trajectory that one thread of the joints phase walks (and that the chain phase accepts or redoes as
+// one unit)
+#ifndef RSIK_JOINT_CHUNK
+#define RSIK_JOINT_CHUNK 8
+#endif
+constexpr int kJointChunk = RSIK_JOINT_CHUNK;
+
 // threads per workgroup of the theta phase: single waves — a workgroup of four has to find four wave slots on ONE compute
 // unit while the throughput phases of the neighbouring blocks keep the chip full (4096 x 1000 steps: 0.486 -> 0.448 ms
 // per pass).  Measured and not kept: a wave that claims its SIMD's whole register file (512 registers, nothing else
@@ -931,8 +947,8 @@ constexpr int kThetaBlock = RSIK_THETA_BLOCK;
 #define RSIK_CHAIN_BLOCK 256
 #endif
 constexpr int kChainBlock = RSIK_CHAIN_BLOCK;  // the chain phase: no such gain from single waves (0.447 / 0.452 ms with 256 / 64)
-constexpr int kSeqBatch = kThetaBatch > kChainBatch ? kThetaBatch : kChainBatch;
-static_assert(kSeqBatch % kThetaBatch == 0 && kSeqBatch % kChainBatch == 0, "block sizes are multiples of both batches");
+constexpr int kSeqBatch = kThetaBatch > kJointChunk ? kThetaBatch : kJointChunk;
+static_assert(kSeqBatch % kThetaBatch == 0 && kSeqBatch % kJointChunk == 0, "block sizes are multiples of the theta batch and of the joint chunk");
 struct ContRunArgs {
     int64_t n;
     int64_t t0;                   // first step of this block
@@ -948,6 +964,9 @@ struct ContRunArgs {
     double* ws;                   // [T][n]: the step's theta goal (phase 1), overwritten by the step's theta (phase 2)
     double* gw;                   // [T][n]: the goal after limit_theta_to_interval's wrap (phase 1 -> phase 2)
     uint8_t* flags;               // [T][n]
+    uint8_t* chunk_event;         // [ceil(T / kJointChunk)][n]: phase 3 -> phase 4, see cont_joints_kernel
+    int8_t* chunk_turns;          // [ceil(T / kJointChunk)][n][8]: whole turns phase 4 found a chunk's joints away from the step
+                                  // before it, applied by phase 5
     double snap_tdag;             // phase 2, single-arm launches: see continuous_next_theta_lean (the kind is a template argument)
     double* theta_carry;          // [n]: previous_theta between the blocks of one run (phase 2's own state)
     int first_block, last_block;
@@ -1135,21 +1154,41 @@ __device__ __forceinline__ void step_joints(const Acc& A, const ContRunArgs& K, 
     limit_wrist_cone(A.utab, jv, o.c4, o.s4, o.c5, o.s5, o.c6, o.s6, K.cos_max, K.sin_max);
 }
 
-// phase 3: one thread per (trajectory, step of the block)
+// phase 3: one thread per (trajectory, step of the block); a wave holds a CHUNK of kJointChunk = 8 consecutive steps of 8
+// neighbouring trajectories (lane = 8 * step + trajectory), so that besides get_joints + the cone clamp it can do the quiet
+// part of the previous_sol recurrence itself.  allow_multiturn (U:493-505) is previous + angle_diff(joint, previous): the
+// representative of the raw joint (mod 2 pi) nearest the previous step's.  Inside a chunk that is a prefix sum of whole
+// turns: lane (s, i) takes the raw joints of step s - 1 from the lane eight below it, turn(s) = -rint((raw(s) - raw(s-1)) /
+// 2 pi) (zero unless a raw angle crossed its branch cut), three shuffle rounds add them up, joint = raw + 2 pi turns; the
+// chunk's first step keeps its raw value.  The turns a chunk AS A WHOLE sits away from the step before it are the
+// sequential phase's business (phase 4 finds them from the chunks' first and last rows, phase 5 adds them in): they are
+// not zero often enough to guess — shoulder pitch and elbow yaw swing by more than pi within a few hundred steps when the
+// arm passes its shoulder singularity (8 % of config 5's steps have them outside [-pi, pi]).  What the reference decides
+// step by step — the continuity thresholds (U:571-589, C:398), the +-6 pi limit (U:535-568), an exact singularity that
+// needs previous_sol (S:751-753, 782-784) — is only DETECTED here, with a margin of 1e-9: the chunk's event byte tells
+// phase 4 to walk that chunk with the reference's own sequence of operations.  So the joints make ONE trip to HBM but
+// for the shifted elements (phase 4 used to read and rewrite all of them, 112 of the 412 bytes a control step moved),
+// and a quiet step's value is its raw joint plus whole turns: within 2 ulp of the reference's previous + angle_diff(raw,
+// previous), no accumulation.
 template <bool MIXED>
 __global__ __launch_bounds__(kBlock) void cont_joints_kernel(const ContRunArgs K) {
+    static_assert(kJointChunk == 8, "lane = 8 * step + trajectory");
     __shared__ double lds_out[kBlock / 64][64 * 7];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const int64_t wave_base = (int64_t)blockIdx.x * kBlock + wave * 64;
-    const int64_t t = blockIdx.y;
-    const bool live = i < K.n;
-    const int64_t ii = live ? i : (K.n - 1);
+    const int tl = lane & 7, sl = lane >> 3;
+    const int64_t n = K.n;
+    const int64_t grp = (int64_t)blockIdx.x * (kBlock / 64) + wave;  // this wave's group of 8 trajectories
+    const int64_t i = grp * 8 + tl;
+    const int64_t c = blockIdx.y;
+    const int64_t t = c * kJointChunk + sl;
+    const bool live = i < n && t < K.T;
+    const int64_t ii = i < n ? i : (n - 1);
+    const int64_t tt = t < K.T ? t : (K.T - 1);
     double m[12];  // loads first: their latency overlaps the table staging
-    load_step_m12(K, t, ii, m);
-    const double theta = RSIK_WS(K, t, ii);
-    const int flag = K.flags[t * K.n + ii];
+    load_step_m12(K, tt, ii, m);
+    const double theta = RSIK_WS(K, tt, ii);
+    const int flag = K.flags[tt * n + ii];
     const bool lane_isl = MIXED ? (K.arm[ii] != 0) : false;
     __shared__ SharedTables lds_tab;
         stage_tables<MIXED, (int)offsetof(ContRunArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>(lds_tab, K.arms);
@@ -1161,14 +1200,59 @@ __global__ __launch_bounds__(kBlock) void cont_joints_kernel(const ContRunArgs K
     double jv[7];
     bool sing;
     step_joints(A, K, r, G, theta, zeros, jv, sing);
-    // an exact singularity needs previous_sol (S:751-753, 782-784): phase 4 recomputes the step; the NaNs make its short
-    // form give up on the batch without reading the flag bytes
-    if (sing) {
+    // whole turns of this step relative to the step before it (none for the chunk's first step), packed as biased
+    // bytes (turn + 8 in 0..16; eight of them add up without a carry) in two words for the prefix sum over the chunk
+    bool ev = sing;
+    unsigned lo = 0, hi = 0;
+    double praw[7];
 #pragma unroll
-        for (int k = 0; k < 7; k++) jv[k] = __builtin_nan("");
+    for (int k = 0; k < 7; k++) {
+        const double below = __shfl_up(jv[k], 8);
+        praw[k] = sl == 0 ? jv[k] : below;
     }
-    store_rows<7>(K.joints + (K.t0 + t) * K.n * 7, wave_base, K.n, lane, lds_out[wave], jv);
-    if (live && sing) K.flags[t * K.n + i] |= 4;
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        const double d = jv[k] - praw[k];
+        const bool known = fabs(d) < 128.0;  // (false for NaN: a singular step here or below)
+        const double turn = known ? -rint(d * 0.15915494309189535) : 0.0;
+        // the chunk's first step is judged by phase 4, which knows the step before it
+        if (sl > 0) ev = ev || !(fabs(fma(turn, kTwoPi, d)) <= (k < 4 ? 0.5 - 1e-9 : 1.0 - 1e-9));
+        ev = ev || !(fabs(turn) <= 8.0);
+        const unsigned b = (unsigned)((int)fmin(fmax(turn, -8.0), 8.0) + 8);
+        if (k < 4) lo |= b << (8 * k);
+        else hi |= b << (8 * (k - 4));
+    }
+#pragma unroll
+    for (int step = 1; step < 8; step *= 2) {  // inclusive prefix sum over the chunk's steps (lane stride 8)
+        const unsigned plo = __shfl_up(lo, 8 * step), phi = __shfl_up(hi, 8 * step);
+        if (sl >= step) { lo += plo; hi += phi; }
+    }
+    double out[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        const int field = (int)(((k < 4 ? lo >> (8 * k) : hi >> (8 * (k - 4))) & 0xffu)) - 8 * (sl + 1);
+        const double o = fma((double)field, kTwoPi, jv[k]);
+        out[k] = sing ? __builtin_nan("") : o;  // (singular: needs previous_sol, phase 4 recomputes the step — flag bit 2)
+    }
+    if (live && sing) K.flags[t * n + i] = (uint8_t)(flag | 4);
+    // one event byte per (chunk, trajectory): OR over the chunk's steps
+    const unsigned long long evm = __ballot(ev && live);
+    if (live && sl == 0) K.chunk_event[c * n + i] = ((evm >> tl) & 0x0101010101010101ull) != 0 ? 1 : 0;
+    // rows out: the wave's 64 rows are 8 runs (one per step) of 8 x 7 consecutive doubles
+    double* lw = lds_out[wave];
+#pragma unroll
+    for (int k = 0; k < 7; k++) lw[lane * 7 + k] = out[k];
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    const int64_t traj_left = n - grp * 8;  // trajectories of this group that exist (>= 1 for a launched wave, maybe <= 0 past the end)
+    double* const base = K.joints + ((K.t0 + c * kJointChunk) * n + grp * 8) * 7;
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        const int idx = k * 64 + lane;
+        const int s_ = idx / 56, off = idx - s_ * 56;
+        const bool ok = (c * kJointChunk + s_ < K.T) && (off < traj_left * 7);
+        if (ok) st_stream(base + (int64_t)s_ * n * 7 + off, lw[idx]);
+    }
 }
 
 // phase 4: eight lanes per trajectory, lane j < 7 owns joint j; sequential over the block's steps: the recurrence on
@@ -1212,9 +1296,8 @@ __global__ __launch_bounds__(kChainBlock) __attribute__((amdgpu_waves_per_eu(1, 
     const __amdgpu_buffer_rsrc_t jbuf = row_buffer(K.joints + K.t0 * n * 7), fbuf = row_buffer(K.flags);
     const unsigned joff = (unsigned)((ii * 7 + jj) * sizeof(double)), foff = (unsigned)ii;
     const unsigned jstride = (unsigned)(n * 7 * sizeof(double)), fstride = (unsigned)n;
-    unsigned jrow = 0, frow = 0;  // the step the wave is at: this lane's joint (jbuf, joff, jrow), its flag byte (fbuf, foff, frow)
     int64_t t_abs = K.t0;
-    auto one = [&](double cur, int f, int64_t t) {  // the step at jrow / frow
+    auto one = [&](double cur, int f, int64_t t, unsigned jrow) {  // step t of the block; this lane's joint of it at (jbuf, joff, jrow)
         if (RSIK_RARE((f & 4) != 0 && !emergency)) {  // the same byte in all 8 lanes of the trajectory
             // exact singularity in get_joints: the step is recomputed with the real previous_sol (every lane of the
             // group computes all seven joints and keeps its own)
@@ -1263,60 +1346,19 @@ __global__ __launch_bounds__(kChainBlock) __attribute__((amdgpu_waves_per_eu(1, 
         emergency = emergency || trips;
         t_abs += 1;
     };
-    // A step in which nothing happens — no +-6 pi limit, no discontinuity, no singular get_joints, no latch, not the first
-    // step after a (re)initialisation — is previous := previous + angle_diff(joint, previous), and the tests that
-    // establish "nothing happens" do not feed the next step.  So a batch first runs in that short form: the modulo without
-    // its fix-ups (they act when the quotient was rounded across an integer; the result then lies outside [0, 2 pi) and
-    // the step fails the first test), seven arithmetic instructions, and two running values that stand for the tests:
-    // the largest |angle_diff| (against the continuity threshold less 1e-9: the reference tests angle_diff(result,
-    // previous), which is this one re-derived, U:571-589) and the largest |result| (against the multiturn limit,
-    // U:535-568).  A singular step arrives as NaN (phase 3) and, like any NaN, surfaces in the batch's last result.
-    // Nine vector instructions a step and no scalar one (rsik_device.hpp `opaque`: a lone wave pays ~16 cycles for every
-    // compare result that a scalar instruction combines); ONE wave-uniform test per batch decides whether the short
-    // form stands, otherwise the batch is done step by step with `one` (operands re-read: only real events get there).
-    // Operands are fetched a batch ahead into two register sets that take turns.
+    // Phase 3 has already done the quiet part of the recurrence (see cont_joints_kernel): this phase walks the block CHUNK
+    // by chunk.  A chunk stands as phase 3 wrote it when its event byte is clear, the trajectory is neither latched nor at
+    // its first step after a (re)initialisation, and its first step lies within the continuity threshold (less 1e-9) of
+    // previous_sol — which also says that phase 3 picked the right turn; previous_sol then becomes the chunk's last row.
+    // Otherwise the chunk's steps go through `one`, the reference's own sequence of operations, in place (it re-bases
+    // whatever representative phase 3 wrote).  Per chunk this reads two rows of the joints and a byte instead of
+    // reading and rewriting every row; the first / last rows and event bytes of kChainBatch chunks are fetched at once.
     const double thr_short = thr - 1e-9;
-    struct Operands { double raw[kChainBatch]; };
-    // (`valid` < kChainBatch: the block's last, partial batch — the steps past its end repeat the last one and are skipped)
-    auto fetch = [&](Operands& o, int ahead, int valid) {
-#pragma unroll
-        for (int u = 0; u < kChainBatch; u++) o.raw[u] = ld_row_f64(jbuf, joff, jrow + (unsigned)(ahead + (u < valid ? u : valid - 1)) * jstride);
-    };
-    int64_t t_blk = 0;  // step of the block that jrow / frow point at
-    auto short_form = [&](const Operands& o, auto partial, int valid) -> bool {  // true: the batch at jrow is done
-        constexpr bool kPartial = decltype(partial)::value;
-        double pv = prev, res[kChainBatch], wmax = 0.0, tmax = 0.0;
-        asm volatile("" : : "v"(o.raw[kChainBatch - 1]));  // one wait for the whole set (see cont_theta_kernel)
-#pragma unroll
-        for (int u = 0; u < kChainBatch; u++) {
-            if (!kPartial || u < valid) {  // (launch-uniform: a scalar branch)
-                const double x0 = (o.raw[u] - pv) + kPi;
-                const double x = fma(-floor(x0 * 0.15915494309189535), kTwoPi, x0);  // pymod_2pi_straight less its fix-ups
-                const double w = x - kPi;
-                pv = pv + w;
-                wmax = __builtin_fmax(wmax, fabs(w));
-                tmax = __builtin_fmax(tmax, fabs(pv));
-            }
-            res[u] = pv;
-        }
-        const bool event = emergency | init | !(wmax <= thr_short) | !(tmax <= lim) | (pv != pv);
-        if (RSIK_RARE(__any(event))) return false;
-        if (owner) {
-#pragma unroll
-            for (int u = 0; u < kChainBatch; u++) {
-                if (!kPartial || u < valid) st_row_f64(jbuf, joff, jrow + (unsigned)u * jstride, res[u]);
-            }
-        }
-        const int done = kPartial ? valid : kChainBatch;
-        prev = pv;
-        jrow += (unsigned)done * jstride;
-        frow += (unsigned)done * fstride;
-        t_abs += done;
-        t_blk += done;
-        return true;
-    };
+    const __amdgpu_buffer_rsrc_t ebuf = row_buffer(K.chunk_event);
     // step by step with `one` (the only copy of it), the operands of the next three steps in flight meanwhile
-    auto stepwise = [&](int64_t count) {
+    auto stepwise = [&](int64_t t_blk, int64_t count) {  // the steps [t_blk, t_blk + count) of the block
+        unsigned jrow = (unsigned)t_blk * jstride, frow = (unsigned)t_blk * fstride;
+        t_abs = K.t0 + t_blk;
         auto at = [&](int64_t k) { return k < count ? k : count - 1; };
         auto raw_at = [&](int64_t k) { return ld_row_f64(jbuf, joff, jrow + (unsigned)k * jstride); };
         auto flag_at = [&](int64_t k) { return ld_row_u8(fbuf, foff, frow + (unsigned)k * fstride); };
@@ -1327,7 +1369,7 @@ __global__ __launch_bounds__(kChainBlock) __attribute__((amdgpu_waves_per_eu(1, 
             const int64_t ahead = at(k + 3) - k;
             const double rn = raw_at(ahead);
             const int fn = flag_at(ahead);
-            one(r0, f0, t_blk);
+            one(r0, f0, t_blk, jrow);
             r0 = r1; r1 = r2; r2 = rn;
             f0 = f1; f1 = f2; f2 = fn;
             jrow += jstride;
@@ -1335,38 +1377,65 @@ __global__ __launch_bounds__(kChainBlock) __attribute__((amdgpu_waves_per_eu(1, 
             t_blk += 1;
         }
     };
-    constexpr int kStepwise = 8;  // steps done one by one after a batch gave up, before the short form is tried again
-    int64_t remaining = K.T;
-    bool latched = false;  // a latched trajectory in this wave: every batch is an event, the short form is not tried again
-#pragma unroll 1
-    while (remaining > 0) {
-        if (!latched) {
-            int64_t nb = remaining / kChainBatch;
-            Operands oa, ob;
-            if (nb > 0) {
-                fetch(oa, 0, kChainBatch);
-#pragma unroll 1
-                for (;;) {
-                    if (nb >= 2) fetch(ob, kChainBatch, kChainBatch);
-                    if (!short_form(oa, std::false_type{}, kChainBatch)) break;
-                    remaining -= kChainBatch;
-                    if (--nb == 0) break;
-                    if (nb >= 2) fetch(oa, kChainBatch, kChainBatch);
-                    if (!short_form(ob, std::false_type{}, kChainBatch)) break;
-                    remaining -= kChainBatch;
-                    if (--nb == 0) break;
-                }
-            }
-            if (nb == 0 && remaining > 0) {  // the partial batch at the end of the block
-                fetch(oa, 0, (int)remaining);
-                if (short_form(oa, std::true_type{}, (int)remaining)) remaining = 0;
-            }
+    const int64_t n_chunks = (K.T + kJointChunk - 1) / kJointChunk;
+    struct Operands { double first[kChainBatch], last[kChainBatch]; int ev[kChainBatch]; };
+    auto chunk_len = [&](int64_t c) { return (K.T - c * kJointChunk) < kJointChunk ? (K.T - c * kJointChunk) : (int64_t)kJointChunk; };
+    auto fetch = [&](Operands& o, int64_t c0) {
+#pragma unroll
+        for (int u = 0; u < kChainBatch; u++) {
+            const int64_t c = (c0 + u) < n_chunks ? (c0 + u) : (n_chunks - 1);  // (past the end: the last chunk again, skipped)
+            const unsigned r_first = (unsigned)(c * kJointChunk) * jstride;
+            o.first[u] = ld_row_f64(jbuf, joff, r_first);
+            o.last[u] = ld_row_f64(jbuf, joff, r_first + (unsigned)(chunk_len(c) - 1) * jstride);
+            o.ev[u] = ld_row_u8(ebuf, foff, (unsigned)c * fstride);
         }
-        if (remaining > 0) {
-            const int64_t count = latched || remaining < kStepwise ? remaining : kStepwise;
-            stepwise(count);
-            remaining -= count;
-            latched = __any(emergency);
+    };
+    // Walks the fetched chunks until one does not stand: returns its index in the batch (kChainBatch: all stood).
+    // Phase 3 left each chunk on the turn of its first step's raw joints; `turns` (this lane's joint, almost always 0) is
+    // how many whole turns that is away from previous_sol.  They go to chunk_turns for phase 5, which adds them to the
+    // chunk's rows — nothing sequential, and only the elements that need it.  The limits (U:535-568): phase 3 cannot test
+    // them without the turn, so they are tested here on the chunk's first step with the slack its other steps can use
+    // up — they lie within (chunk - 1) continuity thresholds of it.
+    const bool limited = jj == 0 || jj == 2 || jj == 6;
+    const double clear_of_limit = 6 * kPi - (kJointChunk - 1) * 1.0 - 1e-6;
+    int8_t* const turns_out = K.chunk_turns + ii * 8 + j;  // (+ chunk * n * 8)
+    auto walk = [&](const Operands& o, int64_t c0) -> int {
+        int stop = kChainBatch;
+#pragma unroll
+        for (int u = 0; u < kChainBatch; u++) {
+            const double turns = -rint((o.first[u] - prev) * 0.15915494309189535);
+            const double sh = turns * kTwoPi;
+            const double f2 = o.first[u] + sh;
+            const bool quiet = !emergency && !init && o.ev[u] == 0 && (fabs(f2 - prev) <= thr_short) && (fabs(turns) <= 100.0) &&
+                               (!limited || fabs(f2) <= clear_of_limit);
+            const bool inside = c0 + u < n_chunks;
+            const bool stands = !__any(!quiet) && inside;  // (wave-uniform)
+            const bool taken = stop == kChainBatch && stands;
+            if (stop == kChainBatch && !stands) stop = u;
+            if (taken) prev = o.last[u] + sh;
+            // (a chunk that goes through `one` instead is rewritten there: no turns to add)
+            if (live && inside) turns_out[(c0 + u) * n * 8] = (int8_t)(taken ? (int)turns : 0);
+        }
+        return stop;
+    };
+    {
+        Operands oa, ob;
+        int64_t c0 = 0;
+        fetch(oa, 0);
+#pragma unroll 1
+        while (c0 < n_chunks) {
+            const bool more = c0 + kChainBatch < n_chunks;
+            if (more) fetch(ob, c0 + kChainBatch);
+            const int stop = walk(oa, c0);
+            if (RSIK_RARE(c0 + stop < n_chunks && stop < kChainBatch)) {
+                // an eventful chunk: the reference's own sequence of operations for its steps, then the walk resumes behind it
+                stepwise((c0 + stop) * kJointChunk, chunk_len(c0 + stop));
+                c0 += stop + 1;
+                if (c0 < n_chunks) fetch(oa, c0);
+            } else {
+                c0 += kChainBatch;
+                oa = ob;
+            }
         }
     }
     if (owner) K.st[(1 + j) * n + i] = prev;
@@ -1374,6 +1443,32 @@ __global__ __launch_bounds__(kChainBlock) __attribute__((amdgpu_waves_per_eu(1, 
         K.st[8 * n + i] = init ? 1.0 : 0.0;
         K.st[9 * n + i] = emergency ? 1.0 : 0.0;
         if (K.last_block && !emergency) K.st[0 * n + i] = RSIK_WS(K, K.T - 1, i);  // previous_theta after the last step
+    }
+}
+
+// phase 5: adds the whole turns phase 4 found (chunk_turns) to the chunk's rows: one thread per (trajectory, chunk), nearly
+// all of which find eight zero bytes and leave.
+__global__ __launch_bounds__(kBlock) void cont_turns_kernel(const ContRunArgs K) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t c = blockIdx.y;
+    if (i >= K.n) return;
+    const unsigned long long packed = *reinterpret_cast<const unsigned long long*>(K.chunk_turns + (c * K.n + i) * 8);
+    if (packed == 0) return;
+    const int64_t t_begin = c * kJointChunk;
+    const int len = (int)((K.T - t_begin) < kJointChunk ? (K.T - t_begin) : kJointChunk);
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        const int turns = (int)(int8_t)((packed >> (8 * k)) & 0xff);
+        if (turns != 0) {
+            const double sh = (double)turns * kTwoPi;
+            double* p = K.joints + ((K.t0 + t_begin) * K.n + i) * 7 + k;
+            double v[kJointChunk];
+#pragma unroll
+            for (int q = 0; q < kJointChunk; q++) v[q] = p[(int64_t)(q < len ? q : len - 1) * K.n * 7];
+#pragma unroll
+            for (int q = 0; q < kJointChunk; q++)
+                if (q < len) p[(int64_t)q * K.n * 7] = v[q] + sh;
+        }
     }
 }
 
@@ -2098,7 +2193,11 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     dim3 grid, block(rsik::kBlock);
     rc = launch_dims(ctx, n, &grid, who);
     if (rc != RSIK_OK) return rc;
-    if (ctx->options[RSIK_OPT_CONT_RUN_MODE] == RSIK_CONT_RUN_STEPS) {
+    // is_reachable_no_limits can only fail (C:385-387) for a projection margin that lets the pulled-back wrist land beyond
+    // u + f (S:343-345); the pipeline's phases do not carry that outcome, the step kernel does.
+    bool no_limits_can_fail = false;
+    for (int slot = 0; slot < 2; slot++) no_limits_can_fail = no_limits_can_fail || !(K0.arms[slot].v[RSIK_C_PROJ_MARGIN] > 1e-12);
+    if (ctx->options[RSIK_OPT_CONT_RUN_MODE] == RSIK_CONT_RUN_STEPS || no_limits_can_fail) {
         for (int64_t k = 0; k < n_steps; k++) {
             rsik::ContinuousArgs K = K0;
             for (int c = 0; c < 12; c++) K.in[c] = m12_steps + ((size_t)k * 12 + c) * (size_t)n;
@@ -2152,7 +2251,8 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         block_T.push_back(n_steps - t0 < T ? n_steps - t0 : T);
     }
     const int64_t n_blocks = (int64_t)block_t0.size();
-    const size_t slot_bytes = (((size_t)T * per_step + 255) / 256) * 256;
+    const size_t chunks_per_block = ((size_t)T + rsik::kJointChunk - 1) / rsik::kJointChunk;
+    const size_t slot_bytes = (((size_t)T * per_step + chunks_per_block * (size_t)n * 9 + 255) / 256) * 256;
     const int slots = n_blocks < kSlots ? (int)n_blocks : kSlots;
     const size_t carry_bytes = (((size_t)n * sizeof(double) + 255) / 256) * 256;
     const size_t need = slot_bytes * slots + carry_bytes;
@@ -2174,7 +2274,7 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         ctx->events.push_back(e);
     }
     hipStream_t s_main = ctx->stream, s_theta = ctx->stream, s_prep = ctx->side[0], s_joints = ctx->side[1], s_chain = ctx->side[2];
-    auto ev = [&](int kind, int64_t b) { return ctx->events[2 + 4 * (size_t)b + kind]; };  // 0 prepared, 1 theta, 2 joints, 3 chain
+    auto ev = [&](int kind, int64_t b) { return ctx->events[2 + 4 * (size_t)b + kind]; };  // 0 prepared, 1 theta, 2 joints, 3 chain (+ turns)
     // (Re)initialisation of the trajectories that start here (C:296-325: the start-up search for previous_theta, ~55 us
     // of lone waves), then the pipeline's streams join in.  The prepare phase depends on the goal matrices alone, not on
     // the trajectory state: its stream forks off BEFORE the initialisation (behind whatever the caller queued ahead of
@@ -2227,6 +2327,10 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         R.ws = reinterpret_cast<double*>(static_cast<char*>(ctx->ws) + slot_bytes * (size_t)(b % slots));
         R.gw = R.ws + (size_t)R.T * (size_t)n;
         R.flags = reinterpret_cast<uint8_t*>(R.gw + (size_t)R.T * (size_t)n);
+        R.chunk_event = R.flags + (size_t)R.T * (size_t)n;
+        // (8-byte rows: the workspace slots are 256-byte aligned and flags + chunk events end on a multiple of 8 when n is;
+        // otherwise round up)
+        R.chunk_turns = reinterpret_cast<int8_t*>((reinterpret_cast<uintptr_t>(R.chunk_event + chunks_per_block * (size_t)n) + 7) & ~(uintptr_t)7);
     };
     auto issue_front = [&](int64_t b) -> int {  // prepare(b), theta(b)
         set_block(b);
@@ -2246,7 +2350,8 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     };
     auto issue_back = [&](int64_t b) -> int {  // joints(b), chain(b)
         set_block(b);
-        const dim3 grid2(grid.x, (unsigned)R.T);
+        // (a wave = 8 trajectories x 8 steps: n / 8 groups, 4 per workgroup)
+        const dim3 grid2((unsigned)((n + 8 * (rsik::kBlock / 64) - 1) / (8 * (rsik::kBlock / 64))), (unsigned)((R.T + rsik::kJointChunk - 1) / rsik::kJointChunk));
         RSIK_HIP(ctx, hipStreamWaitEvent(s_joints, ev(1, b), 0));
         if (arm) hipLaunchKernelGGL(rsik::cont_joints_kernel<true>, grid2, block, 0, s_joints, R);
         else hipLaunchKernelGGL(rsik::cont_joints_kernel<false>, grid2, block, 0, s_joints, R);
@@ -2254,6 +2359,7 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         RSIK_HIP(ctx, hipStreamWaitEvent(s_chain, ev(2, b), 0));
         if (arm) hipLaunchKernelGGL(rsik::cont_chain_kernel<true>, grid8, dim3(rsik::kChainBlock), 0, s_chain, R);
         else hipLaunchKernelGGL(rsik::cont_chain_kernel<false>, grid8, dim3(rsik::kChainBlock), 0, s_chain, R);
+        hipLaunchKernelGGL(rsik::cont_turns_kernel, dim3(grid.x, (unsigned)((R.T + rsik::kJointChunk - 1) / rsik::kJointChunk)), block, 0, s_chain, R);
         RSIK_HIP(ctx, hipEventRecord(ev(3, b), s_chain));
         return RSIK_OK;
     };

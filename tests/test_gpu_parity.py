@@ -633,6 +633,152 @@ def test_control_continuous_against_checker_dvt_and_emergency(torch_mod, orc):
         assert n_em == sum(s.emergency_stop for s in states) and n_em > 0
 
 
+def _g12_groups(g, arm):
+    """Rows of G12 that share the launch-uniform arguments: (is_dvt, mode, d_theta_max, preferred_theta) -> row indices."""
+    keys = np.stack([g[f"{arm}_is_dvt"].astype(float), g[f"{arm}_mode"].astype(float), g[f"{arm}_d_theta_max"],
+                     g[f"{arm}_preferred_theta"]], axis=1)
+    groups = {}
+    for k, key in enumerate(map(tuple, keys)):
+        groups.setdefault(key, []).append(k)
+    return {key: np.array(rows) for key, rows in groups.items()}
+
+
+def _g12_expected_state(S):
+    return np.where(S == 255, 8, S).astype(np.uint8)  # 255 in the file = the emergency text = RSIK_STATE_EMERGENCY
+
+
+@pytest.mark.parametrize("is_dvt", [False, True])
+def test_control_continuous_every_mode_step_kernel(golden_dir, torch_mod, is_dvt):
+    """G12 through rsik_control_continuous_step (one launch per control step): the reference's continuous mode for
+    constrained_mode {unconstrained, low_elbow} x d_theta_max {0.01, 0.05, 0.4} x preferred_theta argument {default,
+    0.5, 2.0: outside both control intervals, so limit_theta_to_interval snaps to either end} x both starts, both arms
+    (control_ik.py:225-252, 350-384; utils.py:93-127, 220-264).  Flags / states exact, carried theta <= 1e-9 at EVERY
+    step, joints <= 1e-7; the trajectory that trips continuity_check with d_theta_max = 0.4 latches at the same step."""
+    g = load(golden_dir, "g12_control_continuous_modes.npz")
+    c = make_control(is_dvt)
+    names = ["unconstrained", "low_elbow"]
+    for arm in ("r_arm", "l_arm"):
+        for (dvt, mode, dth, pref), rows in _g12_groups(g, arm).items():
+            if bool(dvt) != is_dvt:
+                continue
+            M12 = g[f"{arm}_M12"][rows]                                   # [n, steps, 12]
+            J, F, TH, ES = (g[f"{arm}_{k}"][rows] for k in ("joints", "reachable", "previous_theta", "emergency_stop"))
+            S = _g12_expected_state(g[f"{arm}_state"][rows])
+            st = c.new_continuous_state(arm, len(rows))
+            prev = g[f"{arm}_start_pose"][rows]
+            for i in range(M12.shape[1]):
+                m12 = np.ascontiguousarray(M12[:, i].T)
+                res = to_np(c.symbolic_inverse_kinematics_continuous_batch(
+                    arm, m12, st, timed_out=np.full(len(rows), 1 if i == 0 else 0, dtype=np.uint8),
+                    current_pose=(prev if i == 0 else None), current_joints=(g[f"{arm}_start_joints"][rows] if i == 0 else None),
+                    constrained_mode=names[int(mode)], d_theta_max=float(dth), preferred_theta=float(pref)))
+                tag = (arm, dvt, mode, dth, pref, i)
+                np.testing.assert_array_equal(res["reachable"], F[:, i], err_msg=str(tag))
+                np.testing.assert_array_equal(res["state"], S[:, i], err_msg=str(tag))
+                assert np.max(np.abs(st[0].cpu().numpy() - TH[:, i])) < 1e-9, tag
+                assert np.max(np.abs(res["joints"] - J[:, i])) < 1e-7, tag
+                np.testing.assert_array_equal(st[9].cpu().numpy() != 0.0, ES[:, i].astype(bool), err_msg=str(tag))
+
+
+@pytest.mark.parametrize("run_mode", ["pipeline", "steps"])
+def test_control_continuous_every_mode_trajectory_run(golden_dir, torch_mod, run_mode):
+    """G12 through rsik_control_continuous_run: the four-phase trajectory pipeline (whose theta phase replaces
+    limit_theta_to_interval's comparison by a host-derived threshold per interval kind, theta_snap_plan) and the
+    step-per-launch form, against the vectors recorded from the reference — every mode, rate limit and preferred-theta
+    argument, both arms, DVT and not.  Flags / states exact, joints <= 1e-7, carried theta at the end <= 1e-9."""
+    g = load(golden_dir, "g12_control_continuous_modes.npz")
+    A = _abi_mod()
+    names = ["unconstrained", "low_elbow"]
+    ctrl = {False: make_control(False), True: make_control(True)}
+    snapped = 0
+    for arm in ("r_arm", "l_arm"):
+        for (dvt, mode, dth, pref), rows in _g12_groups(g, arm).items():
+            c = ctrl[bool(dvt)]
+            c._solver.set_option(A.OPT_CONT_RUN_MODE, {"pipeline": A.CONT_RUN_PHASED, "steps": A.CONT_RUN_STEPS}[run_mode])
+            M12 = g[f"{arm}_M12"][rows]
+            J, F, TH, ES = (g[f"{arm}_{k}"][rows] for k in ("joints", "reachable", "previous_theta", "emergency_stop"))
+            S = _g12_expected_state(g[f"{arm}_state"][rows])
+            st = c.new_continuous_state(arm, len(rows))
+            m12_steps = torch_mod.as_tensor(np.ascontiguousarray(M12.transpose(1, 2, 0))).cuda()   # [steps, 12, n]
+            res = to_np(c.run_continuous_trajectories(
+                arm, m12_steps, st, first_step_timed_out=True, current_joints=g[f"{arm}_start_joints"][rows],
+                current_pose=g[f"{arm}_start_pose"][rows], constrained_mode=names[int(mode)], d_theta_max=float(dth),
+                preferred_theta=float(pref)))
+            tag = (arm, dvt, mode, dth, pref)
+            np.testing.assert_array_equal(res["reachable"], F.T, err_msg=str(tag))
+            np.testing.assert_array_equal(res["state"], S.T, err_msg=str(tag))
+            assert np.max(np.abs(res["joints"] - np.swapaxes(J, 0, 1))) < 1e-7, tag
+            assert np.max(np.abs(st[0].cpu().numpy() - TH[:, -1])) < 1e-9, tag
+            np.testing.assert_array_equal(st[9].cpu().numpy() != 0.0, ES[:, -1].astype(bool), err_msg=str(tag))
+            snapped += 1
+            c._solver.set_option(A.OPT_CONT_RUN_MODE, A.CONT_RUN_AUTO)
+    assert snapped == 72
+
+
+def test_control_continuous_deliberate_crash(golden_dir, torch_mod, monkeypatch):
+    """control_ik.py:385-387 (G12): when is_reachable_no_limits fails the reference raises RuntimeError.  ControlIK's own
+    solvers cannot get there (projection_margin 1e-8 keeps the pulled-back wrist inside u + f); a solver with a negative
+    margin, swapped in through the public symbolic_ik_solver attribute as in the generator, does.  The scalar call raises
+    the reference's exception (and the call before / after it returns the reference's joints); the batch entry points
+    report RSIK_STATE_NOT_REACHABLE_NO_LIMITS with NaN joints and leave the trajectory state alone."""
+    import contextlib
+    import io
+
+    import reachy2_symbolic_ik_amd.control_ik as cik
+    from reachy2_symbolic_ik_amd import SymbolicIK
+    from scipy.spatial.transform import Rotation as R
+
+    g = load(golden_dir, "g12_control_continuous_modes.npz")
+    A = _abi_mod()
+
+    class Clock:
+        t = 1000.0
+
+        @staticmethod
+        def time():
+            return Clock.t
+
+    monkeypatch.setattr(cik, "time", Clock)
+    eul = np.array([0.0, -np.pi / 2, 0.0])
+
+    def mat(p):
+        M = np.eye(4)
+        M[:3, :3] = R.from_euler("xyz", eul).as_matrix()
+        M[:3, 3] = p
+        return M
+
+    for ai, arm in enumerate(("r_arm", "l_arm")):
+        c = make_control()
+        with contextlib.redirect_stdout(io.StringIO()):
+            c.symbolic_ik_solver[arm] = SymbolicIK(arm, projection_margin=-1e-3, singularity_offset=-1.01,
+                                                   wrist_limit=np.rad2deg(c.orbita3D_max_angle), solver=c._solver)
+        P, raised, J = g[f"{arm}_crash_positions"], g[f"{arm}_crash_raised"], g[f"{arm}_crash_joints"]
+        start = mat(P[0])
+        cj = list(cik.DEFAULT_CURRENT_JOINTS[ai])
+        for i, p in enumerate(P):
+            Clock.t += 1.0 / 120.0
+            with contextlib.redirect_stdout(io.StringIO()):
+                if raised[i][0]:
+                    theta_before = c.previous_theta[arm]
+                    with pytest.raises(RuntimeError) as ei:
+                        c.symbolic_inverse_kinematics(arm, mat(p), "continuous", current_joints=cj, current_pose=start)
+                    assert str(ei.value) == str(raised[i][1]) and c.previous_theta[arm] == theta_before
+                else:
+                    j, ok, st = c.symbolic_inverse_kinematics(arm, mat(p), "continuous", current_joints=cj, current_pose=start)
+                    assert np.max(np.abs(np.asarray(j) - J[i])) < 1e-7, (arm, i)
+        # the same three goals as one trajectory through the batch entry points
+        Ms = np.stack([mat(p) for p in P])[:, None]                      # [3 steps, 1 trajectory, 4, 4]
+        for run_mode in (A.CONT_RUN_STEPS, A.CONT_RUN_AUTO):
+            c._solver.set_option(A.OPT_CONT_RUN_MODE, run_mode)
+            st = c.new_continuous_state(arm, 1)
+            res = to_np(c.run_continuous_trajectories(arm, Ms, st, first_step_timed_out=True, current_joints=np.array([cj]),
+                                                      current_pose=start[None]))
+            assert list(res["state"][:, 0] == A.STATE_NOT_REACHABLE_NO_LIMITS) == [False, True, False]
+            assert np.all(np.isnan(res["joints"][1])) and not res["reachable"][1, 0]
+            assert np.max(np.abs(res["joints"][[0, 2], 0] - J[[0, 2]])) < 1e-7
+        c._solver.set_option(A.OPT_CONT_RUN_MODE, A.CONT_RUN_AUTO)
+
+
 def test_continuous_run_replayed_from_a_graph(torch_mod):
     """rsik_control_continuous_run issues its phases on four streams tied by the context's own events; once a call of the
     same shape has run (workspace, side streams and events exist) the whole run can be captured into a hipGraph — the
@@ -662,11 +808,8 @@ def test_continuous_run_replayed_from_a_graph(torch_mod):
         one()  # the capture stream has run a call of this shape
         torch_mod.cuda.synchronize()
         g = torch_mod.cuda.CUDAGraph()
-        try:
-            with torch_mod.cuda.graph(g, stream=side):
-                one()
-        except RuntimeError as e:  # (a runtime that refuses the capture: bench.py then issues the launches one by one)
-            pytest.skip(f"hipGraph capture refused: {e}")
+        with torch_mod.cuda.graph(g, stream=side):  # a refused capture is the regression this test exists to catch
+            one()
     for v in out.values():
         v.zero_()
     st.zero_()
@@ -678,11 +821,28 @@ def test_continuous_run_replayed_from_a_graph(torch_mod):
     assert torch_mod.equal(ref["cont_state"].view(torch_mod.uint8), st.view(torch_mod.uint8))
 
 
+def _same_run(torch, ref, got, tag, joint_tol=1e-12):
+    """Two runs of the same trajectories (pipeline vs step kernel, or two block sizes of the pipeline): flags, state codes,
+    the carried theta (row 0 of the trajectory state) and its flag rows bit for bit; joints and previous_sol to
+    `joint_tol`.  (The pipeline's joints phase takes the first step of each of its chunks relative to previous_sol at the
+    block's entry instead of the step before: the same turn of the same angle, its last bit free; no accumulation.)"""
+    for k in ref:
+        a, b = ref[k], got[k]
+        if k == "joints":
+            assert float((a - b).abs().max()) <= joint_tol, (tag, k, float((a - b).abs().max()))
+        elif k == "cont_state":
+            assert torch.equal(a[0].view(torch.uint8), b[0].view(torch.uint8)), (tag, "previous_theta")
+            assert float((a[1:8] - b[1:8]).abs().max()) <= joint_tol, (tag, "previous_sol")
+            assert torch.equal(a[8:11], b[8:11]), (tag, "init / emergency / has_previous_sol")
+        else:
+            assert torch.equal(a.view(torch.uint8), b.view(torch.uint8)), (tag, k)
+
+
 @pytest.mark.parametrize("n_traj,n_steps", [(1, 300), (2, 77), (7, 129), (65, 33), (4099, 40)])
 def test_continuous_pipeline_odd_batch_shapes(torch_mod, n_traj, n_steps):
     """The pipeline's sequential phases address their arrays as (buffer, row, lane) and run single-wave workgroups: a
     single trajectory (the reference's own use), a few, one more than a wave, one more than 64 waves — against the step
-    kernel, bit for bit."""
+    kernel (flags, states and the carried theta bit for bit, joints to 1e-12: _same_run)."""
     from bench import make_config5_trajectories
 
     A = _abi_mod()
@@ -699,8 +859,7 @@ def test_continuous_pipeline_odd_batch_shapes(torch_mod, n_traj, n_steps):
         if ref is None:
             ref = got
         else:
-            for k in ref:
-                assert torch_mod.equal(ref[k].view(torch_mod.uint8), got[k].view(torch_mod.uint8)), (n_traj, n_steps, k)
+            _same_run(torch_mod, ref, got, (n_traj, n_steps))
     c._solver.set_option(A.OPT_CONT_RUN_MODE, A.CONT_RUN_AUTO)
 
 
@@ -735,8 +894,7 @@ def test_continuous_pipeline_theta_step_per_interval_kind(torch_mod, arm, mode, 
             ref = got
             assert bool(torch_mod.isfinite(ref["joints"]).all())
         else:
-            for k in ref:
-                assert torch_mod.equal(ref[k].view(torch_mod.uint8), got[k].view(torch_mod.uint8)), (arm, mode, k)
+            _same_run(torch_mod, ref, got, (arm, mode, d_theta_max))
     c._solver.set_option(A.OPT_CONT_RUN_MODE, A.CONT_RUN_AUTO)
 
 
@@ -760,7 +918,7 @@ def test_continuous_run_equals_stepwise(golden_dir, torch_mod, run_mode):
         np.testing.assert_array_equal(res["state"], S.T)
         assert np.max(np.abs(res["joints"] - np.swapaxes(J, 0, 1))) < 1e-7
         out, st2 = _run_continuous(c, arm, Ms, start_joints=g[f"{arm}_start_joints"][sel], start_pose=g[f"{arm}_start_pose"][sel])
-        assert torch_mod.equal(st, st2)
+        _same_run(torch_mod, {"cont_state": st[:11]}, {"cont_state": st2[:11]}, (arm, run_mode))
     # both arms' trajectories in ONE mixed launch (per-trajectory arm byte)
     sel = {a: ~g[f"{a}_is_dvt"].astype(bool) for a in ("r_arm", "l_arm")}
     cat = lambda k: np.concatenate([g[f"r_arm_{k}"][sel["r_arm"]], g[f"l_arm_{k}"][sel["l_arm"]]])  # noqa: E731
@@ -774,7 +932,7 @@ def test_continuous_run_equals_stepwise(golden_dir, torch_mod, run_mode):
     assert np.max(np.abs(res["joints"] - np.swapaxes(J, 0, 1))) < 1e-7
 
 
-def test_continuous_pipeline_block_sizes_are_bit_identical(torch_mod):
+def test_continuous_pipeline_block_sizes_agree(torch_mod):
     """The trajectory pipeline cuts a run into blocks (RSIK_OPT_CONT_BLOCK_STEPS) whose four phases overlap on four
     streams; the operands of the two sequential phases are fetched 16 / 32 steps at a time.  Whatever the block size —
     shorter than a batch, not a multiple of one, the whole run — results and carried state must be the same bits, and
@@ -799,13 +957,13 @@ def test_continuous_pipeline_block_sizes_are_bit_identical(torch_mod):
             ref = got
             assert bool(torch_mod.isfinite(ref["joints"]).all()) and 0.05 < float(ref["reachable"].float().mean()) < 0.95
         else:
-            for k in ref:
-                assert torch_mod.equal(ref[k].view(torch_mod.uint8), got[k].view(torch_mod.uint8)), (mode, blk, k)
+            _same_run(torch_mod, ref, got, (mode, blk))
     c._solver.set_option(A.OPT_CONT_RUN_MODE, A.CONT_RUN_AUTO)
     c._solver.set_option(A.OPT_CONT_BLOCK_STEPS, 0)
 
 
-def test_config5_full_size_against_checker(torch_mod, orc):
+@pytest.mark.parametrize("mode,d_theta_max,preferred", [("unconstrained", 0.01, -4 * np.pi / 6), ("low_elbow", 0.05, 0.5)])
+def test_config5_full_size_against_checker(torch_mod, orc, mode, d_theta_max, preferred):
     """BASELINE config 5 at its stated size: 4096 trajectories x 1000 control steps in one rsik_control_continuous_run
     call (bench.py's generator and call), a 96-trajectory subsample re-walked step by step by the CPU checker's state
     machine: flags and state codes exact, joints <= 1e-7 at every one of the 96 000 trajectory-steps, and the carried
@@ -819,15 +977,19 @@ def test_config5_full_size_against_checker(torch_mod, orc):
     c = make_control()
     assert BENCH_URDF == URDF
     st = c.new_continuous_state("r_arm", n_traj)
-    res = c.run_continuous_trajectories("r_arm", traj, st, first_step_timed_out=True, current_pose=traj[0])
+    res = c.run_continuous_trajectories("r_arm", traj, st, first_step_timed_out=True, current_pose=traj[0],
+                                        constrained_mode=mode, d_theta_max=d_theta_max, preferred_theta=preferred)
     torch_mod.cuda.synchronize()
     J = res["joints"].cpu().numpy()
     F = res["reachable"].cpu().numpy()
     S = res["state"].cpu().numpy()
-    assert np.isfinite(J).all() and st[9].sum().item() == 0
+    assert np.isfinite(J).all()
+    if mode == "unconstrained":
+        assert st[9].sum().item() == 0
+    live = (S != 8)
     step = np.abs(np.diff(J, axis=0))
     assert step[..., :4].max() <= 0.5 and step[..., 4:].max() <= 1.0
-    frac = F.mean()
+    frac = F[live].mean()
     assert 0.2 < frac < 0.5  # 66 % of the steps take the unreachable fallback on this generator
     sub = np.arange(0, n_traj, n_traj // 96)[:96]
     M12 = traj[:, :, torch_mod.as_tensor(sub).cuda()].cpu().numpy()          # [n_steps, 12, 96]
@@ -839,12 +1001,14 @@ def test_config5_full_size_against_checker(torch_mod, orc):
         Ms[:, :3, :3] = M12[:, :9, col].reshape(n_steps, 3, 3)
         Ms[:, :3, 3] = M12[:, 9:, col]
         for i in range(n_steps):
-            j, ok, code = orc.control_continuous_step(a, cs, Ms[i], timed_out=(i == 0), preferred_theta_arg=-4 * np.pi / 6,
-                                                      preferred_theta_self=c.preferred_theta["r_arm"], constrained_mode=0,
-                                                      current_joints=cs.previous_sol, current_pose=Ms[0])
+            j, ok, code = orc.control_continuous_step(a, cs, Ms[i], timed_out=(i == 0), preferred_theta_arg=preferred,
+                                                      preferred_theta_self=c.preferred_theta["r_arm"],
+                                                      constrained_mode=_abi_mod().MODES[mode],
+                                                      current_joints=cs.previous_sol, current_pose=Ms[0], d_theta_max=d_theta_max)
             assert ok == bool(F[i, k]) and code == S[i, k], (k, i)
             worst = max(worst, float(np.max(np.abs(j - J[i, k]))))
         assert abs(cs.previous_theta - float(st[0, k])) < 1e-9
+        assert cs.emergency_stop == bool(st[9, k] != 0)
     assert worst < 1e-7, worst
 
 
