@@ -41,7 +41,11 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 XGMI_LINK_GBS, XGMI_LINKS = 153.0, 7  # per-direction per-link rate and links per GPU (point-to-point mesh)
 NOMINAL_VALU_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 4  # 256 CUs x 4 SIMDs, one wave64 vector instruction per 4 cycles at 2.4 GHz
-BYTES_PER_POSE = {2: 48 + 56 + 16 + 1 + 1, 3: 96 + 56 + 1 + 1, 4: 49 + 56 + 16 + 1 + 1, 5: 96 + 58 + 2 * 88}
+# SURVEY 8(d).  Config 5: 96 in + 58 out per control step for rsik_control_continuous_run (the trajectory state crosses HBM once
+# per pass: the "persistent loop" figure); a caller that launches rsik_control_continuous_step per step also moves the 66-byte
+# state in and out every step (286 B) — both fractions are in the line, the headline one is on 154.
+BYTES_PER_POSE = {2: 48 + 56 + 16 + 1 + 1, 3: 96 + 56 + 1 + 1, 4: 49 + 56 + 16 + 1 + 1, 5: 96 + 58}
+BYTES_PER_STEP_STATE_ROUND_TRIP = 96 + 58 + 2 * 66
 GATHER_BYTES_PER_POSE = 56 + 1  # joints [7] f64 + state u8 (reachable == (state == 0) for rsik_solve)
 URDF = "config_files/reachy2_ik_minimal.urdf"
 SHOULDER_R = np.array([0.0, -0.2, 0.0])
@@ -323,12 +327,24 @@ def launch_ranks(n_ranks, argv):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
+    import tempfile
+
+    procs, logs = [], []
     for r in range(n_ranks):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                   NCCL_DEBUG=os.environ.get("NCCL_DEBUG", "WARN"))  # RCCL's own warnings go to the rank's stderr
+        log = tempfile.TemporaryFile(mode="w+")  # the rank's stderr: shown (tail) if it fails
+        logs.append(log)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stderr=log))
     rc, alive = 0, set(range(n_ranks))
+
+    def show_tail(r, lines=40):
+        logs[r].seek(0)
+        tail = logs[r].read().splitlines()[-lines:]
+        if tail:
+            print(f"---- stderr of rank {r} (last {len(tail)} lines) ----\n" + "\n".join(tail), file=sys.stderr)
+
     try:
         while alive:
             for r in sorted(alive):
@@ -339,6 +355,7 @@ def launch_ranks(n_ranks, argv):
                 if code != 0 and rc == 0:
                     rc = code
                     print(f"bench.py: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr)
+                    show_tail(r)
                     for q in alive:
                         procs[q].terminate()
             time.sleep(0.05)
@@ -350,6 +367,11 @@ def launch_ranks(n_ranks, argv):
                     p.wait(timeout=10)
                 except subprocess.TimeoutExpired:
                     p.kill()
+        if rc == 0:  # rank 0's warnings (RCCL WARN lines, the libdrm notice) still reach the caller's stderr
+            logs[0].seek(0)
+            sys.stderr.write(logs[0].read())
+        for log in logs:
+            log.close()
     return rc
 
 
@@ -375,15 +397,43 @@ def parse_args(argv):
     ap.add_argument("--graph", action="store_true", help="same as --launch graph")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--single-device", action="store_true", help="every rank uses GPU 0 (with --backend gloo: rehearsal on a 1-GPU box)")
+    ap.add_argument("--collective-timeout", type=float, default=120.0, help="N > 1: seconds before a stuck collective fails its rank")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="ranks only meet, all-reduce their rank numbers on the CPU and print the line's skeleton (launcher self-test, no GPU)")
     ap.add_argument("--lib", default="", help="alternative build of librsik_hip.so (A/B timing, probe builds)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="default run (N = 1, no --config): do not time configs 3, 4 and 5 after the headline config")
     args = ap.parse_args(argv)
     if args.graph:
         args.launch = "graph"
     if args.gather_every_step:
         args.gather = "step"
     return args
+
+
+def describe_group(torch, dist, dev, world, rank, args):
+    """What the collective library really sees: every rank's device (uuid, PCI bus id, name), host and pid, all-gathered;
+    two ranks on one device are refused unless --single-device (a rehearsal) says so.  Returned on every rank."""
+    props = torch.cuda.get_device_properties(dev)
+    me = {"rank": rank, "host": socket.gethostname(), "pid": os.getpid(), "device_index": dev.index, "name": props.name,
+          "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": int(getattr(props, "pci_bus_id", -1)),
+          "pci_device_id": int(getattr(props, "pci_device_id", -1)), "pci_domain_id": int(getattr(props, "pci_domain_id", -1)),
+          "visible": os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES", ""))}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, me)
+    ident = [(e["host"], e["uuid"] or (e["pci_domain_id"], e["pci_bus_id"], e["pci_device_id"], e["device_index"])) for e in everyone]
+    distinct = len(set(ident))
+    if distinct != world and not args.single_device:
+        raise SystemExit(f"bench.py: {world} ranks but only {distinct} distinct devices ({ident}): every rank needs a GPU of its own "
+                         "(--single-device rehearses the code path on one)")
+    try:
+        v = torch.cuda.nccl.version()
+        lib_version = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+    except Exception as e:  # noqa: BLE001
+        lib_version = f"unknown ({type(e).__name__})"
+    return {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "distinct_devices": distinct,
+            "collective_library": ("RCCL " + lib_version) if args.backend == "nccl" else args.backend,
+            "ranks": everyone, "collective_timeout_s": args.collective_timeout}
 
 
 def rendezvous_only(args, world, rank):
@@ -401,7 +451,36 @@ def rendezvous_only(args, world, rank):
 
 
 # ------------------------------------------------------------------------------------------ one rank
-def main(argv=None):
+def other_configs_section(headline_cfg):
+    """Configs 3, 4 (one GPU's shard) and 5 timed briefly in the same process after the headline config: K = 20 steps
+    with the same launch policy, the CPU checker on a sample of each.  Headline `config` / `value` are untouched; these are
+    the driver-timed figures for the other BASELINE configs."""
+    section = {}
+    for oc in (3, 4, 5):
+        if oc == headline_cfg:
+            continue
+        t0 = time.perf_counter()
+        try:
+            sub = main(["--config", str(oc), "--steps", "20", "--warmup", "5", "--no-extras", "--no-valu-calibration", "--no-other-configs",
+                        "--cpu-seconds", "2"], return_line=True)
+            r = sub["roofline"]
+            section[str(oc)] = {
+                "workload": sub["config"]["workload"], "metric": sub["metric"], "value": sub["value"], "unit": sub["unit"],
+                "steps": sub["steps"], "ms_per_step": sub["ms_per_step"], "kernel_ms": r["kernel_ms"], "launch": sub["launch"],
+                "algorithmic_bytes_per_pose": r["algorithmic_bytes_per_pose"], "achieved_GBs": r["achieved"], "frac": r["frac"],
+                "traffic": r.get("traffic"),
+                "parity_on_sample": sub.get("cpu_baseline", {}).get("parity_on_sample"),
+                "cpu_baseline": {k: sub.get("cpu_baseline", {}).get(k) for k in ("value", "unit", "cores", "kind", "single_thread")},
+                "wall_s": time.perf_counter() - t0,
+            }
+            if oc == 5:
+                section["5"]["frac_at_286_bytes_state_round_trip_per_step"] = r.get("frac_at_286_bytes_state_round_trip_per_step")
+        except Exception as e:  # the headline line must not be lost to a secondary measurement
+            section[str(oc)] = {"error": f"{type(e).__name__}: {e}"}
+    return section
+
+
+def main(argv=None, return_line=False):
     argv = sys.argv[1:] if argv is None else list(argv)
     args = parse_args(argv)
     in_group = "WORLD_SIZE" in os.environ and "RANK" in os.environ
@@ -437,10 +516,15 @@ def main(argv=None):
     if world > 1:
         import torch.distributed as dist
 
+        import datetime
+
+        # a collective that does not complete fails the rank (and with it the launcher) instead of hanging the box
+        timeout = datetime.timedelta(seconds=args.collective_timeout)
         if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)
+            dist.init_process_group(backend="nccl", device_id=dev, timeout=timeout)
         else:
-            dist.init_process_group(backend=args.backend)
+            dist.init_process_group(backend=args.backend, timeout=timeout)
+        group_info = describe_group(torch, dist, dev, world, rank, args)
     n = args.poses or {2: 1 << 20, 3: 1 << 18, 4: 1 << 20, 5: 4096}[cfg]
     gather_mode = args.gather if (world > 1 and cfg != 5) else "none"
     chunks = max(1, args.chunks) if gather_mode == "step" else 1
@@ -752,7 +836,7 @@ def main(argv=None):
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "launch": ("eager" if graph is None else "K replays of a hipGraph holding one pass (17 kernels on four streams)" if cfg == 5
+            "launch": ("eager" if graph is None else "K replays of a hipGraph holding one pass (21 kernels on four streams)" if cfg == 5
                        else "hipGraph replay of K captured launches"),
             "config": {"workload": workload, "poses_per_gpu": n,
                        "theta_policy": {2: "interval[0]", 3: "discrete sweep nb=64", 4: "interval[0]", 5: "continuous, d_theta_max=0.01"}[cfg],
@@ -789,10 +873,31 @@ def main(argv=None):
                          "frac": (recv / (gather_ms * 1e-3) / 1e9 / (links * XGMI_LINK_GBS)) if gather_ms > 0 else None},
                 "gathered_rows_checked": "checksum of every rank's rows against the solving rank's own checksum" if gather_mode != "none" else None,
             }
+            mg = line["multi_gpu"]
+            # like-for-like reference for the 1 -> N curve: ONE GPU's rate on this same config = its shard's kernel-only rate
+            # (at N = 1 this config has no collective); `--gpus 1` itself runs config 2.  No scaling curve has been measured by
+            # the builder (one GPU per lease): these are the figures to read the driver's curve with.
+            n1 = units / (kernel_ms * 1e-3)
+            mg["n1_same_config"] = {"solves_per_s": n1, "what": f"config {cfg} on one GPU = this run's kernel-only rate per GPU (max over ranks of the kernel time)"}
+            mg["scaling_efficiency_vs_n1_same_config"] = {"kernel_only": 1.0, "end_to_end": mg["end_to_end_solves_per_s"] / (n1 * world)}
+            if gather_mode != "none" and gather_ms > 0:
+                # north star: "all-gather ... only for the final joint array": K sharded steps, ONE all-gather of the last result
+                total_final_ms = kernel_ms * args.steps + gather_ms
+                mg["gather_final"] = {"ms_for_K_steps_plus_one_gather": total_final_ms, "solves_per_s": units * world * args.steps / (total_final_ms * 1e-3),
+                                      "one_all_gather_ms": gather_ms, "from": "the kernel-only and gather-only legs of this run"}
+                mg["gather_step"] = {"ms_per_step": kernel_ms + gather_ms if gather_mode != "step" else elapsed / args.steps * 1e3,
+                                     "solves_per_s": (value if gather_mode == "step" else units * world / ((kernel_ms + gather_ms) * 1e-3)),
+                                     "overlapped": gather_mode == "step"}
+            mg["group"] = group_info
         if cfg == 5:
             line["metric"] = "IK control steps/sec (ControlIK continuous, r_arm trajectories)"
             line["unit"] = "steps/s"
             line["roofline"]["kernel_ms"] = kernel_ms / 1000  # per control step (one launch walks the 1000 steps of a pass)
+            line["roofline"]["algorithmic_bytes_note"] = (
+                "154 B per trajectory-step = 96 (goal matrix) + 58 (joints, reachable, state): the trajectory state stays on chip "
+                "between the steps of a pass (SURVEY 8d's persistent-loop figure)")
+            line["roofline"]["frac_at_286_bytes_state_round_trip_per_step"] = (
+                BYTES_PER_STEP_STATE_ROUND_TRIP * units / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
 
         # ---- what bounds the kernel: counters committed with this build, live clock, cold-HBM run
         build_id = hs.build_id()
@@ -863,6 +968,10 @@ def main(argv=None):
             line["extras"] = extras
         if sample is not None:
             line["cpu_baseline"] = cpu_baseline(cfg, sample, args.cpu_seconds, gpu=gpu_rows)
+        if return_line:
+            return line
+        if world == 1 and args.config == 0 and not args.no_other_configs:
+            line["other_configs"] = other_configs_section(cfg)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

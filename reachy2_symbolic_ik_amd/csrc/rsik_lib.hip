@@ -387,9 +387,17 @@ __global__ __launch_bounds__(kBlock, RSIK_SOLVE_MIN_WAVES) void solve_kernel(con
 //   - the pitch is within ~1e-5 of +-pi/2 (inside 1e-7 of the lock SciPy sets yaw := 0, which moves the joints by up
 //     to ~4e-6 rad: measured on the G8 goldens).
 // mode (RSIK_OPT_EULER_ROUNDTRIP): 0 = as above, 1 = always, 2 = never.
-__device__ __forceinline__ void goal_from_m12(const double (&m)[12], Rot& Rg, V3& pos, int mode) {
+// `special` (optional): set when the matrix did not go through as it came — the identity shortcut, the Euler round trip —
+// or is not a proper rotation whose third row is the cross product of the other two: the trajectory pipeline's joints
+// phase re-reads all twelve entries only for those (cont_joints_kernel).
+__device__ __forceinline__ void goal_from_m12(const double (&m)[12], Rot& Rg, V3& pos, int mode, bool* special = nullptr) {
 #pragma unroll
     for (int k = 0; k < 9; k++) Rg.m[k] = m[k];
+    if (special) {
+        // row 2 against row 0 x row 1, entry by entry (1e-9: far above rounding, far below anything the solver resolves)
+        const double c6 = fma(m[1], m[5], -(m[2] * m[4])), c7 = fma(m[2], m[3], -(m[0] * m[5])), c8 = fma(m[0], m[4], -(m[1] * m[3]));
+        *special = !(fabs(c6 - m[6]) <= 1e-9 && fabs(c7 - m[7]) <= 1e-9 && fabs(c8 - m[8]) <= 1e-9);
+    }
     // np.allclose(R, I) needs all nine entries close; R00 alone rules it out for nearly every goal
     bool eye = RSIK_RARE(np_isclose(Rg.m[0], 1.0));
     if (eye) {
@@ -397,11 +405,13 @@ __device__ __forceinline__ void goal_from_m12(const double (&m)[12], Rot& Rg, V3
         for (int k = 1; k < 9; k++) eye = eye && np_isclose(Rg.m[k], (k % 4 == 0) ? 1.0 : 0.0);
     }
     if (eye) {  // C:212-214 np.allclose(R, I)
+        if (special) *special = true;
 #pragma unroll
         for (int k = 0; k < 9; k++) Rg.m[k] = (k % 4 == 0) ? 1.0 : 0.0;
     } else {
         bool rt = mode == 1;
         if (mode == 0) rt = (fabs(Rg.m[6]) > 1.0 - 1e-10) || !gram_is_identity(Rg.m);
+        if (special && rt) *special = true;
         if (RSIK_RARE(rt)) {
             double eul[3];
             euler_xyz_from_matrix(Rg.m, eul);
@@ -913,7 +923,8 @@ __global__ __launch_bounds__(kBlock) void control_continuous_kernel(const Contin
 // rsik_control_continuous_run: the phased trajectory pipeline (include/rsik.h).  Workspace of one block of T steps:
 //   ws[t][n] doubles  the step's goal for the theta recurrence (phase 1) -> the step's theta (phase 2)
 //   flags[t][n] bytes bit 0 is_reachable succeeded, bit 1 the grid search found a theta; (phase 3) bit 2: get_joints hit an
-//                     exact singularity and needs previous_sol (recomputed in phase 4)
+//                     exact singularity and needs previous_sol (recomputed in phase 4); bit 3: the goal matrix is not a
+//                     plain proper rotation (goal_from_m12's `special`): phase 3 reads all of it
 // Nothing else travels between the phases: the pipeline is bound by HBM traffic, not by arithmetic, so the joint phase
 // re-derives the circle it needs from the goal matrix (the geometric half of is_reachable, ~150 instructions) instead
 // of reading 22 doubles per trajectory-step that the prepare phase would have to write (652 -> 400 B per step).
@@ -924,7 +935,7 @@ __global__ __launch_bounds__(kBlock) void control_continuous_kernel(const Contin
 #define RSIK_THETA_BATCH 16
 #endif
 #ifndef RSIK_CHAIN_BATCH
-#define RSIK_CHAIN_BATCH 8   // chunks of the joints phase whose first / last rows the chain phase fetches at once
+#define RSIK_CHAIN_BATCH 16  // chunks of the joints phase whose first / last rows the chain phase fetches at once
 #endif
 constexpr int kThetaBatch = RSIK_THETA_BATCH, kChainBatch = RSIK_CHAIN_BATCH;
 // consecutive steps of a trajectory that one thread of the joints phase walks (and that the chain phase accepts or redoes as
@@ -996,7 +1007,8 @@ __global__ __launch_bounds__(kBlock) void cont_prepare_kernel(const ContRunArgs 
     const int slot = MIXED ? (A.isl ? 1 : 0) : 0;
     Rot Rg;
     V3 pos;
-    goal_from_m12(m, Rg, pos, K.euler_roundtrip);
+    bool special;
+    goal_from_m12(m, Rg, pos, K.euler_roundtrip, &special);
     const Goal G = make_goal(A, Rg);
     Reach r;
     const ThetaTarget T = continuous_target<PLANE, false>(A, pos, G.woff, K.pref_self[slot], K.pref_self_cs[slot], K.pref_self_sn[slot], r);
@@ -1008,7 +1020,7 @@ __global__ __launch_bounds__(kBlock) void cont_prepare_kernel(const ContRunArgs 
     // what limit_theta_to_interval makes of theta = goal before it looks at the interval (U:93-97): this phase has the
     // issue slots for it, the theta phase (a lone wave per SIMD) has not
     K.gw[t * K.n + i] = wrap_theta_to_pi(goal);
-    K.flags[t * K.n + i] = (uint8_t)((T.ok_limits ? 1 : 0) | (T.found ? 2 : 0));
+    K.flags[t * K.n + i] = (uint8_t)((T.ok_limits ? 1 : 0) | (T.found ? 2 : 0) | (special ? 8 : 0));
     if (K.state) K.state[(K.t0 + t) * K.n + i] = (uint8_t)T.code;
     if (K.reachable) K.reachable[(K.t0 + t) * K.n + i] = (T.ok_limits && T.found) ? 1 : 0;
 }
@@ -1126,11 +1138,19 @@ __global__ __launch_bounds__(kThetaBlock) __attribute__((amdgpu_waves_per_eu(1, 
 // What get_joints reads of a step (S:697-863), re-derived from the step's goal matrix: the goal vectors and the circle
 // is_reachable (flag bit 0 set) or is_reachable_no_limits (clear; C:371) left on the solver — the same device code the
 // step kernel runs, so the joints are the same to the last bit.  `m`: the step's twelve matrix entries.
+// `plain`: the prepare phase found the matrix a plain proper rotation (no identity shortcut, no Euler round trip): taken as it is.
 template <class Acc>
-__device__ __forceinline__ void step_geometry(const Acc& A, const double (&m)[12], int euler_roundtrip, bool no_limits, Reach& r, Goal& G) {
+__device__ __forceinline__ void step_geometry(const Acc& A, const double (&m)[12], int euler_roundtrip, bool no_limits, Reach& r, Goal& G,
+                                              bool plain = false) {
     Rot Rg;
     V3 pos;
-    goal_from_m12(m, Rg, pos, euler_roundtrip);
+    if (plain) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) Rg.m[k] = m[k];
+        pos = {m[9], m[10], m[11]};
+    } else {
+        goal_from_m12(m, Rg, pos, euler_roundtrip);
+    }
     G = make_goal(A, Rg);
     r = reach_impl<false, true>(A, pos, G.woff, no_limits);
 }
@@ -1185,73 +1205,112 @@ __global__ __launch_bounds__(kBlock) void cont_joints_kernel(const ContRunArgs K
     const bool live = i < n && t < K.T;
     const int64_t ii = i < n ? i : (n - 1);
     const int64_t tt = t < K.T ? t : (K.T - 1);
-    double m[12];  // loads first: their latency overlaps the table staging
-    load_step_m12(K, tt, ii, m);
+    // loads first: their latency overlaps the table staging.  Of the goal matrix the first two rows of the rotation and
+    // the translation: for a proper rotation, which the prepare phase has checked (flag bit 3 clear), the third row is their
+    // cross product — to 1e-16, the rounding of the entries themselves — and 24 of the 161 bytes this phase moves per step
+    // need not be read.
+    double m[12];
+    {
+        const double* src = K.m12_steps + (K.t0 + tt) * 12 * n + ii;
+#pragma unroll
+        for (int k = 0; k < 6; k++) m[k] = src[k * n];
+#pragma unroll
+        for (int k = 9; k < 12; k++) m[k] = src[k * n];
+    }
     const double theta = RSIK_WS(K, tt, ii);
     const int flag = K.flags[tt * n + ii];
+    const bool special = (flag & 8) != 0;
+    if (RSIK_RARE(special)) {
+        const double* src = K.m12_steps + (K.t0 + tt) * 12 * n + ii;
+#pragma unroll
+        for (int k = 6; k < 9; k++) m[k] = src[k * n];
+    } else {
+        m[6] = fma(m[1], m[5], -(m[2] * m[4]));
+        m[7] = fma(m[2], m[3], -(m[0] * m[5]));
+        m[8] = fma(m[0], m[4], -(m[1] * m[3]));
+    }
     const bool lane_isl = MIXED ? (K.arm[ii] != 0) : false;
     __shared__ SharedTables lds_tab;
         stage_tables<MIXED, (int)offsetof(ContRunArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>(lds_tab, K.arms);
     const Acc<MIXED> A = make_acc<MIXED>(K.arms, lane_isl, lds_tab);
     Reach r;
     Goal G;
-    step_geometry(A, m, K.euler_roundtrip, (flag & 1) == 0, r, G);
+    step_geometry(A, m, K.euler_roundtrip, (flag & 1) == 0, r, G, !special);
     const double zeros[7] = {0, 0, 0, 0, 0, 0, 0};
     double jv[7];
     bool sing;
     step_joints(A, K, r, G, theta, zeros, jv, sing);
-    // whole turns of this step relative to the step before it (none for the chunk's first step), packed as biased
-    // bytes (turn + 8 in 0..16; eight of them add up without a carry) in two words for the prefix sum over the chunk
-    bool ev = sing;
-    unsigned lo = 0, hi = 0;
-    double praw[7];
+    // Steps relative to the step before (lane - 8; none for the chunk's first step, which phase 4 judges).  Whole turns
+    // only for the four joints whose raw angle has a branch cut to cross — shoulder pitch, elbow yaw, wrist roll, wrist yaw
+    // (atan2 values, S:751-786, 815-848 / U:508-519); shoulder roll is atan2(q_y, q_x >= 0), elbow pitch is clamped to
+    // +-elbow_limit < pi (S:853-861) and wrist pitch is an asin (U:517), whatever the arm's geometry: for those a turn
+    // could only be part of a step beyond the continuity thresholds, which is an event either way.
+    const int below = (sl == 0 ? lane : lane - 8) << 2;
+    auto from_below = [&](double v) {
+        const int lo_ = __builtin_amdgcn_ds_bpermute(below, (int)__double2loint(v));
+        const int hi_ = __builtin_amdgcn_ds_bpermute(below, (int)__double2hiint(v));
+        return __hiloint2double(hi_, lo_);
+    };
+    double worst_a = 0.0, worst_b = 0.0;  // largest |step| among joints 0-3 (threshold 0.5) and 4-6 (1.0), C:398
+    double packed = 0.0;                   // (8 + turn) of joints 6, 4, 2, 0 as base-256 digits: eight of them add up without a carry
+    double turn[7];
 #pragma unroll
-    for (int k = 0; k < 7; k++) {
-        const double below = __shfl_up(jv[k], 8);
-        praw[k] = sl == 0 ? jv[k] : below;
+    for (int k = 6; k >= 0; k--) {
+        const double d = jv[k] - from_below(jv[k]);
+        double x = d;
+        if (k == 0 || k == 2 || k == 4 || k == 6) {
+            const double r = rint(d * 0.15915494309189535);
+            x = fma(-r, kTwoPi, d);
+            packed = fma(packed, 256.0, 8.0 - r);
+        }
+        if (k < 4) worst_a = __builtin_fmax(worst_a, fabs(x));
+        else worst_b = __builtin_fmax(worst_b, fabs(x));
     }
-#pragma unroll
-    for (int k = 0; k < 7; k++) {
-        const double d = jv[k] - praw[k];
-        const bool known = fabs(d) < 128.0;  // (false for NaN: a singular step here or below)
-        const double turn = known ? -rint(d * 0.15915494309189535) : 0.0;
-        // the chunk's first step is judged by phase 4, which knows the step before it
-        if (sl > 0) ev = ev || !(fabs(fma(turn, kTwoPi, d)) <= (k < 4 ? 0.5 - 1e-9 : 1.0 - 1e-9));
-        ev = ev || !(fabs(turn) <= 8.0);
-        const unsigned b = (unsigned)((int)fmin(fmax(turn, -8.0), 8.0) + 8);
-        if (k < 4) lo |= b << (8 * k);
-        else hi |= b << (8 * (k - 4));
-    }
+    // a singular step (NaN joints, here or in the lane below) is an event too: fmax drops NaNs, so it is told by the flags
+    const unsigned long long sing_mask = __ballot(sing);
+    const bool sing_below = sl > 0 && ((sing_mask >> (lane - 8)) & 1ull) != 0;
+    const bool ev = sing || sing_below || !(worst_a <= 0.5 - 1e-9) || !(worst_b <= 1.0 - 1e-9) || !(fabs(packed) < 4.0e9);
+    unsigned word = (unsigned)packed;  // (garbage for a NaN: the chunk is an event then)
 #pragma unroll
     for (int step = 1; step < 8; step *= 2) {  // inclusive prefix sum over the chunk's steps (lane stride 8)
-        const unsigned plo = __shfl_up(lo, 8 * step), phi = __shfl_up(hi, 8 * step);
-        if (sl >= step) { lo += plo; hi += phi; }
+        const unsigned w = (unsigned)__builtin_amdgcn_ds_bpermute((lane - 8 * step) << 2, (int)word);
+        if (sl >= step) word += w;
+    }
+#pragma unroll
+    for (int k = 0; k < 7; k++) turn[k] = 0.0;
+    {
+        const int bias = 8 * (sl + 1);
+        turn[0] = (double)((int)(word & 0xffu) - bias);
+        turn[2] = (double)((int)((word >> 8) & 0xffu) - bias);
+        turn[4] = (double)((int)((word >> 16) & 0xffu) - bias);
+        turn[6] = (double)((int)(word >> 24) - bias);
     }
     double out[7];
 #pragma unroll
     for (int k = 0; k < 7; k++) {
-        const int field = (int)(((k < 4 ? lo >> (8 * k) : hi >> (8 * (k - 4))) & 0xffu)) - 8 * (sl + 1);
-        const double o = fma((double)field, kTwoPi, jv[k]);
+        const double o = (k == 0 || k == 2 || k == 4 || k == 6) ? fma(turn[k], kTwoPi, jv[k]) : jv[k];
         out[k] = sing ? __builtin_nan("") : o;  // (singular: needs previous_sol, phase 4 recomputes the step — flag bit 2)
     }
     if (live && sing) K.flags[t * n + i] = (uint8_t)(flag | 4);
     // one event byte per (chunk, trajectory): OR over the chunk's steps
     const unsigned long long evm = __ballot(ev && live);
     if (live && sl == 0) K.chunk_event[c * n + i] = ((evm >> tl) & 0x0101010101010101ull) != 0 ? 1 : 0;
-    // rows out: the wave's 64 rows are 8 runs (one per step) of 8 x 7 consecutive doubles
+    // rows out: the wave's 64 rows are 8 runs (one per step) of 8 x 7 consecutive doubles; 32-bit offsets from the chunk's
+    // first row (a block's joints stay below 2 GB, see rsik_control_continuous_run)
     double* lw = lds_out[wave];
 #pragma unroll
     for (int k = 0; k < 7; k++) lw[lane * 7 + k] = out[k];
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
-    const int64_t traj_left = n - grp * 8;  // trajectories of this group that exist (>= 1 for a launched wave, maybe <= 0 past the end)
-    double* const base = K.joints + ((K.t0 + c * kJointChunk) * n + grp * 8) * 7;
+    const int traj_left = (int)((n - grp * 8) < 8 ? (n - grp * 8) : 8);  // trajectories of this group that exist (<= 0 past the end)
+    const int steps_left = (int)((K.T - c * kJointChunk) < kJointChunk ? (K.T - c * kJointChunk) : kJointChunk);
+    const __amdgpu_buffer_rsrc_t obuf = row_buffer(K.joints + ((K.t0 + c * kJointChunk) * n + grp * 8) * 7);
+    const unsigned row_bytes = (unsigned)(n * 7 * sizeof(double));
 #pragma unroll
     for (int k = 0; k < 7; k++) {
         const int idx = k * 64 + lane;
         const int s_ = idx / 56, off = idx - s_ * 56;
-        const bool ok = (c * kJointChunk + s_ < K.T) && (off < traj_left * 7);
-        if (ok) st_stream(base + (int64_t)s_ * n * 7 + off, lw[idx]);
+        if (s_ < steps_left && off < traj_left * 7) st_row_f64(obuf, (unsigned)s_ * row_bytes + (unsigned)off * 8u, 0, lw[idx]);
     }
 }
 
@@ -1446,8 +1505,9 @@ __global__ __launch_bounds__(kChainBlock) __attribute__((amdgpu_waves_per_eu(1, 
     }
 }
 
-// phase 5: adds the whole turns phase 4 found (chunk_turns) to the chunk's rows: one thread per (trajectory, chunk), nearly
-// all of which find eight zero bytes and leave.
+// phase 5: adds the whole turns phase 4 found (chunk_turns) to the chunk's rows: one thread per (chunk, trajectory), most of
+// which find eight zero bytes and leave; the others read the elements of every joint that turns (all at once: one memory
+// round trip), add and write them back.
 __global__ __launch_bounds__(kBlock) void cont_turns_kernel(const ContRunArgs K) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t c = blockIdx.y;
@@ -1456,18 +1516,24 @@ __global__ __launch_bounds__(kBlock) void cont_turns_kernel(const ContRunArgs K)
     if (packed == 0) return;
     const int64_t t_begin = c * kJointChunk;
     const int len = (int)((K.T - t_begin) < kJointChunk ? (K.T - t_begin) : kJointChunk);
+    double* const p = K.joints + ((K.t0 + t_begin) * K.n + i) * 7;
+    const int64_t row = K.n * 7;
+    double v[7][kJointChunk];
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        if (((packed >> (8 * k)) & 0xff) != 0) {
+#pragma unroll
+            for (int q = 0; q < kJointChunk; q++) v[k][q] = p[(int64_t)(q < len ? q : len - 1) * row + k];
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 7; k++) {
         const int turns = (int)(int8_t)((packed >> (8 * k)) & 0xff);
         if (turns != 0) {
             const double sh = (double)turns * kTwoPi;
-            double* p = K.joints + ((K.t0 + t_begin) * K.n + i) * 7 + k;
-            double v[kJointChunk];
-#pragma unroll
-            for (int q = 0; q < kJointChunk; q++) v[q] = p[(int64_t)(q < len ? q : len - 1) * K.n * 7];
 #pragma unroll
             for (int q = 0; q < kJointChunk; q++)
-                if (q < len) p[(int64_t)q * K.n * 7] = v[q] + sh;
+                if (q < len) p[(int64_t)q * row + k] = v[k][q] + sh;
         }
     }
 }
@@ -2228,12 +2294,12 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     // got slower, 2.4 ms per pass.)
     // A run is cut into blocks of steps; four workspace slots are in flight (block b + 4 reuses the slot of block b once
     // chain(b) has finished).
-    constexpr int kSlots = 4;
-    // (the sequential phases address a block's arrays through 2 GB buffer windows: rows of n * 56 bytes, blocks of <= 128 MB
-    // of workspace, i.e. <= 442 MB of joints)
+    constexpr int kSlots = 8;
+    // (the sequential phases address a block's arrays through 2 GB buffer windows: rows of n * 56 bytes, blocks of <= 384 MB
+    // of workspace, i.e. <= 1.3 GB of joints; every block costs the host five launches, so blocks are as long as that allows)
     if (n > (int64_t)30 << 20) return fail(ctx, RSIK_E_INVALID, std::string(who) + ": more than 30 Mi trajectories in one call");
     const size_t per_step = (size_t)n * (2 * sizeof(double) + 1);
-    int64_t T_max = (int64_t)((size_t)128 << 20) / (int64_t)per_step;
+    int64_t T_max = (int64_t)((size_t)384 << 20) / (int64_t)per_step;
     if (T_max < 1) T_max = 1;
     if (T_max > 65535) T_max = 65535;  // gridDim.y
     // block size: a quarter of the run (the phases of neighbouring blocks overlap: more blocks, shorter fill and drain;
@@ -2265,7 +2331,7 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         for (auto& st : ctx->side) RSIK_HIP(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         ctx->have_side = true;
     }
-    const size_t n_events = 2 + 4 * (size_t)n_blocks;
+    const size_t n_events = 2 + 5 * (size_t)n_blocks;
     while (ctx->events.size() < n_events) {
         hipEvent_t e;
         // (hipEventReleaseToDevice / hipEventDisableSystemFence measured: 0.443 / 0.428 against 0.429-0.439 ms per pass — the
@@ -2274,7 +2340,7 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         ctx->events.push_back(e);
     }
     hipStream_t s_main = ctx->stream, s_theta = ctx->stream, s_prep = ctx->side[0], s_joints = ctx->side[1], s_chain = ctx->side[2];
-    auto ev = [&](int kind, int64_t b) { return ctx->events[2 + 4 * (size_t)b + kind]; };  // 0 prepared, 1 theta, 2 joints, 3 chain (+ turns)
+    auto ev = [&](int kind, int64_t b) { return ctx->events[2 + 5 * (size_t)b + kind]; };  // 0 prepared, 1 theta, 2 joints, 3 chain, 4 turns
     // (Re)initialisation of the trajectories that start here (C:296-325: the start-up search for previous_theta, ~55 us
     // of lone waves), then the pipeline's streams join in.  The prepare phase depends on the goal matrices alone, not on
     // the trajectory state: its stream forks off BEFORE the initialisation (behind whatever the caller queued ahead of
@@ -2335,7 +2401,7 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     auto issue_front = [&](int64_t b) -> int {  // prepare(b), theta(b)
         set_block(b);
         const dim3 grid2(grid.x, (unsigned)R.T);
-        if (b >= slots) RSIK_HIP(ctx, hipStreamWaitEvent(s_prep, ev(3, b - slots), 0));  // the slot's previous block is done
+        if (b >= slots) RSIK_HIP(ctx, hipStreamWaitEvent(s_prep, ev(4, b - slots), 0));  // the slot's previous block is done
         if (arm) { if (plane_binds) hipLaunchKernelGGL((rsik::cont_prepare_kernel<true, true>), grid2, block, 0, s_prep, R); else hipLaunchKernelGGL((rsik::cont_prepare_kernel<true, false>), grid2, block, 0, s_prep, R); }
         else { if (plane_binds) hipLaunchKernelGGL((rsik::cont_prepare_kernel<false, true>), grid2, block, 0, s_prep, R); else hipLaunchKernelGGL((rsik::cont_prepare_kernel<false, false>), grid2, block, 0, s_prep, R); }
         RSIK_HIP(ctx, hipEventRecord(ev(0, b), s_prep));
@@ -2359,8 +2425,14 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         RSIK_HIP(ctx, hipStreamWaitEvent(s_chain, ev(2, b), 0));
         if (arm) hipLaunchKernelGGL(rsik::cont_chain_kernel<true>, grid8, dim3(rsik::kChainBlock), 0, s_chain, R);
         else hipLaunchKernelGGL(rsik::cont_chain_kernel<false>, grid8, dim3(rsik::kChainBlock), 0, s_chain, R);
-        hipLaunchKernelGGL(rsik::cont_turns_kernel, dim3(grid.x, (unsigned)((R.T + rsik::kJointChunk - 1) / rsik::kJointChunk)), block, 0, s_chain, R);
         RSIK_HIP(ctx, hipEventRecord(ev(3, b), s_chain));
+        // phase 5 is independent parallel work behind chain(b): on the prepare stream where no prepare launch will be issued
+        // after it (every block of a run that has a workspace slot per block, else the last block only: a prepare must not
+        // queue behind it), so that the chain stream goes straight on to chain(b + 1); otherwise on the chain stream
+        hipStream_t s_turns = (n_blocks <= slots || b == n_blocks - 1) ? s_prep : s_chain;
+        if (s_turns != s_chain) RSIK_HIP(ctx, hipStreamWaitEvent(s_turns, ev(3, b), 0));
+        hipLaunchKernelGGL(rsik::cont_turns_kernel, dim3(grid.x, (unsigned)((R.T + rsik::kJointChunk - 1) / rsik::kJointChunk)), block, 0, s_turns, R);
+        RSIK_HIP(ctx, hipEventRecord(ev(4, b), s_turns));
         return RSIK_OK;
     };
     const int64_t head = n_blocks < slots ? n_blocks : slots;
@@ -2374,6 +2446,7 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     }
     // the caller's stream continues once the last chain (hence every phase of every block) is done
     RSIK_HIP(ctx, hipStreamWaitEvent(s_main, ev(3, n_blocks - 1), 0));
+    RSIK_HIP(ctx, hipStreamWaitEvent(s_main, ev(4, n_blocks - 1), 0));  // (the turns kernels of one stream run in order)
     RSIK_HIP(ctx, hipGetLastError());
     return RSIK_OK;
 }

@@ -18,7 +18,7 @@ traj = bench.make_config5_trajectories(n, n_steps, seed=20250204, device=0)
 ctrl = bench._quiet(ControlIK, urdf_path=bench.URDF, device=0)
 cont0 = ctrl.new_continuous_state("r_arm", n)
 ref = None
-for blk in [0, 64, 128, 192, 256, 352, 512, 1000, 0]:
+for blk in [int(b) for b in os.environ.get("C5_BLOCKS", "0,64,128,192,256,352,512,1000,0").split(",")]:
     ctrl._solver.set_option(_abi.OPT_CONT_BLOCK_STEPS, blk)
     out = {"joints": torch.empty((n_steps, n, 7), dtype=torch.float64, device="cuda"),
            "reachable": torch.empty((n_steps, n), dtype=torch.uint8, device="cuda"),

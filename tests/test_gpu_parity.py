@@ -821,11 +821,13 @@ def test_continuous_run_replayed_from_a_graph(torch_mod):
     assert torch_mod.equal(ref["cont_state"].view(torch_mod.uint8), st.view(torch_mod.uint8))
 
 
-def _same_run(torch, ref, got, tag, joint_tol=1e-12):
+def _same_run(torch, ref, got, tag, joint_tol=1e-10):
     """Two runs of the same trajectories (pipeline vs step kernel, or two block sizes of the pipeline): flags, state codes,
     the carried theta (row 0 of the trajectory state) and its flag rows bit for bit; joints and previous_sol to
-    `joint_tol`.  (The pipeline's joints phase takes the first step of each of its chunks relative to previous_sol at the
-    block's entry instead of the step before: the same turn of the same angle, its last bit free; no accumulation.)"""
+    `joint_tol`.  (The pipeline's joints phase writes a quiet step as raw joint + whole turns instead of previous +
+    angle_diff(raw, previous) and rebuilds the goal rotation's third row from the other two: both within the last bit of
+    their inputs, no accumulation — but where the arm is stretched out the elbow-yaw / wrist-yaw split amplifies a last bit
+    2e4 times (see test_control_continuous_golden_default_start), hence 1e-10 and not 1e-14.)"""
     for k in ref:
         a, b = ref[k], got[k]
         if k == "joints":
