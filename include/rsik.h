@@ -18,6 +18,10 @@
  *     by the caller unless the name ends in `_host`.  The library never frees or retains them.
  *   - Work is enqueued on the context's HIP stream (rsik_set_stream) and is asynchronous;
  *     rsik_sync waits for it.
+ *   - Threads: a context is NOT thread-safe (it holds the stream, the arm constants, the options and the
+ *     continuous pipeline's workspace that the next call uses; the reference's objects are not re-entrant either,
+ *     symbolic_ik.py:143-144,185).  Use it from one thread at a time; several contexts — one per thread, per stream or
+ *     per GPU — are independent and may be used concurrently.
  *   - Angles in radians, lengths in metres, everything IEEE float64.
  *   - Rows of unreachable poses in joints / interval / elbow are filled with NaN.
  */
@@ -31,7 +35,7 @@
 extern "C" {
 #endif
 
-#define RSIK_ABI_VERSION 3
+#define RSIK_ABI_VERSION 4
 
 /* ---- status codes ---- */
 #define RSIK_OK 0
@@ -257,24 +261,33 @@ int rsik_control_continuous_step(rsik_ctx *ctx, int64_t n, const double *const m
 
 /*
  * rsik_control_continuous_run — n_steps consecutive control steps of n trajectories from one host call (the whole
- * trajectory batch resident in HBM).  The result equals n_steps calls of rsik_control_continuous_step, but the work is
- * not done step by step: most of a control step does not depend on the previous one — the goal conversion,
- * is_reachable / is_reachable_no_limits and the 10-point search for the target theta (control_ik.py:327-388 up to the
- * rate limiter) are functions of the pose alone — so the batch is solved in four phases per block of steps:
+ * trajectory batch resident in HBM).  The result equals n_steps calls of rsik_control_continuous_step (flags, state
+ * codes and the carried theta bit for bit, joints to the last bits: see phase 3), but the work is not done step by
+ * step: most of a control step does not depend on the previous one — the goal conversion, is_reachable /
+ * is_reachable_no_limits and the 10-point search for the target theta (control_ik.py:327-388 up to the rate limiter)
+ * are functions of the pose alone — so the batch is solved in five phases per block of steps:
  *   1. prepare   one thread per (step, trajectory), chip-filling: is_reachable + the search for the target theta; the
  *                step's goal for the rate limiter (the search's theta / the preferred theta / "stay") -> workspace
  *   2. theta     one thread per trajectory, sequential over steps: the d_theta_max rate limiter and
  *                limit_theta_to_interval (the only recurrence on previous_theta)
- *   3. joints    one thread per (step, trajectory): the circle of is_reachable / is_reachable_no_limits re-derived from
- *                the goal matrix, get_joints at the limited theta + the Orbita3D cone clamp
- *   4. chain     eight lanes per trajectory (one per joint), sequential over steps: allow_multiturn, the +-6 pi clamp,
- *                continuity_check and the emergency latch (the recurrence on previous_sol); steps whose get_joints
- *                hit an exact singularity (fallback to previous_sol[0] / [2]) are recomputed here
+ *   3. joints    one thread per (step, trajectory), a wave = 8 consecutive steps of 8 trajectories: the circle of
+ *                is_reachable / is_reachable_no_limits re-derived from the goal matrix, get_joints at the limited theta,
+ *                the Orbita3D cone clamp, and allow_multiturn INSIDE the 8-step chunk (whole turns relative to the step
+ *                before, a shuffle prefix sum); continuity / limit / singularity events are detected, not decided
+ *   4. chain     eight lanes per trajectory (one per joint), sequential over CHUNKS: checks each chunk's first step
+ *                against previous_sol (continuity_check, the +-6 pi clamp, the emergency latch) and finds the whole
+ *                turns the chunk sits away from it; only a chunk with an event is walked step by step with the
+ *                reference's own sequence of operations (also: steps whose get_joints hit an exact singularity)
+ *   5. turns     adds those whole turns to the rows of the chunks that need them
  * The phases of neighbouring blocks overlap on four streams (the caller's and three of the context's).  The workspace
- * (two doubles + one byte per step and trajectory of the four blocks in flight), the side streams and the events
- * belong to the context and are created on first use: a call can be captured into a hipGraph once a call of the same
- * shape has run (the side streams join the capture through the events the call records).  At most 30 Mi trajectories
- * per call.  4096 trajectories x 1000 steps: see DESIGN.md section 4.
+ * (17 bytes per step and trajectory + 9 per 8-step chunk, of up to eight blocks in flight), the side streams and the
+ * events belong to the context: they are created by the first call that needs them, or ahead of time by
+ * rsik_control_continuous_reserve.  A call can be captured into a hipGraph (the side streams join the capture through
+ * the events the call records) provided it has nothing to create: reserve first, or run a call of at least that size
+ * first — otherwise the call fails with RSIK_E_INVALID instead of allocating inside the capture.  A captured graph
+ * stays valid after later, larger calls (an outgrown workspace is kept until rsik_destroy).  A solver whose
+ * projection_margin is not positive (RSIK_STATE_NOT_REACHABLE_NO_LIMITS possible) is run step by step.  At most 30 Mi
+ * trajectories per call.  4096 trajectories x 1000 steps: see DESIGN.md section 4.
  *   m12_steps        device [n_steps][12][n]: the goal matrices of every step
  *   current_pose_m12_soa / current_joints   used by the first step only (see rsik_control_continuous_step)
  *   first_step_timed_out  non-zero: every trajectory (re)initialises on the first step (the reference's behaviour for
@@ -287,6 +300,13 @@ int rsik_control_continuous_run(rsik_ctx *ctx, int64_t n, int64_t n_steps, const
                                 int constrained_mode, double d_theta_max, const double *current_joints,
                                 double orbita3d_max_angle, double *cont_state, double *joints_steps,
                                 uint8_t *reachable_steps, uint8_t *state_steps);
+
+/*
+ * rsik_control_continuous_reserve — creates what rsik_control_continuous_run(n, n_steps) would create on first use
+ * (workspace, side streams, events), so that the run itself allocates nothing: call it before capturing such a run into
+ * a hipGraph on a context that has not yet run one of that size.  Uses RSIK_OPT_CONT_BLOCK_STEPS as set at the time.
+ */
+int rsik_control_continuous_reserve(rsik_ctx *ctx, int64_t n, int64_t n_steps);
 
 /*
  * Solver-state entry points: the scalar drop-in API.  A SymbolicIK object keeps self.goal_pose,

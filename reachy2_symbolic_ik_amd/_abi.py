@@ -24,7 +24,7 @@ def use_library(path: str) -> None:
     LIB_PATH = os.path.abspath(path)
 
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 RSIK_OK = 0
 RSIK_E_INVALID, RSIK_E_NO_DEVICE, RSIK_E_HIP, RSIK_E_NOT_SET = -1, -2, -3, -4
 
@@ -61,6 +61,7 @@ PROTOTYPES = {
                                                C.c_int, C.c_double, _vp, C.c_double, _vp, _vp, _vp, _vp]),
     "rsik_control_continuous_run": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp, C.POINTER(_vp), _vp, C.c_int, C.c_int, C.c_double, _dp,
                                               C.c_int, C.c_double, _vp, C.c_double, _vp, _vp, _vp, _vp]),
+    "rsik_control_continuous_reserve": (C.c_int, [_vp, C.c_int64, C.c_int64]),
     "rsik_reach_state": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp), _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "rsik_joints_from_state": (C.c_int, [_vp, C.c_int64, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     "rsik_elbow_from_state": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp]),

@@ -77,7 +77,17 @@ class HipSolver:
         self._arm_gen += 1
 
     def synchronize(self) -> None:
-        self._check(self.lib.rsik_sync(self._h))
+        """Waits for the work on the CURRENT torch stream of this device (the stream every non-planned call uses)."""
+        with torch.cuda.device(self.device):
+            self._bind_stream()  # (a planned launch may have left the context on another, possibly destroyed, stream)
+            self._check(self.lib.rsik_sync(self._h))
+
+    def control_continuous_reserve(self, n: int, n_steps: int) -> None:
+        """rsik_control_continuous_reserve: workspace, side streams and events of a control_continuous_run(n, n_steps), so
+        that the run allocates nothing — needed before such a run is captured into a hipGraph on a fresh context."""
+        with torch.cuda.device(self.device):
+            self._bind_stream()
+            self._check(self.lib.rsik_control_continuous_reserve(self._h, int(n), int(n_steps)))
 
     # ------------------------------------------------------------------ checks
     def _dev_f64(self, t: torch.Tensor, shape: Sequence[int], name: str) -> torch.Tensor:
@@ -197,6 +207,8 @@ class HipSolver:
                 raise RuntimeError("HipSolver.plan: the arm constants were changed after this launch was planned")
             set_stream(h, planned if stream is None else C.c_void_p(stream))
             rc = fn(h, *args)
+            if stream is not None:  # a caller's (capture) stream may not outlive the call: never leave the context on it
+                set_stream(h, planned)
             if rc != _abi.RSIK_OK:
                 check(rc)
 
@@ -318,8 +330,9 @@ class HipSolver:
         orbita3d_max_angle: float = float(np.deg2rad(42.5)),
         out: Optional[Dict[str, torch.Tensor]] = None,
     ) -> Dict[str, torch.Tensor]:
-        """m12_steps: [n_steps, 12, n] float64 on the device.  Runs every step (one launch each, issued from C) and
-        returns joints [n_steps, n, 7], reachable / state [n_steps, n]; `cont_state` is updated in place."""
+        """m12_steps: [n_steps, 12, n] float64 on the device.  All steps of all trajectories from one C call (the phased
+        trajectory pipeline of rsik_control_continuous_run, or a launch of the step kernel per control step under
+        RSIK_CONT_RUN_STEPS); returns joints [n_steps, n, 7], reachable / state [n_steps, n]; `cont_state` is updated in place."""
         if m12_steps.dim() != 3 or m12_steps.shape[1] != 12:
             raise ValueError("m12_steps must have shape [n_steps, 12, n]")
         n_steps, _, n = (int(v) for v in m12_steps.shape)

@@ -1807,6 +1807,7 @@ struct rsik_ctx {
     int options[RSIK_OPT_COUNT];
     void* ws;          // workspace of rsik_control_continuous_run's phased pipeline (device), grown on demand
     size_t ws_bytes;
+    std::vector<void*> retired_ws;   // outgrown workspaces: kept until rsik_destroy (a captured hipGraph may still point into them)
     hipStream_t side[3];             // the pipeline's own streams (prepare / joints / chain), created on first use
     std::vector<hipEvent_t> events;  // reusable, timing disabled
     bool have_side;
@@ -1868,6 +1869,7 @@ int rsik_create(int device_id, rsik_ctx** out) {
 int rsik_destroy(rsik_ctx* ctx) {
     if (ctx && hipSetDevice(ctx->device) == hipSuccess) {
         if (ctx->ws) (void)hipFree(ctx->ws);
+        for (void* w : ctx->retired_ws) (void)hipFree(w);
         for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
         if (ctx->have_side)
             for (hipStream_t st : ctx->side) (void)hipStreamDestroy(st);
@@ -2235,6 +2237,91 @@ int rsik_control_continuous_step(rsik_ctx* ctx, int64_t n, const double* const m
     return RSIK_OK;
 }
 
+// How rsik_control_continuous_run cuts a run of n trajectories x n_steps steps into blocks, and what it needs for that.
+struct ContPlan {
+    int64_t T;                           // steps per block (the last one may be shorter)
+    std::vector<int64_t> block_t0, block_T;
+    size_t per_step, chunks_per_block, slot_bytes, carry_bytes, need;
+    int slots;
+    size_t n_events;
+};
+constexpr int kContSlots = 8;  // workspace slots in flight (block b + 8 reuses the slot of block b once its phase 5 has finished)
+static int cont_plan(rsik_ctx* ctx, const char* who, int64_t n, int64_t n_steps, ContPlan& P) {
+    // (the sequential phases address a block's arrays through 2 GB buffer windows: rows of n * 56 bytes, blocks of <= 384 MB
+    // of workspace, i.e. <= 1.3 GB of joints; every block costs the host five launches, so blocks are as long as that allows)
+    if (n > (int64_t)30 << 20) return fail(ctx, RSIK_E_INVALID, std::string(who) + ": more than 30 Mi trajectories in one call");
+    P.per_step = (size_t)n * (2 * sizeof(double) + 1);
+    int64_t T_max = (int64_t)((size_t)384 << 20) / (int64_t)P.per_step;
+    if (T_max < 1) T_max = 1;
+    if (T_max > 65535) T_max = 65535;  // gridDim.y
+    // block size: a quarter of the run (the phases of neighbouring blocks overlap: more blocks, shorter fill and drain;
+    // fewer blocks, fewer of the ~12 us hand-overs between dependent launches: 4096 x 1000 steps take 0.49 / 0.48 / 0.46 /
+    // 0.48 / 0.50 ms with blocks of 128 / 192 / 256 / 512 / 1000 steps), a multiple of the theta batch and of the joint
+    // chunk; RSIK_OPT_CONT_BLOCK_STEPS overrides
+    int64_t T = ctx->options[RSIK_OPT_CONT_BLOCK_STEPS] > 0 ? ctx->options[RSIK_OPT_CONT_BLOCK_STEPS] : (n_steps + 3) / 4;
+    if (T < 64 && ctx->options[RSIK_OPT_CONT_BLOCK_STEPS] == 0) T = 64;
+    T = (T + rsik::kSeqBatch - 1) / rsik::kSeqBatch * rsik::kSeqBatch;
+    if (T > T_max) T = T_max >= rsik::kSeqBatch ? T_max / rsik::kSeqBatch * rsik::kSeqBatch : T_max;
+    if (T > n_steps) T = n_steps;
+    P.T = T;
+    P.block_t0.clear(); P.block_T.clear();
+    for (int64_t t0 = 0; t0 < n_steps; t0 += T) {
+        P.block_t0.push_back(t0);
+        P.block_T.push_back(n_steps - t0 < T ? n_steps - t0 : T);
+    }
+    const int64_t n_blocks = (int64_t)P.block_t0.size();
+    P.chunks_per_block = ((size_t)T + rsik::kJointChunk - 1) / rsik::kJointChunk;
+    P.slot_bytes = (((size_t)T * P.per_step + P.chunks_per_block * (size_t)n * 9 + 8 + 255) / 256) * 256;
+    P.slots = n_blocks < kContSlots ? (int)n_blocks : kContSlots;
+    P.carry_bytes = (((size_t)n * sizeof(double) + 255) / 256) * 256;
+    P.need = P.slot_bytes * P.slots + P.carry_bytes;
+    P.n_events = 2 + 5 * (size_t)n_blocks;
+    return RSIK_OK;
+}
+// Workspace, side streams and events for a plan.  Nothing here may happen while the caller's stream is capturing (device
+// allocation, stream and event creation are not capturable): a capture needs rsik_control_continuous_reserve, or an
+// earlier run of at least this size, first.  An outgrown workspace is retired, not freed: a hipGraph captured earlier
+// still points into it.
+static int cont_resources(rsik_ctx* ctx, const char* who, const ContPlan& P) {
+    const bool grow = ctx->ws_bytes < P.need, streams = !ctx->have_side, events = ctx->events.size() < P.n_events;
+    if (!grow && !streams && !events) return RSIK_OK;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(ctx->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        return fail(ctx, RSIK_E_INVALID, std::string(who) + ": the stream is capturing and this run needs a larger workspace / its streams / "
+                    "more events than the context holds: call rsik_control_continuous_reserve(ctx, n, n_steps) before the capture");
+    if (grow) {
+        void* fresh = nullptr;
+        RSIK_HIP(ctx, hipMalloc(&fresh, P.need));
+        if (ctx->ws) ctx->retired_ws.push_back(ctx->ws);
+        ctx->ws = fresh;
+        ctx->ws_bytes = P.need;
+    }
+    if (streams) {
+        for (auto& st : ctx->side) RSIK_HIP(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        ctx->have_side = true;
+    }
+    while (ctx->events.size() < P.n_events) {
+        hipEvent_t e;
+        // (hipEventReleaseToDevice / hipEventDisableSystemFence measured: 0.443 / 0.428 against 0.429-0.439 ms per pass — the
+        // ~12 us between dependent launches on different streams are not the cache write-back of the event's release)
+        RSIK_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->events.push_back(e);
+    }
+    return RSIK_OK;
+}
+
+int rsik_control_continuous_reserve(rsik_ctx* ctx, int64_t n, int64_t n_steps) {
+    const char* who = "rsik_control_continuous_reserve";
+    if (!ctx) return RSIK_E_INVALID;
+    if (n < 0 || n_steps < 0) return fail(ctx, RSIK_E_INVALID, std::string(who) + ": negative size");
+    if (n == 0 || n_steps == 0) return RSIK_OK;
+    RSIK_HIP(ctx, hipSetDevice(ctx->device));
+    ContPlan P;
+    int rc = cont_plan(ctx, who, n, n_steps, P);
+    if (rc != RSIK_OK) return rc;
+    return cont_resources(ctx, who, P);
+}
+
 // The whole trajectory batch: the phased pipeline (include/rsik.h), or — RSIK_CONT_RUN_STEPS — one launch of the step
 // kernel per control step.
 int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const double* m12_steps,
@@ -2292,53 +2379,16 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     // its own: theta(b + 1) queued up behind chain(b)'s wait for joints(b), 0.85 -> 1.28 ms per 1000-step pass.  (Giving
     // the sequential phases compute units of their own with hipExtStreamCreateWithCUMask was measured too: every kernel
     // got slower, 2.4 ms per pass.)
-    // A run is cut into blocks of steps; four workspace slots are in flight (block b + 4 reuses the slot of block b once
-    // chain(b) has finished).
-    constexpr int kSlots = 8;
-    // (the sequential phases address a block's arrays through 2 GB buffer windows: rows of n * 56 bytes, blocks of <= 384 MB
-    // of workspace, i.e. <= 1.3 GB of joints; every block costs the host five launches, so blocks are as long as that allows)
-    if (n > (int64_t)30 << 20) return fail(ctx, RSIK_E_INVALID, std::string(who) + ": more than 30 Mi trajectories in one call");
-    const size_t per_step = (size_t)n * (2 * sizeof(double) + 1);
-    int64_t T_max = (int64_t)((size_t)384 << 20) / (int64_t)per_step;
-    if (T_max < 1) T_max = 1;
-    if (T_max > 65535) T_max = 65535;  // gridDim.y
-    // block size: a quarter of the run (the phases of neighbouring blocks overlap: more blocks, shorter fill and drain;
-    // fewer blocks, fewer of the ~12 us hand-overs between dependent launches on the critical chain -> chain -> chain
-    // path: 4096 x 1000 steps take 0.77 / 0.70 / 0.66 / 0.63 / 0.69 ms with blocks of 64 / 96 / 128 / 256 / 504 steps), a
-    // multiple of the sequential phases' batch; RSIK_OPT_CONT_BLOCK_STEPS overrides
-    int64_t T = ctx->options[RSIK_OPT_CONT_BLOCK_STEPS] > 0 ? ctx->options[RSIK_OPT_CONT_BLOCK_STEPS] : (n_steps + 3) / 4;
-    if (T < 64 && ctx->options[RSIK_OPT_CONT_BLOCK_STEPS] == 0) T = 64;
-    T = (T + rsik::kSeqBatch - 1) / rsik::kSeqBatch * rsik::kSeqBatch;
-    if (T > T_max) T = T_max;
-    if (T > n_steps) T = n_steps;
-    std::vector<int64_t> block_t0, block_T;
-    for (int64_t t0 = 0; t0 < n_steps; t0 += T) {
-        block_t0.push_back(t0);
-        block_T.push_back(n_steps - t0 < T ? n_steps - t0 : T);
-    }
+    // A run is cut into blocks of steps; up to eight workspace slots are in flight (block b + 8 reuses the slot of block b
+    // once its last phase has finished).
+    ContPlan P;
+    if ((rc = cont_plan(ctx, who, n, n_steps, P)) != RSIK_OK) return rc;
+    if ((rc = cont_resources(ctx, who, P)) != RSIK_OK) return rc;
+    const std::vector<int64_t>&block_t0 = P.block_t0, &block_T = P.block_T;
     const int64_t n_blocks = (int64_t)block_t0.size();
-    const size_t chunks_per_block = ((size_t)T + rsik::kJointChunk - 1) / rsik::kJointChunk;
-    const size_t slot_bytes = (((size_t)T * per_step + chunks_per_block * (size_t)n * 9 + 255) / 256) * 256;
-    const int slots = n_blocks < kSlots ? (int)n_blocks : kSlots;
-    const size_t carry_bytes = (((size_t)n * sizeof(double) + 255) / 256) * 256;
-    const size_t need = slot_bytes * slots + carry_bytes;
-    if (ctx->ws_bytes < need) {
-        if (ctx->ws) { RSIK_HIP(ctx, hipDeviceSynchronize()); RSIK_HIP(ctx, hipFree(ctx->ws)); ctx->ws = nullptr; ctx->ws_bytes = 0; }
-        RSIK_HIP(ctx, hipMalloc(&ctx->ws, need));
-        ctx->ws_bytes = need;
-    }
-    if (!ctx->have_side) {
-        for (auto& st : ctx->side) RSIK_HIP(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        ctx->have_side = true;
-    }
-    const size_t n_events = 2 + 5 * (size_t)n_blocks;
-    while (ctx->events.size() < n_events) {
-        hipEvent_t e;
-        // (hipEventReleaseToDevice / hipEventDisableSystemFence measured: 0.443 / 0.428 against 0.429-0.439 ms per pass — the
-        // ~12 us between dependent launches on different streams are not the cache write-back of the event's release)
-        RSIK_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        ctx->events.push_back(e);
-    }
+    const size_t slot_bytes = P.slot_bytes, carry_bytes = P.carry_bytes, chunks_per_block = P.chunks_per_block;
+    const int slots = P.slots;
+    (void)carry_bytes;
     hipStream_t s_main = ctx->stream, s_theta = ctx->stream, s_prep = ctx->side[0], s_joints = ctx->side[1], s_chain = ctx->side[2];
     auto ev = [&](int kind, int64_t b) { return ctx->events[2 + 5 * (size_t)b + kind]; };  // 0 prepared, 1 theta, 2 joints, 3 chain, 4 turns
     // (Re)initialisation of the trajectories that start here (C:296-325: the start-up search for previous_theta, ~55 us

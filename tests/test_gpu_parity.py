@@ -780,36 +780,48 @@ def test_control_continuous_deliberate_crash(golden_dir, torch_mod, monkeypatch)
 
 
 def test_continuous_run_replayed_from_a_graph(torch_mod):
-    """rsik_control_continuous_run issues its phases on four streams tied by the context's own events; once a call of the
-    same shape has run (workspace, side streams and events exist) the whole run can be captured into a hipGraph — the
-    side streams join the capture through those events — and replayed: same bits as the run issued launch by launch
-    (bench.py --config 5 times such replays)."""
+    """rsik_control_continuous_run issues its phases on four streams tied by the context's own events; the whole run can be
+    captured into a hipGraph — the side streams join the capture through those events — and replayed: same bits as the
+    run issued launch by launch (bench.py --config 5 times such replays).  The capture happens on a FRESH context:
+    rsik_control_continuous_reserve creates the workspace, side streams and events the run would otherwise create inside
+    the capture; without it the call refuses (RSIK_E_INVALID) instead of allocating while the stream is capturing."""
     from bench import make_config5_trajectories
+    from reachy2_symbolic_ik_amd import _abi
 
     n_traj, n_steps = 700, 150
     traj = make_config5_trajectories(n_traj, n_steps, seed=4242)
-    c = make_control()
-    st0 = c.new_continuous_state("r_arm", n_traj)
+    eager = make_control()
+    st0 = eager.new_continuous_state("r_arm", n_traj)
     st = st0.clone()
     out = {"joints": torch_mod.empty((n_steps, n_traj, 7), dtype=torch_mod.float64, device="cuda"),
            "reachable": torch_mod.empty((n_steps, n_traj), dtype=torch_mod.uint8, device="cuda"),
            "state": torch_mod.empty((n_steps, n_traj), dtype=torch_mod.uint8, device="cuda")}
 
-    def one():
+    def one(c):
         st.copy_(st0)
         c.run_continuous_trajectories("r_arm", traj, st, first_step_timed_out=True, current_pose=traj[0], out=out)
 
-    one()
+    one(eager)
     torch_mod.cuda.synchronize()
     ref = {k: v.clone() for k, v in out.items()}
     ref["cont_state"] = st.clone()
+
     side = torch_mod.cuda.Stream()
+    # (a) a fresh context that has reserved nothing refuses the capture with a clear message (and leaves the capture usable)
+    fresh = make_control()
+    fresh._upload_arms()
     with torch_mod.cuda.stream(side):
-        one()  # the capture stream has run a call of this shape
-        torch_mod.cuda.synchronize()
+        g0 = torch_mod.cuda.CUDAGraph()
+        with torch_mod.cuda.graph(g0, stream=side):
+            with pytest.raises(_abi.RsikError) as ei:
+                one(fresh)
+            assert "rsik_control_continuous_reserve" in str(ei.value)
+    # (b) after reserve the same context captures the run without ever having run it
+    fresh._solver.control_continuous_reserve(n_traj, n_steps)
+    with torch_mod.cuda.stream(side):
         g = torch_mod.cuda.CUDAGraph()
         with torch_mod.cuda.graph(g, stream=side):  # a refused capture is the regression this test exists to catch
-            one()
+            one(fresh)
     for v in out.values():
         v.zero_()
     st.zero_()
@@ -819,6 +831,75 @@ def test_continuous_run_replayed_from_a_graph(torch_mod):
     for k, v in out.items():
         assert torch_mod.equal(ref[k].view(torch_mod.uint8), v.view(torch_mod.uint8)), k
     assert torch_mod.equal(ref["cont_state"].view(torch_mod.uint8), st.view(torch_mod.uint8))
+    # (c) a later, larger eager run on the same context outgrows the workspace: the graph must stay valid (the old
+    # workspace is retired, not freed)
+    big = make_config5_trajectories(n_traj * 3, n_steps * 2, seed=5)
+    st_big = fresh.new_continuous_state("r_arm", n_traj * 3)
+    fresh.run_continuous_trajectories("r_arm", big, st_big, first_step_timed_out=True, current_pose=big[0])
+    torch_mod.cuda.synchronize()
+    for v in out.values():
+        v.zero_()
+    g.replay()
+    torch_mod.cuda.synchronize()
+    for k, v in out.items():
+        assert torch_mod.equal(ref[k].view(torch_mod.uint8), v.view(torch_mod.uint8)), k
+
+
+def test_two_threads_two_contexts(torch_mod, orc):
+    """include/rsik.h: a context is used by one thread at a time; contexts are independent.  Two threads, each with a
+    context and a stream of its own, solve different batches concurrently (rsik_solve and the continuous pipeline, whose
+    workspace and side streams are per context): each must get exactly what it gets alone."""
+    import threading
+
+    from bench import make_config5_trajectories
+    from reachy2_symbolic_ik_amd import HipSolver, SymbolicIK
+
+    rng = np.random.default_rng(99)
+    jobs = []
+    for k in range(2):
+        n = 50_000 + 7_000 * k
+        pos = np.array([0.0, -0.2, 0.0]) + rng.uniform(-0.7, 0.7, size=(n, 3))
+        eul = rng.uniform(-np.pi, np.pi, size=(n, 3))
+        traj = make_config5_trajectories(300 + 50 * k, 96, seed=31 + k)
+        jobs.append({"pos": pos, "eul": eul, "traj": traj})
+
+    def work(job, reps):
+        import contextlib
+        import io
+
+        stream = torch_mod.cuda.Stream()
+        with torch_mod.cuda.stream(stream):
+            solver = HipSolver(0)
+            with contextlib.redirect_stdout(io.StringIO()):
+                ik = SymbolicIK("r_arm", solver=solver)
+            c = make_control()
+            soa = soa_of = torch_mod.as_tensor(np.ascontiguousarray(np.concatenate([job["pos"].T, job["eul"].T], axis=0))).cuda()
+            res = None
+            for _ in range(reps):
+                res = ik.solve_batch(soa_of)
+                st = c.new_continuous_state("r_arm", job["traj"].shape[2])
+                run = c.run_continuous_trajectories("r_arm", job["traj"], st, first_step_timed_out=True, current_pose=job["traj"][0])
+            stream.synchronize()
+            job["got"] = {k: v.clone() for k, v in res.items()}
+            job["got_run"] = {k: v.clone() for k, v in run.items()}
+            del soa
+
+    for job in jobs:  # alone, one after the other
+        work(job, 1)
+        job["alone"], job["alone_run"] = job.pop("got"), job.pop("got_run")
+    threads = [threading.Thread(target=work, args=(job, 5)) for job in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch_mod.cuda.synchronize()
+    for job in jobs:
+        for k, v in job["alone"].items():
+            assert torch_mod.equal(v.view(torch_mod.uint8), job["got"][k].view(torch_mod.uint8)), k
+        for k, v in job["alone_run"].items():
+            assert torch_mod.equal(v.view(torch_mod.uint8), job["got_run"][k].view(torch_mod.uint8)), k
+    ref = orc.solve_batch(orc.Arm("r_arm", 0.03), orc.Arm("l_arm", 0.03), jobs[0]["pos"][:2000], jobs[0]["eul"][:2000])
+    np.testing.assert_array_equal(jobs[0]["got"]["state"][:2000].cpu().numpy(), ref["state"])
 
 
 def _same_run(torch, ref, got, tag, joint_tol=1e-10):
