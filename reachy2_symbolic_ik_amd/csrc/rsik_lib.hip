@@ -566,23 +566,38 @@ __device__ __forceinline__ void sweep_theta_grid(const DiscreteArgs& K, uint64_t
 #define RSIK_DISC_MIN_WAVES 3  // 168 VGPR (28 B scratch) beats 182 VGPR at 2 waves/SIMD: 37.6 vs 39.0 us on config 3
 #endif
 // PLANE = false: the singularity-plane half of is_elbow_ok can never fail for these arms (decided on the host).
+#ifndef RSIK_DISC_BLOCK
+#define RSIK_DISC_BLOCK 256
+#endif
+constexpr int kDiscBlock = RSIK_DISC_BLOCK;  // threads per workgroup of the discrete kernel
 template <bool MIXED, bool PLANE>
-__global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR void control_discrete_kernel(const DiscreteArgs K) {
-    __shared__ double lds_slab[kBlock / 64][kDiscRows][64];
+__global__ __launch_bounds__(kDiscBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR void control_discrete_kernel(const DiscreteArgs K) {
+    __shared__ double lds_slab[kDiscBlock / 64][kDiscRows][64];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const int64_t wave_base = (int64_t)blockIdx.x * kBlock + wave * 64;
+    const int64_t i = (int64_t)blockIdx.x * kDiscBlock + threadIdx.x;
+    const int64_t wave_base = (int64_t)blockIdx.x * kDiscBlock + wave * 64;
     const bool live = i < K.n;
     const int64_t ii = live ? i : (K.n - 1);
 
+#ifdef RSIK_TIMELINE_PROBE
+    uint64_t probe_t[6];
+    probe_t[0] = __builtin_amdgcn_s_memrealtime();
+#define RSIK_DISC_PROBE(k) do { __builtin_amdgcn_sched_barrier(0); probe_t[k] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define RSIK_DISC_PROBE(k) do { } while (0)
+#endif
     // the twelve goal-matrix loads (and the arm byte) are issued before the table staging so that their latency overlaps it
     double m12[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) m12[k] = K.in[k][ii];
     const bool lane_isl = MIXED ? (K.arm[ii] != 0) : false;
         __shared__ SharedTables lds_tab;
-    stage_tables<MIXED, (int)offsetof(DiscreteArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>(lds_tab, K.arms);
+    stage_tables<MIXED, (int)offsetof(DiscreteArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC)), kDiscBlock>(lds_tab, K.arms);
+#ifdef RSIK_TIMELINE_PROBE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (probe build only: the head ends when the twelve columns are in)
+#endif
+    RSIK_DISC_PROBE(1);
     const Acc<MIXED> A = make_acc<MIXED>(K.arms, lane_isl, lds_tab);
     const int slot = MIXED ? (A.isl ? 1 : 0) : 0;
 
@@ -638,6 +653,7 @@ __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR void co
     // wave-cooperative sweep (cost ~ number of such poses); when most lanes need it, every lane searches its own
     // pose serially — the whole grid if it is short, else the 4 / 6 arc-end candidates (grid_theta_candidates).
     RSIK_MARK("disc_grid");
+    RSIK_DISC_PROBE(2);
     const uint64_t need_mask = __ballot(need);
     const int cnt = __popcll(need_mask);
     const bool walk = K.nb <= 4;  // a grid this short is cheaper to walk than to analyse
@@ -676,6 +692,7 @@ __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR void co
     }
 
     RSIK_MARK("disc_joints");
+    RSIK_DISC_PROBE(3);
     const double* prev = K.prev_sol[slot];
     double jv[7];
     double c4, s4, c5, s5, c6, s6;
@@ -706,12 +723,26 @@ __global__ __launch_bounds__(kBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR void co
     RSIK_MARK("disc_safety");
     const int em = safety_checks(A.utab, jv, c4, s4, c5, s5, c6, s6, prev, K.max_angle, K.cos_max, K.sin_max);
     RSIK_MARK("disc_store");
+    RSIK_DISC_PROBE(4);
     store_rows<7>(K.joints, wave_base, K.n, lane, &lds_slab[wave][0][0], jv);
     if (live) {
         if (K.reachable) K.reachable[i] = found ? 1 : 0;
         if (K.state) K.state[i] = (uint8_t)st_code;
         if (K.emergency) K.emergency[i] = (uint8_t)em;  // RSIK_EMERGENCY_* cause bits
     }
+#ifdef RSIK_TIMELINE_PROBE
+    // diagnostic build only (scripts/disc_timeline_probe.py): lane 0 of every wave overwrites its joints row with the six
+    // 100 MHz stamps (start, inputs + tables in, reach + shortcut done, theta chosen, joints + safety done, stores
+    // acknowledged) and the hardware id; lane 1 its row's first entry with the XCC id
+    __builtin_amdgcn_s_waitcnt(0);
+    RSIK_DISC_PROBE(5);
+    if (live && lane == 0) {
+        const uint32_t hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+        for (int k = 0; k < 6; k++) K.joints[i * 7 + k] = (double)probe_t[k];
+        K.joints[i * 7 + 6] = (double)hw;
+    }
+    if (live && lane == 1) K.joints[i * 7] = (double)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2083,8 +2114,8 @@ static int theta_snap_plan(double l0, double l1, double d_theta_max, double* tda
     return wrap ? rsik::kSnapWrap : rsik::kSnapInner;
 }
 
-static int launch_dims(rsik_ctx* ctx, int64_t n, dim3* grid, const char* who) {
-    const int64_t blocks = (n + rsik::kBlock - 1) / rsik::kBlock;
+static int launch_dims(rsik_ctx* ctx, int64_t n, dim3* grid, const char* who, int threads = rsik::kBlock) {
+    const int64_t blocks = (n + threads - 1) / threads;
     if (blocks > 0x7fffffffLL) return fail(ctx, RSIK_E_INVALID, std::string(who) + ": n too large for one launch");
     *grid = dim3((unsigned)blocks);
     return RSIK_OK;
@@ -2150,8 +2181,8 @@ int rsik_control_discrete(rsik_ctx* ctx, int64_t n, const double* const m12_soa[
     K.sin_max = std::sin(orbita3d_max_angle);
     K.joints = joints; K.reachable = reachable; K.state = state; K.emergency = emergency;
     RSIK_HIP(ctx, hipSetDevice(ctx->device));
-    dim3 grid, block(rsik::kBlock);
-    rc = launch_dims(ctx, n, &grid, "rsik_control_discrete");
+    dim3 grid, block(rsik::kDiscBlock);
+    rc = launch_dims(ctx, n, &grid, "rsik_control_discrete", rsik::kDiscBlock);
     if (rc != RSIK_OK) return rc;
     if (arm) {
         if (plane_binds) hipLaunchKernelGGL((rsik::control_discrete_kernel<true, true>), grid, block, 0, ctx->stream, K);

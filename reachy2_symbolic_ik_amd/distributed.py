@@ -137,8 +137,16 @@ def solve_sharded(solve_fn: Callable[[torch.Tensor, Dict[str, torch.Tensor]], No
     n = int(columns.shape[1])
     plan = ShardPlan(n, world, max(1, int(chunks)))
     gather = tuple(gather)
-    if spec is None:
-        spec = {"joints": ((7,), torch.float64), "state": ((), torch.uint8)}
+    if spec is None:  # what rsik_solve / rsik_control_discrete can write per pose
+        spec = {"joints": ((7,), torch.float64), "state": ((), torch.uint8), "reachable": ((), torch.uint8),
+                "interval": ((2,), torch.float64), "elbow": ((3,), torch.float64)}
+    unknown = [k for k in gather if k not in spec]
+    if unknown:
+        raise ValueError(f"solve_sharded: gather names {unknown} are not in spec (known: {sorted(spec)}); pass "
+                         "spec={name: (trailing shape, dtype)} for other arrays")
+    if not callable(solve_fn):
+        raise TypeError("solve_sharded: solve_fn(columns, out) must be callable; it fills the views in `out` "
+                        "(it does not return the arrays)")
     buffers = ShardedBuffers(plan, rank, {k: spec[k] for k in gather}, columns.device)
     pending = []
     for c in range(plan.chunks):

@@ -902,13 +902,14 @@ def test_two_threads_two_contexts(torch_mod, orc):
     np.testing.assert_array_equal(jobs[0]["got"]["state"][:2000].cpu().numpy(), ref["state"])
 
 
-def _same_run(torch, ref, got, tag, joint_tol=1e-10):
+def _same_run(torch, ref, got, tag, joint_tol=1e-9):
     """Two runs of the same trajectories (pipeline vs step kernel, or two block sizes of the pipeline): flags, state codes,
     the carried theta (row 0 of the trajectory state) and its flag rows bit for bit; joints and previous_sol to
     `joint_tol`.  (The pipeline's joints phase writes a quiet step as raw joint + whole turns instead of previous +
     angle_diff(raw, previous) and rebuilds the goal rotation's third row from the other two: both within the last bit of
     their inputs, no accumulation — but where the arm is stretched out the elbow-yaw / wrist-yaw split amplifies a last bit
-    2e4 times (see test_control_continuous_golden_default_start), hence 1e-10 and not 1e-14.)"""
+    2e4 times and more (see test_control_continuous_golden_default_start; 1.2e-10 over 32 M eventful trajectory-steps,
+    scripts/soak_pipeline.py), hence 1e-9 and not 1e-14.)"""
     for k in ref:
         a, b = ref[k], got[k]
         if k == "joints":
