@@ -328,7 +328,9 @@ __global__ __launch_bounds__(kBlock, RSIK_SOLVE_MIN_WAVES) void solve_kernel(con
             for (int k = 0; k < 7; k++) jrow[k] = o.j[k];
             erow[0] = o.elbow.x; erow[1] = o.elbow.y; erow[2] = o.elbow.z;
         } else {
-            const double nan = __builtin_nan("");
+            // (`opaque`: the value is made inside this branch — otherwise the compiler merges the two branches' LDS writes and
+            // every wave, reachable or not, first fills ten registers pairs with NaN: 20 v_mov in the all-reachable config 2)
+            const double nan = opaque(__builtin_nan(""));
 #pragma unroll
             for (int k = 0; k < 7; k++) jrow[k] = nan;
             erow[0] = nan; erow[1] = nan; erow[2] = nan;
