@@ -40,6 +40,16 @@ def _check_two_rank_line(d, gather):
         assert par["rows"] >= 2 * 1024 and par["max_abs_joint_error_rad"] < 1e-6
     if gather == "step":
         assert abs(m["end_to_end_solves_per_s"] - d["value"]) < 1e-6 * d["value"]
+    # what the collective library saw, and the like-for-like reference for the driver's scaling curve
+    g = m["group"]
+    assert g["world_size"] == 2 and len(g["ranks"]) == 2 and {r["rank"] for r in g["ranks"]} == {0, 1}
+    assert all(r["pid"] > 0 and r["name"] for r in g["ranks"]) and g["collective_timeout_s"] > 0
+    assert m["n1_same_config"]["solves_per_s"] > 0
+    eff = m["scaling_efficiency_vs_n1_same_config"]
+    assert eff["kernel_only"] == 1.0 and 0 < eff["end_to_end"] <= 1.0 + 1e-9
+    if gather != "none":
+        assert m["gather_final"]["solves_per_s"] > 0 and m["gather_step"]["solves_per_s"] > 0
+        assert m["gather_final"]["ms_for_K_steps_plus_one_gather"] > m["gather_final"]["one_all_gather_ms"] > 0
 
 
 @pytest.mark.parametrize("gather", ["step", "final", "none"])
@@ -58,6 +68,22 @@ def test_bench_two_ranks_gloo_config3_and_config5():
     assert d["n_gpus"] == 2 and d["unit"] == "steps/s" and d["config"]["collective"] == "none"
 
 
+def test_bench_rank_without_a_device_fails_the_launcher():
+    """`--gpus 2` on a box with one GPU and no --single-device: rank 1 has no device of its own and fails; the launcher stops
+    the other rank, exits non-zero and shows the failing rank's stderr (never a silent hang, never a shared device: ranks
+    that do end up on one device are refused by describe_group unless --single-device says it is a rehearsal)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("on a multi-GPU box every rank gets its own device")
+    # one visible GPU: LOCAL_RANK 1 has no device of its own -> the rank fails at set_device; the launcher must fail too
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--poses", "4096", "--steps", "1",
+                        "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
+    assert "rank" in p.stderr and "exited with code" in p.stderr
+
+
 def test_bench_two_ranks_rccl():
     import torch
 
@@ -66,6 +92,8 @@ def test_bench_two_ranks_rccl():
     d = _bench("--gpus", "2", "--poses", "262144", "--steps", "5", "--warmup", "2", "--cpu-seconds", "2")
     _check_two_rank_line(d, "step")
     assert "rehearsal" not in d["config"]["collective"] and d["multi_gpu"]["xgmi"]["achieved"] > 0
+    g = d["multi_gpu"]["group"]
+    assert g["distinct_devices"] == 2 and g["collective_library"].startswith("RCCL") and g["backend"] == "nccl"
 
 
 def _rccl_worker(rank, world, port, result_dir):
