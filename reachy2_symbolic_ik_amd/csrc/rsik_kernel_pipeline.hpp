@@ -45,7 +45,30 @@ constexpr int kThetaBlock = RSIK_THETA_BLOCK;
 constexpr int kChainBlock = RSIK_CHAIN_BLOCK;  // the chain phase: no such gain from single waves (0.447 / 0.452 ms with 256 / 64)
 constexpr int kSeqBatch = kThetaBatch > kJointChunk ? kThetaBatch : kJointChunk;
 static_assert(kSeqBatch % kThetaBatch == 0 && kSeqBatch % kJointChunk == 0, "block sizes are multiples of the theta batch and of the joint chunk");
+// -DRSIK_PIPE_TIMING (diagnostic builds, scripts/probes/c5_untraced_timeline.py): every phase kernel records when its
+// first sampled workgroup starts and its last one ends (100 MHz counter, atomicMin / atomicMax by one thread of every 32nd
+// workgroup): the pipeline's timeline WITHOUT a profiler in the way.
+#ifdef RSIK_PIPE_TIMING
+struct PipeStamp {
+    unsigned long long* t;
+    bool on;
+    __device__ PipeStamp(unsigned long long* tmin, unsigned long long* tmax, int slot)
+        : t(tmax ? tmax + slot : nullptr), on(tmin && threadIdx.x == 0 && (blockIdx.x & 31) == 0 && (blockIdx.y & 3) == 0) {
+        if (on) atomicMin(tmin + slot, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    }
+    __device__ ~PipeStamp() {
+        if (on) atomicMax(t, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    }
+};
+#define RSIK_PIPE_STAMP(K, phase) PipeStamp pipe_stamp_((K).tmin, (K).tmax, (K).tslot * 5 + (phase))
+#else
+#define RSIK_PIPE_STAMP(K, phase)
+#endif
 struct ContRunArgs {
+#ifdef RSIK_PIPE_TIMING
+    unsigned long long *tmin, *tmax;
+    int tslot;
+#endif
     int64_t n;
     int64_t t0;                   // first step of this block
     int64_t T;                    // steps in this block
@@ -77,6 +100,7 @@ struct ContRunArgs {
 // phase 1: one thread per (trajectory, step of the block)
 template <bool MIXED, bool PLANE>
 __global__ __launch_bounds__(kBlock) void cont_prepare_kernel(const ContRunArgs K) {
+    RSIK_PIPE_STAMP(K, 0);
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t t = blockIdx.y;
     const bool live = i < K.n;
@@ -134,6 +158,7 @@ __device__ __forceinline__ int ld_row_u8(__amdgpu_buffer_rsrc_t buf, unsigned la
 // single-arm launches), kSnapGeneric = the reference's own sequence of operations for any interval.
 template <bool MIXED, int KIND>
 __global__ __launch_bounds__(kThetaBlock) __attribute__((amdgpu_waves_per_eu(1, 1))) void cont_theta_kernel(const ContRunArgs K) {
+    RSIK_PIPE_STAMP(K, 1);
     static_assert(!MIXED || KIND == kSnapGeneric, "a mixed launch has an interval per lane");
     // a serial phase: its few waves share their SIMDs with the chip-filling phases of the neighbouring blocks (other
     // streams) and must win the issue arbitration, or every instruction waits behind throughput work
@@ -277,6 +302,7 @@ __device__ __forceinline__ void step_joints(const Acc& A, const ContRunArgs& K, 
 // previous), no accumulation.
 template <bool MIXED>
 __global__ __launch_bounds__(kBlock) void cont_joints_kernel(const ContRunArgs K) {
+    RSIK_PIPE_STAMP(K, 2);
     static_assert(kJointChunk == 8, "lane = 8 * step + trajectory");
     __shared__ double lds_out[kBlock / 64][64 * 7];
     const int lane = threadIdx.x & 63;
@@ -404,6 +430,7 @@ __global__ __launch_bounds__(kBlock) void cont_joints_kernel(const ContRunArgs K
 // latch C:205-210, C:398-405).
 template <bool MIXED>
 __global__ __launch_bounds__(kChainBlock) __attribute__((amdgpu_waves_per_eu(1, 1))) void cont_chain_kernel(const ContRunArgs K) {
+    RSIK_PIPE_STAMP(K, 3);
     // a serial phase beside throughput phases (see cont_theta_kernel), one step below the theta phase, which is the
     // critical path where the two share a SIMD (0.544 -> 0.536 ms per 4096 x 1000 pass)
     __builtin_amdgcn_s_setprio(2);
@@ -594,6 +621,7 @@ __global__ __launch_bounds__(kChainBlock) __attribute__((amdgpu_waves_per_eu(1, 
 // which find eight zero bytes and leave; the others read the elements of every joint that turns (all at once: one memory
 // round trip), add and write them back.
 __global__ __launch_bounds__(kBlock) void cont_turns_kernel(const ContRunArgs K) {
+    RSIK_PIPE_STAMP(K, 4);
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t c = blockIdx.y;
     if (i >= K.n) return;

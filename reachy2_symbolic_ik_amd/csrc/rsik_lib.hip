@@ -620,6 +620,28 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     const size_t slot_bytes = P.slot_bytes, carry_bytes = P.carry_bytes, chunks_per_block = P.chunks_per_block;
     const int slots = P.slots;
     (void)carry_bytes;
+#ifdef RSIK_PIPE_TIMING
+    static unsigned long long* pipe_t = nullptr;  // [2][5 * 64]: min stamps, then max stamps
+    static std::vector<unsigned long long> pipe_prev;
+    static int64_t pipe_prev_blocks = 0;
+    if (!pipe_t) { if (hipMalloc(&pipe_t, 2 * 320 * sizeof(unsigned long long)) != hipSuccess) pipe_t = nullptr; }
+    if (pipe_t && getenv("RSIK_PIPE_TIMING_PRINT") && pipe_prev_blocks > 0) {  // the PREVIOUS run's stamps (that run has been synchronised by now)
+        unsigned long long h[640];
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(h, pipe_t, sizeof h, hipMemcpyDeviceToHost);
+        unsigned long long base = ~0ull;
+        for (int k = 0; k < 320; k++) if (h[k] < base) base = h[k];
+        static const char* names[5] = {"prepare", "theta", "joints", "chain", "turns"};
+        for (int64_t b = 0; b < pipe_prev_blocks && b < 64; b++)
+            for (int ph = 0; ph < 5; ph++)
+                if (h[b * 5 + ph] != ~0ull)
+                    fprintf(stderr, "[pipe] %-8s(%lld) %8.2f -> %8.2f us\n", names[ph], (long long)b, (h[b * 5 + ph] - base) / 100.0, (h[320 + b * 5 + ph] - base) / 100.0);
+    }
+    if (pipe_t) {
+        (void)hipMemsetAsync(pipe_t, 0xff, 320 * sizeof(unsigned long long), ctx->stream);
+        (void)hipMemsetAsync(pipe_t + 320, 0, 320 * sizeof(unsigned long long), ctx->stream);
+    }
+#endif
     hipStream_t s_main = ctx->stream, s_theta = ctx->stream, s_prep = ctx->side[0], s_joints = ctx->side[1], s_chain = ctx->side[2];
     auto ev = [&](int kind, int64_t b) { return ctx->events[2 + 5 * (size_t)b + kind]; };  // 0 prepared, 1 theta, 2 joints, 3 chain, 4 turns
     // (Re)initialisation of the trajectories that start here (C:296-325: the start-up search for previous_theta, ~55 us
@@ -657,16 +679,27 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     R.st = cont_state; R.joints = joints_steps; R.reachable = reachable_steps; R.state = state_steps;
     R.theta_carry = reinterpret_cast<double*>(static_cast<char*>(ctx->ws) + slot_bytes * slots);
     const dim3 grid8((unsigned)((n * 8 + rsik::kChainBlock - 1) / rsik::kChainBlock));  // (n <= 30 Mi: fits)
-    // The order in which the host issues the launches matters: a launch + its event calls cost the host ~10 us, a block's
-    // four ~50 us, and a kernel that reaches its queue late starts late whatever its dependencies say.  The critical
-    // path is theta(0) -> theta(1) -> ... (and chain behind it), fed by prepare(b): so the blocks that have a workspace
-    // slot of their own get their prepare + theta launches first, then their joints + chain launches; a block that
-    // reuses a slot can only be issued once the chain that frees the slot has been (its event must have been recorded).
+    // What a pass really looks like was measured with in-kernel stamps (a -DRSIK_PIPE_TIMING build,
+    // scripts/probes/c5_untraced_timeline.py; the profiler's kernel trace delays launches and shows another schedule): a
+    // dependency between launches on DIFFERENT streams costs the dependent kernel 15-40 us after its last parent has
+    // finished, launch by launch and in a graph replay alike (theta(b) -> joints(b): 31-41 us in a replay), a kernel
+    // behind its predecessor on the SAME stream 4-7 us.  Keeping the whole critical chain on one in-order stream (init,
+    // theta(b), joints(b) alternately, prepares beside it) removes those hand-overs but also the overlap of theta(b + 1)
+    // with joints(b): 0.42 ms launch by launch (the best eager figure) but 0.40-0.43 replayed, against 0.39 for the
+    // overlapped form below, which stays.  A block that reuses a workspace slot can only be issued once the block that
+    // frees it has been (its event must have been recorded).
     const bool plane_binds = singularity_plane_binds(R.arms);
     // the theta phase's step, specialised for the control interval where that is proven equivalent (single-arm launches)
     int snap_kind = rsik::kSnapGeneric;
     if (!arm) snap_kind = theta_snap_plan(R.lim[0][0], R.lim[0][1], d_theta_max, &R.snap_tdag);
+#ifdef RSIK_PIPE_TIMING
+    R.tmin = pipe_t; R.tmax = pipe_t ? pipe_t + 320 : nullptr;
+    pipe_prev_blocks = n_blocks;
+#endif
     auto set_block = [&](int64_t b) {
+#ifdef RSIK_PIPE_TIMING
+        R.tslot = (int)(b < 64 ? b : 63);
+#endif
         R.t0 = block_t0[b];
         R.T = block_T[b];
         R.first_block = b == 0;
@@ -679,13 +712,17 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         // otherwise round up)
         R.chunk_turns = reinterpret_cast<int8_t*>((reinterpret_cast<uintptr_t>(R.chunk_event + chunks_per_block * (size_t)n) + 7) & ~(uintptr_t)7);
     };
-    auto issue_front = [&](int64_t b) -> int {  // prepare(b), theta(b)
+    auto issue_prepare = [&](int64_t b) -> int {
         set_block(b);
         const dim3 grid2(grid.x, (unsigned)R.T);
         if (b >= slots) RSIK_HIP(ctx, hipStreamWaitEvent(s_prep, ev(4, b - slots), 0));  // the slot's previous block is done
         if (arm) { if (plane_binds) hipLaunchKernelGGL((rsik::cont_prepare_kernel<true, true>), grid2, block, 0, s_prep, R); else hipLaunchKernelGGL((rsik::cont_prepare_kernel<true, false>), grid2, block, 0, s_prep, R); }
         else { if (plane_binds) hipLaunchKernelGGL((rsik::cont_prepare_kernel<false, true>), grid2, block, 0, s_prep, R); else hipLaunchKernelGGL((rsik::cont_prepare_kernel<false, false>), grid2, block, 0, s_prep, R); }
         RSIK_HIP(ctx, hipEventRecord(ev(0, b), s_prep));
+        return RSIK_OK;
+    };
+    auto issue_theta = [&](int64_t b) -> int {
+        set_block(b);
         RSIK_HIP(ctx, hipStreamWaitEvent(s_theta, ev(0, b), 0));
         const dim3 grid_t((unsigned)((n + rsik::kThetaBlock - 1) / rsik::kThetaBlock)), block_t(rsik::kThetaBlock);
         if (arm) hipLaunchKernelGGL((rsik::cont_theta_kernel<true, rsik::kSnapGeneric>), grid_t, block_t, 0, s_theta, R);
@@ -717,12 +754,22 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         return RSIK_OK;
     };
     const int64_t head = n_blocks < slots ? n_blocks : slots;
-    for (int64_t b = 0; b < head; b++)
-        if ((rc = issue_front(b)) != RSIK_OK) return rc;
+    // Issue order of the blocks that have a workspace slot of their own (it is also the order of the nodes in a captured
+    // graph): prepare(0), theta(0), then the other prepares back to back, the other thetas, then joints + chain + turns of
+    // every block.  Measured on graph replays of 4096 x 1000 steps against three other orders (prepare / theta
+    // alternating: 0.394-0.411 ms; all prepares, all thetas: 0.398-0.401; thetas and backs alternating: 0.414-0.416):
+    // 0.387-0.392 ms.
+    if ((rc = issue_prepare(0)) != RSIK_OK) return rc;
+    if ((rc = issue_theta(0)) != RSIK_OK) return rc;
+    for (int64_t b = 1; b < head; b++)
+        if ((rc = issue_prepare(b)) != RSIK_OK) return rc;
+    for (int64_t b = 1; b < head; b++)
+        if ((rc = issue_theta(b)) != RSIK_OK) return rc;
     for (int64_t b = 0; b < head; b++)
         if ((rc = issue_back(b)) != RSIK_OK) return rc;
     for (int64_t b = head; b < n_blocks; b++) {
-        if ((rc = issue_front(b)) != RSIK_OK) return rc;
+        if ((rc = issue_prepare(b)) != RSIK_OK) return rc;
+        if ((rc = issue_theta(b)) != RSIK_OK) return rc;
         if ((rc = issue_back(b)) != RSIK_OK) return rc;
     }
     // the caller's stream continues once the last chain (hence every phase of every block) is done
