@@ -15,6 +15,7 @@ struct DiscreteArgs {
     int log2p;            // sweep sub-group width P = 1 << log2p  (P = pow2ceil(min(nb, 64)))
     int sweep_mode;       // 0 auto, 1 always the exhaustive wave-cooperative sweep, 2 always the per-lane search
     int euler_roundtrip;  // RSIK_OPT_EULER_ROUNDTRIP
+    int stagger;          // non-zero: a single-round launch, waves lower their issue priority as they advance (RSIK_DISC_PRIO)
     double pref[2];       // preferred theta per arm slot (already mirrored for l, C:252)
     double pref_cs[2], pref_sn[2];  // its cosine / sine (host libm, once per launch)
     double lim[2][2];     // interval_limit per arm slot (C:225-250)
@@ -120,6 +121,15 @@ __device__ __forceinline__ void sweep_theta_grid(const DiscreteArgs& K, uint64_t
 #define RSIK_DISC_MIN_WAVES 3  // 168 VGPR (28 B scratch) beats 182 VGPR at 2 waves/SIMD: 37.6 vs 39.0 us on config 3
 #endif
 // PLANE = false: the singularity-plane half of is_elbow_ok can never fail for these arms (decided on the host).
+// Issue priority by progress.  A launch of up to one workgroup per resident slot (262 144 matrices on MI355X: BASELINE
+// config 3) is a single round: the four waves of a SIMD start together, the hardware serves the oldest first, and from the
+// moment the first of them finishes the SIMD runs with fewer and fewer waves to hide its latencies behind
+// (profiles/r03/timeline/discrete_*: first waves done at 9 us, last at 15.4).  So in such a launch (DiscreteArgs.stagger,
+// set by the host) a wave LOWERS its priority as it advances — reach 3, search 2, joints 1, safety 0 — and the SIMD
+// always serves the wave that is furthest behind: all four stay in flight to the end.  15.8 -> 14.5 us at 262 144 matrices,
+// 11.2 -> 10.4 at 131 072; a launch of several rounds wants the opposite (its old waves should finish and make room:
+// +4 % at 524 288, +15 % at 1 M with the priorities on), hence the switch.
+#define RSIK_DISC_PRIO(p) do { if (K.stagger) __builtin_amdgcn_s_setprio(p); } while (0)
 #ifndef RSIK_DISC_BLOCK
 #define RSIK_DISC_BLOCK 256
 #endif
@@ -169,6 +179,7 @@ __global__ __launch_bounds__(kDiscBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR voi
         for (int k = 0; k < 6; k++) lds_slab[wave][k][lane] = pk[k];
     }
     RSIK_MARK("disc_reach");
+    RSIK_DISC_PRIO(3);
     Reach r = reach_g<false, false>(A, pos, G.woff);
     RSIK_MARK("disc_shortcut");
     const double pref = K.pref[slot];
@@ -207,6 +218,7 @@ __global__ __launch_bounds__(kDiscBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR voi
     // wave-cooperative sweep (cost ~ number of such poses); when most lanes need it, every lane searches its own
     // pose serially — the whole grid if it is short, else the 4 / 6 arc-end candidates (grid_theta_candidates).
     RSIK_MARK("disc_grid");
+    RSIK_DISC_PRIO(2);
     RSIK_DISC_PROBE(2);
     const uint64_t need_mask = __ballot(need);
     const int cnt = __popcll(need_mask);
@@ -246,6 +258,7 @@ __global__ __launch_bounds__(kDiscBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR voi
     }
 
     RSIK_MARK("disc_joints");
+    RSIK_DISC_PRIO(1);
     RSIK_DISC_PROBE(3);
     const double* prev = K.prev_sol[slot];
     double jv[7];
@@ -275,6 +288,7 @@ __global__ __launch_bounds__(kDiscBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR voi
         c6 = K.prev_cs[slot][2]; s6 = K.prev_sn[slot][2];
     }
     RSIK_MARK("disc_safety");
+    RSIK_DISC_PRIO(0);
     const int em = safety_checks(A.utab, jv, c4, s4, c5, s5, c6, s6, prev, K.max_angle, K.cos_max, K.sin_max);
     RSIK_MARK("disc_store");
     RSIK_DISC_PROBE(4);

@@ -32,6 +32,7 @@
 // =====================================================================================
 struct rsik_ctx {
     int device;
+    int compute_units;  // of the device (256 on MI355X): which launches are a single round
     hipStream_t stream;
     bool have_arm[2];
     rsik::ArmC arms[2];
@@ -86,6 +87,11 @@ int rsik_create(int device_id, rsik_ctx** out) {
     rsik_ctx* c = new (std::nothrow) rsik_ctx();
     if (!c) return fail(nullptr, RSIK_E_INVALID, "rsik_create: out of host memory");
     c->device = device_id;
+    c->compute_units = 256;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) c->compute_units = cus;
+    }
     c->stream = nullptr;
     c->have_arm[0] = c->have_arm[1] = false;
     for (int k = 0; k < RSIK_OPT_COUNT; k++) c->options[k] = 0;
@@ -362,6 +368,8 @@ int rsik_control_discrete(rsik_ctx* ctx, int64_t n, const double* const m12_soa[
     K.log2p = lg;
     K.sweep_mode = ctx->options[RSIK_OPT_SWEEP_MODE];  // 0 unless a test / A-B run forces one of the two strategies
     K.euler_roundtrip = ctx->options[RSIK_OPT_EULER_ROUNDTRIP];
+    // one round = every workgroup resident at once: 4 workgroups per compute unit (their LDS slabs)
+    K.stagger = n <= (int64_t)ctx->compute_units * 4 * rsik::kDiscBlock ? 1 : 0;
     for (int slot = 0; slot < 2; slot++) {
         const int a = arm ? slot : arm_uniform;
         control_limits(a, constrained_mode, preferred_theta, K.lim[slot], &K.pref[slot]);

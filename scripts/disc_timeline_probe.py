@@ -88,3 +88,8 @@ start = np.array([T[inv == s_, 1].min() for s_ in range(len(uniq))])
 print("SIMD: first wave computing at (us): p10 %.2f median %.2f p90 %.2f; busy span (first compute -> last store): median %.2f p90 %.2f" % (
     np.percentile(start, 10), np.median(start), np.percentile(start, 90), np.median(fin - start), np.percentile(fin - start, 90)))
 # lanes that went through the grid search, per wave, against the wave's finish time
+wx = (slot // (8 * 2 * 16 * 4))
+print("per XCD: first wave start / median wave start / median 'inputs in' / last finish (us):")
+for x in np.unique(wx):
+    m = wx == x
+    print("   XCD %d: %5.2f %5.2f %5.2f %6.2f   waves %d" % (x, T[m, 0].min(), np.median(T[m, 0]), np.median(T[m, 1]), T[m, 5].max(), m.sum()))
