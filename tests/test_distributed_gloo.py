@@ -85,6 +85,13 @@ def _worker(rank, world, port, n, seed, result_dir):
         np.testing.assert_array_equal(full["reachable"].numpy(), ref["reachable"])
         np.testing.assert_array_equal(full["state"].numpy(), ref["state"])
         np.testing.assert_array_equal(np.nan_to_num(full["joints"].numpy(), nan=-99.0), np.nan_to_num(ref["joints"], nan=-99.0))
+        # the default spec knows what rsik_solve writes per pose; a name outside the spec is refused with a clear message
+        dflt = solve_sharded(solve_fn, cols, gather=("joints", "reachable"))
+        np.testing.assert_array_equal(dflt["reachable"].numpy(), ref["reachable"])
+        with pytest.raises(ValueError, match="not in spec"):
+            solve_sharded(solve_fn, cols, gather=("joints", "velocity"))
+        with pytest.raises(TypeError, match="callable"):
+            solve_sharded({"joints": None}, cols)
         # preallocated result buffer path
         lo, hi = shard_range(n, rank, world)
         buf = torch.empty((world * shard_size(n, world), 7), dtype=torch.float64)
