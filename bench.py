@@ -702,7 +702,10 @@ def main(argv=None, return_line=False):
                 for _ in range(1 if cfg == 5 else args.steps):
                     launch_all(cs)
             graph_replays = args.steps if cfg == 5 else 1
-            graph.replay()  # untimed
+            # untimed: the captured graph replayed once (configs 2-4: that is K launches); config 5's graph holds ONE pass, so
+            # the W warm-up steps are repeated as replays — the thing that is timed (the eager warm-up above ran another form)
+            for _ in range(max(1, args.warmup) if cfg == 5 else 1):
+                graph.replay()
             fence()
         except Exception as e:  # capture refused: time K eager launches instead (reported in "launch")
             print(f"bench.py: hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches", file=sys.stderr)
@@ -836,7 +839,7 @@ def main(argv=None, return_line=False):
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "launch": ("eager" if graph is None else "K replays of a hipGraph holding one pass (21 kernels on four streams)" if cfg == 5
+            "launch": ("eager" if graph is None else "K replays of a hipGraph holding one pass (two blocks under capture: 11 kernels on four streams)" if cfg == 5
                        else "hipGraph replay of K captured launches"),
             "config": {"workload": workload, "poses_per_gpu": n,
                        "theta_policy": {2: "interval[0]", 3: "discrete sweep nb=64", 4: "interval[0]", 5: "continuous, d_theta_max=0.01"}[cfg],

@@ -279,6 +279,8 @@ int rsik_control_continuous_step(rsik_ctx *ctx, int64_t n, const double *const m
  *                turns the chunk sits away from it; only a chunk with an event is walked step by step with the
  *                reference's own sequence of operations (also: steps whose get_joints hit an exact singularity)
  *   5. turns     adds those whole turns to the rows of the chunks that need them
+ * A run is cut into blocks of steps: four when it is issued launch by launch, two when it is being captured into a
+ * hipGraph (RSIK_OPT_CONT_BLOCK_STEPS overrides); the results do not depend on the cut.
  * The phases of neighbouring blocks overlap on four streams (the caller's and three of the context's).  The workspace
  * (17 bytes per step and trajectory + 9 per 8-step chunk, of up to eight blocks in flight), the side streams and the
  * events belong to the context: they are created by the first call that needs them, or ahead of time by

@@ -485,7 +485,11 @@ struct ContPlan {
     size_t n_events;
 };
 constexpr int kContSlots = 8;  // workspace slots in flight (block b + 8 reuses the slot of block b once its phase 5 has finished)
-static int cont_plan(rsik_ctx* ctx, const char* who, int64_t n, int64_t n_steps, ContPlan& P) {
+// `capturing`: the call is being recorded into a hipGraph.  A replay executes the dependency DAG with 15-40 us per edge
+// whatever the streams were, so fewer, longer blocks pay there (4096 x 1000 steps replayed: 0.379 ms with two blocks,
+// 0.383 with three, 0.395 with four); launched eagerly four blocks are best (0.43 against 0.46 with two: more overlap for
+// the same host-side issue cost).
+static int cont_plan(rsik_ctx* ctx, const char* who, int64_t n, int64_t n_steps, bool capturing, ContPlan& P) {
     // (the sequential phases address a block's arrays through 2 GB buffer windows: rows of n * 56 bytes, blocks of <= 384 MB
     // of workspace, i.e. <= 1.3 GB of joints; every block costs the host five launches, so blocks are as long as that allows)
     if (n > (int64_t)30 << 20) return fail(ctx, RSIK_E_INVALID, std::string(who) + ": more than 30 Mi trajectories in one call");
@@ -493,11 +497,12 @@ static int cont_plan(rsik_ctx* ctx, const char* who, int64_t n, int64_t n_steps,
     int64_t T_max = (int64_t)((size_t)384 << 20) / (int64_t)P.per_step;
     if (T_max < 1) T_max = 1;
     if (T_max > 65535) T_max = 65535;  // gridDim.y
-    // block size: a quarter of the run (the phases of neighbouring blocks overlap: more blocks, shorter fill and drain;
+    // block size: a quarter of the run, half of it under capture (the phases of neighbouring blocks overlap: more blocks, shorter fill and drain;
     // fewer blocks, fewer of the ~12 us hand-overs between dependent launches: 4096 x 1000 steps take 0.49 / 0.48 / 0.46 /
     // 0.48 / 0.50 ms with blocks of 128 / 192 / 256 / 512 / 1000 steps), a multiple of the theta batch and of the joint
     // chunk; RSIK_OPT_CONT_BLOCK_STEPS overrides
-    int64_t T = ctx->options[RSIK_OPT_CONT_BLOCK_STEPS] > 0 ? ctx->options[RSIK_OPT_CONT_BLOCK_STEPS] : (n_steps + 3) / 4;
+    const int64_t parts = capturing ? 2 : 4;
+    int64_t T = ctx->options[RSIK_OPT_CONT_BLOCK_STEPS] > 0 ? ctx->options[RSIK_OPT_CONT_BLOCK_STEPS] : (n_steps + parts - 1) / parts;
     if (T < 64 && ctx->options[RSIK_OPT_CONT_BLOCK_STEPS] == 0) T = 64;
     T = (T + rsik::kSeqBatch - 1) / rsik::kSeqBatch * rsik::kSeqBatch;
     if (T > T_max) T = T_max >= rsik::kSeqBatch ? T_max / rsik::kSeqBatch * rsik::kSeqBatch : T_max;
@@ -555,9 +560,13 @@ int rsik_control_continuous_reserve(rsik_ctx* ctx, int64_t n, int64_t n_steps) {
     if (n < 0 || n_steps < 0) return fail(ctx, RSIK_E_INVALID, std::string(who) + ": negative size");
     if (n == 0 || n_steps == 0) return RSIK_OK;
     RSIK_HIP(ctx, hipSetDevice(ctx->device));
-    ContPlan P;
-    int rc = cont_plan(ctx, who, n, n_steps, P);
+    // what an eager run and what a captured run of this size need (their block sizes differ): the larger of each
+    ContPlan P, Pc;
+    int rc = cont_plan(ctx, who, n, n_steps, false, P);
     if (rc != RSIK_OK) return rc;
+    if ((rc = cont_plan(ctx, who, n, n_steps, true, Pc)) != RSIK_OK) return rc;
+    if (Pc.need > P.need) P.need = Pc.need;
+    if (Pc.n_events > P.n_events) P.n_events = Pc.n_events;
     return cont_resources(ctx, who, P);
 }
 
@@ -621,8 +630,21 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     // A run is cut into blocks of steps; up to eight workspace slots are in flight (block b + 8 reuses the slot of block b
     // once its last phase has finished).
     ContPlan P;
-    if ((rc = cont_plan(ctx, who, n, n_steps, P)) != RSIK_OK) return rc;
-    if ((rc = cont_resources(ctx, who, P)) != RSIK_OK) return rc;
+    bool capturing = false;
+    {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        capturing = hipStreamIsCapturing(ctx->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    }
+    if ((rc = cont_plan(ctx, who, n, n_steps, capturing, P)) != RSIK_OK) return rc;
+    {
+        // the context holds what BOTH forms of a run of this size need, so that a run that was first issued eagerly can be
+        // captured afterwards (and the other way round) without creating anything
+        ContPlan other, both = P;
+        if ((rc = cont_plan(ctx, who, n, n_steps, !capturing, other)) != RSIK_OK) return rc;
+        if (other.need > both.need) both.need = other.need;
+        if (other.n_events > both.n_events) both.n_events = other.n_events;
+        if ((rc = cont_resources(ctx, who, both)) != RSIK_OK) return rc;
+    }
     const std::vector<int64_t>&block_t0 = P.block_t0, &block_T = P.block_T;
     const int64_t n_blocks = (int64_t)block_t0.size();
     const size_t slot_bytes = P.slot_bytes, carry_bytes = P.carry_bytes, chunks_per_block = P.chunks_per_block;
