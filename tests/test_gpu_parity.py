@@ -845,6 +845,30 @@ def test_continuous_run_replayed_from_a_graph(torch_mod):
         assert torch_mod.equal(ref[k].view(torch_mod.uint8), v.view(torch_mod.uint8)), k
 
 
+def test_capture_continuous_trajectories_convenience(torch_mod):
+    """ControlIK.capture_continuous_trajectories: the run recorded on a fresh context (two blocks under capture, four when
+    issued eagerly: the results do not depend on the cut) and replayed gives the eager run's bits."""
+    from bench import make_config5_trajectories
+
+    n_traj, n_steps = 520, 203
+    traj = make_config5_trajectories(n_traj, n_steps, seed=77)
+    eager = make_control()
+    st0 = eager.new_continuous_state("r_arm", n_traj)
+    st = st0.clone()
+    ref = eager.run_continuous_trajectories("r_arm", traj, st, first_step_timed_out=True, current_pose=traj[0])
+    torch_mod.cuda.synchronize()
+    c = make_control()
+    st2 = st0.clone()
+    graph, out = c.capture_continuous_trajectories("r_arm", traj, st2, first_step_timed_out=True, current_pose=traj[0])
+    for _ in range(2):
+        st2.copy_(st0)
+        graph.replay()
+    torch_mod.cuda.synchronize()
+    for k in ref:
+        assert torch_mod.equal(ref[k].view(torch_mod.uint8), out[k].view(torch_mod.uint8)), k
+    assert torch_mod.equal(st.view(torch_mod.uint8), st2.view(torch_mod.uint8))
+
+
 def test_two_threads_two_contexts(torch_mod, orc):
     """include/rsik.h: a context is used by one thread at a time; contexts are independent.  Two threads, each with a
     context and a stream of its own, solve different batches concurrently (rsik_solve and the continuous pipeline, whose
