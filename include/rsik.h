@@ -64,6 +64,7 @@ extern "C" {
 #define RSIK_EMERGENCY_ELBOW_YAW 2       /* "EMERGENCY STOP: elbow yaw limit reached"       joint 2 */
 #define RSIK_EMERGENCY_WRIST_YAW 4       /* "EMERGENCY STOP: wrist yaw limit reached"       joint 6 */
 #define RSIK_EMERGENCY_CONTINUITY 8      /* " EMERGENCY STOP: joints are not continuous ..." continuous mode only */
+#define RSIK_EMERGENCY_INTERNAL 64       /* rsik_control_continuous_run: a wave's bounded wait for the chunk before it ran out (never seen) */
 
 /* ---- arms ---- */
 #define RSIK_ARM_R 0
@@ -171,6 +172,7 @@ int rsik_set_arm(rsik_ctx *ctx, int arm, const double *consts_host, int count);
 #define RSIK_CONT_RUN_AUTO 0
 #define RSIK_CONT_RUN_PHASED 1
 #define RSIK_CONT_RUN_STEPS 2
+#define RSIK_CONT_RUN_CHAINED 3  /* the pipeline with its sequential fourth and fifth phase (rounds 2-3): for comparison */
 /* Tuning of rsik_control_continuous_run's phased pipeline (results do not depend on it):
  *   RSIK_OPT_CONT_BLOCK_STEPS  control steps per block of the pipeline: 0 (default) = a quarter of the run, at least 64;
  *                              n > 0 = n (rounded up to the sequential phases' batch of steps) */

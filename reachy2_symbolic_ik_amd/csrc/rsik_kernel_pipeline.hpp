@@ -89,6 +89,8 @@ struct ContRunArgs {
     double snap_tdag;             // phase 2, single-arm launches: see continuous_next_theta_lean (the kind is a template argument)
     double* theta_carry;          // [n]: previous_theta between the blocks of one run (phase 2's own state)
     int first_block, last_block;
+    unsigned long long* lb;       // [chunks of the run][4][n]: the look-back words of cont_joints_lb_kernel (NULL: the five-phase form)
+    int64_t chunk0;               // chunks of the run before this block
     double* st;                   // cont_state
     double* joints;               // [n_steps][n][7]
     uint8_t* reachable;           // [n_steps][n] or NULL
@@ -132,6 +134,12 @@ __global__ __launch_bounds__(kBlock) void cont_prepare_kernel(const ContRunArgs 
     K.flags[t * K.n + i] = (uint8_t)((T.ok_limits ? 1 : 0) | (T.found ? 2 : 0) | (special ? 8 : 0));
     if (K.state) K.state[(K.t0 + t) * K.n + i] = (uint8_t)T.code;
     if (K.reachable) K.reachable[(K.t0 + t) * K.n + i] = (T.ok_limits && T.found) ? 1 : 0;
+    // the look-back words of this block's chunks start every run at zero (cont_joints_lb_kernel)
+    if (K.lb && (t & (kJointChunk - 1)) == 0) {
+        unsigned long long* w = K.lb + (K.chunk0 + t / kJointChunk) * 4 * K.n + i;
+#pragma unroll
+        for (int k = 0; k < 4; k++) w[k * K.n] = 0ull;
+    }
 }
 
 // Row + lane addressing for the sequential phases: a step's row starts `row` bytes into the block's array (the same for

@@ -25,6 +25,7 @@
 #include "rsik_kernel_discrete.hpp"
 #include "rsik_kernel_continuous.hpp"
 #include "rsik_kernel_pipeline.hpp"
+#include "rsik_kernel_lookback.hpp"
 #include "rsik_kernel_state.hpp"
 
 // =====================================================================================
@@ -480,7 +481,9 @@ int rsik_control_continuous_step(rsik_ctx* ctx, int64_t n, const double* const m
 struct ContPlan {
     int64_t T;                           // steps per block (the last one may be shorter)
     std::vector<int64_t> block_t0, block_T;
-    size_t per_step, chunks_per_block, slot_bytes, carry_bytes, need;
+    size_t per_step, chunks_per_block, slot_bytes, carry_bytes, lb_bytes, need;
+    std::vector<int64_t> block_chunk0;   // chunks of the run before each block
+    int64_t chunks_total;
     int slots;
     size_t n_events;
 };
@@ -509,16 +512,23 @@ static int cont_plan(rsik_ctx* ctx, const char* who, int64_t n, int64_t n_steps,
     if (T > n_steps) T = n_steps;
     P.T = T;
     P.block_t0.clear(); P.block_T.clear();
+    P.block_chunk0.clear();
+    P.chunks_total = 0;
     for (int64_t t0 = 0; t0 < n_steps; t0 += T) {
+        const int64_t Tb = n_steps - t0 < T ? n_steps - t0 : T;
         P.block_t0.push_back(t0);
-        P.block_T.push_back(n_steps - t0 < T ? n_steps - t0 : T);
+        P.block_T.push_back(Tb);
+        P.block_chunk0.push_back(P.chunks_total);
+        P.chunks_total += (Tb + rsik::kJointChunk - 1) / rsik::kJointChunk;
     }
     const int64_t n_blocks = (int64_t)P.block_t0.size();
     P.chunks_per_block = ((size_t)T + rsik::kJointChunk - 1) / rsik::kJointChunk;
     P.slot_bytes = (((size_t)T * P.per_step + P.chunks_per_block * (size_t)n * 9 + 8 + 255) / 256) * 256;
     P.slots = n_blocks < kContSlots ? (int)n_blocks : kContSlots;
     P.carry_bytes = (((size_t)n * sizeof(double) + 255) / 256) * 256;
-    P.need = P.slot_bytes * P.slots + P.carry_bytes;
+    // the look-back words of the joints phase (four per chunk and trajectory, for the whole run)
+    P.lb_bytes = (((size_t)P.chunks_total * 4 * sizeof(unsigned long long) * (size_t)n + 255) / 256) * 256;
+    P.need = P.slot_bytes * P.slots + P.carry_bytes + P.lb_bytes;
     P.n_events = 2 + 5 * (size_t)n_blocks;
     return RSIK_OK;
 }
@@ -672,6 +682,8 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         (void)hipMemsetAsync(pipe_t + 320, 0, 320 * sizeof(unsigned long long), ctx->stream);
     }
 #endif
+    // the joints phase finishes its rows itself (rsik_kernel_lookback.hpp) unless the five-phase form is asked for
+    const bool chained = ctx->options[RSIK_OPT_CONT_RUN_MODE] == RSIK_CONT_RUN_CHAINED;
     hipStream_t s_main = ctx->stream, s_theta = ctx->stream, s_prep = ctx->side[0], s_joints = ctx->side[1], s_chain = ctx->side[2];
     auto ev = [&](int kind, int64_t b) { return ctx->events[2 + 5 * (size_t)b + kind]; };  // 0 prepared, 1 theta, 2 joints, 3 chain, 4 turns
     // (Re)initialisation of the trajectories that start here (C:296-325: the start-up search for previous_theta, ~55 us
@@ -691,7 +703,7 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     }
     RSIK_HIP(ctx, hipEventRecord(ctx->events[0], s_main));
     RSIK_HIP(ctx, hipStreamWaitEvent(s_joints, ctx->events[0], 0));
-    RSIK_HIP(ctx, hipStreamWaitEvent(s_chain, ctx->events[0], 0));
+    if (chained) RSIK_HIP(ctx, hipStreamWaitEvent(s_chain, ctx->events[0], 0));
     rsik::ContRunArgs R;
     std::memset(&R, 0, sizeof R);
     R.n = n;
@@ -708,6 +720,7 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     R.max_angle = K0.max_angle; R.cos_max = K0.cos_max; R.sin_max = K0.sin_max;
     R.st = cont_state; R.joints = joints_steps; R.reachable = reachable_steps; R.state = state_steps;
     R.theta_carry = reinterpret_cast<double*>(static_cast<char*>(ctx->ws) + slot_bytes * slots);
+    unsigned long long* const lb_words = reinterpret_cast<unsigned long long*>(static_cast<char*>(ctx->ws) + slot_bytes * slots + P.carry_bytes);
     const dim3 grid8((unsigned)((n * 8 + rsik::kChainBlock - 1) / rsik::kChainBlock));  // (n <= 30 Mi: fits)
     // What a pass really looks like was measured with in-kernel stamps (a -DRSIK_PIPE_TIMING build,
     // scripts/probes/c5_untraced_timeline.py; the profiler's kernel trace delays launches and shows another schedule): a
@@ -734,6 +747,8 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         R.T = block_T[b];
         R.first_block = b == 0;
         R.last_block = b == n_blocks - 1;
+        R.lb = chained ? nullptr : lb_words;
+        R.chunk0 = P.block_chunk0[b];
         R.ws = reinterpret_cast<double*>(static_cast<char*>(ctx->ws) + slot_bytes * (size_t)(b % slots));
         R.gw = R.ws + (size_t)R.T * (size_t)n;
         R.flags = reinterpret_cast<uint8_t*>(R.gw + (size_t)R.T * (size_t)n);
@@ -767,6 +782,15 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         // (a wave = 8 trajectories x 8 steps: n / 8 groups, 4 per workgroup)
         const dim3 grid2((unsigned)((n + 8 * (rsik::kBlock / 64) - 1) / (8 * (rsik::kBlock / 64))), (unsigned)((R.T + rsik::kJointChunk - 1) / rsik::kJointChunk));
         RSIK_HIP(ctx, hipStreamWaitEvent(s_joints, ev(1, b), 0));
+        if (!chained) {
+            // one launch, workgroups in chunk-major order
+            const dim3 grid1(grid2.x * grid2.y);
+            if (arm) hipLaunchKernelGGL(rsik::cont_joints_lb_kernel<true>, grid1, block, 0, s_joints, R);
+            else hipLaunchKernelGGL(rsik::cont_joints_lb_kernel<false>, grid1, block, 0, s_joints, R);
+            RSIK_HIP(ctx, hipEventRecord(ev(2, b), s_joints));
+            RSIK_HIP(ctx, hipEventRecord(ev(4, b), s_joints));
+            return RSIK_OK;
+        }
         if (arm) hipLaunchKernelGGL(rsik::cont_joints_kernel<true>, grid2, block, 0, s_joints, R);
         else hipLaunchKernelGGL(rsik::cont_joints_kernel<false>, grid2, block, 0, s_joints, R);
         RSIK_HIP(ctx, hipEventRecord(ev(2, b), s_joints));
@@ -803,11 +827,20 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         if ((rc = issue_back(b)) != RSIK_OK) return rc;
     }
     // the caller's stream continues once the last chain (hence every phase of every block) is done
-    RSIK_HIP(ctx, hipStreamWaitEvent(s_main, ev(3, n_blocks - 1), 0));
-    RSIK_HIP(ctx, hipStreamWaitEvent(s_main, ev(4, n_blocks - 1), 0));  // (the turns kernels of one stream run in order)
+    if (chained) RSIK_HIP(ctx, hipStreamWaitEvent(s_main, ev(3, n_blocks - 1), 0));
+    RSIK_HIP(ctx, hipStreamWaitEvent(s_main, ev(4, n_blocks - 1), 0));  // (the turns kernels of one stream run in order; so do the joints kernels)
     RSIK_HIP(ctx, hipGetLastError());
     return RSIK_OK;
 }
+
+#ifdef RSIK_LB_STATS
+extern "C" __attribute__((visibility("default"))) int rsik_debug_lb_stats(unsigned long long* out16, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(rsik::g_lb_stats), 16 * sizeof(unsigned long long)) != hipSuccess) return -2;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rsik::g_lb_stats), z, sizeof z) != hipSuccess) return -3; }
+    return 0;
+}
+#endif
 
 int rsik_matrix_to_pose(rsik_ctx* ctx, int64_t n, const double* const m12_soa[12], int identity_shortcut,
                         double* const pose_soa[6]) {
