@@ -64,7 +64,6 @@ extern "C" {
 #define RSIK_EMERGENCY_ELBOW_YAW 2       /* "EMERGENCY STOP: elbow yaw limit reached"       joint 2 */
 #define RSIK_EMERGENCY_WRIST_YAW 4       /* "EMERGENCY STOP: wrist yaw limit reached"       joint 6 */
 #define RSIK_EMERGENCY_CONTINUITY 8      /* " EMERGENCY STOP: joints are not continuous ..." continuous mode only */
-#define RSIK_EMERGENCY_INTERNAL 64       /* rsik_control_continuous_run: a wave's bounded wait for the chunk before it ran out (never seen) */
 
 /* ---- arms ---- */
 #define RSIK_ARM_R 0
@@ -172,7 +171,6 @@ int rsik_set_arm(rsik_ctx *ctx, int arm, const double *consts_host, int count);
 #define RSIK_CONT_RUN_AUTO 0
 #define RSIK_CONT_RUN_PHASED 1
 #define RSIK_CONT_RUN_STEPS 2
-#define RSIK_CONT_RUN_CHAINED 3  /* the pipeline with its sequential fourth and fifth phase (rounds 2-3): for comparison */
 /* Tuning of rsik_control_continuous_run's phased pipeline (results do not depend on it):
  *   RSIK_OPT_CONT_BLOCK_STEPS  control steps per block of the pipeline: 0 (default) = a quarter of the run, at least 64;
  *                              n > 0 = n (rounded up to the sequential phases' batch of steps) */
@@ -267,7 +265,7 @@ int rsik_control_continuous_step(rsik_ctx *ctx, int64_t n, const double *const m
  * codes and the carried theta bit for bit, joints to the last bits: see phase 3), but the work is not done step by
  * step: most of a control step does not depend on the previous one — the goal conversion, is_reachable /
  * is_reachable_no_limits and the 10-point search for the target theta (control_ik.py:327-388 up to the rate limiter)
- * are functions of the pose alone — so the batch is solved in five phases per block of steps:
+ * are functions of the pose alone — so the batch is solved in four phases per block of steps:
  *   1. prepare   one thread per (step, trajectory), chip-filling: is_reachable + the search for the target theta; the
  *                step's goal for the rate limiter (the search's theta / the preferred theta / "stay") -> workspace
  *   2. theta     one thread per trajectory, sequential over steps: the d_theta_max rate limiter and
@@ -278,13 +276,13 @@ int rsik_control_continuous_step(rsik_ctx *ctx, int64_t n, const double *const m
  *                before, a shuffle prefix sum); continuity / limit / singularity events are detected, not decided
  *   4. chain     eight lanes per trajectory (one per joint), sequential over CHUNKS: checks each chunk's first step
  *                against previous_sol (continuity_check, the +-6 pi clamp, the emergency latch) and finds the whole
- *                turns the chunk sits away from it; only a chunk with an event is walked step by step with the
- *                reference's own sequence of operations (also: steps whose get_joints hit an exact singularity)
- *   5. turns     adds those whole turns to the rows of the chunks that need them
+ *                turns the chunk sits away from it, which it adds to the chunk's rows where they are not zero (fp64 atomic
+ *                adds that nobody waits for); only a chunk with an event is walked step by step with the reference's own
+ *                sequence of operations (also: steps whose get_joints hit an exact singularity)
  * A run is cut into blocks of steps: four when it is issued launch by launch, two when it is being captured into a
  * hipGraph (RSIK_OPT_CONT_BLOCK_STEPS overrides); the results do not depend on the cut.
  * The phases of neighbouring blocks overlap on four streams (the caller's and three of the context's).  The workspace
- * (17 bytes per step and trajectory + 9 per 8-step chunk, of up to eight blocks in flight), the side streams and the
+ * (17 bytes per step and trajectory + 1 per 8-step chunk, of up to eight blocks in flight), the side streams and the
  * events belong to the context: they are created by the first call that needs them, or ahead of time by
  * rsik_control_continuous_reserve.  A call can be captured into a hipGraph (the side streams join the capture through
  * the events the call records) provided it has nothing to create: reserve first, or run a call of at least that size

@@ -1,4 +1,4 @@
-// rsik_kernel_pipeline.hpp — rsik_control_continuous_run: the five phases of the trajectory pipeline
+// rsik_kernel_pipeline.hpp — rsik_control_continuous_run: the four phases of the trajectory pipeline
 // (one translation unit: included by rsik_lib.hip, in this order, inside nothing)
 #pragma once
 
@@ -84,13 +84,9 @@ struct ContRunArgs {
     double* gw;                   // [T][n]: the goal after limit_theta_to_interval's wrap (phase 1 -> phase 2)
     uint8_t* flags;               // [T][n]
     uint8_t* chunk_event;         // [ceil(T / kJointChunk)][n]: phase 3 -> phase 4, see cont_joints_kernel
-    int8_t* chunk_turns;          // [ceil(T / kJointChunk)][n][8]: whole turns phase 4 found a chunk's joints away from the step
-                                  // before it, applied by phase 5
     double snap_tdag;             // phase 2, single-arm launches: see continuous_next_theta_lean (the kind is a template argument)
     double* theta_carry;          // [n]: previous_theta between the blocks of one run (phase 2's own state)
     int first_block, last_block;
-    unsigned long long* lb;       // [chunks of the run][4][n]: the look-back words of cont_joints_lb_kernel (NULL: the five-phase form)
-    int64_t chunk0;               // chunks of the run before this block
     double* st;                   // cont_state
     double* joints;               // [n_steps][n][7]
     uint8_t* reachable;           // [n_steps][n] or NULL
@@ -134,12 +130,6 @@ __global__ __launch_bounds__(kBlock) void cont_prepare_kernel(const ContRunArgs 
     K.flags[t * K.n + i] = (uint8_t)((T.ok_limits ? 1 : 0) | (T.found ? 2 : 0) | (special ? 8 : 0));
     if (K.state) K.state[(K.t0 + t) * K.n + i] = (uint8_t)T.code;
     if (K.reachable) K.reachable[(K.t0 + t) * K.n + i] = (T.ok_limits && T.found) ? 1 : 0;
-    // the look-back words of this block's chunks start every run at zero (cont_joints_lb_kernel)
-    if (K.lb && (t & (kJointChunk - 1)) == 0) {
-        unsigned long long* w = K.lb + (K.chunk0 + t / kJointChunk) * 4 * K.n + i;
-#pragma unroll
-        for (int k = 0; k < 4; k++) w[k * K.n] = 0ull;
-    }
 }
 
 // Row + lane addressing for the sequential phases: a step's row starts `row` bytes into the block's array (the same for
@@ -299,7 +289,7 @@ __device__ __forceinline__ void step_joints(const Acc& A, const ContRunArgs& K, 
 // turns: lane (s, i) takes the raw joints of step s - 1 from the lane eight below it, turn(s) = -rint((raw(s) - raw(s-1)) /
 // 2 pi) (zero unless a raw angle crossed its branch cut), three shuffle rounds add them up, joint = raw + 2 pi turns; the
 // chunk's first step keeps its raw value.  The turns a chunk AS A WHOLE sits away from the step before it are the
-// sequential phase's business (phase 4 finds them from the chunks' first and last rows, phase 5 adds them in): they are
+// sequential phase's business (phase 4 finds them from the chunks' first and last rows and adds them in): they are
 // not zero often enough to guess — shoulder pitch and elbow yaw swing by more than pi within a few hundred steps when the
 // arm passes its shoulder singularity (8 % of config 5's steps have them outside [-pi, pi]).  What the reference decides
 // step by step — the continuity thresholds (U:571-589, C:398), the +-6 pi limit (U:535-568), an exact singularity that
@@ -571,13 +561,17 @@ __global__ __launch_bounds__(kChainBlock) __attribute__((amdgpu_waves_per_eu(1, 
     };
     // Walks the fetched chunks until one does not stand: returns its index in the batch (kChainBatch: all stood).
     // Phase 3 left each chunk on the turn of its first step's raw joints; `turns` (this lane's joint, almost always 0) is
-    // how many whole turns that is away from previous_sol.  They go to chunk_turns for phase 5, which adds them to the
-    // chunk's rows — nothing sequential, and only the elements that need it.  The limits (U:535-568): phase 3 cannot test
+    // how many whole turns that is away from previous_sol; they are added to the chunk's rows below — only the elements
+    // that need it, and without waiting for them.  The limits (U:535-568): phase 3 cannot test
     // them without the turn, so they are tested here on the chunk's first step with the slack its other steps can use
     // up — they lie within (chunk - 1) continuity thresholds of it.
     const bool limited = jj == 0 || jj == 2 || jj == 6;
     const double clear_of_limit = 6 * kPi - (kJointChunk - 1) * 1.0 - 1e-6;
-    int8_t* const turns_out = K.chunk_turns + ii * 8 + j;  // (+ chunk * n * 8)
+    // this lane's joint in the first row of the block: a quiet chunk that sits `turns` whole turns away gets them added to
+    // its (up to) eight rows right here, by fire-and-forget fp64 atomic adds (v + turns * 2 pi, the one rounding a read-
+    // modify-write would do; nothing reads those elements again in this launch) — no fifth phase, no hand-over to it
+    double* const jcol = K.joints + (K.t0 * n + ii) * 7 + jj;
+    const int64_t row_doubles = n * 7;
     auto walk = [&](const Operands& o, int64_t c0) -> int {
         int stop = kChainBatch;
 #pragma unroll
@@ -593,7 +587,13 @@ __global__ __launch_bounds__(kChainBlock) __attribute__((amdgpu_waves_per_eu(1, 
             if (stop == kChainBatch && !stands) stop = u;
             if (taken) prev = o.last[u] + sh;
             // (a chunk that goes through `one` instead is rewritten there: no turns to add)
-            if (live && inside) turns_out[(c0 + u) * n * 8] = (int8_t)(taken ? (int)turns : 0);
+            if (RSIK_RARE(taken && turns != 0.0) && owner) {
+                double* p = jcol + (c0 + u) * kJointChunk * row_doubles;
+                const int len = (int)chunk_len(c0 + u);
+#pragma unroll
+                for (int q = 0; q < kJointChunk; q++)
+                    if (q < len) (void)__hip_atomic_fetch_add(p + q * row_doubles, sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         return stop;
     };
@@ -622,40 +622,6 @@ __global__ __launch_bounds__(kChainBlock) __attribute__((amdgpu_waves_per_eu(1, 
         K.st[8 * n + i] = init ? 1.0 : 0.0;
         K.st[9 * n + i] = emergency ? 1.0 : 0.0;
         if (K.last_block && !emergency) K.st[0 * n + i] = RSIK_WS(K, K.T - 1, i);  // previous_theta after the last step
-    }
-}
-
-// phase 5: adds the whole turns phase 4 found (chunk_turns) to the chunk's rows: one thread per (chunk, trajectory), most of
-// which find eight zero bytes and leave; the others read the elements of every joint that turns (all at once: one memory
-// round trip), add and write them back.
-__global__ __launch_bounds__(kBlock) void cont_turns_kernel(const ContRunArgs K) {
-    RSIK_PIPE_STAMP(K, 4);
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const int64_t c = blockIdx.y;
-    if (i >= K.n) return;
-    const unsigned long long packed = *reinterpret_cast<const unsigned long long*>(K.chunk_turns + (c * K.n + i) * 8);
-    if (packed == 0) return;
-    const int64_t t_begin = c * kJointChunk;
-    const int len = (int)((K.T - t_begin) < kJointChunk ? (K.T - t_begin) : kJointChunk);
-    double* const p = K.joints + ((K.t0 + t_begin) * K.n + i) * 7;
-    const int64_t row = K.n * 7;
-    double v[7][kJointChunk];
-#pragma unroll
-    for (int k = 0; k < 7; k++) {
-        if (((packed >> (8 * k)) & 0xff) != 0) {
-#pragma unroll
-            for (int q = 0; q < kJointChunk; q++) v[k][q] = p[(int64_t)(q < len ? q : len - 1) * row + k];
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 7; k++) {
-        const int turns = (int)(int8_t)((packed >> (8 * k)) & 0xff);
-        if (turns != 0) {
-            const double sh = (double)turns * kTwoPi;
-#pragma unroll
-            for (int q = 0; q < kJointChunk; q++)
-                if (q < len) p[(int64_t)q * row + k] = v[k][q] + sh;
-        }
     }
 }
 

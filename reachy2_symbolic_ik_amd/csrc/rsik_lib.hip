@@ -25,7 +25,6 @@
 #include "rsik_kernel_discrete.hpp"
 #include "rsik_kernel_continuous.hpp"
 #include "rsik_kernel_pipeline.hpp"
-#include "rsik_kernel_lookback.hpp"
 #include "rsik_kernel_state.hpp"
 
 // =====================================================================================
@@ -481,20 +480,18 @@ int rsik_control_continuous_step(rsik_ctx* ctx, int64_t n, const double* const m
 struct ContPlan {
     int64_t T;                           // steps per block (the last one may be shorter)
     std::vector<int64_t> block_t0, block_T;
-    size_t per_step, chunks_per_block, slot_bytes, carry_bytes, lb_bytes, need;
-    std::vector<int64_t> block_chunk0;   // chunks of the run before each block
-    int64_t chunks_total;
+    size_t per_step, chunks_per_block, slot_bytes, carry_bytes, need;
     int slots;
     size_t n_events;
 };
-constexpr int kContSlots = 8;  // workspace slots in flight (block b + 8 reuses the slot of block b once its phase 5 has finished)
+constexpr int kContSlots = 8;  // workspace slots in flight (block b + 8 reuses the slot of block b once its chain phase has finished)
 // `capturing`: the call is being recorded into a hipGraph.  A replay executes the dependency DAG with 15-40 us per edge
 // whatever the streams were, so fewer, longer blocks pay there (4096 x 1000 steps replayed: 0.379 ms with two blocks,
 // 0.383 with three, 0.395 with four); launched eagerly four blocks are best (0.43 against 0.46 with two: more overlap for
 // the same host-side issue cost).
 static int cont_plan(rsik_ctx* ctx, const char* who, int64_t n, int64_t n_steps, bool capturing, ContPlan& P) {
     // (the sequential phases address a block's arrays through 2 GB buffer windows: rows of n * 56 bytes, blocks of <= 384 MB
-    // of workspace, i.e. <= 1.3 GB of joints; every block costs the host five launches, so blocks are as long as that allows)
+    // of workspace, i.e. <= 1.3 GB of joints; every block costs the host four launches, so blocks are as long as that allows)
     if (n > (int64_t)30 << 20) return fail(ctx, RSIK_E_INVALID, std::string(who) + ": more than 30 Mi trajectories in one call");
     P.per_step = (size_t)n * (2 * sizeof(double) + 1);
     int64_t T_max = (int64_t)((size_t)384 << 20) / (int64_t)P.per_step;
@@ -512,24 +509,17 @@ static int cont_plan(rsik_ctx* ctx, const char* who, int64_t n, int64_t n_steps,
     if (T > n_steps) T = n_steps;
     P.T = T;
     P.block_t0.clear(); P.block_T.clear();
-    P.block_chunk0.clear();
-    P.chunks_total = 0;
     for (int64_t t0 = 0; t0 < n_steps; t0 += T) {
-        const int64_t Tb = n_steps - t0 < T ? n_steps - t0 : T;
         P.block_t0.push_back(t0);
-        P.block_T.push_back(Tb);
-        P.block_chunk0.push_back(P.chunks_total);
-        P.chunks_total += (Tb + rsik::kJointChunk - 1) / rsik::kJointChunk;
+        P.block_T.push_back(n_steps - t0 < T ? n_steps - t0 : T);
     }
     const int64_t n_blocks = (int64_t)P.block_t0.size();
     P.chunks_per_block = ((size_t)T + rsik::kJointChunk - 1) / rsik::kJointChunk;
-    P.slot_bytes = (((size_t)T * P.per_step + P.chunks_per_block * (size_t)n * 9 + 8 + 255) / 256) * 256;
+    P.slot_bytes = (((size_t)T * P.per_step + P.chunks_per_block * (size_t)n + 255) / 256) * 256;
     P.slots = n_blocks < kContSlots ? (int)n_blocks : kContSlots;
     P.carry_bytes = (((size_t)n * sizeof(double) + 255) / 256) * 256;
-    // the look-back words of the joints phase (four per chunk and trajectory, for the whole run)
-    P.lb_bytes = (((size_t)P.chunks_total * 4 * sizeof(unsigned long long) * (size_t)n + 255) / 256) * 256;
-    P.need = P.slot_bytes * P.slots + P.carry_bytes + P.lb_bytes;
-    P.n_events = 2 + 5 * (size_t)n_blocks;
+    P.need = P.slot_bytes * P.slots + P.carry_bytes;
+    P.n_events = 2 + 4 * (size_t)n_blocks;
     return RSIK_OK;
 }
 // Workspace, side streams and events for a plan.  Nothing here may happen while the caller's stream is capturing (device
@@ -682,10 +672,8 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         (void)hipMemsetAsync(pipe_t + 320, 0, 320 * sizeof(unsigned long long), ctx->stream);
     }
 #endif
-    // the joints phase finishes its rows itself (rsik_kernel_lookback.hpp) unless the five-phase form is asked for
-    const bool chained = ctx->options[RSIK_OPT_CONT_RUN_MODE] == RSIK_CONT_RUN_CHAINED;
     hipStream_t s_main = ctx->stream, s_theta = ctx->stream, s_prep = ctx->side[0], s_joints = ctx->side[1], s_chain = ctx->side[2];
-    auto ev = [&](int kind, int64_t b) { return ctx->events[2 + 5 * (size_t)b + kind]; };  // 0 prepared, 1 theta, 2 joints, 3 chain, 4 turns
+    auto ev = [&](int kind, int64_t b) { return ctx->events[2 + 4 * (size_t)b + kind]; };  // 0 prepared, 1 theta, 2 joints, 3 chain
     // (Re)initialisation of the trajectories that start here (C:296-325: the start-up search for previous_theta, ~55 us
     // of lone waves), then the pipeline's streams join in.  The prepare phase depends on the goal matrices alone, not on
     // the trajectory state: its stream forks off BEFORE the initialisation (behind whatever the caller queued ahead of
@@ -703,7 +691,7 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     }
     RSIK_HIP(ctx, hipEventRecord(ctx->events[0], s_main));
     RSIK_HIP(ctx, hipStreamWaitEvent(s_joints, ctx->events[0], 0));
-    if (chained) RSIK_HIP(ctx, hipStreamWaitEvent(s_chain, ctx->events[0], 0));
+    RSIK_HIP(ctx, hipStreamWaitEvent(s_chain, ctx->events[0], 0));
     rsik::ContRunArgs R;
     std::memset(&R, 0, sizeof R);
     R.n = n;
@@ -720,7 +708,6 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     R.max_angle = K0.max_angle; R.cos_max = K0.cos_max; R.sin_max = K0.sin_max;
     R.st = cont_state; R.joints = joints_steps; R.reachable = reachable_steps; R.state = state_steps;
     R.theta_carry = reinterpret_cast<double*>(static_cast<char*>(ctx->ws) + slot_bytes * slots);
-    unsigned long long* const lb_words = reinterpret_cast<unsigned long long*>(static_cast<char*>(ctx->ws) + slot_bytes * slots + P.carry_bytes);
     const dim3 grid8((unsigned)((n * 8 + rsik::kChainBlock - 1) / rsik::kChainBlock));  // (n <= 30 Mi: fits)
     // What a pass really looks like was measured with in-kernel stamps (a -DRSIK_PIPE_TIMING build,
     // scripts/probes/c5_untraced_timeline.py; the profiler's kernel trace delays launches and shows another schedule): a
@@ -747,20 +734,15 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         R.T = block_T[b];
         R.first_block = b == 0;
         R.last_block = b == n_blocks - 1;
-        R.lb = chained ? nullptr : lb_words;
-        R.chunk0 = P.block_chunk0[b];
         R.ws = reinterpret_cast<double*>(static_cast<char*>(ctx->ws) + slot_bytes * (size_t)(b % slots));
         R.gw = R.ws + (size_t)R.T * (size_t)n;
         R.flags = reinterpret_cast<uint8_t*>(R.gw + (size_t)R.T * (size_t)n);
         R.chunk_event = R.flags + (size_t)R.T * (size_t)n;
-        // (8-byte rows: the workspace slots are 256-byte aligned and flags + chunk events end on a multiple of 8 when n is;
-        // otherwise round up)
-        R.chunk_turns = reinterpret_cast<int8_t*>((reinterpret_cast<uintptr_t>(R.chunk_event + chunks_per_block * (size_t)n) + 7) & ~(uintptr_t)7);
     };
     auto issue_prepare = [&](int64_t b) -> int {
         set_block(b);
         const dim3 grid2(grid.x, (unsigned)R.T);
-        if (b >= slots) RSIK_HIP(ctx, hipStreamWaitEvent(s_prep, ev(4, b - slots), 0));  // the slot's previous block is done
+        if (b >= slots) RSIK_HIP(ctx, hipStreamWaitEvent(s_prep, ev(3, b - slots), 0));  // the slot's previous block is done
         if (arm) { if (plane_binds) hipLaunchKernelGGL((rsik::cont_prepare_kernel<true, true>), grid2, block, 0, s_prep, R); else hipLaunchKernelGGL((rsik::cont_prepare_kernel<true, false>), grid2, block, 0, s_prep, R); }
         else { if (plane_binds) hipLaunchKernelGGL((rsik::cont_prepare_kernel<false, true>), grid2, block, 0, s_prep, R); else hipLaunchKernelGGL((rsik::cont_prepare_kernel<false, false>), grid2, block, 0, s_prep, R); }
         RSIK_HIP(ctx, hipEventRecord(ev(0, b), s_prep));
@@ -782,15 +764,6 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         // (a wave = 8 trajectories x 8 steps: n / 8 groups, 4 per workgroup)
         const dim3 grid2((unsigned)((n + 8 * (rsik::kBlock / 64) - 1) / (8 * (rsik::kBlock / 64))), (unsigned)((R.T + rsik::kJointChunk - 1) / rsik::kJointChunk));
         RSIK_HIP(ctx, hipStreamWaitEvent(s_joints, ev(1, b), 0));
-        if (!chained) {
-            // one launch, workgroups in chunk-major order
-            const dim3 grid1(grid2.x * grid2.y);
-            if (arm) hipLaunchKernelGGL(rsik::cont_joints_lb_kernel<true>, grid1, block, 0, s_joints, R);
-            else hipLaunchKernelGGL(rsik::cont_joints_lb_kernel<false>, grid1, block, 0, s_joints, R);
-            RSIK_HIP(ctx, hipEventRecord(ev(2, b), s_joints));
-            RSIK_HIP(ctx, hipEventRecord(ev(4, b), s_joints));
-            return RSIK_OK;
-        }
         if (arm) hipLaunchKernelGGL(rsik::cont_joints_kernel<true>, grid2, block, 0, s_joints, R);
         else hipLaunchKernelGGL(rsik::cont_joints_kernel<false>, grid2, block, 0, s_joints, R);
         RSIK_HIP(ctx, hipEventRecord(ev(2, b), s_joints));
@@ -798,18 +771,11 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         if (arm) hipLaunchKernelGGL(rsik::cont_chain_kernel<true>, grid8, dim3(rsik::kChainBlock), 0, s_chain, R);
         else hipLaunchKernelGGL(rsik::cont_chain_kernel<false>, grid8, dim3(rsik::kChainBlock), 0, s_chain, R);
         RSIK_HIP(ctx, hipEventRecord(ev(3, b), s_chain));
-        // phase 5 is independent parallel work behind chain(b): on the prepare stream where no prepare launch will be issued
-        // after it (every block of a run that has a workspace slot per block, else the last block only: a prepare must not
-        // queue behind it), so that the chain stream goes straight on to chain(b + 1); otherwise on the chain stream
-        hipStream_t s_turns = (n_blocks <= slots || b == n_blocks - 1) ? s_prep : s_chain;
-        if (s_turns != s_chain) RSIK_HIP(ctx, hipStreamWaitEvent(s_turns, ev(3, b), 0));
-        hipLaunchKernelGGL(rsik::cont_turns_kernel, dim3(grid.x, (unsigned)((R.T + rsik::kJointChunk - 1) / rsik::kJointChunk)), block, 0, s_turns, R);
-        RSIK_HIP(ctx, hipEventRecord(ev(4, b), s_turns));
         return RSIK_OK;
     };
     const int64_t head = n_blocks < slots ? n_blocks : slots;
     // Issue order of the blocks that have a workspace slot of their own (it is also the order of the nodes in a captured
-    // graph): prepare(0), theta(0), then the other prepares back to back, the other thetas, then joints + chain + turns of
+    // graph): prepare(0), theta(0), then the other prepares back to back, the other thetas, then joints + chain of
     // every block.  Measured on graph replays of 4096 x 1000 steps against three other orders (prepare / theta
     // alternating: 0.394-0.411 ms; all prepares, all thetas: 0.398-0.401; thetas and backs alternating: 0.414-0.416):
     // 0.387-0.392 ms.
@@ -827,20 +793,10 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         if ((rc = issue_back(b)) != RSIK_OK) return rc;
     }
     // the caller's stream continues once the last chain (hence every phase of every block) is done
-    if (chained) RSIK_HIP(ctx, hipStreamWaitEvent(s_main, ev(3, n_blocks - 1), 0));
-    RSIK_HIP(ctx, hipStreamWaitEvent(s_main, ev(4, n_blocks - 1), 0));  // (the turns kernels of one stream run in order; so do the joints kernels)
+    RSIK_HIP(ctx, hipStreamWaitEvent(s_main, ev(3, n_blocks - 1), 0));
     RSIK_HIP(ctx, hipGetLastError());
     return RSIK_OK;
 }
-
-#ifdef RSIK_LB_STATS
-extern "C" __attribute__((visibility("default"))) int rsik_debug_lb_stats(unsigned long long* out16, int reset) {
-    if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(rsik::g_lb_stats), 16 * sizeof(unsigned long long)) != hipSuccess) return -2;
-    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rsik::g_lb_stats), z, sizeof z) != hipSuccess) return -3; }
-    return 0;
-}
-#endif
 
 int rsik_matrix_to_pose(rsik_ctx* ctx, int64_t n, const double* const m12_soa[12], int identity_shortcut,
                         double* const pose_soa[6]) {
