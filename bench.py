@@ -839,7 +839,7 @@ def main(argv=None, return_line=False):
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "launch": ("eager" if graph is None else "K replays of a hipGraph holding one pass (two blocks under capture: 11 kernels on four streams)" if cfg == 5
+            "launch": ("eager" if graph is None else "K replays of a hipGraph holding one pass (two blocks under capture: 9 kernels on four streams)" if cfg == 5
                        else "hipGraph replay of K captured launches"),
             "config": {"workload": workload, "poses_per_gpu": n,
                        "theta_policy": {2: "interval[0]", 3: "discrete sweep nb=64", 4: "interval[0]", 5: "continuous, d_theta_max=0.01"}[cfg],
