@@ -85,7 +85,7 @@ struct ContRunArgs {
     uint8_t* flags;               // [T][n]
     uint8_t* chunk_event;         // [ceil(T / kJointChunk)][n]: phase 3 -> phase 4, see cont_joints_kernel
     double snap_tdag;             // phase 2, single-arm launches: see continuous_next_theta_lean (the kind is a template argument)
-    double* theta_carry;          // [n]: previous_theta between the blocks of one run (phase 2's own state)
+    double* theta_carry;          // [2][n]: previous_theta between the blocks of one run (phase 2's own state); row 1: see cont_theta_kernel
     int first_block, last_block;
     double* st;                   // cont_state
     double* joints;               // [n_steps][n][7]
@@ -186,10 +186,10 @@ __global__ __launch_bounds__(kThetaBlock) __attribute__((amdgpu_waves_per_eu(1, 
     auto generic = [&](double g) {
         return continuous_next_theta_goal((g != g) ? prev_theta : g, prev_theta, K.d_theta_max, l0, l1, dmax_v, l1v);
     };
-    auto one = [&](double g, double gw, unsigned dst_row) {
+    auto one = [&](double g, double gw) {
         if constexpr (KIND == kSnapGeneric) prev_theta = generic(g);
         else prev_theta = continuous_next_theta_lean<KIND>(g, gw, prev_theta, dmax_v, l0v, l1v, tdag_v);
-        st_row_f64(wbuf, off, dst_row, prev_theta);
+        return prev_theta;
     };
     int64_t left = K.T;
     if (KIND != kSnapGeneric && K.first_block && left > 0) {
@@ -215,24 +215,51 @@ __global__ __launch_bounds__(kThetaBlock) __attribute__((amdgpu_waves_per_eu(1, 
         row += (unsigned)(kPartial ? valid : kThetaBatch) * stride;
         // one wait for the whole set (it was fetched a batch ago) instead of one per operand: a wait is an issue slot too
         asm volatile("" : : "v"(o.g[kThetaBatch - 1]), "v"(o.gw[KIND != kSnapGeneric ? kThetaBatch - 1 : 0]));
+        // the batch's results leave together, behind its last step: a store between two steps would sit between the loads of
+        // the batch after this one and those of the batch after that in the wave's one in-order memory counter, and the wait
+        // for the former would wait for its acknowledgement too
+        double res[kThetaBatch];
 #pragma unroll
         for (int u = 0; u < kThetaBatch; u++) {
-            if (!kPartial || u < valid) one(o.g[u], o.gw[u], r0 + (unsigned)u * stride);  // (launch-uniform: a scalar branch)
+            if (!kPartial || u < valid) res[u] = one(o.g[u], o.gw[u]);  // (launch-uniform: a scalar branch)
+        }
+#pragma unroll
+        for (int u = 0; u < kThetaBatch; u++) {
+            if (!kPartial || u < valid) st_row_f64(wbuf, off, r0 + (unsigned)u * stride, res[u]);
         }
     };
     int64_t batches = left / kThetaBatch;
     left -= batches * kThetaBatch;
     Operands a, b;
     if (batches > 0) fetch(a, 0, kThetaBatch);
+    // Two batches per turn, each fetched while the one before it is computed.  The turn runs only while a third full batch
+    // exists, so that its second fetch needs no branch around it: where a path with and a path without that fetch meet, the
+    // compiler can only wait for the smaller number of operations in flight — on the path with the fetch that is the batch
+    // about to be computed AND half of the one just requested, a memory round trip every 32 steps (~30 % of this phase).
+    if (batches >= 3) {
+        // (and the turn is entered the way it is re-entered — a batch in flight, then a batch's worth of stores — or the wait
+        // at its top, where the two ways in meet, is again for the smaller count: the stores of the batch just computed)
+#pragma unroll
+        for (int u = 0; u < kThetaBatch; u++) {
+            K.theta_carry[K.n + i] = 0.0;  // (a second row of the carry array that nothing reads; a constant: no load to wait for)
+            asm volatile("" ::: "memory");
+        }
+    }
 #pragma unroll 1
-    while (batches >= 2) {
+    while (batches >= 3) {
         fetch(b, kThetaBatch, kThetaBatch);
         compute(a, std::false_type{}, kThetaBatch);
-        if (batches > 2) fetch(a, kThetaBatch, kThetaBatch);
+        fetch(a, kThetaBatch, kThetaBatch);
         compute(b, std::false_type{}, kThetaBatch);
         batches -= 2;
     }
-    if (batches == 1) {
+    if (batches == 2) {
+        fetch(b, kThetaBatch, kThetaBatch);
+        compute(a, std::false_type{}, kThetaBatch);
+        if (left > 0) fetch(a, kThetaBatch, (int)left);
+        compute(b, std::false_type{}, kThetaBatch);
+        if (left > 0) compute(a, std::true_type{}, (int)left);
+    } else if (batches == 1) {
         if (left > 0) fetch(b, kThetaBatch, (int)left);
         compute(a, std::false_type{}, kThetaBatch);
         if (left > 0) compute(b, std::true_type{}, (int)left);
@@ -570,9 +597,14 @@ __global__ __launch_bounds__(kChainBlock) __attribute__((amdgpu_waves_per_eu(1, 
     // this lane's joint in the first row of the block: a quiet chunk that sits `turns` whole turns away gets them added to
     // its (up to) eight rows right here, by fire-and-forget fp64 atomic adds (v + turns * 2 pi, the one rounding a read-
     // modify-write would do; nothing reads those elements again in this launch) — no fifth phase, no hand-over to it
-    // (4096 x 1000 steps: this phase alone 52 -> 71 us, the fifth phase was 25 us and a hand-over.  Measured and not kept: the
-    // eight lanes of a trajectory sharing the rows of the joint that turned — one atomic instruction instead of eight, seven
-    // shuffles to find out which: 97 us; the atomics noted in LDS and issued in one go after the walk: 80 us.)
+    // What they cost this phase is their number, not how they are issued: ~520 element updates per wave and 1000 steps, each a
+    // miss in L2, ~40 ns apiece through the compute unit's memory pipeline, which the next batch's operand loads share (4096 x
+    // 1000 steps, this phase alone: 45 us without them, 69 with; the fifth phase was 25 us and a hand-over).  Measured and not
+    // kept: the eight lanes of a trajectory sharing the rows of the joint that turned — one atomic instruction instead of
+    // eight, seven shuffles to find out which: 97 us; noted in LDS per lane and issued in one go after the walk: 80 us; noted
+    // in LDS per wave (ballot + prefix count) and added with all 64 lanes, one instruction per eight notes: 66 us, no faster
+    // within a pass; workgroups of 64 / 128 threads instead of 256, so that more compute units share them: 62 / 59 us, no
+    // faster within a pass either.
     double* const jcol = K.joints + (K.t0 * n + ii) * 7 + jj;
     const int64_t row_doubles = n * 7;
     auto walk = [&](const Operands& o, int64_t c0) -> int {
@@ -593,9 +625,13 @@ __global__ __launch_bounds__(kChainBlock) __attribute__((amdgpu_waves_per_eu(1, 
             if (RSIK_RARE(taken && turns != 0.0) && owner) {
                 double* p = jcol + (c0 + u) * kJointChunk * row_doubles;
                 const int len = (int)chunk_len(c0 + u);
+                // (written as an instruction: the compiler counts the memory operations a wave has in flight — one counter for
+                // loads, stores and atomics, in issue order — to wait for exactly the loads it needs, and a data-dependent number
+                // of atomics among them would make it wait for everything, the operands just requested for the next batch
+                // included.  Atomics it does not see only prolong a wait where they really are still in flight.)
 #pragma unroll
                 for (int q = 0; q < kJointChunk; q++)
-                    if (q < len) (void)__hip_atomic_fetch_add(p + q * row_doubles, sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (q < len) asm volatile("global_atomic_add_f64 %0, %1, off" : : "v"(p + q * row_doubles), "v"(sh) : "memory");
             }
         }
         return stop;
@@ -606,8 +642,11 @@ __global__ __launch_bounds__(kChainBlock) __attribute__((amdgpu_waves_per_eu(1, 
         fetch(oa, 0);
 #pragma unroll 1
         while (c0 < n_chunks) {
-            const bool more = c0 + kChainBatch < n_chunks;
-            if (more) fetch(ob, c0 + kChainBatch);
+            // the next batch's operands, always (past the end `fetch` repeats the last chunk): with a branch around it the two
+            // paths meet with different numbers of loads in flight and the compiler waits for all of them before the walk —
+            // the batch just requested included, a memory round trip per batch (this phase alone 52 -> 45 us without the
+            // atomics, 74 -> 69 with them)
+            fetch(ob, c0 + kChainBatch);
             const int stop = walk(oa, c0);
             if (RSIK_RARE(c0 + stop < n_chunks && stop < kChainBatch)) {
                 // an eventful chunk: the reference's own sequence of operations for its steps, then the walk resumes behind it

@@ -517,7 +517,7 @@ static int cont_plan(rsik_ctx* ctx, const char* who, int64_t n, int64_t n_steps,
     P.chunks_per_block = ((size_t)T + rsik::kJointChunk - 1) / rsik::kJointChunk;
     P.slot_bytes = (((size_t)T * P.per_step + P.chunks_per_block * (size_t)n + 255) / 256) * 256;
     P.slots = n_blocks < kContSlots ? (int)n_blocks : kContSlots;
-    P.carry_bytes = (((size_t)n * sizeof(double) + 255) / 256) * 256;
+    P.carry_bytes = (((size_t)n * 2 * sizeof(double) + 255) / 256) * 256;
     P.need = P.slot_bytes * P.slots + P.carry_bytes;
     P.n_events = 2 + 4 * (size_t)n_blocks;
     return RSIK_OK;
