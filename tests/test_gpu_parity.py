@@ -971,6 +971,37 @@ def test_continuous_pipeline_odd_batch_shapes(torch_mod, n_traj, n_steps):
     c._solver.set_option(A.OPT_CONT_RUN_MODE, A.CONT_RUN_AUTO)
 
 
+def test_continuous_pipeline_every_short_length(torch_mod):
+    """The sequential phases fetch their operands in batches (16 steps / 16 chunks) with the next batch in flight, and the
+    loops that do it have a turn of two batches, a tail for two, one or no full batch left, and a partial batch — for a run's
+    first block (whose first step is taken separately) and for the blocks behind it.  Every run length from 1 to 80 steps
+    as one block, and every length from 49 to 130 cut into blocks of 48, against one launch of the step kernel per step."""
+    from bench import make_config5_trajectories
+
+    A = _abi_mod()
+    n_traj = 72
+    traj_all = make_config5_trajectories(n_traj, 130, seed=4242)
+    c = make_control()
+    for blk, lengths in ((0, range(1, 81)), (48, range(49, 131))):
+        for n_steps in lengths:
+            traj = traj_all[:n_steps].contiguous()
+            ref = None
+            for run_mode in (A.CONT_RUN_STEPS, A.CONT_RUN_PHASED):
+                c._solver.set_option(A.OPT_CONT_RUN_MODE, run_mode)
+                c._solver.set_option(A.OPT_CONT_BLOCK_STEPS, blk)
+                st = c.new_continuous_state("r_arm", n_traj)
+                res = c.run_continuous_trajectories("r_arm", traj, st, first_step_timed_out=True, current_pose=traj[0])
+                torch_mod.cuda.synchronize()
+                got = {k: v.clone() for k, v in res.items()}
+                got["cont_state"] = st[:11].clone()
+                if ref is None:
+                    ref = got
+                else:
+                    _same_run(torch_mod, ref, got, (blk, n_steps))
+    c._solver.set_option(A.OPT_CONT_RUN_MODE, A.CONT_RUN_AUTO)
+    c._solver.set_option(A.OPT_CONT_BLOCK_STEPS, 0)
+
+
 @pytest.mark.parametrize("arm", ["r_arm", "l_arm"])
 @pytest.mark.parametrize("mode", ["unconstrained", "low_elbow"])
 @pytest.mark.parametrize("d_theta_max", [0.01, 0.4])
