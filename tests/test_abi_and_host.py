@@ -245,3 +245,22 @@ def test_header_is_plain_c_and_links(tmp_path):
                            "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_integration_doc_names_every_entry_point():
+    """INTEGRATION.md is where a maintainer of the reference looks for what each C entry point replaces: every function
+    include/rsik.h declares is named there, and the ABI version it quotes is the header's."""
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "rsik.h")).read()
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    names = set(re.findall(r"\b(rsik_[a-z0-9_]+)\s*\(", header))
+    assert len(names) >= 30
+    # (families are written `rsik_malloc / rsik_free / rsik_memcpy_*` and `rsik_control_continuous_step` / `_run` there)
+    missing = [n for n in sorted(names)
+               if n not in doc and not any(n.startswith(stem[:-1]) for stem in re.findall(r"rsik_[a-z0-9_]+_\*", doc))
+               and not (n.endswith("_run") and n[: -len("_run")] + "_step` / `_run" in doc)]
+    assert not missing, missing
+    version = int(re.search(r"#define\s+RSIK_ABI_VERSION\s+(\d+)", header).group(1))
+    assert f"ABI version ({version})" in doc
