@@ -1666,3 +1666,14 @@ def test_interval_closed_form_hands_over_at_decision_boundaries(torch_mod, orc):
     assert np.max(np.abs(res["interval"][m & ~tight] - ref["interval"][m & ~tight])) < TOL
     if tight.any():
         assert np.max(np.abs(res["interval"][tight] - ref["interval"][tight])) < 1e-7
+
+
+def test_integration_md_snippet_runs(torch_mod, capsys):
+    """INTEGRATION.md section 1 lists the batched entry points as a code block; scripts/integration_snippet.py is that block with
+    inputs around it.  It must run as written, and the FK of what solve_batch returns must reproduce the poses."""
+    import runpy
+
+    ns = runpy.run_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "integration_snippet.py"))
+    err, ok = ns["err"], ns["ok"]
+    assert bool(ok.any()) and float(err[ok].abs().max()) < 1e-12
+    assert tuple(ns["out"]["joints"].shape) == (40, 64, 7)
