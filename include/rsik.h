@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define RSIK_ABI_VERSION 4
+#define RSIK_ABI_VERSION 5
 
 /* ---- status codes ---- */
 #define RSIK_OK 0
@@ -161,9 +161,10 @@ int rsik_set_arm(rsik_ctx *ctx, int arm, const double *consts_host, int count);
  *                           exhaustive wave-cooperative sweep, 2 = always the per-lane search
  *   RSIK_OPT_NO_TIPZ        non-zero: never use the goal stage specialised for tip_x = tip_y = 0
  *   RSIK_OPT_NO_MIRROR      non-zero: mixed r/l launches read every constant per lane (no mirror-image shortcut)
- *   RSIK_OPT_CONT_RUN_MODE  rsik_control_continuous_run: 0 / 1 = the phased trajectory pipeline (see there), 2 = one launch
- *                           of the step kernel per control step, exactly what n_steps calls of
- *                           rsik_control_continuous_step issue */
+ *   RSIK_OPT_CONT_RUN_MODE  rsik_control_continuous_run: 0 = chosen by the library, 1 = the phased trajectory pipeline
+ *                           (kernels per block of steps on four streams), 2 = one launch of the step kernel per control
+ *                           step, exactly what n_steps calls of rsik_control_continuous_step issue, 3 = the single
+ *                           self-scheduling launch (see there; RSIK_E_INVALID if the run does not qualify) */
 #define RSIK_OPT_SWEEP_MODE 1
 #define RSIK_OPT_NO_TIPZ 2
 #define RSIK_OPT_NO_MIRROR 3
@@ -171,11 +172,24 @@ int rsik_set_arm(rsik_ctx *ctx, int arm, const double *consts_host, int count);
 #define RSIK_CONT_RUN_AUTO 0
 #define RSIK_CONT_RUN_PHASED 1
 #define RSIK_CONT_RUN_STEPS 2
-/* Tuning of rsik_control_continuous_run's phased pipeline (results do not depend on it):
- *   RSIK_OPT_CONT_BLOCK_STEPS  control steps per block of the pipeline: 0 (default) = a quarter of the run, at least 64;
- *                              n > 0 = n (rounded up to the sequential phases' batch of steps) */
+#define RSIK_CONT_RUN_FUSED 3
+#define RSIK_CONT_RUN_FLAGS 4
+/* Tuning of rsik_control_continuous_run (results do not depend on it):
+ *   RSIK_OPT_CONT_BLOCK_STEPS  control steps per block: 0 (default) = a quarter of the run, at least 64 (phased pipeline) /
+ *                              64 (single launch); n > 0 = n (rounded up to the sequential phases' batch of steps)
+ *   RSIK_OPT_CONT_LOOKAHEAD    single launch: blocks the prepare items are handed out ahead of the joints items (0 = default)
+ *   RSIK_OPT_CONT_PREP_STEPS   single launch: control steps per prepare item (0 = default; a divisor of the block)
+ *   RSIK_OPT_CONT_CHAIN_LAG    single launch: blocks the chain items are handed out behind the joints items (0 = default)
+ *   RSIK_OPT_CONT_JOINT_GROUPS single launch: sub-groups of eight trajectories per joints item (0 = default; 1, 2, 4 or 8)
+ *   RSIK_OPT_CONT_TRACE        single launch, diagnostic: non-zero = keep a record (start, ready, end, what, where) of up to
+ *                              that many thousand work items per run for rsik_control_continuous_trace */
 #define RSIK_OPT_CONT_BLOCK_STEPS 5
-#define RSIK_OPT_COUNT 6
+#define RSIK_OPT_CONT_LOOKAHEAD 6
+#define RSIK_OPT_CONT_PREP_STEPS 7
+#define RSIK_OPT_CONT_TRACE 8
+#define RSIK_OPT_CONT_CHAIN_LAG 9
+#define RSIK_OPT_CONT_JOINT_GROUPS 10
+#define RSIK_OPT_COUNT 11
 int rsik_set_option(rsik_ctx *ctx, int option, int value);
 int rsik_get_option(const rsik_ctx *ctx, int option, int *value);
 
@@ -309,6 +323,25 @@ int rsik_control_continuous_run(rsik_ctx *ctx, int64_t n, int64_t n_steps, const
  * a hipGraph on a context that has not yet run one of that size.  Uses RSIK_OPT_CONT_BLOCK_STEPS as set at the time.
  */
 int rsik_control_continuous_reserve(rsik_ctx *ctx, int64_t n, int64_t n_steps);
+
+/*
+ * rsik_control_continuous_release — waits for the device and frees everything rsik_control_continuous_run keeps in the
+ * context between calls: the workspace, workspaces it has outgrown while a captured hipGraph could still point into them,
+ * the diagnostic trace.  After it, hipGraphs captured from this context's continuous runs must not be replayed any more.
+ * (Without a capture an outgrown workspace is freed when it is outgrown; the context then holds one, of the largest run
+ * so far, grown geometrically.)
+ */
+int rsik_control_continuous_release(rsik_ctx *ctx);
+
+/*
+ * rsik_control_continuous_trace — diagnostic (RSIK_OPT_CONT_TRACE): the work-item records of the last single-launch run,
+ * four 64-bit words each: claimed, dependencies met, done (100 MHz device clock), and what / where — kind [0:3] (0 chain,
+ * 1 joints, 2 prepare, 3 one block of a theta wave), block [4:19], group [20:31], sub-item [32:39], XCD [40:43], the low
+ * 16 bits of the hardware id (wave, SIMD, pipe, CU, SH, SE) [44:59].  Synchronises the context's stream.
+ *   records_host   host buffer for up to max_records records (may be NULL to ask for the count only)
+ *   n_records      out: records copied (or available, with records_host NULL)
+ */
+int rsik_control_continuous_trace(rsik_ctx *ctx, unsigned long long *records_host, size_t max_records, size_t *n_records);
 
 /*
  * Solver-state entry points: the scalar drop-in API.  A SymbolicIK object keeps self.goal_pose,

@@ -23,6 +23,15 @@ namespace rsik {
 #define RSIK_CHAIN_BATCH 16  // chunks of the joints phase whose first / last rows the chain phase fetches at once
 #endif
 constexpr int kThetaBatch = RSIK_THETA_BATCH, kChainBatch = RSIK_CHAIN_BATCH;
+// analysis builds: the phased kernels with the coherent (sc1) accesses of the single-launch form / at a fixed occupancy
+#ifndef RSIK_PHASED_COH
+#define RSIK_PHASED_COH false
+#endif
+#ifdef RSIK_PHASED_OCC
+#define RSIK_PHASED_OCC_ATTR __attribute__((amdgpu_waves_per_eu(RSIK_PHASED_OCC, RSIK_PHASED_OCC)))
+#else
+#define RSIK_PHASED_OCC_ATTR
+#endif
 // consecutive steps of a trajectory that one thread of the joints phase walks (and that the chain phase accepts or redoes as
 // one unit)
 #ifndef RSIK_JOINT_CHUNK
@@ -95,9 +104,63 @@ struct ContRunArgs {
 };
 #define RSIK_WS(K, t, i) (K).ws[(int64_t)(t) * (K).n + (i)]
 
+// Accesses to data that ANOTHER compute unit produces or consumes while the same kernel runs (the single-launch form,
+// rsik_kernel_fused.hpp): the eight XCDs' L2 caches are not coherent with each other for ordinary accesses, so such data
+// is written through and read past them — relaxed agent-scope atomics, i.e. the `sc1` forms of the plain instructions.
+// COH = false (the phased kernels, where a kernel boundary does the job): ordinary accesses, the code as it was.
+template <bool COH>
+__device__ __forceinline__ double ldc_f64(const double* p) {
+    if constexpr (COH) return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<unsigned long long*>(const_cast<double*>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    else return *p;
+}
+// (RSIK_COH_PLAIN_STORES: a timing experiment — the coherent forms' stores as ordinary ones; the results are not valid)
+#ifndef RSIK_COH_PLAIN_STORES
+#define RSIK_COH_PLAIN_STORES 0
+#endif
+template <bool COH>
+__device__ __forceinline__ void stc_f64(double* p, double v) {
+    if constexpr (COH && !RSIK_COH_PLAIN_STORES) __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <bool COH>
+__device__ __forceinline__ int ldc_u8(const uint8_t* p) {
+    if constexpr (COH) return (int)__hip_atomic_load(const_cast<uint8_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return (int)*p;
+}
+template <bool COH>
+__device__ __forceinline__ void stc_u8(uint8_t* p, uint8_t v) {
+    if constexpr (COH && !RSIK_COH_PLAIN_STORES) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
+// phase 1, one (step, trajectory): `m` the step's twelve matrix entries, `t` the step's row in the workspace arrays, `t_abs`
+// its row in the run's outputs.  Shared by the phased kernel below and the single-launch form (COH, see above).
+template <bool MIXED, bool PLANE, bool COH>
+__device__ __forceinline__ void cont_prepare_step(const ContRunArgs& K, const Acc<MIXED>& A, int slot, const double (&m)[12], int64_t t,
+                                                  int64_t t_abs, int64_t i, bool live) {
+    Rot Rg;
+    V3 pos;
+    bool special;
+    goal_from_m12(m, Rg, pos, K.euler_roundtrip, &special);
+    const Goal G = make_goal(A, Rg);
+    Reach r;
+    const ThetaTarget T = continuous_target<PLANE, false>(A, pos, G.woff, K.pref_self[slot], K.pref_self_cs[slot], K.pref_self_sn[slot], r);
+    if (!live) return;
+    // the step's goal for the theta phase: the search's theta, NaN = nothing found, stay (U:252-264 with goal =
+    // previous_theta), or the preferred theta of an unreachable pose (U:115-127)
+    const double goal = T.ok_limits ? (T.found ? T.theta : __builtin_nan("")) : K.pref_arg[slot];
+    stc_f64<COH>(&RSIK_WS(K, t, i), goal);
+    // what limit_theta_to_interval makes of theta = goal before it looks at the interval (U:93-97): this phase has the
+    // issue slots for it, the theta phase (a lone wave per SIMD) has not
+    stc_f64<COH>(&K.gw[t * K.n + i], wrap_theta_to_pi(goal));
+    stc_u8<COH>(&K.flags[t * K.n + i], (uint8_t)((T.ok_limits ? 1 : 0) | (T.found ? 2 : 0) | (special ? 8 : 0)));
+    if (K.state) stc_u8<COH>(&K.state[t_abs * K.n + i], (uint8_t)T.code);
+    if (K.reachable) stc_u8<COH>(&K.reachable[t_abs * K.n + i], (T.ok_limits && T.found) ? 1 : 0);
+}
+
 // phase 1: one thread per (trajectory, step of the block)
 template <bool MIXED, bool PLANE>
-__global__ __launch_bounds__(kBlock) void cont_prepare_kernel(const ContRunArgs K) {
+__global__ __launch_bounds__(kBlock) RSIK_PHASED_OCC_ATTR void cont_prepare_kernel(const ContRunArgs K) {
     RSIK_PIPE_STAMP(K, 0);
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t t = blockIdx.y;
@@ -112,24 +175,7 @@ __global__ __launch_bounds__(kBlock) void cont_prepare_kernel(const ContRunArgs 
         stage_tables<MIXED, (int)offsetof(ContRunArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>(lds_tab, K.arms);
     const Acc<MIXED> A = make_acc<MIXED>(K.arms, lane_isl, lds_tab);
     const int slot = MIXED ? (A.isl ? 1 : 0) : 0;
-    Rot Rg;
-    V3 pos;
-    bool special;
-    goal_from_m12(m, Rg, pos, K.euler_roundtrip, &special);
-    const Goal G = make_goal(A, Rg);
-    Reach r;
-    const ThetaTarget T = continuous_target<PLANE, false>(A, pos, G.woff, K.pref_self[slot], K.pref_self_cs[slot], K.pref_self_sn[slot], r);
-    if (!live) return;
-    // the step's goal for the theta phase: the search's theta, NaN = nothing found, stay (U:252-264 with goal =
-    // previous_theta), or the preferred theta of an unreachable pose (U:115-127)
-    const double goal = T.ok_limits ? (T.found ? T.theta : __builtin_nan("")) : K.pref_arg[slot];
-    RSIK_WS(K, t, i) = goal;
-    // what limit_theta_to_interval makes of theta = goal before it looks at the interval (U:93-97): this phase has the
-    // issue slots for it, the theta phase (a lone wave per SIMD) has not
-    K.gw[t * K.n + i] = wrap_theta_to_pi(goal);
-    K.flags[t * K.n + i] = (uint8_t)((T.ok_limits ? 1 : 0) | (T.found ? 2 : 0) | (special ? 8 : 0));
-    if (K.state) K.state[(K.t0 + t) * K.n + i] = (uint8_t)T.code;
-    if (K.reachable) K.reachable[(K.t0 + t) * K.n + i] = (T.ok_limits && T.found) ? 1 : 0;
+    cont_prepare_step<MIXED, PLANE, RSIK_PHASED_COH>(K, A, slot, m, t, K.t0 + t, i, live);
 }
 
 // Row + lane addressing for the sequential phases: a step's row starts `row` bytes into the block's array (the same for
@@ -141,19 +187,131 @@ typedef unsigned RowWords2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t row_buffer(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
 }
+// (AUX = 16: the `sc1` form, for rows another compute unit writes or reads while the kernel runs — see ldc_f64)
+template <int AUX = 0>
 __device__ __forceinline__ double ld_row_f64(__amdgpu_buffer_rsrc_t buf, unsigned lane, unsigned row) {
-    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(buf, lane, row, 0));
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(buf, lane, row, AUX));
 }
+template <int AUX = 0>
 __device__ __forceinline__ void st_row_f64(__amdgpu_buffer_rsrc_t buf, unsigned lane, unsigned row, double v) {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(RowWords2, v), buf, lane, row, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(RowWords2, v), buf, lane, row, RSIK_COH_PLAIN_STORES ? 0 : AUX);
 }
+template <int AUX = 0>
 __device__ __forceinline__ int ld_row_u8(__amdgpu_buffer_rsrc_t buf, unsigned lane, unsigned row) {
-    return (int)__builtin_amdgcn_raw_buffer_load_b8(buf, lane, row, 0);
+    return (int)__builtin_amdgcn_raw_buffer_load_b8(buf, lane, row, AUX);
 }
 
 // phase 2: one thread per trajectory walks the block's steps: the recurrence on previous_theta.
 // KIND: kSnapInner / kSnapWrap = the step specialised for the launch's control interval (continuous_next_theta_lean;
 // single-arm launches), kSnapGeneric = the reference's own sequence of operations for any interval.
+// cont_theta_walk: T steps of one trajectory per lane; `ws` / `gw` = the rows of the first of them, `first_generic`: the first
+// step goes through the generic form (the state a run starts from is the caller's), `scratch`: n doubles nothing reads.
+// BATCH steps' operands are fetched at once, a batch ahead.  Returns previous_theta after the last step.
+template <int KIND, bool COH, int BATCH>
+__device__ __forceinline__ double cont_theta_walk(const ContRunArgs& K, int64_t i, double l0, double l1, double* ws, double* gw, int64_t T,
+                                                  bool first_generic, double prev_theta, double* scratch) {
+    constexpr int AUX = COH ? 16 : 0;
+    // A lone wave per SIMD: every instruction of a step is paid in full (~4.5 cycles each, rsik_device.hpp `opaque`), and
+    // the memory round trip of a step's operands would double a step, so they are fetched BATCH steps at a time,
+    // one batch ahead of the one being computed, into two register sets that take turns (no copies); what is left of the
+    // block after the last full batch goes step by step.
+    const int64_t n = K.n;
+    // this trajectory's goal / theta of the step the wave is at: (wbuf, off, row), its wrapped goal (gbuf, off, row); a step
+    // further is `stride` bytes further
+    const __amdgpu_buffer_rsrc_t wbuf = row_buffer(ws), gbuf = row_buffer(gw);
+    const unsigned off = (unsigned)(i * sizeof(double)), stride = (unsigned)(n * sizeof(double));
+    unsigned row = 0;
+    // launch constants that a select or a sign transfer needs as a vector operand: pinned in vector registers once
+    const double dmax_v = opaque(K.d_theta_max), l0v = opaque(l0), l1v = opaque(l1), tdag_v = opaque(K.snap_tdag);
+    // `g` is the step's goal as the prepare phase encoded it: the search's theta, the preferred theta for an unreachable
+    // pose, NaN = "stay".  Straight-line arithmetic only.
+    auto generic = [&](double g) {
+        return continuous_next_theta_goal((g != g) ? prev_theta : g, prev_theta, K.d_theta_max, l0, l1, dmax_v, l1v);
+    };
+    auto one = [&](double g, double gw_) {
+        if constexpr (KIND == kSnapGeneric) prev_theta = generic(g);
+        else prev_theta = continuous_next_theta_lean<KIND>(g, gw_, prev_theta, dmax_v, l0v, l1v, tdag_v);
+        return prev_theta;
+    };
+    int64_t left = T;
+    if (KIND != kSnapGeneric && first_generic && left > 0) {
+        // the state a run starts from is the caller's: only from the first result on is previous_theta known to lie in
+        // [-pi, pi], which the specialised step relies on
+        prev_theta = generic(ld_row_f64<AUX>(wbuf, off, row));
+        st_row_f64<AUX>(wbuf, off, row, prev_theta);
+        row += stride; left -= 1;
+    }
+    struct Operands { double g[BATCH], gw[BATCH]; };
+    // (`valid` < BATCH: the block's last, partial batch — the steps past its end repeat the last one and are skipped)
+    auto fetch = [&](Operands& o, int ahead, int valid) {
+#pragma unroll
+        for (int u = 0; u < BATCH; u++) {
+            const unsigned at = row + (unsigned)(ahead + (u < valid ? u : valid - 1)) * stride;
+            o.g[u] = ld_row_f64<AUX>(wbuf, off, at);
+            if constexpr (KIND != kSnapGeneric) o.gw[u] = ld_row_f64<AUX>(gbuf, off, at);
+        }
+    };
+    auto compute = [&](const Operands& o, auto partial, int valid) {  // the batch at `row`; leaves `row` at the next one
+        constexpr bool kPartial = decltype(partial)::value;
+        const unsigned r0 = row;
+        row += (unsigned)(kPartial ? valid : BATCH) * stride;
+        // one wait for the whole set (it was fetched a batch ago) instead of one per operand: a wait is an issue slot too
+        asm volatile("" : : "v"(o.g[BATCH - 1]), "v"(o.gw[KIND != kSnapGeneric ? BATCH - 1 : 0]));
+        // the batch's results leave together, behind its last step: a store between two steps would sit between the loads of
+        // the batch after this one and those of the batch after that in the wave's one in-order memory counter, and the wait
+        // for the former would wait for its acknowledgement too
+        double res[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; u++) {
+            if (!kPartial || u < valid) res[u] = one(o.g[u], o.gw[u]);  // (launch-uniform: a scalar branch)
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; u++) {
+            if (!kPartial || u < valid) st_row_f64<AUX>(wbuf, off, r0 + (unsigned)u * stride, res[u]);
+        }
+    };
+    int64_t batches = left / BATCH;
+    left -= batches * BATCH;
+    Operands a, b;
+    if (batches > 0) fetch(a, 0, BATCH);
+    // Two batches per turn, each fetched while the one before it is computed.  The turn runs only while a third full batch
+    // exists, so that its second fetch needs no branch around it: where a path with and a path without that fetch meet, the
+    // compiler can only wait for the smaller number of operations in flight — on the path with the fetch that is the batch
+    // about to be computed AND half of the one just requested, a memory round trip every 32 steps (~30 % of this phase).
+    if (batches >= 3) {
+        // (and the turn is entered the way it is re-entered — a batch in flight, then a batch's worth of stores — or the wait
+        // at its top, where the two ways in meet, is again for the smaller count: the stores of the batch just computed)
+#pragma unroll
+        for (int u = 0; u < BATCH; u++) {
+            scratch[i] = 0.0;  // (a row that nothing reads; a constant: no load to wait for)
+            asm volatile("" ::: "memory");
+        }
+    }
+#pragma unroll 1
+    while (batches >= 3) {
+        fetch(b, BATCH, BATCH);
+        compute(a, std::false_type{}, BATCH);
+        fetch(a, BATCH, BATCH);
+        compute(b, std::false_type{}, BATCH);
+        batches -= 2;
+    }
+    if (batches == 2) {
+        fetch(b, BATCH, BATCH);
+        compute(a, std::false_type{}, BATCH);
+        if (left > 0) fetch(a, BATCH, (int)left);
+        compute(b, std::false_type{}, BATCH);
+        if (left > 0) compute(a, std::true_type{}, (int)left);
+    } else if (batches == 1) {
+        if (left > 0) fetch(b, BATCH, (int)left);
+        compute(a, std::false_type{}, BATCH);
+        if (left > 0) compute(b, std::true_type{}, (int)left);
+    } else if (left > 0) {
+        fetch(a, 0, (int)left);
+        compute(a, std::true_type{}, (int)left);
+    }
+    return prev_theta;
+}
+
 template <bool MIXED, int KIND>
 __global__ __launch_bounds__(kThetaBlock) __attribute__((amdgpu_waves_per_eu(1, 1))) void cont_theta_kernel(const ContRunArgs K) {
     RSIK_PIPE_STAMP(K, 1);
@@ -167,107 +325,9 @@ __global__ __launch_bounds__(kThetaBlock) __attribute__((amdgpu_waves_per_eu(1, 
     // previous_theta travels from block to block in theta_carry: this phase runs ahead of phase 4 (other streams), which
     // alone decides what ends up in the state's row 0 — the theta of the last step, or of the step that latched the
     // emergency stop (C:205-210; what this phase computes for a latched trajectory is never looked at).
-    double prev_theta = K.first_block ? K.st[0 * K.n + i] : K.theta_carry[i];
-    const double l0 = K.lim[slot][0], l1 = K.lim[slot][1];
-    // A lone wave per SIMD: every instruction of a step is paid in full (~4.5 cycles each, rsik_device.hpp `opaque`), and
-    // the memory round trip of a step's operands would double a step, so they are fetched kThetaBatch steps at a time,
-    // one batch ahead of the one being computed, into two register sets that take turns (no copies); what is left of the
-    // block after the last full batch goes step by step.
-    const int64_t n = K.n;
-    // this trajectory's goal / theta of the step the wave is at: (wbuf, off, row), its wrapped goal (gbuf, off, row); a step
-    // further is `stride` bytes further
-    const __amdgpu_buffer_rsrc_t wbuf = row_buffer(K.ws), gbuf = row_buffer(K.gw);
-    const unsigned off = (unsigned)(i * sizeof(double)), stride = (unsigned)(n * sizeof(double));
-    unsigned row = 0;
-    // launch constants that a select or a sign transfer needs as a vector operand: pinned in vector registers once
-    const double dmax_v = opaque(K.d_theta_max), l0v = opaque(l0), l1v = opaque(l1), tdag_v = opaque(K.snap_tdag);
-    // `g` is the step's goal as the prepare phase encoded it: the search's theta, the preferred theta for an unreachable
-    // pose, NaN = "stay".  Straight-line arithmetic only.
-    auto generic = [&](double g) {
-        return continuous_next_theta_goal((g != g) ? prev_theta : g, prev_theta, K.d_theta_max, l0, l1, dmax_v, l1v);
-    };
-    auto one = [&](double g, double gw) {
-        if constexpr (KIND == kSnapGeneric) prev_theta = generic(g);
-        else prev_theta = continuous_next_theta_lean<KIND>(g, gw, prev_theta, dmax_v, l0v, l1v, tdag_v);
-        return prev_theta;
-    };
-    int64_t left = K.T;
-    if (KIND != kSnapGeneric && K.first_block && left > 0) {
-        // the state a run starts from is the caller's: only from the first result on is previous_theta known to lie in
-        // [-pi, pi], which the specialised step relies on
-        prev_theta = generic(ld_row_f64(wbuf, off, row));
-        st_row_f64(wbuf, off, row, prev_theta);
-        row += stride; left -= 1;
-    }
-    struct Operands { double g[kThetaBatch], gw[kThetaBatch]; };
-    // (`valid` < kThetaBatch: the block's last, partial batch — the steps past its end repeat the last one and are skipped)
-    auto fetch = [&](Operands& o, int ahead, int valid) {
-#pragma unroll
-        for (int u = 0; u < kThetaBatch; u++) {
-            const unsigned at = row + (unsigned)(ahead + (u < valid ? u : valid - 1)) * stride;
-            o.g[u] = ld_row_f64(wbuf, off, at);
-            if constexpr (KIND != kSnapGeneric) o.gw[u] = ld_row_f64(gbuf, off, at);
-        }
-    };
-    auto compute = [&](const Operands& o, auto partial, int valid) {  // the batch at `row`; leaves `row` at the next one
-        constexpr bool kPartial = decltype(partial)::value;
-        const unsigned r0 = row;
-        row += (unsigned)(kPartial ? valid : kThetaBatch) * stride;
-        // one wait for the whole set (it was fetched a batch ago) instead of one per operand: a wait is an issue slot too
-        asm volatile("" : : "v"(o.g[kThetaBatch - 1]), "v"(o.gw[KIND != kSnapGeneric ? kThetaBatch - 1 : 0]));
-        // the batch's results leave together, behind its last step: a store between two steps would sit between the loads of
-        // the batch after this one and those of the batch after that in the wave's one in-order memory counter, and the wait
-        // for the former would wait for its acknowledgement too
-        double res[kThetaBatch];
-#pragma unroll
-        for (int u = 0; u < kThetaBatch; u++) {
-            if (!kPartial || u < valid) res[u] = one(o.g[u], o.gw[u]);  // (launch-uniform: a scalar branch)
-        }
-#pragma unroll
-        for (int u = 0; u < kThetaBatch; u++) {
-            if (!kPartial || u < valid) st_row_f64(wbuf, off, r0 + (unsigned)u * stride, res[u]);
-        }
-    };
-    int64_t batches = left / kThetaBatch;
-    left -= batches * kThetaBatch;
-    Operands a, b;
-    if (batches > 0) fetch(a, 0, kThetaBatch);
-    // Two batches per turn, each fetched while the one before it is computed.  The turn runs only while a third full batch
-    // exists, so that its second fetch needs no branch around it: where a path with and a path without that fetch meet, the
-    // compiler can only wait for the smaller number of operations in flight — on the path with the fetch that is the batch
-    // about to be computed AND half of the one just requested, a memory round trip every 32 steps (~30 % of this phase).
-    if (batches >= 3) {
-        // (and the turn is entered the way it is re-entered — a batch in flight, then a batch's worth of stores — or the wait
-        // at its top, where the two ways in meet, is again for the smaller count: the stores of the batch just computed)
-#pragma unroll
-        for (int u = 0; u < kThetaBatch; u++) {
-            K.theta_carry[K.n + i] = 0.0;  // (a second row of the carry array that nothing reads; a constant: no load to wait for)
-            asm volatile("" ::: "memory");
-        }
-    }
-#pragma unroll 1
-    while (batches >= 3) {
-        fetch(b, kThetaBatch, kThetaBatch);
-        compute(a, std::false_type{}, kThetaBatch);
-        fetch(a, kThetaBatch, kThetaBatch);
-        compute(b, std::false_type{}, kThetaBatch);
-        batches -= 2;
-    }
-    if (batches == 2) {
-        fetch(b, kThetaBatch, kThetaBatch);
-        compute(a, std::false_type{}, kThetaBatch);
-        if (left > 0) fetch(a, kThetaBatch, (int)left);
-        compute(b, std::false_type{}, kThetaBatch);
-        if (left > 0) compute(a, std::true_type{}, (int)left);
-    } else if (batches == 1) {
-        if (left > 0) fetch(b, kThetaBatch, (int)left);
-        compute(a, std::false_type{}, kThetaBatch);
-        if (left > 0) compute(b, std::true_type{}, (int)left);
-    } else if (left > 0) {
-        fetch(a, 0, (int)left);
-        compute(a, std::true_type{}, (int)left);
-    }
-    K.theta_carry[i] = prev_theta;
+    const double prev_theta = K.first_block ? K.st[0 * K.n + i] : K.theta_carry[i];
+    K.theta_carry[i] = cont_theta_walk<KIND, false, kThetaBatch>(K, i, K.lim[slot][0], K.lim[slot][1], K.ws, K.gw, K.T, K.first_block != 0,
+                                                                 prev_theta, K.theta_carry + K.n);
 }
 
 // What get_joints reads of a step (S:697-863), re-derived from the step's goal matrix: the goal vectors and the circle
@@ -325,18 +385,18 @@ __device__ __forceinline__ void step_joints(const Acc& A, const ContRunArgs& K, 
 // for the shifted elements (phase 4 used to read and rewrite all of them, 112 of the 412 bytes a control step moved),
 // and a quiet step's value is its raw joint plus whole turns: within 2 ulp of the reference's previous + angle_diff(raw,
 // previous), no accumulation.
-template <bool MIXED>
-__global__ __launch_bounds__(kBlock) void cont_joints_kernel(const ContRunArgs K) {
-    RSIK_PIPE_STAMP(K, 2);
+// One wave: chunk `c` (steps 8 c ... 8 c + 7 of the K arrays) of the trajectories 8 grp ... 8 grp + 7; `lw`: 64 x 7 doubles of LDS
+// of the wave's own.  Shared by the phased kernel below and the single-launch form (COH: theta, flags in; rows, events out
+// cross compute units while the kernel runs).
+// STAGE: the workgroup's tables are staged here, behind the chunk's loads (their latency overlaps the staging's round trip).
+template <bool MIXED, bool COH, bool STAGE = false>
+__device__ __forceinline__ void cont_joints_chunk(const ContRunArgs& K, SharedTables& lds_tab, double* lw, int64_t grp, int64_t c) {
     static_assert(kJointChunk == 8, "lane = 8 * step + trajectory");
-    __shared__ double lds_out[kBlock / 64][64 * 7];
+    constexpr int AUX = COH ? 16 : 0;
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
     const int tl = lane & 7, sl = lane >> 3;
     const int64_t n = K.n;
-    const int64_t grp = (int64_t)blockIdx.x * (kBlock / 64) + wave;  // this wave's group of 8 trajectories
     const int64_t i = grp * 8 + tl;
-    const int64_t c = blockIdx.y;
     const int64_t t = c * kJointChunk + sl;
     const bool live = i < n && t < K.T;
     const int64_t ii = i < n ? i : (n - 1);
@@ -353,8 +413,8 @@ __global__ __launch_bounds__(kBlock) void cont_joints_kernel(const ContRunArgs K
 #pragma unroll
         for (int k = 9; k < 12; k++) m[k] = src[k * n];
     }
-    const double theta = RSIK_WS(K, tt, ii);
-    const int flag = K.flags[tt * n + ii];
+    const double theta = ldc_f64<COH>(&RSIK_WS(K, tt, ii));
+    const int flag = ldc_u8<COH>(&K.flags[tt * n + ii]);
     const bool special = (flag & 8) != 0;
     if (RSIK_RARE(special)) {
         const double* src = K.m12_steps + (K.t0 + tt) * 12 * n + ii;
@@ -366,8 +426,7 @@ __global__ __launch_bounds__(kBlock) void cont_joints_kernel(const ContRunArgs K
         m[8] = fma(m[0], m[4], -(m[1] * m[3]));
     }
     const bool lane_isl = MIXED ? (K.arm[ii] != 0) : false;
-    __shared__ SharedTables lds_tab;
-        stage_tables<MIXED, (int)offsetof(ContRunArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>(lds_tab, K.arms);
+    if constexpr (STAGE) stage_tables<MIXED, (int)offsetof(ContRunArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>(lds_tab, K.arms);
     const Acc<MIXED> A = make_acc<MIXED>(K.arms, lane_isl, lds_tab);
     Reach r;
     Goal G;
@@ -427,13 +486,12 @@ __global__ __launch_bounds__(kBlock) void cont_joints_kernel(const ContRunArgs K
         const double o = (k == 0 || k == 2 || k == 4 || k == 6) ? fma(turn[k], kTwoPi, jv[k]) : jv[k];
         out[k] = sing ? __builtin_nan("") : o;  // (singular: needs previous_sol, phase 4 recomputes the step — flag bit 2)
     }
-    if (live && sing) K.flags[t * n + i] = (uint8_t)(flag | 4);
+    if (live && sing) stc_u8<COH>(&K.flags[t * n + i], (uint8_t)(flag | 4));
     // one event byte per (chunk, trajectory): OR over the chunk's steps
     const unsigned long long evm = __ballot(ev && live);
-    if (live && sl == 0) K.chunk_event[c * n + i] = ((evm >> tl) & 0x0101010101010101ull) != 0 ? 1 : 0;
+    if (live && sl == 0) stc_u8<COH>(&K.chunk_event[c * n + i], ((evm >> tl) & 0x0101010101010101ull) != 0 ? 1 : 0);
     // rows out: the wave's 64 rows are 8 runs (one per step) of 8 x 7 consecutive doubles; 32-bit offsets from the chunk's
     // first row (a block's joints stay below 2 GB, see rsik_control_continuous_run)
-    double* lw = lds_out[wave];
 #pragma unroll
     for (int k = 0; k < 7; k++) lw[lane * 7 + k] = out[k];
     __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -446,35 +504,52 @@ __global__ __launch_bounds__(kBlock) void cont_joints_kernel(const ContRunArgs K
     for (int k = 0; k < 7; k++) {
         const int idx = k * 64 + lane;
         const int s_ = idx / 56, off = idx - s_ * 56;
-        if (s_ < steps_left && off < traj_left * 7) st_row_f64(obuf, (unsigned)s_ * row_bytes + (unsigned)off * 8u, 0, lw[idx]);
+        if (s_ < steps_left && off < traj_left * 7) st_row_f64<AUX>(obuf, (unsigned)s_ * row_bytes + (unsigned)off * 8u, 0, lw[idx]);
     }
+    __builtin_amdgcn_wave_barrier();  // (the wave's slab is free again)
+}
+
+template <bool MIXED>
+__global__ __launch_bounds__(kBlock) RSIK_PHASED_OCC_ATTR void cont_joints_kernel(const ContRunArgs K) {
+    RSIK_PIPE_STAMP(K, 2);
+    __shared__ double lds_out[kBlock / 64][64 * 7];
+    __shared__ SharedTables lds_tab;
+    const int wave = threadIdx.x >> 6;
+    cont_joints_chunk<MIXED, RSIK_PHASED_COH, true>(K, lds_tab, lds_out[wave], (int64_t)blockIdx.x * (kBlock / 64) + wave, (int64_t)blockIdx.y);
 }
 
 // phase 4: eight lanes per trajectory, lane j < 7 owns joint j; sequential over the block's steps: the recurrence on
 // previous_sol (allow_multiturn U:493-505, multiturn_safety_check U:535-568, continuity_check U:571-589, the emergency
 // latch C:205-210, C:398-405).
-template <bool MIXED>
-__global__ __launch_bounds__(kChainBlock) __attribute__((amdgpu_waves_per_eu(1, 1))) void cont_chain_kernel(const ContRunArgs K) {
-    RSIK_PIPE_STAMP(K, 3);
-    // a serial phase beside throughput phases (see cont_theta_kernel), one step below the theta phase, which is the
-    // critical path where the two share a SIMD (0.544 -> 0.536 ms per 4096 x 1000 pass)
-    __builtin_amdgcn_s_setprio(2);
-    const int64_t gid = (int64_t)blockIdx.x * kChainBlock + threadIdx.x;
-    const int64_t i = gid >> 3;
-    const int j = (int)(gid & 7);
+// cont_chain_walk: trajectory i, lane j of its eight (gid = 8 i + j), over T steps: rows tw0 ... of the workspace arrays (chunk rows
+// tw0 / 8 ...), steps t_abs0 ... of the run.  BATCH chunks' operands are fetched at once.  `last`: the run ends with these steps.
+// Shared by the phased kernel below and the single-launch form (COH: everything but the goal matrices crosses compute units
+// while the kernel runs — the trajectory state included, which the walk of the block before left in cont_state).
+// `carry` (the single-launch form's chain waves, which walk a run block by block): the trajectory state of this lane between two
+// calls — taken from cont_state when `first`, left in cont_state when `last`, in registers in between.
+struct ChainCarry { double prev; bool init, emergency; };
+template <bool MIXED, bool COH, int BATCH>
+__device__ __forceinline__ void cont_chain_walk(const ContRunArgs& K, SharedTables& lds_tab, int64_t i, int j, int64_t tw0, int64_t t_abs0,
+                                                int64_t T, bool last, ChainCarry* carry = nullptr, bool first = true) {
+    constexpr int AUX = COH ? 16 : 0;
     const int lane = threadIdx.x & 63;
     const int gshift = lane & ~7;
     const bool live = i < K.n;
     const int64_t ii = live ? i : (K.n - 1);
     const int jj = j < 7 ? j : 6;
     const bool owner = live && j < 7;
-    __shared__ SharedTables lds_tab;
-        stage_tables<MIXED, (int)offsetof(ContRunArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC)), kChainBlock>(lds_tab, K.arms);
     const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[ii] != 0) : false, lds_tab);
     const int64_t n = K.n;
-    double prev = K.st[(1 + jj) * n + ii];
-    bool init = K.st[8 * n + ii] != 0.0;
-    bool emergency = K.st[9 * n + ii] != 0.0;
+    const int64_t tm0 = t_abs0 - K.t0;  // (load_step_m12 counts from K.t0)
+    double prev;
+    bool init, emergency;
+    if (carry && !first) {
+        prev = carry->prev; init = carry->init; emergency = carry->emergency;
+    } else {
+        prev = ldc_f64<COH>(&K.st[(1 + jj) * n + ii]);
+        init = ldc_f64<COH>(&K.st[8 * n + ii]) != 0.0;
+        emergency = ldc_f64<COH>(&K.st[9 * n + ii]) != 0.0;
+    }
     const double thr = jj < 4 ? 0.5 : 1.0;                                       // continuity thresholds, C:398
     const double lim = (jj == 0 || jj == 2 || jj == 6) ? 6 * kPi : __builtin_inf();  // multiturn limit of this lane's joint (U:535-568)
     const int hit_bit = jj == 0 ? RSIK_EMERGENCY_SHOULDER_PITCH : (jj == 2 ? RSIK_EMERGENCY_ELBOW_YAW : RSIK_EMERGENCY_WRIST_YAW);
@@ -485,14 +560,14 @@ __global__ __launch_bounds__(kChainBlock) __attribute__((amdgpu_waves_per_eu(1, 
         v |= __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);  // row_half_mirror
         return v;
     };
-    // Operands of kChainBatch steps are fetched together, one batch ahead (see cont_theta_kernel).  A step is straight-line
+    // Operands of BATCH steps are fetched together, one batch ahead (see cont_theta_kernel).  A step is straight-line
     // code: a latched trajectory (rare) goes through the same arithmetic and only its selects differ.
     // this lane's joint of the step the wave is at: jrow[joff]; its flag byte: frow[foff] (ld_row); a step further is
     // step_stride doubles / n bytes further
-    const __amdgpu_buffer_rsrc_t jbuf = row_buffer(K.joints + K.t0 * n * 7), fbuf = row_buffer(K.flags);
+    const __amdgpu_buffer_rsrc_t jbuf = row_buffer(K.joints + t_abs0 * n * 7), fbuf = row_buffer(K.flags + tw0 * n);
     const unsigned joff = (unsigned)((ii * 7 + jj) * sizeof(double)), foff = (unsigned)ii;
     const unsigned jstride = (unsigned)(n * 7 * sizeof(double)), fstride = (unsigned)n;
-    int64_t t_abs = K.t0;
+    int64_t t_abs = t_abs0;
     auto one = [&](double cur, int f, int64_t t, unsigned jrow) {  // step t of the block; this lane's joint of it at (jbuf, joff, jrow)
         if (RSIK_RARE((f & 4) != 0 && !emergency)) {  // the same byte in all 8 lanes of the trajectory
             // exact singularity in get_joints: the step is recomputed with the real previous_sol (every lane of the
@@ -503,11 +578,11 @@ __global__ __launch_bounds__(kChainBlock) __attribute__((amdgpu_waves_per_eu(1, 
             Reach r;
             Goal G;
             double m[12];
-            load_step_m12(K, t, ii, m);
+            load_step_m12(K, tm0 + t, ii, m);
             step_geometry(A, m, K.euler_roundtrip, (f & 1) == 0, r, G);
             double jv[7];
             bool sing;
-            step_joints(A, K, r, G, RSIK_WS(K, t, ii), pv, jv, sing);
+            step_joints(A, K, r, G, ldc_f64<COH>(&RSIK_WS(K, tw0 + t, ii)), pv, jv, sing);
             cur = jv[0];
 #pragma unroll
             for (int k = 1; k < 7; k++) cur = (jj == k) ? jv[k] : cur;
@@ -523,18 +598,18 @@ __global__ __launch_bounds__(kChainBlock) __attribute__((amdgpu_waves_per_eu(1, 
         const double accepted = disc ? prev : clamped;
         const bool trips = cause != 0 && !emergency;
         const double result = emergency ? prev : accepted;                    // latched (C:205-210): previous_sol
-        if (owner) st_row_f64(jbuf, joff, jrow, result);
+        if (owner) st_row_f64<AUX>(jbuf, joff, jrow, result);
         if (RSIK_RARE(emergency || trips) && live) {
             if (emergency) {
                 if (j == 7) {
-                    if (K.state) K.state[t_abs * n + i] = (uint8_t)RSIK_STATE_EMERGENCY;
-                    if (K.reachable) K.reachable[t_abs * n + i] = 0;
+                    if (K.state) stc_u8<COH>(&K.state[t_abs * n + i], (uint8_t)RSIK_STATE_EMERGENCY);
+                    if (K.reachable) stc_u8<COH>(&K.reachable[t_abs * n + i], 0);
                 }
             } else if (j == 7) {
-                K.st[11 * n + i] = (double)cause;
-                K.st[0 * n + i] = RSIK_WS(K, t, i);  // previous_theta of the step that tripped (phase 2 ran ahead)
+                stc_f64<COH>(&K.st[11 * n + i], (double)cause);
+                stc_f64<COH>(&K.st[0 * n + i], ldc_f64<COH>(&RSIK_WS(K, tw0 + t, i)));  // previous_theta of the step that tripped (phase 2 ran ahead)
             } else if (disc) {
-                K.st[(12 + j) * n + i] = clamped;       // the joints that failed the check
+                stc_f64<COH>(&K.st[(12 + j) * n + i], clamped);       // the joints that failed the check
             }
         }
         prev = (emergency || trips) ? prev : accepted;
@@ -548,16 +623,16 @@ __global__ __launch_bounds__(kChainBlock) __attribute__((amdgpu_waves_per_eu(1, 
     // previous_sol — which also says that phase 3 picked the right turn; previous_sol then becomes the chunk's last row.
     // Otherwise the chunk's steps go through `one`, the reference's own sequence of operations, in place (it re-bases
     // whatever representative phase 3 wrote).  Per chunk this reads two rows of the joints and a byte instead of
-    // reading and rewriting every row; the first / last rows and event bytes of kChainBatch chunks are fetched at once.
+    // reading and rewriting every row; the first / last rows and event bytes of BATCH chunks are fetched at once.
     const double thr_short = thr - 1e-9;
-    const __amdgpu_buffer_rsrc_t ebuf = row_buffer(K.chunk_event);
+    const __amdgpu_buffer_rsrc_t ebuf = row_buffer(K.chunk_event + (tw0 / kJointChunk) * n);
     // step by step with `one` (the only copy of it), the operands of the next three steps in flight meanwhile
     auto stepwise = [&](int64_t t_blk, int64_t count) {  // the steps [t_blk, t_blk + count) of the block
         unsigned jrow = (unsigned)t_blk * jstride, frow = (unsigned)t_blk * fstride;
-        t_abs = K.t0 + t_blk;
+        t_abs = t_abs0 + t_blk;
         auto at = [&](int64_t k) { return k < count ? k : count - 1; };
-        auto raw_at = [&](int64_t k) { return ld_row_f64(jbuf, joff, jrow + (unsigned)k * jstride); };
-        auto flag_at = [&](int64_t k) { return ld_row_u8(fbuf, foff, frow + (unsigned)k * fstride); };
+        auto raw_at = [&](int64_t k) { return ld_row_f64<AUX>(jbuf, joff, jrow + (unsigned)k * jstride); };
+        auto flag_at = [&](int64_t k) { return ld_row_u8<AUX>(fbuf, foff, frow + (unsigned)k * fstride); };
         double r0 = raw_at(0), r1 = raw_at(at(1)), r2 = raw_at(at(2));
         int f0 = flag_at(0), f1 = flag_at(at(1)), f2 = flag_at(at(2));
 #pragma unroll 1
@@ -573,20 +648,20 @@ __global__ __launch_bounds__(kChainBlock) __attribute__((amdgpu_waves_per_eu(1, 
             t_blk += 1;
         }
     };
-    const int64_t n_chunks = (K.T + kJointChunk - 1) / kJointChunk;
-    struct Operands { double first[kChainBatch], last[kChainBatch]; int ev[kChainBatch]; };
-    auto chunk_len = [&](int64_t c) { return (K.T - c * kJointChunk) < kJointChunk ? (K.T - c * kJointChunk) : (int64_t)kJointChunk; };
+    const int64_t n_chunks = (T + kJointChunk - 1) / kJointChunk;
+    struct Operands { double first[BATCH], last[BATCH]; int ev[BATCH]; };
+    auto chunk_len = [&](int64_t c) { return (T - c * kJointChunk) < kJointChunk ? (T - c * kJointChunk) : (int64_t)kJointChunk; };
     auto fetch = [&](Operands& o, int64_t c0) {
 #pragma unroll
-        for (int u = 0; u < kChainBatch; u++) {
+        for (int u = 0; u < BATCH; u++) {
             const int64_t c = (c0 + u) < n_chunks ? (c0 + u) : (n_chunks - 1);  // (past the end: the last chunk again, skipped)
             const unsigned r_first = (unsigned)(c * kJointChunk) * jstride;
-            o.first[u] = ld_row_f64(jbuf, joff, r_first);
-            o.last[u] = ld_row_f64(jbuf, joff, r_first + (unsigned)(chunk_len(c) - 1) * jstride);
-            o.ev[u] = ld_row_u8(ebuf, foff, (unsigned)c * fstride);
+            o.first[u] = ld_row_f64<AUX>(jbuf, joff, r_first);
+            o.last[u] = ld_row_f64<AUX>(jbuf, joff, r_first + (unsigned)(chunk_len(c) - 1) * jstride);
+            o.ev[u] = ld_row_u8<AUX>(ebuf, foff, (unsigned)c * fstride);
         }
     };
-    // Walks the fetched chunks until one does not stand: returns its index in the batch (kChainBatch: all stood).
+    // Walks the fetched chunks until one does not stand: returns its index in the batch (BATCH: all stood).
     // Phase 3 left each chunk on the turn of its first step's raw joints; `turns` (this lane's joint, almost always 0) is
     // how many whole turns that is away from previous_sol; they are added to the chunk's rows below — only the elements
     // that need it, and without waiting for them.  The limits (U:535-568): phase 3 cannot test
@@ -605,12 +680,12 @@ __global__ __launch_bounds__(kChainBlock) __attribute__((amdgpu_waves_per_eu(1, 
     // in LDS per wave (ballot + prefix count) and added with all 64 lanes, one instruction per eight notes: 66 us, no faster
     // within a pass; workgroups of 64 / 128 threads instead of 256, so that more compute units share them: 62 / 59 us, no
     // faster within a pass either.
-    double* const jcol = K.joints + (K.t0 * n + ii) * 7 + jj;
+    double* const jcol = K.joints + (t_abs0 * n + ii) * 7 + jj;
     const int64_t row_doubles = n * 7;
     auto walk = [&](const Operands& o, int64_t c0) -> int {
-        int stop = kChainBatch;
+        int stop = BATCH;
 #pragma unroll
-        for (int u = 0; u < kChainBatch; u++) {
+        for (int u = 0; u < BATCH; u++) {
             const double turns = -rint((o.first[u] - prev) * 0.15915494309189535);
             const double sh = turns * kTwoPi;
             const double f2 = o.first[u] + sh;
@@ -618,8 +693,8 @@ __global__ __launch_bounds__(kChainBlock) __attribute__((amdgpu_waves_per_eu(1, 
                                (!limited || fabs(f2) <= clear_of_limit);
             const bool inside = c0 + u < n_chunks;
             const bool stands = !__any(!quiet) && inside;  // (wave-uniform)
-            const bool taken = stop == kChainBatch && stands;
-            if (stop == kChainBatch && !stands) stop = u;
+            const bool taken = stop == BATCH && stands;
+            if (stop == BATCH && !stands) stop = u;
             if (taken) prev = o.last[u] + sh;
             // (a chunk that goes through `one` instead is rewritten there: no turns to add)
             if (RSIK_RARE(taken && turns != 0.0) && owner) {
@@ -646,25 +721,42 @@ __global__ __launch_bounds__(kChainBlock) __attribute__((amdgpu_waves_per_eu(1, 
             // paths meet with different numbers of loads in flight and the compiler waits for all of them before the walk —
             // the batch just requested included, a memory round trip per batch (this phase alone 52 -> 45 us without the
             // atomics, 74 -> 69 with them)
-            fetch(ob, c0 + kChainBatch);
+            fetch(ob, c0 + BATCH);
             const int stop = walk(oa, c0);
-            if (RSIK_RARE(c0 + stop < n_chunks && stop < kChainBatch)) {
+            if (RSIK_RARE(c0 + stop < n_chunks && stop < BATCH)) {
                 // an eventful chunk: the reference's own sequence of operations for its steps, then the walk resumes behind it
                 stepwise((c0 + stop) * kJointChunk, chunk_len(c0 + stop));
                 c0 += stop + 1;
                 if (c0 < n_chunks) fetch(oa, c0);
             } else {
-                c0 += kChainBatch;
+                c0 += BATCH;
                 oa = ob;
             }
         }
     }
-    if (owner) K.st[(1 + j) * n + i] = prev;
-    if (live && j == 7) {
-        K.st[8 * n + i] = init ? 1.0 : 0.0;
-        K.st[9 * n + i] = emergency ? 1.0 : 0.0;
-        if (K.last_block && !emergency) K.st[0 * n + i] = RSIK_WS(K, K.T - 1, i);  // previous_theta after the last step
+    if (carry) {
+        carry->prev = prev; carry->init = init; carry->emergency = emergency;
+        if (!last) return;
     }
+    if (owner) stc_f64<COH>(&K.st[(1 + j) * n + i], prev);
+    if (live && j == 7) {
+        stc_f64<COH>(&K.st[8 * n + i], init ? 1.0 : 0.0);
+        stc_f64<COH>(&K.st[9 * n + i], emergency ? 1.0 : 0.0);
+        if (last && !emergency) stc_f64<COH>(&K.st[0 * n + i], ldc_f64<COH>(&RSIK_WS(K, tw0 + T - 1, i)));  // previous_theta after the last step
+    }
+}
+
+// phase 4: the chain walk over the block
+template <bool MIXED>
+__global__ __launch_bounds__(kChainBlock) __attribute__((amdgpu_waves_per_eu(1, 1))) void cont_chain_kernel(const ContRunArgs K) {
+    RSIK_PIPE_STAMP(K, 3);
+    // a serial phase beside throughput phases (see cont_theta_kernel), one step below the theta phase, which is the
+    // critical path where the two share a SIMD (0.544 -> 0.536 ms per 4096 x 1000 pass)
+    __builtin_amdgcn_s_setprio(2);
+    const int64_t gid = (int64_t)blockIdx.x * kChainBlock + threadIdx.x;
+    __shared__ SharedTables lds_tab;
+        stage_tables<MIXED, (int)offsetof(ContRunArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC)), kChainBlock>(lds_tab, K.arms);
+    cont_chain_walk<MIXED, false, kChainBatch>(K, lds_tab, gid >> 3, (int)(gid & 7), 0, K.t0, K.T, K.last_block != 0);
 }
 
 }  // namespace rsik

@@ -25,6 +25,8 @@
 #include "rsik_kernel_discrete.hpp"
 #include "rsik_kernel_continuous.hpp"
 #include "rsik_kernel_pipeline.hpp"
+#include "rsik_kernel_fused.hpp"
+#include "rsik_kernel_flags.hpp"
 #include "rsik_kernel_state.hpp"
 
 // =====================================================================================
@@ -37,9 +39,13 @@ struct rsik_ctx {
     bool have_arm[2];
     rsik::ArmC arms[2];
     int options[RSIK_OPT_COUNT];
-    void* ws;          // workspace of rsik_control_continuous_run's phased pipeline (device), grown on demand
+    void* ws;          // workspace of rsik_control_continuous_run (device: the phased pipeline's slots, or the single launch's arrays), grown on demand
     size_t ws_bytes;
-    std::vector<void*> retired_ws;   // outgrown workspaces: kept until rsik_destroy (a captured hipGraph may still point into them)
+    bool ws_captured;                // a run recorded into a hipGraph points into the current workspace
+    std::vector<void*> retired_ws;   // outgrown workspaces a captured hipGraph may still point into: kept until rsik_destroy / _release
+    unsigned long long* trace;       // RSIK_OPT_CONT_TRACE: the single launch's item records (device), or NULL
+    size_t trace_cap;
+    unsigned* fused_sync;            // sync area of the last single-launch run (inside ws): its abort word is read by rsik_sync
     hipStream_t side[3];             // the pipeline's own streams (prepare / joints / chain), created on first use
     std::vector<hipEvent_t> events;  // reusable, timing disabled
     bool have_side;
@@ -97,6 +103,10 @@ int rsik_create(int device_id, rsik_ctx** out) {
     for (int k = 0; k < RSIK_OPT_COUNT; k++) c->options[k] = 0;
     c->ws = nullptr;
     c->ws_bytes = 0;
+    c->ws_captured = false;
+    c->trace = nullptr;
+    c->trace_cap = 0;
+    c->fused_sync = nullptr;
     c->have_side = false;
     for (auto& st : c->side) st = nullptr;
     *out = c;
@@ -106,6 +116,7 @@ int rsik_create(int device_id, rsik_ctx** out) {
 int rsik_destroy(rsik_ctx* ctx) {
     if (ctx && hipSetDevice(ctx->device) == hipSuccess) {
         if (ctx->ws) (void)hipFree(ctx->ws);
+        if (ctx->trace) (void)hipFree(ctx->trace);
         for (void* w : ctx->retired_ws) (void)hipFree(w);
         for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
         if (ctx->have_side)
@@ -127,6 +138,15 @@ int rsik_sync(rsik_ctx* ctx) {
     if (!ctx) return RSIK_E_INVALID;
     RSIK_HIP(ctx, hipSetDevice(ctx->device));
     RSIK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->fused_sync) {
+        // the single-launch continuous run bounds every wait inside the kernel; a wait that ran out left its mark here
+        unsigned aborted[4] = {0, 0, 0, 0};
+        RSIK_HIP(ctx, hipMemcpy(aborted, ctx->fused_sync + rsik::kSyncAbort, sizeof aborted, hipMemcpyDeviceToHost));
+        ctx->fused_sync = nullptr;
+        if (aborted[0] != 0)
+            return fail(ctx, RSIK_E_HIP, "rsik_control_continuous_run: a wait inside the pipeline ran out (3 s; sync word " + std::to_string(aborted[1]) +
+                        " wanted " + std::to_string(aborted[2]) + ", was " + std::to_string(aborted[3]) + "); the run's outputs are incomplete");
+    }
     return RSIK_OK;
 }
 
@@ -143,7 +163,7 @@ int rsik_set_arm(rsik_ctx* ctx, int arm, const double* consts_host, int count) {
 int rsik_set_option(rsik_ctx* ctx, int option, int value) {
     if (!ctx) return RSIK_E_INVALID;
     if (option < 0 || option >= RSIK_OPT_COUNT) return fail(ctx, RSIK_E_INVALID, "rsik_set_option: unknown option");
-    static const int max_value[RSIK_OPT_COUNT] = {RSIK_EULER_NEVER, 2, 1, 1, RSIK_CONT_RUN_STEPS, 65535};
+    static const int max_value[RSIK_OPT_COUNT] = {RSIK_EULER_NEVER, 2, 1, 1, RSIK_CONT_RUN_FLAGS, 65535, 64, 64, 1024, 64, 8};
     if (value < 0 || value > max_value[option]) return fail(ctx, RSIK_E_INVALID, "rsik_set_option: value out of range");
     ctx->options[option] = value;
     return RSIK_OK;
@@ -526,25 +546,44 @@ static int cont_plan(rsik_ctx* ctx, const char* who, int64_t n, int64_t n_steps,
 // allocation, stream and event creation are not capturable): a capture needs rsik_control_continuous_reserve, or an
 // earlier run of at least this size, first.  An outgrown workspace is retired, not freed: a hipGraph captured earlier
 // still points into it.
-static int cont_resources(rsik_ctx* ctx, const char* who, const ContPlan& P) {
-    const bool grow = ctx->ws_bytes < P.need, streams = !ctx->have_side, events = ctx->events.size() < P.n_events;
+static int cont_resources(rsik_ctx* ctx, const char* who, size_t need, bool want_streams, size_t n_events) {
+    const bool grow = ctx->ws_bytes < need, streams = want_streams && !ctx->have_side, events = ctx->events.size() < n_events;
     if (!grow && !streams && !events) return RSIK_OK;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(ctx->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
         return fail(ctx, RSIK_E_INVALID, std::string(who) + ": the stream is capturing and this run needs a larger workspace / its streams / "
                     "more events than the context holds: call rsik_control_continuous_reserve(ctx, n, n_steps) before the capture");
     if (grow) {
+        // geometric growth (a sweep over rising sizes reallocates a logarithmic number of times)
+        size_t want = need;
+        if (ctx->ws_bytes > 0 && want < ctx->ws_bytes + ctx->ws_bytes / 2) want = ctx->ws_bytes + ctx->ws_bytes / 2;
         void* fresh = nullptr;
-        RSIK_HIP(ctx, hipMalloc(&fresh, P.need));
-        if (ctx->ws) ctx->retired_ws.push_back(ctx->ws);
+        if (hipMalloc(&fresh, want) != hipSuccess) {
+            (void)hipGetLastError();
+            want = need;
+            RSIK_HIP(ctx, hipMalloc(&fresh, want));
+        }
+        if (ctx->ws) {
+            if (ctx->ws_captured) {
+                // a hipGraph recorded from this context still points into the old workspace: kept until rsik_destroy or
+                // rsik_control_continuous_release
+                ctx->retired_ws.push_back(ctx->ws);
+            } else {
+                // nothing but runs already issued can use it: wait for them, free it
+                RSIK_HIP(ctx, hipDeviceSynchronize());
+                RSIK_HIP(ctx, hipFree(ctx->ws));
+            }
+        }
         ctx->ws = fresh;
-        ctx->ws_bytes = P.need;
+        ctx->ws_bytes = want;
+        ctx->ws_captured = false;
+        ctx->fused_sync = nullptr;
     }
     if (streams) {
         for (auto& st : ctx->side) RSIK_HIP(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         ctx->have_side = true;
     }
-    while (ctx->events.size() < P.n_events) {
+    while (ctx->events.size() < n_events) {
         hipEvent_t e;
         // (hipEventReleaseToDevice / hipEventDisableSystemFence measured: 0.443 / 0.428 against 0.429-0.439 ms per pass — the
         // ~12 us between dependent launches on different streams are not the cache write-back of the event's release)
@@ -552,6 +591,66 @@ static int cont_resources(rsik_ctx* ctx, const char* who, const ContPlan& P) {
         ctx->events.push_back(e);
     }
     return RSIK_OK;
+}
+
+// The single-launch form of a run (rsik_kernel_fused.hpp): how it is cut, what it needs, whether it qualifies.
+struct FusedPlan {
+    int S, Sp, L, CL, B, G, PI, CH, JQ, Jh, theta_wgs, chain_waves, grid;
+    unsigned tickets;
+    size_t off_gw, off_flags, off_events, off_scratch, off_sync, sync_words, need;
+    bool flags_ok;  // the run also fits the flag-synchronised form (rsik_kernel_flags.hpp): its grids are (tiles, steps)
+};
+static bool fused_plan(const rsik_ctx* ctx, int64_t n, int64_t n_steps, FusedPlan& P, std::string* why) {
+    auto no = [&](const char* msg) { if (why) *why = msg; return false; };
+    const int64_t G = (n + 63) / 64;
+    const int64_t theta_wgs = (G + 3) / 4;
+    // theta workgroups own a compute unit each: at most a quarter of the chip (16 384 trajectories on 256 compute units);
+    // beyond that the sequential phases fill the chip by themselves and the phased pipeline is the better form
+    if (theta_wgs * 4 > ctx->compute_units || ctx->compute_units - theta_wgs < 1) return no("too many trajectories for the theta workgroups (a quarter of the compute units at most)");
+    int S = ctx->options[RSIK_OPT_CONT_BLOCK_STEPS] > 0 ? ctx->options[RSIK_OPT_CONT_BLOCK_STEPS] : 64;
+    S = (S + 7) / 8 * 8;
+    if (S > 4096) S = 4096;
+    int Sp = ctx->options[RSIK_OPT_CONT_PREP_STEPS] > 0 ? ctx->options[RSIK_OPT_CONT_PREP_STEPS] : 4;
+    if (Sp > S) Sp = S;
+    while (S % Sp != 0) Sp--;
+    const int64_t B = (n_steps + S - 1) / S;
+    P.S = S; P.Sp = Sp; P.PI = S / Sp; P.CH = S / 8;
+    P.L = ctx->options[RSIK_OPT_CONT_LOOKAHEAD] > 0 ? ctx->options[RSIK_OPT_CONT_LOOKAHEAD] : 6;
+    P.CL = ctx->options[RSIK_OPT_CONT_CHAIN_LAG] > 0 ? ctx->options[RSIK_OPT_CONT_CHAIN_LAG] : 2;
+    P.Jh = ctx->options[RSIK_OPT_CONT_JOINT_GROUPS] > 0 ? ctx->options[RSIK_OPT_CONT_JOINT_GROUPS] : 2;
+    while (8 % P.Jh != 0) P.Jh--;
+    P.JQ = 8 / P.Jh;
+    P.G = (int)G; P.theta_wgs = (int)theta_wgs;
+    if (B > 1000000) return no("too many blocks");
+    P.B = (int)B;
+    const long long tickets = (long long)G * B * (P.PI + P.CH * P.JQ);
+    if (tickets >= (1ll << 31)) return no("too many work items");
+    P.tickets = (unsigned)tickets;
+    // a block's rows are addressed through 2 GB buffer windows: S steps of n x 7 doubles
+    if ((long long)S * n * 56 >= (1ll << 31)) return no("block too large for a buffer window");
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t cells = (size_t)n * (size_t)n_steps;
+    P.off_gw = up(cells * sizeof(double));
+    P.off_flags = P.off_gw + up(cells * sizeof(double));
+    P.off_events = P.off_flags + up(cells);
+    P.off_scratch = P.off_events + up((size_t)B * P.CH * (size_t)n);
+    P.off_sync = P.off_scratch + up((size_t)n * sizeof(double));
+    P.sync_words = (size_t)rsik::kSyncArrays + 2 * (size_t)B * G + (size_t)G;
+    P.need = P.off_sync + up(P.sync_words * sizeof(unsigned));
+    if (P.need > ((size_t)6 << 30)) return no("workspace above 6 GB");
+    long long workers = (tickets + rsik::kFusedWaves - 1) / rsik::kFusedWaves;
+    if (workers > ctx->compute_units - theta_wgs) workers = ctx->compute_units - theta_wgs;
+    if (workers < 1) workers = 1;
+    P.grid = (int)(theta_wgs + workers);
+    // the chain sub-groups (eight trajectories each) go to the last waves of the worker workgroups: enough of them per
+    // workgroup for all sub-groups, at most half of a workgroup's waves
+    P.chain_waves = (int)((G * 8 + workers - 1) / workers);
+    P.flags_ok = n_steps <= 65535;
+    if (P.chain_waves > rsik::kFusedWaves / 2) {
+        if (ctx->options[RSIK_OPT_CONT_RUN_MODE] == RSIK_CONT_RUN_FUSED) return no("too many trajectories for the chain waves (half of the worker waves at most)");
+        P.chain_waves = rsik::kFusedWaves / 2;  // (only the single launch uses them)
+    }
+    return true;
 }
 
 int rsik_control_continuous_reserve(rsik_ctx* ctx, int64_t n, int64_t n_steps) {
@@ -567,7 +666,44 @@ int rsik_control_continuous_reserve(rsik_ctx* ctx, int64_t n, int64_t n_steps) {
     if ((rc = cont_plan(ctx, who, n, n_steps, true, Pc)) != RSIK_OK) return rc;
     if (Pc.need > P.need) P.need = Pc.need;
     if (Pc.n_events > P.n_events) P.n_events = Pc.n_events;
-    return cont_resources(ctx, who, P);
+    // ... and what the single launch needs, if the run qualifies for it
+    FusedPlan F;
+    const int mode = ctx->options[RSIK_OPT_CONT_RUN_MODE];
+    const bool fused_ok = fused_plan(ctx, n, n_steps, F, nullptr);
+    if ((mode == RSIK_CONT_RUN_FUSED || mode == RSIK_CONT_RUN_FLAGS) && fused_ok) return cont_resources(ctx, who, F.need, mode == RSIK_CONT_RUN_FLAGS, 3);
+    return cont_resources(ctx, who, P.need, true, P.n_events);
+}
+
+int rsik_control_continuous_release(rsik_ctx* ctx) {
+    if (!ctx) return RSIK_E_INVALID;
+    RSIK_HIP(ctx, hipSetDevice(ctx->device));
+    RSIK_HIP(ctx, hipDeviceSynchronize());
+    for (void* w : ctx->retired_ws) (void)hipFree(w);
+    ctx->retired_ws.clear();
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    ctx->ws = nullptr;
+    ctx->ws_bytes = 0;
+    ctx->ws_captured = false;
+    ctx->fused_sync = nullptr;
+    if (ctx->trace) (void)hipFree(ctx->trace);
+    ctx->trace = nullptr;
+    ctx->trace_cap = 0;
+    return RSIK_OK;
+}
+
+int rsik_control_continuous_trace(rsik_ctx* ctx, unsigned long long* records_host, size_t max_records, size_t* n_records) {
+    if (!ctx || !n_records) return RSIK_E_INVALID;
+    *n_records = 0;
+    if (!ctx->trace) return RSIK_OK;
+    RSIK_HIP(ctx, hipSetDevice(ctx->device));
+    RSIK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned long long count = 0;
+    RSIK_HIP(ctx, hipMemcpy(&count, ctx->trace, sizeof count, hipMemcpyDeviceToHost));
+    if (count > ctx->trace_cap) count = ctx->trace_cap;
+    if (records_host && count > max_records) count = max_records;
+    if (count > 0 && records_host) RSIK_HIP(ctx, hipMemcpy(records_host, ctx->trace + 4, (size_t)count * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    *n_records = (size_t)count;
+    return RSIK_OK;
 }
 
 // The whole trajectory batch: the phased pipeline (include/rsik.h), or — RSIK_CONT_RUN_STEPS — one launch of the step
@@ -619,6 +755,128 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         RSIK_HIP(ctx, hipGetLastError());
         return RSIK_OK;
     }
+    bool capturing = false;
+    {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        capturing = hipStreamIsCapturing(ctx->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    }
+    // ---- the single self-scheduling launch (rsik_kernel_fused.hpp), where the run qualifies
+    {
+        FusedPlan FP;
+        std::string why;
+        const int mode = ctx->options[RSIK_OPT_CONT_RUN_MODE];
+        const bool qualifies = fused_plan(ctx, n, n_steps, FP, &why);
+        if (mode == RSIK_CONT_RUN_FUSED && !qualifies) return fail(ctx, RSIK_E_INVALID, std::string(who) + ": RSIK_CONT_RUN_FUSED: " + why);
+        if (mode == RSIK_CONT_RUN_FLAGS && !(qualifies && FP.flags_ok))
+            return fail(ctx, RSIK_E_INVALID, std::string(who) + ": RSIK_CONT_RUN_FLAGS: " + (qualifies ? std::string("more than 65535 steps") : why));
+        // (the flag-synchronised form holds the caller's stream on a value in device memory, which a hipGraph capture does not take)
+        if (mode == RSIK_CONT_RUN_FLAGS && capturing) return fail(ctx, RSIK_E_INVALID, std::string(who) + ": RSIK_CONT_RUN_FLAGS cannot be captured into a hipGraph");
+        // (RSIK_CONT_RUN_AUTO: the phased pipeline, until one of the two newer forms has proven faster on every size — DESIGN.md section 4)
+        const bool as_flags = qualifies && FP.flags_ok && !capturing && mode == RSIK_CONT_RUN_FLAGS;
+        if (qualifies && (mode == RSIK_CONT_RUN_FUSED || as_flags)) {
+            if ((rc = cont_resources(ctx, who, FP.need, as_flags, as_flags ? 3 : 0)) != RSIK_OK) return rc;
+            const int trace_k = ctx->options[RSIK_OPT_CONT_TRACE];
+            if (trace_k > 0 && !capturing && ctx->trace_cap < (size_t)trace_k * 1000) {
+                if (ctx->trace) { RSIK_HIP(ctx, hipDeviceSynchronize()); (void)hipFree(ctx->trace); ctx->trace = nullptr; ctx->trace_cap = 0; }
+                RSIK_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->trace), (4 + (size_t)trace_k * 1000 * 4) * sizeof(unsigned long long)));
+                ctx->trace_cap = (size_t)trace_k * 1000;
+            }
+            char* base = static_cast<char*>(ctx->ws);
+            rsik::FusedArgs F;
+            std::memset(&F, 0, sizeof F);
+            rsik::ContRunArgs& R = F.R;
+            R.n = n; R.t0 = 0; R.T = n_steps;
+            R.m12_steps = m12_steps;
+            R.arm = arm;
+            R.euler_roundtrip = K0.euler_roundtrip;
+            for (int slot = 0; slot < 2; slot++) {
+                R.pref_arg[slot] = K0.pref_arg[slot]; R.pref_self[slot] = K0.pref_self[slot];
+                R.pref_self_cs[slot] = K0.pref_self_cs[slot]; R.pref_self_sn[slot] = K0.pref_self_sn[slot];
+                R.lim[slot][0] = K0.lim[slot][0]; R.lim[slot][1] = K0.lim[slot][1];
+                R.arms[slot] = K0.arms[slot];
+            }
+            R.d_theta_max = d_theta_max;
+            R.max_angle = K0.max_angle; R.cos_max = K0.cos_max; R.sin_max = K0.sin_max;
+            R.ws = reinterpret_cast<double*>(base);
+            R.gw = reinterpret_cast<double*>(base + FP.off_gw);
+            R.flags = reinterpret_cast<uint8_t*>(base + FP.off_flags);
+            R.chunk_event = reinterpret_cast<uint8_t*>(base + FP.off_events);
+            R.first_block = 1; R.last_block = 1;
+            R.st = cont_state; R.joints = joints_steps; R.reachable = reachable_steps; R.state = state_steps;
+            F.sync = reinterpret_cast<unsigned*>(base + FP.off_sync);
+            F.scratch = reinterpret_cast<double*>(base + FP.off_scratch);
+            F.trace = (trace_k > 0 && ctx->trace) ? ctx->trace : nullptr;
+            F.trace_cap = (unsigned)ctx->trace_cap;
+            F.S = FP.S; F.Sp = FP.Sp; F.L = FP.L; F.CL = FP.CL; F.B = FP.B; F.G = FP.G; F.PI = FP.PI; F.CH = FP.CH; F.JQ = FP.JQ; F.Jh = FP.Jh;
+            F.theta_wgs = FP.theta_wgs; F.chain_waves = FP.chain_waves; F.tickets = FP.tickets;
+            F.flags_mode = as_flags ? 1 : 0;
+            F.snap_kind = rsik::kSnapGeneric;
+            if (!arm) F.snap_kind = theta_snap_plan(R.lim[0][0], R.lim[0][1], d_theta_max, &R.snap_tdag);
+            // the sync area starts every run at zero; the (re)initialisation of the trajectories that start here
+            // (C:296-325) runs first, then the one launch
+            RSIK_HIP(ctx, hipMemsetAsync(F.sync, 0, FP.sync_words * sizeof(unsigned), ctx->stream));
+            if (F.trace) RSIK_HIP(ctx, hipMemsetAsync(F.trace, 0, 4 * sizeof(unsigned long long), ctx->stream));
+            if (as_flags) {
+                // ---- the flag-synchronised form (rsik_kernel_flags.hpp).  The two persistent kernels fork off first — the
+                // (re)initialisation, which only the theta waves' start depends on, ahead of them on their stream — then the two
+                // chip-filling kernels back to back on the caller's stream, which joins the other two at the end.
+                hipStream_t s_main = ctx->stream, s_theta = ctx->side[0], s_chain = ctx->side[1];
+                RSIK_HIP(ctx, hipEventRecord(ctx->events[0], s_main));
+                RSIK_HIP(ctx, hipStreamWaitEvent(s_theta, ctx->events[0], 0));
+                RSIK_HIP(ctx, hipStreamWaitEvent(s_chain, ctx->events[0], 0));
+                // the theta workgroups first: each needs a compute unit to itself and must be running before the chip-filling
+                // kernels take the chip (a joints workgroup polls for its thetas: with the theta workgroups still waiting for a
+                // compute unit behind a chip full of such workgroups, nobody would move) — the caller's stream waits for their
+                // count in device memory before it goes on
+                if (arm) hipLaunchKernelGGL(rsik::flags_theta_kernel<true>, dim3((unsigned)FP.theta_wgs), dim3(768), 0, s_theta, F);
+                else hipLaunchKernelGGL(rsik::flags_theta_kernel<false>, dim3((unsigned)FP.theta_wgs), dim3(768), 0, s_theta, F);
+                RSIK_HIP(ctx, hipEventRecord(ctx->events[1], s_theta));
+                // (the chain waves are small and many: let loose first, they would sit on every compute unit and leave the theta
+                // workgroups none to themselves)
+                RSIK_HIP(ctx, hipStreamWaitValue32(s_chain, F.sync + rsik::kSyncAlive, (uint32_t)FP.theta_wgs, hipStreamWaitValueGte, 0xffffffffu));
+                if (arm) hipLaunchKernelGGL(rsik::flags_chain_kernel<true>, dim3((unsigned)FP.G * 8u), dim3(64), 0, s_chain, F);
+                else hipLaunchKernelGGL(rsik::flags_chain_kernel<false>, dim3((unsigned)FP.G * 8u), dim3(64), 0, s_chain, F);
+                RSIK_HIP(ctx, hipEventRecord(ctx->events[2], s_chain));
+                {
+                    const bool pair = !singularity_plane_binds(K0.arms);
+                    dim3 grid_init = grid;
+                    if (pair && (rc = launch_dims(ctx, n * 2, &grid_init, who)) != RSIK_OK) return rc;
+                    if (arm) { if (pair) hipLaunchKernelGGL((rsik::cont_init_kernel<true, true>), grid_init, block, 0, s_main, K0); else hipLaunchKernelGGL((rsik::cont_init_kernel<true, false>), grid_init, block, 0, s_main, K0); }
+                    else { if (pair) hipLaunchKernelGGL((rsik::cont_init_kernel<false, true>), grid_init, block, 0, s_main, K0); else hipLaunchKernelGGL((rsik::cont_init_kernel<false, false>), grid_init, block, 0, s_main, K0); }
+                }
+                if (!getenv("RSIK_FLAGS_NO_WAITVALUE"))
+                    RSIK_HIP(ctx, hipStreamWaitValue32(s_main, F.sync + rsik::kSyncAlive, (uint32_t)FP.theta_wgs, hipStreamWaitValueGte, 0xffffffffu));
+                const bool pb = singularity_plane_binds(R.arms);
+                const dim3 pgrid(grid.x, (unsigned)n_steps);
+                if (arm) { if (pb) hipLaunchKernelGGL((rsik::flags_prepare_kernel<true, true>), pgrid, block, 0, s_main, F); else hipLaunchKernelGGL((rsik::flags_prepare_kernel<true, false>), pgrid, block, 0, s_main, F); }
+                else { if (pb) hipLaunchKernelGGL((rsik::flags_prepare_kernel<false, true>), pgrid, block, 0, s_main, F); else hipLaunchKernelGGL((rsik::flags_prepare_kernel<false, false>), pgrid, block, 0, s_main, F); }
+                const dim3 jgrid((unsigned)((n + 31) / 32), (unsigned)((n_steps + rsik::kJointChunk - 1) / rsik::kJointChunk));
+                if (arm) hipLaunchKernelGGL(rsik::flags_joints_kernel<true>, jgrid, block, 0, s_main, F);
+                else hipLaunchKernelGGL(rsik::flags_joints_kernel<false>, jgrid, block, 0, s_main, F);
+                RSIK_HIP(ctx, hipStreamWaitEvent(s_main, ctx->events[1], 0));
+                RSIK_HIP(ctx, hipStreamWaitEvent(s_main, ctx->events[2], 0));
+                RSIK_HIP(ctx, hipGetLastError());
+                if (capturing) ctx->ws_captured = true;
+                ctx->fused_sync = F.sync;
+                return RSIK_OK;
+            }
+            {
+                const bool pair = !singularity_plane_binds(K0.arms);
+                dim3 grid_init = grid;
+                if (pair && (rc = launch_dims(ctx, n * 2, &grid_init, who)) != RSIK_OK) return rc;
+                if (arm) { if (pair) hipLaunchKernelGGL((rsik::cont_init_kernel<true, true>), grid_init, block, 0, ctx->stream, K0); else hipLaunchKernelGGL((rsik::cont_init_kernel<true, false>), grid_init, block, 0, ctx->stream, K0); }
+                else { if (pair) hipLaunchKernelGGL((rsik::cont_init_kernel<false, true>), grid_init, block, 0, ctx->stream, K0); else hipLaunchKernelGGL((rsik::cont_init_kernel<false, false>), grid_init, block, 0, ctx->stream, K0); }
+            }
+            const dim3 fgrid((unsigned)FP.grid), fblock(rsik::kFusedThreads);
+            const bool pb = singularity_plane_binds(R.arms);
+            if (arm) { if (pb) hipLaunchKernelGGL((rsik::cont_fused_kernel<true, true>), fgrid, fblock, 0, ctx->stream, F); else hipLaunchKernelGGL((rsik::cont_fused_kernel<true, false>), fgrid, fblock, 0, ctx->stream, F); }
+            else { if (pb) hipLaunchKernelGGL((rsik::cont_fused_kernel<false, true>), fgrid, fblock, 0, ctx->stream, F); else hipLaunchKernelGGL((rsik::cont_fused_kernel<false, false>), fgrid, fblock, 0, ctx->stream, F); }
+            RSIK_HIP(ctx, hipGetLastError());
+            if (capturing) ctx->ws_captured = true;
+            ctx->fused_sync = F.sync;
+            return RSIK_OK;
+        }
+    }
     // ---- phased pipeline.  The four phases of a block run on four streams (theta on the caller's, the others on the
     // context's own), ordered by events: prepare(b) -> theta(b) -> joints(b) -> chain(b), theta(b) after theta(b-1),
     // chain(b) after chain(b-1).  The two sequential phases (a lone wave per SIMD on a few CUs) then run beside each other
@@ -630,11 +888,6 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     // A run is cut into blocks of steps; up to eight workspace slots are in flight (block b + 8 reuses the slot of block b
     // once its last phase has finished).
     ContPlan P;
-    bool capturing = false;
-    {
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        capturing = hipStreamIsCapturing(ctx->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
-    }
     if ((rc = cont_plan(ctx, who, n, n_steps, capturing, P)) != RSIK_OK) return rc;
     {
         // the context holds what BOTH forms of a run of this size need, so that a run that was first issued eagerly can be
@@ -643,8 +896,10 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         if ((rc = cont_plan(ctx, who, n, n_steps, !capturing, other)) != RSIK_OK) return rc;
         if (other.need > both.need) both.need = other.need;
         if (other.n_events > both.n_events) both.n_events = other.n_events;
-        if ((rc = cont_resources(ctx, who, both)) != RSIK_OK) return rc;
+        if ((rc = cont_resources(ctx, who, both.need, true, both.n_events)) != RSIK_OK) return rc;
     }
+    if (capturing) ctx->ws_captured = true;
+    ctx->fused_sync = nullptr;
     const std::vector<int64_t>&block_t0 = P.block_t0, &block_T = P.block_T;
     const int64_t n_blocks = (int64_t)block_t0.size();
     const size_t slot_bytes = P.slot_bytes, carry_bytes = P.carry_bytes, chunks_per_block = P.chunks_per_block;

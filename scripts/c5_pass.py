@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Six 4096 x 1000 passes of the continuous pipeline (config 5) and nothing else: the command rocprofv3 traces for
-scripts/c5_timeline.py.  usage: c5_pass.py [alternative librsik_hip.so | -] [steps per block]
+scripts/c5_timeline.py.  usage: c5_pass.py [alternative librsik_hip.so | -] [steps per block] [run mode: 1 phased (default), 3 single launch]
 (steps per block = 1000: one block, the four phases one after the other, i.e. each kernel's time with the chip to itself)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,6 +14,7 @@ traj = bench.make_config5_trajectories(n, n_steps, seed=20250204, device=0)
 ctrl = bench._quiet(ControlIK, urdf_path=bench.URDF, device=0)
 cont0 = ctrl.new_continuous_state("r_arm", n)
 ctrl._solver.set_option(_abi.OPT_CONT_BLOCK_STEPS, blk)
+ctrl._solver.set_option(_abi.OPT_CONT_RUN_MODE, int(sys.argv[3]) if len(sys.argv) > 3 else _abi.CONT_RUN_PHASED)
 out = {"joints": torch.empty((n_steps, n, 7), dtype=torch.float64, device="cuda"),
        "reachable": torch.empty((n_steps, n), dtype=torch.uint8, device="cuda"),
        "state": torch.empty((n_steps, n), dtype=torch.uint8, device="cuda")}
