@@ -41,14 +41,12 @@ __global__ __launch_bounds__(kBlock) void flags_prepare_kernel(const FusedArgs F
     stage_tables<MIXED, (int)offsetof(ContRunArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>(lds_tab, K.arms);
     const Acc<MIXED> A = make_acc<MIXED>(K.arms, lane_isl, lds_tab);
     const int slot = MIXED ? (A.isl ? 1 : 0) : 0;
-    cont_prepare_step<MIXED, PLANE, true>(K, A, slot, m, t, t, i, live);
-    // the step's goals of this tile are in memory (every wave's stores acknowledged, then the workgroup's barrier): one
-    // count for each group of 64 trajectories the tile holds
-    stores_done();
-    __syncthreads();
+    // (goals as tagged pairs: nothing to wait for — the workgroup ends like the phased kernel's, but for a count that tells the
+    // theta loaders how far the steps of the block have got: issued behind the stores, not waiting for them)
+    cont_prepare_step<MIXED, PLANE, true, true>(K, A, slot, m, t, t, i, live);
     constexpr int kGroups = kBlock / 64;
-    if (threadIdx.x < kGroups) {
-        const int g = (int)blockIdx.x * kGroups + (int)threadIdx.x;
+    if ((threadIdx.x & 63) == 0) {
+        const int g = (int)blockIdx.x * kGroups + (int)(threadIdx.x >> 6);
         if (g < F.G) sync_add(F.sync + kSyncArrays + (size_t)(t / F.S) * F.G + g, 1u);
     }
 }
@@ -64,12 +62,9 @@ __global__ __launch_bounds__(kBlock) void flags_joints_kernel(const FusedArgs F)
     const int b = (int)((c * kJointChunk) / F.S);
     const int g = (int)(blockIdx.x >> 1);  // 32 trajectories per workgroup: two workgroups per group of 64
     unsigned* const jdone = F.sync + kSyncArrays + (size_t)F.B * F.G;
-    unsigned* const tprog = jdone + (size_t)F.B * F.G;
-    stage_tables<MIXED, (int)offsetof(ContRunArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>(lds_tab, K.arms);
-    // the chunk's thetas are in memory once the group's theta wave has published the block (a wait that runs out leaves the
-    // chunk's rows unwritten; the run is reported as failed, see rsik_sync)
-    if (sync_wait(F, tprog + g, (unsigned)(b + 1)))
-        cont_joints_chunk<MIXED, true, false>(K, lds_tab, lds_out[wave], (int64_t)blockIdx.x * (kBlock / 64) + wave, c);
+    // (thetas as tagged pairs: the chunk's loads wait for the theta wave only if it really is behind)
+    cont_joints_chunk<MIXED, true, true, true>(K, lds_tab, lds_out[wave], (int64_t)blockIdx.x * (kBlock / 64) + wave, c);
+    // the chain wave reads and updates the rows in place: they must be in memory before it is told
     stores_done();
     __syncthreads();
     if (threadIdx.x == 0) sync_add(jdone + (size_t)b * F.G + g, 1u);
@@ -86,17 +81,19 @@ __global__ __launch_bounds__(768) void flags_theta_kernel(const FusedArgs F) {
     if (threadIdx.x == 0) sync_add(F.sync + kSyncAlive, 1u);  // (this workgroup runs: the host lets the chip-filling kernels go once all do)
     __syncthreads();
     asm volatile("v_mov_b32 v167, 0" ::: "v167");  // (168 registers x 12 waves: the compute unit's register file, nothing else fits)
-    fused_theta_wave<MIXED>(fk, (int)blockIdx.x, (int)(threadIdx.x >> 6), ring);
+    fused_theta_wave<MIXED, true>(fk, (int)blockIdx.x, (int)(threadIdx.x >> 6), ring);
 }
 
 // the chain waves as a kernel: one wave (eight trajectories, eight lanes each) per workgroup
+// (at most 128 registers: a chain wave shares its SIMD with the chip-filling kernels' waves — with the 266 the compiler would
+// take, half of the chip's SIMDs held two of those instead of six: the prepare kernel 135 -> 215 us, the joints kernel 220 -> 405)
 template <bool MIXED>
-__global__ __launch_bounds__(64) void flags_chain_kernel(const FusedArgs F) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void flags_chain_kernel(const FusedArgs F) {
     __shared__ SharedTables lds_tab;
     const FusedArgsK fk = (FusedArgsK)__builtin_amdgcn_kernarg_segment_ptr();
     stage_tables<MIXED, 0, 64>(lds_tab, F.R.arms);
     __builtin_amdgcn_s_setprio(2);
-    (void)fused_chain_wave<MIXED>(fk, (int)blockIdx.x, (LdsTabPtr)&lds_tab);
+    (void)fused_chain_wave<MIXED, true>(fk, (int)blockIdx.x, (LdsTabPtr)&lds_tab);
 }
 
 }  // namespace rsik

@@ -256,9 +256,12 @@ __device__ __forceinline__ void theta_walker(FusedArgsK fk, int g, int w, ThetaR
     }
     // (the batches after that: steps t ... t + 7; with the first step gone they sit one step off the loader's, which is fine:
     // the counters count steps)
+    unsigned long long waited = 0;  // (traced runs: ticks of the block spent waiting for the ring to fill)
 #pragma unroll 1
     while (t + kRingBatch <= N) {
+        const unsigned long long tw = traced ? __builtin_amdgcn_s_memrealtime() : 0ull;
         if (!ring_wait(F, ring, &ring->filled[w], (unsigned)(t + kRingBatch))) return;
+        if (traced) waited += __builtin_amdgcn_s_memrealtime() - tw;
         f64x2v c[kRingBatch];
 #pragma unroll
         for (int u = 0; u < kRingBatch; u++) c[u] = cells[((t + u) & (kRingSteps - 1)) * 64];
@@ -272,8 +275,9 @@ __device__ __forceinline__ void theta_walker(FusedArgsK fk, int g, int w, ThetaR
         if (lane == 0) lds_store(&ring->done[w], (unsigned)t);
         if (traced && (t / S) != ((t - kRingBatch) / S)) {  // (a block's last step went by)
             const FusedArgs& Ft = fused_args(fk);
-            fused_trace(Ft, 3, (t - kRingBatch) / S, g, 0, t_blk, t_blk);
+            fused_trace(Ft, 3, (t - kRingBatch) / S, g, 0, t_blk, t_blk + waited);
             t_blk = __builtin_amdgcn_s_memrealtime();
+            waited = 0;
         }
     }
 #pragma unroll 1
@@ -288,6 +292,54 @@ __device__ __forceinline__ void theta_walker(FusedArgsK fk, int g, int w, ThetaR
     if (traced) fused_trace(fused_args(fk), 3, (N - 1) / S, g, 1, t_blk, t_blk);
 }
 
+// The loader keeps three batches of loads in flight — and counts them itself: its loads are asm statements the compiler does
+// not see as memory operations, waited for by `s_waitcnt vmcnt(N)` with N = the loads issued since (one in-order counter).
+// (With loads the compiler tracks, the rare paths of this loop — the poll at a block's start, the reload of a stale batch —
+// made it wait for everything at every batch: one batch per memory round trip, 230 ns a step, the walker starved half the time.)
+// PAIRS (the flag-synchronised form): the goals arrive as (goal, tag) pairs that are valid by themselves — no counter to
+// poll; a batch with an old tag in it is loaded again — and the wrapped goal is formed here, where issue slots are free.
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+template <bool PAIRS>
+struct LoaderSet;
+template <>
+struct LoaderSet<true> { u32x4v p[kRingBatch]; };               // (goal, tag)
+template <>
+struct LoaderSet<false> { u32x2v g[kRingBatch], gw[kRingBatch]; };  // goal, wrapped goal
+constexpr int kLoaderOpsPerSet = 8;  // PAIRS: one load per step; else two (see issue)
+template <bool PAIRS>
+__device__ __forceinline__ void loader_issue(LoaderSet<PAIRS>& o, const ContRunArgs& K, int64_t i, int t, int N) {
+#pragma unroll
+    for (int u = 0; u < kRingBatch; u++) {
+        const int64_t row = (t + u) < N ? (t + u) : (N - 1);  // (rows past the end repeat the last one and are never used)
+        if constexpr (PAIRS) {
+            const double* a = K.gw + (row * K.n + i) * 2;
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(o.p[u]) : "v"(a) : "memory");
+        } else {
+            const double* a = K.ws + row * K.n + i;
+            const double* b = K.gw + row * K.n + i;
+            asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(o.g[u]) : "v"(a) : "memory");
+            asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(o.gw[u]) : "v"(b) : "memory");
+        }
+    }
+}
+// all but the `newer` most recent loads have returned; the set's registers may be read from here on
+template <bool PAIRS, int NEWER>
+__device__ __forceinline__ void loader_wait(LoaderSet<PAIRS>& o) {
+    if constexpr (PAIRS) {
+        asm volatile("s_waitcnt vmcnt(%8)"
+                     : "+v"(o.p[0]), "+v"(o.p[1]), "+v"(o.p[2]), "+v"(o.p[3]), "+v"(o.p[4]), "+v"(o.p[5]), "+v"(o.p[6]), "+v"(o.p[7])
+                     : "n"(NEWER)
+                     : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(%16)"
+                     : "+v"(o.g[0]), "+v"(o.g[1]), "+v"(o.g[2]), "+v"(o.g[3]), "+v"(o.g[4]), "+v"(o.g[5]), "+v"(o.g[6]), "+v"(o.g[7]), "+v"(o.gw[0]),
+                       "+v"(o.gw[1]), "+v"(o.gw[2]), "+v"(o.gw[3]), "+v"(o.gw[4]), "+v"(o.gw[5]), "+v"(o.gw[6]), "+v"(o.gw[7])
+                     : "n"(NEWER)
+                     : "memory");
+    }
+}
+template <bool PAIRS>
 __device__ __forceinline__ void theta_loader(FusedArgsK fk, int g, int w, ThetaRingPtr ring) {
     const int lane = threadIdx.x & 63;
     const FusedArgs& F = fused_args(fk);
@@ -295,55 +347,106 @@ __device__ __forceinline__ void theta_loader(FusedArgsK fk, int g, int w, ThetaR
     int64_t i = (int64_t)g * 64 + lane;
     if (i >= K.n) i = K.n - 1;
     const int N = (int)K.T, S = F.S;
-    const int64_t n = K.n;
     const int NB = (N + kRingBatch - 1) / kRingBatch;
     typedef double f64x2v __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(3))) f64x2v* CellPtr;
     const CellPtr cells = (CellPtr)&ring->cell[w][0][lane][0];
-    struct Set { double g[kRingBatch], gw[kRingBatch]; };
-    // issue(k): batch k's sixteen loads (rows past the end repeat the last one and are never used); at a block's first batch
-    // the block's prepare items must have signalled.  land(k): into the ring, once the writer has freed the slots.
+    constexpr int kOps = PAIRS ? kRingBatch : 2 * kRingBatch;  // loads per batch
     bool ok = true;
-    auto issue = [&](Set& o, int k) {
-        const int t = k * kRingBatch;
-        if (t < N && (t % S) == 0) {
-            // the block's goals are there: every prepare item of it has signalled (flags mode: a workgroup per step)
+    // a block's goals are there (the single launch: every prepare item of it has signalled; polled at a block's first batch)
+    auto block_ready = [&](int t) {
+        if (!PAIRS && t < N && (t % S) == 0) {
             const unsigned want = F.flags_mode ? (unsigned)((N - t) < S ? (N - t) : S) : (unsigned)F.PI;
             ok = ok && sync_wait(F, F.sync + kSyncArrays + (size_t)(t / S) * F.G + g, want);
         }
-#pragma unroll
-        for (int u = 0; u < kRingBatch; u++) {
-            const int64_t row = (t + u) < N ? (t + u) : (N - 1);
-            o.g[u] = ldc_f64<true>(K.ws + row * n + i);
-            o.gw[u] = ldc_f64<true>(K.gw + row * n + i);
-        }
     };
-    auto land = [&](const Set& o, int k) {
+    auto land = [&](LoaderSet<PAIRS>& o, int k) {
         const int t = k * kRingBatch;
         const int cnt = (N - t) < kRingBatch ? (N - t) : kRingBatch;
+        double gg[kRingBatch], gw[kRingBatch];
+        if constexpr (PAIRS) {
+            // every pair of the batch carries this run's tag?  Else the prepare kernel has not got there yet: wait for its
+            // count of the block's steps (a hint: bumped behind the stores, not waiting for them), then the whole batch again
+            auto stale = [&]() {
+                bool bad = false;
+#pragma unroll
+                for (int u = 0; u < kRingBatch; u++) {
+                    const f64x2v c = __builtin_bit_cast(f64x2v, o.p[u]);
+                    bad = bad || (u < cnt && c.y != K.epoch);
+                }
+                return __any(bad) != 0;
+            };
+            if (stale()) {
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                const int t_last = t + cnt - 1;
+                const unsigned* hint = F.sync + kSyncArrays + (size_t)(t_last / S) * F.G + g;
+                const unsigned want = (unsigned)(t_last % S) + 1u;
+                do {
+                    do {
+                        __builtin_amdgcn_s_sleep(16);
+                    } while (sync_load(hint) < want && sync_load(F.sync + kSyncAbort) == 0 && __builtin_amdgcn_s_memrealtime() - t0 <= kFusedWaitTicks);
+                    if (sync_load(F.sync + kSyncAbort) != 0 || __builtin_amdgcn_s_memrealtime() - t0 > kFusedWaitTicks) {
+                        sync_store(F.sync + kSyncAbort, 1u);
+                        lds_store(&ring->abort, 1u);
+                        ok = false;
+                        break;
+                    }
+                    loader_issue<PAIRS>(o, K, i, t, N);
+                    loader_wait<PAIRS, 0>(o);  // (everything: the two batches behind this one have landed as well)
+                } while (stale());
+            }
+#pragma unroll
+            for (int u = 0; u < kRingBatch; u++) {
+                gg[u] = __builtin_bit_cast(f64x2v, o.p[u]).x;
+                gw[u] = wrap_theta_to_pi(gg[u]);  // U:93-97, see cont_prepare_step
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < kRingBatch; u++) {
+                gg[u] = __builtin_bit_cast(double, o.g[u]);
+                gw[u] = __builtin_bit_cast(double, o.gw[u]);
+            }
+        }
         if (k >= kRingSteps / kRingBatch) ok = ok && ring_wait(F, ring, &ring->written[w], (unsigned)(t - kRingSteps + kRingBatch));
 #pragma unroll
         for (int u = 0; u < kRingBatch; u++) {
             f64x2v c;
-            c.x = o.g[u]; c.y = o.gw[u];
+            c.x = gg[u]; c.y = gw[u];
             if (u < cnt) cells[((t + u) & (kRingSteps - 1)) * 64] = c;
         }
         lds_done();
         if (lane == 0) lds_store(&ring->filled[w], (unsigned)(t + cnt));
     };
-    Set a, b, c;
-    issue(a, 0); issue(b, 1); issue(c, 2);
+    // three batches in flight, always (past the run's end: loads of its last row, never looked at), so that "all but the last
+    // two batches' loads" is the batch to land
+    LoaderSet<PAIRS> a, b, c;
+    block_ready(0);
+    loader_issue<PAIRS>(a, K, i, 0, N);
+    block_ready(kRingBatch);
+    loader_issue<PAIRS>(b, K, i, kRingBatch, N);
+    block_ready(2 * kRingBatch);
+    loader_issue<PAIRS>(c, K, i, 2 * kRingBatch, N);
 #pragma unroll 1
     for (int k = 0; k < NB && ok; k += 3) {
+        loader_wait<PAIRS, 2 * kOps>(a);
         land(a, k);
-        issue(a, k + 3);
-        if (k + 1 < NB && ok) { land(b, k + 1); }
-        issue(b, k + 4);
-        if (k + 2 < NB && ok) { land(c, k + 2); }
-        issue(c, k + 5);
+        block_ready((k + 3) * kRingBatch);
+        loader_issue<PAIRS>(a, K, i, (k + 3) * kRingBatch, N);
+        loader_wait<PAIRS, 2 * kOps>(b);
+        if (k + 1 < NB && ok) land(b, k + 1);
+        block_ready((k + 4) * kRingBatch);
+        loader_issue<PAIRS>(b, K, i, (k + 4) * kRingBatch, N);
+        loader_wait<PAIRS, 2 * kOps>(c);
+        if (k + 2 < NB && ok) land(c, k + 2);
+        block_ready((k + 5) * kRingBatch);
+        loader_issue<PAIRS>(c, K, i, (k + 5) * kRingBatch, N);
     }
+    loader_wait<PAIRS, 0>(a);  // (nothing of this wave's is in flight when it leaves)
+    loader_wait<PAIRS, 0>(b);
+    loader_wait<PAIRS, 0>(c);
 }
 
+template <bool PAIRS>
 __device__ __forceinline__ void theta_writer(FusedArgsK fk, int g, int w, ThetaRingPtr ring) {
     const int lane = threadIdx.x & 63;
     const FusedArgs& F = fused_args(fk);
@@ -368,7 +471,12 @@ __device__ __forceinline__ void theta_writer(FusedArgsK fk, int g, int w, ThetaR
 #pragma unroll
         for (int u = 0; u < kRingBatch; u++) {
             const int64_t row = t + (u < cnt ? u : cnt - 1);  // (a short last batch stores its last step again: eight stores, always)
-            stc_f64<true>(K.ws + row * n + i, th[u]);
+            if constexpr (PAIRS) st_pair(K.ws, row * n + i, th[u], K.epoch);  // (valid by itself: no progress word, no wait)
+            else stc_f64<true>(K.ws + row * n + i, th[u]);
+        }
+        if constexpr (PAIRS) {
+            if (lane == 0) sync_store(tprog, (unsigned)(t + cnt));  // (steps stored, not yet acknowledged: the joints kernel's hint)
+            continue;
         }
         if (pending >= 0) {
             // the stores of the batch before this one — a block's last — have been acknowledged once all but this batch's eight
@@ -388,7 +496,7 @@ __device__ __forceinline__ void theta_writer(FusedArgsK fk, int g, int w, ThetaR
 }
 
 // one wave of a theta workgroup (role = the workgroup's index among them)
-template <bool MIXED>
+template <bool MIXED, bool PAIRS = false>
 __device__ __noinline__ void fused_theta_wave(FusedArgsK fk_, int role_, int wave_, ThetaRingPtr ring) {
     const FusedArgsK fk = uniform(fk_);
     const int wave = uniform(wave_), w = wave & 3;
@@ -400,8 +508,8 @@ __device__ __noinline__ void fused_theta_wave(FusedArgsK fk_, int role_, int wav
         kind = F.snap_kind;
     }
     if (wave >= 12 || g >= n_groups) return;
-    if (wave >= 8) { theta_writer(fk, g, w, ring); return; }
-    if (wave >= 4) { theta_loader(fk, g, w, ring); return; }
+    if (wave >= 8) { theta_writer<PAIRS>(fk, g, w, ring); return; }
+    if (wave >= 4) { theta_loader<PAIRS>(fk, g, w, ring); return; }
     __builtin_amdgcn_s_setprio(3);
     if constexpr (MIXED) {
         theta_walker<true, kSnapGeneric>(fk, g, w, ring);
@@ -487,7 +595,7 @@ __device__ __noinline__ unsigned long long fused_item_joints(FusedArgsK fk_, int
 // of block b + 1 waits for the item of block b, which some other wave holds, slowed by three busy waves on its SIMD and a
 // hand-over through memory: 23 us a block, 380 us a run, with a thousand waves parked in such waits.)  The first waves of
 // the worker workgroups to start take the sub-groups, a counter hands them out — to waves that run, like every role.
-template <bool MIXED>
+template <bool MIXED, bool PAIRS = false>
 __device__ __noinline__ bool fused_chain_wave(FusedArgsK fk_, int sg_, LdsTabPtr tab3) {
     const FusedArgsK fk = uniform(fk_);
     const int sg = uniform(sg_);
@@ -517,7 +625,7 @@ __device__ __noinline__ bool fused_chain_wave(FusedArgsK fk_, int sg_, LdsTabPtr
         }
         if (!sync_wait(F, jdone + (size_t)b * F.G + g, want)) return false;
         const unsigned long long t_ready = F.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
-        cont_chain_walk<MIXED, true, kFusedChainBatch>(K, lds_tab, i, lane & 7, t0, t0, T, b == F.B - 1, &carry, b == 0);
+        cont_chain_walk<MIXED, true, kFusedChainBatch, PAIRS>(K, lds_tab, i, lane & 7, t0, t0, T, b == F.B - 1, &carry, b == 0);
         fused_trace(F, 0, b, g, h, t_start, t_ready);
     }
     return true;

@@ -96,6 +96,9 @@ struct ContRunArgs {
     double snap_tdag;             // phase 2, single-arm launches: see continuous_next_theta_lean (the kind is a template argument)
     double* theta_carry;          // [2][n]: previous_theta between the blocks of one run (phase 2's own state); row 1: see cont_theta_kernel
     int first_block, last_block;
+    double epoch;                 // PAIRS layout (rsik_kernel_flags.hpp): this run's tag, see ld_pair / st_pair
+    unsigned* abort_word;         // PAIRS layout: raised when a wait for a tagged value runs out (else NULL)
+    const unsigned* theta_hint;   // PAIRS layout: per group of 64 trajectories, steps whose thetas the theta wave has stored (a hint)
     double* st;                   // cont_state
     double* joints;               // [n_steps][n][7]
     uint8_t* reachable;           // [n_steps][n] or NULL
@@ -132,10 +135,52 @@ __device__ __forceinline__ void stc_u8(uint8_t* p, uint8_t v) {
     if constexpr (COH && !RSIK_COH_PLAIN_STORES) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else *p = v;
 }
+// The PAIRS layout of the flag-synchronised form: a value that one kernel hands to another while both run travels as a
+// 16-byte (value, tag) pair, written by ONE written-through store and read by ONE L2-bypassing load — a pair is valid by
+// itself: its tag is this run's epoch (the host counts runs; fresh workspace is zeroed, epochs start at 1).  Neither side
+// needs a counter, a drain or a poll: a consumer that finds an old tag loads the pair again.  Addressing: `pairs` = the
+// array (the same for every lane: one buffer descriptor in scalar registers), `cell` = the pair's index in it (per lane;
+// the array stays below 2 GB, the host sees to that).
+typedef double f64x2p __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4p __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f64x2p ld_pair(const double* pairs, int64_t cell) {
+    const __amdgpu_buffer_rsrc_t buf = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(pairs), 0, 0x7fffffff, 0x00020000);
+    return __builtin_bit_cast(f64x2p, __builtin_amdgcn_raw_buffer_load_b128(buf, (unsigned)(cell * 16), 0, 16));
+}
+__device__ __forceinline__ void st_pair(double* pairs, int64_t cell, double value, double tag) {
+    const __amdgpu_buffer_rsrc_t buf = __builtin_amdgcn_make_buffer_rsrc(pairs, 0, 0x7fffffff, 0x00020000);
+    f64x2p v;
+    v.x = value; v.y = tag;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4p, v), buf, (unsigned)(cell * 16), 0, 16);
+}
+// the value of pair (t, i) once its tag is this run's (every lane of the wave loads; `need`: this lane's pair matters).
+// A wave that finds an old tag does not keep loading pairs — thousands of waves doing that take the memory system away from
+// the producer they wait for — it polls `hint` (one word, bumped by the producer behind its stores, without waiting for
+// them: a hint, not a promise) until that reaches `want`, then loads again.  Bounded: three seconds, then the run's abort
+// word is raised and whatever is there is returned.
+__device__ __forceinline__ double pair_value(const ContRunArgs& K, const double* pairs, int64_t t, int64_t i, bool need, const unsigned* hint,
+                                             unsigned want) {
+    f64x2p p = ld_pair(pairs, t * K.n + i);
+    if (__builtin_expect(__any(need && p.y != K.epoch), 0)) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        do {
+            do {
+                __builtin_amdgcn_s_sleep(16);
+            } while (__hip_atomic_load(const_cast<unsigned*>(hint), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want &&
+                     __builtin_amdgcn_s_memrealtime() - t0 <= 300000000ull);
+            p = ld_pair(pairs, t * K.n + i);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull || __hip_atomic_load(K.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                __hip_atomic_store(K.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        } while (__any(need && p.y != K.epoch));
+    }
+    return p.x;
+}
 
 // phase 1, one (step, trajectory): `m` the step's twelve matrix entries, `t` the step's row in the workspace arrays, `t_abs`
 // its row in the run's outputs.  Shared by the phased kernel below and the single-launch form (COH, see above).
-template <bool MIXED, bool PLANE, bool COH>
+template <bool MIXED, bool PLANE, bool COH, bool PAIRS = false>
 __device__ __forceinline__ void cont_prepare_step(const ContRunArgs& K, const Acc<MIXED>& A, int slot, const double (&m)[12], int64_t t,
                                                   int64_t t_abs, int64_t i, bool live) {
     Rot Rg;
@@ -149,10 +194,14 @@ __device__ __forceinline__ void cont_prepare_step(const ContRunArgs& K, const Ac
     // the step's goal for the theta phase: the search's theta, NaN = nothing found, stay (U:252-264 with goal =
     // previous_theta), or the preferred theta of an unreachable pose (U:115-127)
     const double goal = T.ok_limits ? (T.found ? T.theta : __builtin_nan("")) : K.pref_arg[slot];
-    stc_f64<COH>(&RSIK_WS(K, t, i), goal);
-    // what limit_theta_to_interval makes of theta = goal before it looks at the interval (U:93-97): this phase has the
-    // issue slots for it, the theta phase (a lone wave per SIMD) has not
-    stc_f64<COH>(&K.gw[t * K.n + i], wrap_theta_to_pi(goal));
+    if constexpr (PAIRS) {
+        st_pair(K.gw, t * K.n + i, goal, K.epoch);  // (the wrapped form is the theta loader's business there)
+    } else {
+        stc_f64<COH>(&RSIK_WS(K, t, i), goal);
+        // what limit_theta_to_interval makes of theta = goal before it looks at the interval (U:93-97): this phase has the
+        // issue slots for it, the theta phase (a lone wave per SIMD) has not
+        stc_f64<COH>(&K.gw[t * K.n + i], wrap_theta_to_pi(goal));
+    }
     stc_u8<COH>(&K.flags[t * K.n + i], (uint8_t)((T.ok_limits ? 1 : 0) | (T.found ? 2 : 0) | (special ? 8 : 0)));
     if (K.state) stc_u8<COH>(&K.state[t_abs * K.n + i], (uint8_t)T.code);
     if (K.reachable) stc_u8<COH>(&K.reachable[t_abs * K.n + i], (T.ok_limits && T.found) ? 1 : 0);
@@ -389,7 +438,7 @@ __device__ __forceinline__ void step_joints(const Acc& A, const ContRunArgs& K, 
 // of the wave's own.  Shared by the phased kernel below and the single-launch form (COH: theta, flags in; rows, events out
 // cross compute units while the kernel runs).
 // STAGE: the workgroup's tables are staged here, behind the chunk's loads (their latency overlaps the staging's round trip).
-template <bool MIXED, bool COH, bool STAGE = false>
+template <bool MIXED, bool COH, bool STAGE = false, bool PAIRS = false>
 __device__ __forceinline__ void cont_joints_chunk(const ContRunArgs& K, SharedTables& lds_tab, double* lw, int64_t grp, int64_t c) {
     static_assert(kJointChunk == 8, "lane = 8 * step + trajectory");
     constexpr int AUX = COH ? 16 : 0;
@@ -413,7 +462,9 @@ __device__ __forceinline__ void cont_joints_chunk(const ContRunArgs& K, SharedTa
 #pragma unroll
         for (int k = 9; k < 12; k++) m[k] = src[k * n];
     }
-    const double theta = ldc_f64<COH>(&RSIK_WS(K, tt, ii));
+    double theta;
+    if constexpr (PAIRS) theta = pair_value(K, K.ws, tt, ii, true, K.theta_hint + (grp >> 3), (unsigned)((c + 1) * kJointChunk < K.T ? (c + 1) * kJointChunk : K.T));  // (waits for the theta wave, if it has to)
+    else theta = ldc_f64<COH>(&RSIK_WS(K, tt, ii));
     const int flag = ldc_u8<COH>(&K.flags[tt * n + ii]);
     const bool special = (flag & 8) != 0;
     if (RSIK_RARE(special)) {
@@ -528,10 +579,15 @@ __global__ __launch_bounds__(kBlock) RSIK_PHASED_OCC_ATTR void cont_joints_kerne
 // `carry` (the single-launch form's chain waves, which walk a run block by block): the trajectory state of this lane between two
 // calls — taken from cont_state when `first`, left in cont_state when `last`, in registers in between.
 struct ChainCarry { double prev; bool init, emergency; };
-template <bool MIXED, bool COH, int BATCH>
+template <bool MIXED, bool COH, int BATCH, bool PAIRS = false>
 __device__ __forceinline__ void cont_chain_walk(const ContRunArgs& K, SharedTables& lds_tab, int64_t i, int j, int64_t tw0, int64_t t_abs0,
                                                 int64_t T, bool last, ChainCarry* carry = nullptr, bool first = true) {
     constexpr int AUX = COH ? 16 : 0;
+    // a step's theta (behind the joints phase, which has read it: it is there)
+    auto theta_at = [&](int64_t t_ws, int64_t ix) {
+        if constexpr (PAIRS) return ldc_f64<COH>(K.ws + (t_ws * K.n + ix) * 2);
+        else return ldc_f64<COH>(&RSIK_WS(K, t_ws, ix));
+    };
     const int lane = threadIdx.x & 63;
     const int gshift = lane & ~7;
     const bool live = i < K.n;
@@ -582,7 +638,7 @@ __device__ __forceinline__ void cont_chain_walk(const ContRunArgs& K, SharedTabl
             step_geometry(A, m, K.euler_roundtrip, (f & 1) == 0, r, G);
             double jv[7];
             bool sing;
-            step_joints(A, K, r, G, ldc_f64<COH>(&RSIK_WS(K, tw0 + t, ii)), pv, jv, sing);
+            step_joints(A, K, r, G, theta_at(tw0 + t, ii), pv, jv, sing);
             cur = jv[0];
 #pragma unroll
             for (int k = 1; k < 7; k++) cur = (jj == k) ? jv[k] : cur;
@@ -607,7 +663,7 @@ __device__ __forceinline__ void cont_chain_walk(const ContRunArgs& K, SharedTabl
                 }
             } else if (j == 7) {
                 stc_f64<COH>(&K.st[11 * n + i], (double)cause);
-                stc_f64<COH>(&K.st[0 * n + i], ldc_f64<COH>(&RSIK_WS(K, tw0 + t, i)));  // previous_theta of the step that tripped (phase 2 ran ahead)
+                stc_f64<COH>(&K.st[0 * n + i], theta_at(tw0 + t, i));  // previous_theta of the step that tripped (phase 2 ran ahead)
             } else if (disc) {
                 stc_f64<COH>(&K.st[(12 + j) * n + i], clamped);       // the joints that failed the check
             }
@@ -742,7 +798,7 @@ __device__ __forceinline__ void cont_chain_walk(const ContRunArgs& K, SharedTabl
     if (live && j == 7) {
         stc_f64<COH>(&K.st[8 * n + i], init ? 1.0 : 0.0);
         stc_f64<COH>(&K.st[9 * n + i], emergency ? 1.0 : 0.0);
-        if (last && !emergency) stc_f64<COH>(&K.st[0 * n + i], ldc_f64<COH>(&RSIK_WS(K, tw0 + T - 1, i)));  // previous_theta after the last step
+        if (last && !emergency) stc_f64<COH>(&K.st[0 * n + i], theta_at(tw0 + T - 1, i));  // previous_theta after the last step
     }
 }
 

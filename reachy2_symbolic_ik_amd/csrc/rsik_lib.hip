@@ -46,6 +46,12 @@ struct rsik_ctx {
     unsigned long long* trace;       // RSIK_OPT_CONT_TRACE: the single launch's item records (device), or NULL
     size_t trace_cap;
     unsigned* fused_sync;            // sync area of the last single-launch run (inside ws): its abort word is read by rsik_sync
+    unsigned* edge_words;            // the phased pipeline's dependency words (device): see cont_edges
+    size_t edge_count;
+    unsigned edge_seq;               // runs issued with them: the value a word must reach
+    int can_wait_value;              // hipDeviceAttributeCanUseStreamWaitValue
+    double flags_epoch;              // the flag-synchronised form's run counter (the tag of its (value, tag) pairs)
+    bool flags_ws_clean;             // the current workspace has been zeroed since it was allocated (no stale tags in it)
     hipStream_t side[3];             // the pipeline's own streams (prepare / joints / chain), created on first use
     std::vector<hipEvent_t> events;  // reusable, timing disabled
     bool have_side;
@@ -107,6 +113,13 @@ int rsik_create(int device_id, rsik_ctx** out) {
     c->trace = nullptr;
     c->trace_cap = 0;
     c->fused_sync = nullptr;
+    c->flags_epoch = 0.0;
+    c->flags_ws_clean = false;
+    c->edge_words = nullptr;
+    c->edge_count = 0;
+    c->edge_seq = 0;
+    c->can_wait_value = 0;
+    (void)hipDeviceGetAttribute(&c->can_wait_value, hipDeviceAttributeCanUseStreamWaitValue, device_id);
     c->have_side = false;
     for (auto& st : c->side) st = nullptr;
     *out = c;
@@ -117,6 +130,7 @@ int rsik_destroy(rsik_ctx* ctx) {
     if (ctx && hipSetDevice(ctx->device) == hipSuccess) {
         if (ctx->ws) (void)hipFree(ctx->ws);
         if (ctx->trace) (void)hipFree(ctx->trace);
+        if (ctx->edge_words) (void)hipFree(ctx->edge_words);
         for (void* w : ctx->retired_ws) (void)hipFree(w);
         for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
         if (ctx->have_side)
@@ -578,6 +592,7 @@ static int cont_resources(rsik_ctx* ctx, const char* who, size_t need, bool want
         ctx->ws_bytes = want;
         ctx->ws_captured = false;
         ctx->fused_sync = nullptr;
+        ctx->flags_ws_clean = false;
     }
     if (streams) {
         for (auto& st : ctx->side) RSIK_HIP(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -630,8 +645,9 @@ static bool fused_plan(const rsik_ctx* ctx, int64_t n, int64_t n_steps, FusedPla
     if ((long long)S * n * 56 >= (1ll << 31)) return no("block too large for a buffer window");
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
     const size_t cells = (size_t)n * (size_t)n_steps;
-    P.off_gw = up(cells * sizeof(double));
-    P.off_flags = P.off_gw + up(cells * sizeof(double));
+    // (goal and theta arrays sized for the flag-synchronised form's 16-byte pairs; the single launch uses half of each)
+    P.off_gw = up(cells * 2 * sizeof(double));
+    P.off_flags = P.off_gw + up(cells * 2 * sizeof(double));
     P.off_events = P.off_flags + up(cells);
     P.off_scratch = P.off_events + up((size_t)B * P.CH * (size_t)n);
     P.off_sync = P.off_scratch + up((size_t)n * sizeof(double));
@@ -645,7 +661,7 @@ static bool fused_plan(const rsik_ctx* ctx, int64_t n, int64_t n_steps, FusedPla
     // the chain sub-groups (eight trajectories each) go to the last waves of the worker workgroups: enough of them per
     // workgroup for all sub-groups, at most half of a workgroup's waves
     P.chain_waves = (int)((G * 8 + workers - 1) / workers);
-    P.flags_ok = n_steps <= 65535;
+    P.flags_ok = n_steps <= 65535 && cells * 16 < ((size_t)1 << 31);  // (grids of (tiles, steps); pair arrays below 2 GB)
     if (P.chain_waves > rsik::kFusedWaves / 2) {
         if (ctx->options[RSIK_OPT_CONT_RUN_MODE] == RSIK_CONT_RUN_FUSED) return no("too many trajectories for the chain waves (half of the worker waves at most)");
         P.chain_waves = rsik::kFusedWaves / 2;  // (only the single launch uses them)
@@ -810,6 +826,17 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
             F.S = FP.S; F.Sp = FP.Sp; F.L = FP.L; F.CL = FP.CL; F.B = FP.B; F.G = FP.G; F.PI = FP.PI; F.CH = FP.CH; F.JQ = FP.JQ; F.Jh = FP.Jh;
             F.theta_wgs = FP.theta_wgs; F.chain_waves = FP.chain_waves; F.tickets = FP.tickets;
             F.flags_mode = as_flags ? 1 : 0;
+            if (as_flags) {
+                // tagged pairs: a workspace that has not been zeroed since it was allocated could hold anything, this run's tag included
+                if (!ctx->flags_ws_clean) {
+                    RSIK_HIP(ctx, hipMemsetAsync(base, 0, FP.off_flags, ctx->stream));
+                    ctx->flags_ws_clean = true;
+                }
+                ctx->flags_epoch += 1.0;
+                R.epoch = ctx->flags_epoch;
+                R.abort_word = reinterpret_cast<unsigned*>(base + FP.off_sync) + rsik::kSyncAbort;
+                R.theta_hint = reinterpret_cast<unsigned*>(base + FP.off_sync) + rsik::kSyncArrays + 2 * (size_t)FP.B * FP.G;  // (= tprog)
+            }
             F.snap_kind = rsik::kSnapGeneric;
             if (!arm) F.snap_kind = theta_snap_plan(R.lim[0][0], R.lim[0][1], d_theta_max, &R.snap_tdag);
             // the sync area starts every run at zero; the (re)initialisation of the trajectories that start here
@@ -928,14 +955,40 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     }
 #endif
     hipStream_t s_main = ctx->stream, s_theta = ctx->stream, s_prep = ctx->side[0], s_joints = ctx->side[1], s_chain = ctx->side[2];
-    auto ev = [&](int kind, int64_t b) { return ctx->events[2 + 4 * (size_t)b + kind]; };  // 0 prepared, 1 theta, 2 joints, 3 chain
+    // Dependencies between the streams.  Recorded into a hipGraph they are events (the only form a capture takes).  Issued
+    // launch by launch they are words in device memory: the producer's stream writes this run's sequence number behind its
+    // kernel (hipStreamWriteValue32), the consumer's stream waits for the word to reach it (hipStreamWaitValue32) — measured
+    // on an otherwise idle chip (scripts/probes/edge_probe.hip): the dependent kernel starts 3.8 us after its parent's end,
+    // against 10.6 us behind an event (15-55 us inside a pass).  Words are per (kind, block) and only ever grow.
+    const bool by_value = !capturing && ctx->can_wait_value != 0 && !getenv("RSIK_EDGES_BY_EVENT");
+    if (by_value) {
+        const size_t need_words = P.n_events;
+        if (ctx->edge_count < need_words) {
+            if (ctx->edge_words) { RSIK_HIP(ctx, hipDeviceSynchronize()); RSIK_HIP(ctx, hipFree(ctx->edge_words)); ctx->edge_words = nullptr; }
+            RSIK_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->edge_words), need_words * 2 * sizeof(unsigned)));
+            RSIK_HIP(ctx, hipMemset(ctx->edge_words, 0, need_words * 2 * sizeof(unsigned)));
+            ctx->edge_count = need_words * 2;
+            ctx->edge_seq = 0;
+        }
+        ctx->edge_seq += 1;
+    }
+    const unsigned seq = ctx->edge_seq;
+    auto edge_id = [&](int kind, int64_t b) { return 2 + 4 * (size_t)b + kind; };  // 0 prepared, 1 theta, 2 joints, 3 chain; ids 0, 1: the run's start
+    auto signal = [&](hipStream_t st, size_t id) -> hipError_t {
+        if (by_value) return hipStreamWriteValue32(st, ctx->edge_words + id, seq, 0);
+        return hipEventRecord(ctx->events[id], st);
+    };
+    auto wait_for = [&](hipStream_t st, size_t id) -> hipError_t {
+        if (by_value) return hipStreamWaitValue32(st, ctx->edge_words + id, seq, hipStreamWaitValueGte, 0xffffffffu);
+        return hipStreamWaitEvent(st, ctx->events[id], 0);
+    };
     // (Re)initialisation of the trajectories that start here (C:296-325: the start-up search for previous_theta, ~55 us
     // of lone waves), then the pipeline's streams join in.  The prepare phase depends on the goal matrices alone, not on
     // the trajectory state: its stream forks off BEFORE the initialisation (behind whatever the caller queued ahead of
     // this call), so prepare(0) runs beside it and theta(0) starts when both are done; the joints and chain streams fork
     // behind it.
-    RSIK_HIP(ctx, hipEventRecord(ctx->events[1], s_main));
-    RSIK_HIP(ctx, hipStreamWaitEvent(s_prep, ctx->events[1], 0));
+    RSIK_HIP(ctx, signal(s_main, 1));
+    RSIK_HIP(ctx, wait_for(s_prep, 1));
     {
         // two lanes per trajectory where get_joints cannot move the solver's state (no elbow projection possible)
         const bool pair = !singularity_plane_binds(K0.arms);
@@ -944,9 +997,9 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         if (arm) { if (pair) hipLaunchKernelGGL((rsik::cont_init_kernel<true, true>), grid_init, block, 0, s_main, K0); else hipLaunchKernelGGL((rsik::cont_init_kernel<true, false>), grid_init, block, 0, s_main, K0); }
         else { if (pair) hipLaunchKernelGGL((rsik::cont_init_kernel<false, true>), grid_init, block, 0, s_main, K0); else hipLaunchKernelGGL((rsik::cont_init_kernel<false, false>), grid_init, block, 0, s_main, K0); }
     }
-    RSIK_HIP(ctx, hipEventRecord(ctx->events[0], s_main));
-    RSIK_HIP(ctx, hipStreamWaitEvent(s_joints, ctx->events[0], 0));
-    RSIK_HIP(ctx, hipStreamWaitEvent(s_chain, ctx->events[0], 0));
+    RSIK_HIP(ctx, signal(s_main, 0));
+    RSIK_HIP(ctx, wait_for(s_joints, 0));
+    RSIK_HIP(ctx, wait_for(s_chain, 0));
     rsik::ContRunArgs R;
     std::memset(&R, 0, sizeof R);
     R.n = n;
@@ -997,35 +1050,35 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     auto issue_prepare = [&](int64_t b) -> int {
         set_block(b);
         const dim3 grid2(grid.x, (unsigned)R.T);
-        if (b >= slots) RSIK_HIP(ctx, hipStreamWaitEvent(s_prep, ev(3, b - slots), 0));  // the slot's previous block is done
+        if (b >= slots) RSIK_HIP(ctx, wait_for(s_prep, edge_id(3, b - slots)));  // the slot's previous block is done
         if (arm) { if (plane_binds) hipLaunchKernelGGL((rsik::cont_prepare_kernel<true, true>), grid2, block, 0, s_prep, R); else hipLaunchKernelGGL((rsik::cont_prepare_kernel<true, false>), grid2, block, 0, s_prep, R); }
         else { if (plane_binds) hipLaunchKernelGGL((rsik::cont_prepare_kernel<false, true>), grid2, block, 0, s_prep, R); else hipLaunchKernelGGL((rsik::cont_prepare_kernel<false, false>), grid2, block, 0, s_prep, R); }
-        RSIK_HIP(ctx, hipEventRecord(ev(0, b), s_prep));
+        RSIK_HIP(ctx, signal(s_prep, edge_id(0, b)));
         return RSIK_OK;
     };
     auto issue_theta = [&](int64_t b) -> int {
         set_block(b);
-        RSIK_HIP(ctx, hipStreamWaitEvent(s_theta, ev(0, b), 0));
+        RSIK_HIP(ctx, wait_for(s_theta, edge_id(0, b)));
         const dim3 grid_t((unsigned)((n + rsik::kThetaBlock - 1) / rsik::kThetaBlock)), block_t(rsik::kThetaBlock);
         if (arm) hipLaunchKernelGGL((rsik::cont_theta_kernel<true, rsik::kSnapGeneric>), grid_t, block_t, 0, s_theta, R);
         else if (snap_kind == rsik::kSnapInner) hipLaunchKernelGGL((rsik::cont_theta_kernel<false, rsik::kSnapInner>), grid_t, block_t, 0, s_theta, R);
         else if (snap_kind == rsik::kSnapWrap) hipLaunchKernelGGL((rsik::cont_theta_kernel<false, rsik::kSnapWrap>), grid_t, block_t, 0, s_theta, R);
         else hipLaunchKernelGGL((rsik::cont_theta_kernel<false, rsik::kSnapGeneric>), grid_t, block_t, 0, s_theta, R);
-        RSIK_HIP(ctx, hipEventRecord(ev(1, b), s_theta));
+        RSIK_HIP(ctx, signal(s_theta, edge_id(1, b)));
         return RSIK_OK;
     };
     auto issue_back = [&](int64_t b) -> int {  // joints(b), chain(b)
         set_block(b);
         // (a wave = 8 trajectories x 8 steps: n / 8 groups, 4 per workgroup)
         const dim3 grid2((unsigned)((n + 8 * (rsik::kBlock / 64) - 1) / (8 * (rsik::kBlock / 64))), (unsigned)((R.T + rsik::kJointChunk - 1) / rsik::kJointChunk));
-        RSIK_HIP(ctx, hipStreamWaitEvent(s_joints, ev(1, b), 0));
+        RSIK_HIP(ctx, wait_for(s_joints, edge_id(1, b)));
         if (arm) hipLaunchKernelGGL(rsik::cont_joints_kernel<true>, grid2, block, 0, s_joints, R);
         else hipLaunchKernelGGL(rsik::cont_joints_kernel<false>, grid2, block, 0, s_joints, R);
-        RSIK_HIP(ctx, hipEventRecord(ev(2, b), s_joints));
-        RSIK_HIP(ctx, hipStreamWaitEvent(s_chain, ev(2, b), 0));
+        RSIK_HIP(ctx, signal(s_joints, edge_id(2, b)));
+        RSIK_HIP(ctx, wait_for(s_chain, edge_id(2, b)));
         if (arm) hipLaunchKernelGGL(rsik::cont_chain_kernel<true>, grid8, dim3(rsik::kChainBlock), 0, s_chain, R);
         else hipLaunchKernelGGL(rsik::cont_chain_kernel<false>, grid8, dim3(rsik::kChainBlock), 0, s_chain, R);
-        RSIK_HIP(ctx, hipEventRecord(ev(3, b), s_chain));
+        RSIK_HIP(ctx, signal(s_chain, edge_id(3, b)));
         return RSIK_OK;
     };
     const int64_t head = n_blocks < slots ? n_blocks : slots;
@@ -1048,7 +1101,7 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         if ((rc = issue_back(b)) != RSIK_OK) return rc;
     }
     // the caller's stream continues once the last chain (hence every phase of every block) is done
-    RSIK_HIP(ctx, hipStreamWaitEvent(s_main, ev(3, n_blocks - 1), 0));
+    RSIK_HIP(ctx, wait_for(s_main, edge_id(3, n_blocks - 1)));
     RSIK_HIP(ctx, hipGetLastError());
     return RSIK_OK;
 }

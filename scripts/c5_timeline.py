@@ -4,7 +4,7 @@ relative to the pass's init kernel (shows which phases overlap).  usage: c5_time
 import csv
 import sys
 
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if "cont_" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "rsik::cont_" in r["Kernel_Name"] or "rsik::flags_" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 inits = [k for k, r in enumerate(rows) if "cont_init" in r["Kernel_Name"]]
 a = inits[-2] if len(inits) >= 2 else inits[-1]
