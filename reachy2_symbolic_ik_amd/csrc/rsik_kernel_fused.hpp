@@ -60,6 +60,9 @@ struct FusedArgs {
     int theta_wgs;              // workgroups that take the theta role
     int chain_waves;            // waves per worker workgroup that try for a chain sub-group first (see fused_chain_wave)
     int flags_mode;             // the launch is one of rsik_kernel_flags.hpp's: pdone / jdone count workgroups, see there
+    const unsigned* init_word;  // flags mode: reaches init_seq once the (re)initialisation kernel has finished (written by its stream)
+    unsigned init_seq;
+    const unsigned* jwords;     // flags mode: word b reaches init_seq once the joints launch of block b has completed (its stream writes it)
     unsigned tickets;           // items of the run
     unsigned trace_cap;
 };
@@ -186,6 +189,7 @@ constexpr int kRingSteps = 32, kRingBatch = 8;
 struct ThetaRing {
     double cell[4][kRingSteps][64][2];
     unsigned filled[4], done[4], written[4], abort;
+    unsigned char tagb[4][kRingSteps][64];  // PAIRS: the low byte of a step's tag (state code, flags) on its way from loader to writer
 };
 typedef __attribute__((address_space(3))) ThetaRing* ThetaRingPtr;
 typedef __attribute__((address_space(3))) unsigned* LdsU32Ptr;
@@ -228,6 +232,7 @@ __device__ __forceinline__ void theta_walker(FusedArgsK fk, int g, int w, ThetaR
     const bool traced = F.trace != nullptr;
     // the state the run starts from: written (by the (re)initialisation) before the first goals were, so read behind them
     if (N > 0 && !ring_wait(F, ring, &ring->filled[w], 1u)) return;
+    if (F.init_word != nullptr && !sync_wait(F, F.init_word, F.init_seq)) return;
     double prev_theta = ldc_f64<true>(&K.st[0 * K.n + i]);
     // launch constants that a select or a sign transfer needs as a vector operand: pinned in vector registers once
     const double d_max = K.d_theta_max;
@@ -372,7 +377,7 @@ __device__ __forceinline__ void theta_loader(FusedArgsK fk, int g, int w, ThetaR
 #pragma unroll
                 for (int u = 0; u < kRingBatch; u++) {
                     const f64x2v c = __builtin_bit_cast(f64x2v, o.p[u]);
-                    bad = bad || (u < cnt && c.y != K.epoch);
+                    bad = bad || (u < cnt && !pair_tag_valid(c.y, K.epoch));
                 }
                 return __any(bad) != 0;
             };
@@ -413,6 +418,9 @@ __device__ __forceinline__ void theta_loader(FusedArgsK fk, int g, int w, ThetaR
             f64x2v c;
             c.x = gg[u]; c.y = gw[u];
             if (u < cnt) cells[((t + u) & (kRingSteps - 1)) * 64] = c;
+            if constexpr (PAIRS) {
+                if (u < cnt) ring->tagb[w][(t + u) & (kRingSteps - 1)][lane] = (unsigned char)pair_tag_low(__builtin_bit_cast(f64x2v, o.p[u]).y, K.epoch);
+            }
         }
         lds_done();
         if (lane == 0) lds_store(&ring->filled[w], (unsigned)(t + cnt));
@@ -464,18 +472,29 @@ __device__ __forceinline__ void theta_writer(FusedArgsK fk, int g, int w, ThetaR
         const int cnt = (N - t) < kRingBatch ? (N - t) : kRingBatch;
         if (!ring_wait(F, ring, &ring->done[w], (unsigned)(t + cnt))) return;
         double th[kRingBatch];
+        unsigned tb[kRingBatch];
 #pragma unroll
-        for (int u = 0; u < kRingBatch; u++) th[u] = cells[((t + (u < cnt ? u : cnt - 1)) & (kRingSteps - 1)) * 128];
+        for (int u = 0; u < kRingBatch; u++) {
+            const int slot = (t + (u < cnt ? u : cnt - 1)) & (kRingSteps - 1);
+            th[u] = cells[slot * 128];
+            if constexpr (PAIRS) tb[u] = ring->tagb[w][slot][lane];
+        }
         lds_done();
         if (lane == 0) lds_store(&ring->written[w], (unsigned)(t + cnt));  // (the slots are free: the values are in registers)
 #pragma unroll
         for (int u = 0; u < kRingBatch; u++) {
             const int64_t row = t + (u < cnt ? u : cnt - 1);  // (a short last batch stores its last step again: eight stores, always)
-            if constexpr (PAIRS) st_pair(K.ws, row * n + i, th[u], K.epoch);  // (valid by itself: no progress word, no wait)
+            if constexpr (PAIRS) st_pair(K.ws, row * n + i, th[u], pair_tag(K.epoch, 0, (int)tb[u]));  // (valid by itself: no progress word, no wait)
             else stc_f64<true>(K.ws + row * n + i, th[u]);
         }
         if constexpr (PAIRS) {
-            if (lane == 0) sync_store(tprog, (unsigned)(t + cnt));  // (steps stored, not yet acknowledged: the joints kernel's hint)
+            // hints, issued behind the stores without waiting for them: the group's steps stored (a joints wave that found an old
+            // tag polls it), and per block the groups that are through it (the host's streams hold the block's joints launch on it)
+            if (lane == 0) {
+                sync_store(tprog, (unsigned)(t + cnt));
+                const int t_next = t + cnt;
+                if (t_next == N || (t_next % S) == 0) sync_add(F.sync + kSyncArrays + 2 * (size_t)F.B * F.G + F.G + (size_t)((t_next - 1) / S), 1u);  // tdone[block]
+            }
             continue;
         }
         if (pending >= 0) {
@@ -495,6 +514,201 @@ __device__ __forceinline__ void theta_writer(FusedArgsK fk, int g, int w, ThetaR
     }
 }
 
+// ---- the flag-synchronised form's loader and writer (PAIRS: the goals come, and the thetas go, as tagged 16-byte pairs).
+// Both share their walker's SIMD, and a wave issues one instruction every ~4.5 cycles whatever it is: what these two execute per
+// batch of eight steps comes on top of the walker's ~320 instructions.  So the hot loops below are written for their
+// instruction count: full batches only (the run's last, partial batch goes step by step behind them), no per-step bounds or
+// block tests, rows addressed by a scalar base + a constant per-lane offset (no per-lane address arithmetic), loads counted by
+// hand (see LoaderSet), validity = one 32-bit compare per pair.  (The first version of these loops — generic lambdas, clamped
+// rows, per-step predicates — ran to ~950 instructions a batch: the loader alone took 2 us per batch, the walker waited for it
+// half of the time, 230-500 ns a step.)
+__device__ __forceinline__ void theta_loader_pairs(FusedArgsK fk, int g, int w, ThetaRingPtr ring) {
+    const int lane = threadIdx.x & 63;
+    const FusedArgs& F = fused_args(fk);
+    const ContRunArgs& K = F.R;
+    int64_t i = (int64_t)g * 64 + lane;
+    if (i >= K.n) i = K.n - 1;
+    const int N = (int)K.T, S = F.S;
+    const unsigned E = (unsigned)K.epoch;
+    const unsigned voff = (unsigned)(i * 16);
+    const char* const base = reinterpret_cast<const char*>(K.gw);
+    const unsigned long long row_bytes = (unsigned long long)K.n * 16ull;
+    typedef double f64x2v __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) f64x2v* CellPtr;
+    typedef __attribute__((address_space(3))) unsigned char* BytePtr;
+    const CellPtr cells = (CellPtr)&ring->cell[w][0][lane][0];   // a step further: 64 cells further
+    const BytePtr tags = (BytePtr)&ring->tagb[w][0][lane];        // a step further: 64 bytes further
+    struct Set { u32x4v p[kRingBatch]; };
+    auto issue = [&](Set& o, int t) {  // the pairs of steps t ... t + 7 (all inside the run)
+        const char* row = base + (unsigned long long)t * row_bytes;
+#pragma unroll
+        for (int u = 0; u < kRingBatch; u++) {
+            asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(o.p[u]) : "v"(voff), "s"(row) : "memory");
+            row += row_bytes;
+        }
+    };
+    auto wait_set = [&](Set& o, auto newer) {
+        asm volatile("s_waitcnt vmcnt(%8)"
+                     : "+v"(o.p[0]), "+v"(o.p[1]), "+v"(o.p[2]), "+v"(o.p[3]), "+v"(o.p[4]), "+v"(o.p[5]), "+v"(o.p[6]), "+v"(o.p[7])
+                     : "n"(decltype(newer)::value)
+                     : "memory");
+    };
+    bool ok = true;
+    auto land = [&](Set& o, int t) {
+        // every pair carries this run's epoch?  Else the prepare kernel has not got there yet: poll its count of the block's
+        // steps (a hint), then the whole batch again
+        auto stale = [&]() {
+            unsigned bad = 0;
+#pragma unroll
+            for (int u = 0; u < kRingBatch; u++) bad |= o.p[u].w ^ E;
+            return __any(bad != 0) != 0;
+        };
+        if (__builtin_expect(stale(), 0)) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            const int t_last = t + kRingBatch - 1;
+            const unsigned* hint = F.sync + kSyncArrays + (size_t)(t_last / S) * F.G + g;
+            const unsigned want = (unsigned)(t_last % S) + 1u;
+            do {
+                do {
+                    __builtin_amdgcn_s_sleep(16);
+                } while (sync_load(hint) < want && sync_load(F.sync + kSyncAbort) == 0 && __builtin_amdgcn_s_memrealtime() - t0 <= kFusedWaitTicks);
+                if (sync_load(F.sync + kSyncAbort) != 0 || __builtin_amdgcn_s_memrealtime() - t0 > kFusedWaitTicks) {
+                    sync_store(F.sync + kSyncAbort, 1u);
+                    lds_store(&ring->abort, 1u);
+                    ok = false;
+                    return;
+                }
+                issue(o, t);
+                wait_set(o, std::integral_constant<int, 0>{});  // (everything: the batches behind this one have landed as well)
+            } while (stale());
+        }
+        if (t >= kRingSteps) ok = ok && ring_wait(F, ring, &ring->written[w], (unsigned)(t - kRingSteps + kRingBatch));
+#pragma unroll
+        for (int u = 0; u < kRingBatch; u++) {
+            const unsigned long long gbits = ((unsigned long long)o.p[u].y << 32) | o.p[u].x;
+            const double gg = __builtin_bit_cast(double, gbits);
+            f64x2v c;
+            c.x = gg;
+            c.y = wrap_theta_to_pi(gg);  // U:93-97, see cont_prepare_step
+            const int slot = (t + u) & (kRingSteps - 1);
+            cells[slot * 64] = c;
+            tags[slot * 64] = (unsigned char)o.p[u].z;
+        }
+        lds_done();
+        if (lane == 0) lds_store(&ring->filled[w], (unsigned)(t + kRingBatch));
+    };
+    // three batches in flight, always: past the last full batch the last one is requested again (never looked at), so that
+    // "all but the last two batches' loads" is always the batch to land
+    const int nfull = N / kRingBatch;
+    if (nfull > 0) {
+        auto clampk = [&](int k) { return (k < nfull ? k : nfull - 1) * kRingBatch; };
+        Set a, b, c;
+        issue(a, clampk(0));
+        issue(b, clampk(1));
+        issue(c, clampk(2));
+#pragma unroll 1
+        for (int k = 0; k < nfull && ok; k += 3) {
+            wait_set(a, std::integral_constant<int, 2 * kRingBatch>{});
+            land(a, k * kRingBatch);
+            issue(a, clampk(k + 3));
+            wait_set(b, std::integral_constant<int, 2 * kRingBatch>{});
+            if (k + 1 < nfull && ok) land(b, (k + 1) * kRingBatch);
+            issue(b, clampk(k + 4));
+            wait_set(c, std::integral_constant<int, 2 * kRingBatch>{});
+            if (k + 2 < nfull && ok) land(c, (k + 2) * kRingBatch);
+            issue(c, clampk(k + 5));
+        }
+        wait_set(a, std::integral_constant<int, 0>{});  // (nothing of this wave's is in flight from here on)
+        wait_set(b, std::integral_constant<int, 0>{});
+        wait_set(c, std::integral_constant<int, 0>{});
+    }
+    // the run's last steps (less than a batch), one at a time
+    for (int t = nfull * kRingBatch; t < N && ok; t++) {
+        const unsigned* hint = F.sync + kSyncArrays + (size_t)(t / S) * F.G + g;
+        f64x2p p = ld_pair(K.gw, (int64_t)t * K.n + i);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__any(!pair_tag_valid(p.y, K.epoch))) {
+            __builtin_amdgcn_s_sleep(16);
+            if (sync_load(F.sync + kSyncAbort) != 0 || __builtin_amdgcn_s_memrealtime() - t0 > kFusedWaitTicks) {
+                sync_store(F.sync + kSyncAbort, 1u);
+                lds_store(&ring->abort, 1u);
+                ok = false;
+                break;
+            }
+            if (sync_load(hint) >= (unsigned)(t % S) + 1u) p = ld_pair(K.gw, (int64_t)t * K.n + i);
+        }
+        if (!ok) break;
+        if (t >= kRingSteps) ok = ok && ring_wait(F, ring, &ring->written[w], (unsigned)(t - kRingSteps + 1));
+        f64x2v c;
+        c.x = p.x;
+        c.y = wrap_theta_to_pi(p.x);
+        cells[(t & (kRingSteps - 1)) * 64] = c;
+        tags[(t & (kRingSteps - 1)) * 64] = (unsigned char)pair_tag_low(p.y, K.epoch);
+        lds_done();
+        if (lane == 0) lds_store(&ring->filled[w], (unsigned)(t + 1));
+    }
+}
+
+__device__ __forceinline__ void theta_writer_pairs(FusedArgsK fk, int g, int w, ThetaRingPtr ring) {
+    const int lane = threadIdx.x & 63;
+    const FusedArgs& F = fused_args(fk);
+    const ContRunArgs& K = F.R;
+    int64_t i = (int64_t)g * 64 + lane;
+    if (i >= K.n) i = K.n - 1;
+    const int N = (int)K.T, S = F.S;
+    const unsigned E = (unsigned)K.epoch;
+    unsigned* const tprog = F.sync + kSyncArrays + 2 * (size_t)F.B * F.G + g;       // the group's steps stored: a joints wave's hint
+    unsigned* const tdone = F.sync + kSyncArrays + 2 * (size_t)F.B * F.G + F.G;     // per block: groups through it (the host's gate)
+    typedef __attribute__((address_space(3))) double* ThPtr;
+    typedef __attribute__((address_space(3))) unsigned char* BytePtr;
+    const ThPtr cells = (ThPtr)&ring->cell[w][0][lane][0];  // theta of a step: 128 doubles further per step
+    const BytePtr tags = (BytePtr)&ring->tagb[w][0][lane];
+    const __amdgpu_buffer_rsrc_t buf = __builtin_amdgcn_make_buffer_rsrc(K.ws, 0, 0x7fffffff, 0x00020000);
+    const unsigned voff = (unsigned)(i * 16);
+    const unsigned row_bytes = (unsigned)(K.n * 16);  // (the pair arrays stay below 2 GB: fused_plan)
+    auto store_step = [&](int t, double th, unsigned low) {  // (theta, tag): valid by itself, nobody waits for it
+        u32x4v v;
+        const unsigned long long tb = __builtin_bit_cast(unsigned long long, th);
+        v.x = (unsigned)tb; v.y = (unsigned)(tb >> 32); v.z = low; v.w = E;
+        __builtin_amdgcn_raw_buffer_store_b128(v, buf, voff, (unsigned)t * row_bytes, 16);
+    };
+    auto hints = [&](int t_next) {  // issued behind the stores, not waiting for them
+        if (lane == 0) {
+            sync_store(tprog, (unsigned)t_next);
+            if (t_next == N || (t_next % S) == 0) sync_add(tdone + (t_next - 1) / S, 1u);
+        }
+    };
+    const int nfull = N / kRingBatch;
+#pragma unroll 1
+    for (int k = 0; k < nfull; k++) {
+        const int t = k * kRingBatch;
+        if (!ring_wait(F, ring, &ring->done[w], (unsigned)(t + kRingBatch))) return;
+        double th[kRingBatch];
+        unsigned tb[kRingBatch];
+#pragma unroll
+        for (int u = 0; u < kRingBatch; u++) {
+            const int slot = (t + u) & (kRingSteps - 1);
+            th[u] = cells[slot * 128];
+            tb[u] = tags[slot * 64];
+        }
+        lds_done();
+        if (lane == 0) lds_store(&ring->written[w], (unsigned)(t + kRingBatch));  // (the slots are free: the values are in registers)
+#pragma unroll
+        for (int u = 0; u < kRingBatch; u++) store_step(t + u, th[u], tb[u]);
+        hints(t + kRingBatch);
+    }
+    for (int t = nfull * kRingBatch; t < N; t++) {
+        if (!ring_wait(F, ring, &ring->done[w], (unsigned)(t + 1))) return;
+        const int slot = t & (kRingSteps - 1);
+        const double th = cells[slot * 128];
+        const unsigned tb = tags[slot * 64];
+        lds_done();
+        if (lane == 0) lds_store(&ring->written[w], (unsigned)(t + 1));
+        store_step(t, th, tb);
+        hints(t + 1);
+    }
+}
+
 // one wave of a theta workgroup (role = the workgroup's index among them)
 template <bool MIXED, bool PAIRS = false>
 __device__ __noinline__ void fused_theta_wave(FusedArgsK fk_, int role_, int wave_, ThetaRingPtr ring) {
@@ -508,8 +722,16 @@ __device__ __noinline__ void fused_theta_wave(FusedArgsK fk_, int role_, int wav
         kind = F.snap_kind;
     }
     if (wave >= 12 || g >= n_groups) return;
-    if (wave >= 8) { theta_writer<PAIRS>(fk, g, w, ring); return; }
-    if (wave >= 4) { theta_loader<PAIRS>(fk, g, w, ring); return; }
+    if (wave >= 8) {
+        if constexpr (PAIRS) theta_writer_pairs(fk, g, w, ring);
+        else theta_writer<false>(fk, g, w, ring);
+        return;
+    }
+    if (wave >= 4) {
+        if constexpr (PAIRS) theta_loader_pairs(fk, g, w, ring);
+        else theta_loader<false>(fk, g, w, ring);
+        return;
+    }
     __builtin_amdgcn_s_setprio(3);
     if constexpr (MIXED) {
         theta_walker<true, kSnapGeneric>(fk, g, w, ring);
@@ -618,12 +840,14 @@ __device__ __noinline__ bool fused_chain_wave(FusedArgsK fk_, int sg_, LdsTabPtr
         const unsigned long long t_start = F.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
         const int64_t t0 = (int64_t)b * F.S;
         const int64_t T = (K.T - t0) < F.S ? (K.T - t0) : (int64_t)F.S;
-        unsigned want = (unsigned)(F.CH * F.JQ);
-        if (F.flags_mode) {  // a workgroup of the joints kernel per chunk and 32 trajectories
-            const int64_t left = K.n - (int64_t)g * 64;
-            want = (unsigned)((T + kJointChunk - 1) / kJointChunk) * (left > 32 ? 2u : 1u);
+        if (F.flags_mode) {
+            // the block's joints launch has completed (a kernel boundary: its rows are in memory) and, before the first block,
+            // the (re)initialisation
+            if (b == 0 && !sync_wait(F, F.init_word, F.init_seq)) return false;
+            if (!sync_wait(F, F.jwords + b, F.init_seq)) return false;
+        } else if (!sync_wait(F, jdone + (size_t)b * F.G + g, (unsigned)(F.CH * F.JQ))) {
+            return false;
         }
-        if (!sync_wait(F, jdone + (size_t)b * F.G + g, want)) return false;
         const unsigned long long t_ready = F.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
         cont_chain_walk<MIXED, true, kFusedChainBatch, PAIRS>(K, lds_tab, i, lane & 7, t0, t0, T, b == F.B - 1, &carry, b == 0);
         fused_trace(F, 0, b, g, h, t_start, t_ready);

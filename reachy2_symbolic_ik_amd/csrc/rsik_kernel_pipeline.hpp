@@ -70,8 +70,10 @@ struct PipeStamp {
     }
 };
 #define RSIK_PIPE_STAMP(K, phase) PipeStamp pipe_stamp_((K).tmin, (K).tmax, (K).tslot * 5 + (phase))
+#define RSIK_PIPE_STAMP_AT(K, slot, phase) PipeStamp pipe_stamp_((K).tmin, (K).tmax, ((slot) < 64 ? (int)(slot) : 63) * 5 + (phase))
 #else
 #define RSIK_PIPE_STAMP(K, phase)
+#define RSIK_PIPE_STAMP_AT(K, slot, phase)
 #endif
 struct ContRunArgs {
 #ifdef RSIK_PIPE_TIMING
@@ -153,15 +155,28 @@ __device__ __forceinline__ void st_pair(double* pairs, int64_t cell, double valu
     v.x = value; v.y = tag;
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4p, v), buf, (unsigned)(cell * 16), 0, 16);
 }
+// A tag = 64 bits: the run's epoch (a 32-bit count, as the double K.epoch) in the high word, 16 x the step's state code + its flag
+// bits (cont_prepare_step) in the low one: whoever holds a valid pair also holds what the prepare phase found out about the
+// step, and nothing else has to cross with it.  (Integer words: a validity check is one 32-bit compare.)
+__device__ __forceinline__ double pair_tag(double epoch, int state, int flags) {
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)epoch << 32) | (unsigned)(state * 16 + flags));
+}
+__device__ __forceinline__ bool pair_tag_valid(double tag, double epoch) {
+    return (unsigned)(__builtin_bit_cast(unsigned long long, tag) >> 32) == (unsigned)epoch;
+}
+__device__ __forceinline__ int pair_tag_low(double tag, double epoch) {
+    (void)epoch;
+    return (int)(unsigned)__builtin_bit_cast(unsigned long long, tag);
+}
 // the value of pair (t, i) once its tag is this run's (every lane of the wave loads; `need`: this lane's pair matters).
 // A wave that finds an old tag does not keep loading pairs — thousands of waves doing that take the memory system away from
 // the producer they wait for — it polls `hint` (one word, bumped by the producer behind its stores, without waiting for
 // them: a hint, not a promise) until that reaches `want`, then loads again.  Bounded: three seconds, then the run's abort
 // word is raised and whatever is there is returned.
-__device__ __forceinline__ double pair_value(const ContRunArgs& K, const double* pairs, int64_t t, int64_t i, bool need, const unsigned* hint,
+__device__ __forceinline__ f64x2p pair_value(const ContRunArgs& K, const double* pairs, int64_t t, int64_t i, bool need, const unsigned* hint,
                                              unsigned want) {
     f64x2p p = ld_pair(pairs, t * K.n + i);
-    if (__builtin_expect(__any(need && p.y != K.epoch), 0)) {
+    if (__builtin_expect(__any(need && !pair_tag_valid(p.y, K.epoch)), 0)) {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         do {
             do {
@@ -173,9 +188,9 @@ __device__ __forceinline__ double pair_value(const ContRunArgs& K, const double*
                 __hip_atomic_store(K.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
-        } while (__any(need && p.y != K.epoch));
+        } while (__any(need && !pair_tag_valid(p.y, K.epoch)));
     }
-    return p.x;
+    return p;
 }
 
 // phase 1, one (step, trajectory): `m` the step's twelve matrix entries, `t` the step's row in the workspace arrays, `t_abs`
@@ -195,7 +210,10 @@ __device__ __forceinline__ void cont_prepare_step(const ContRunArgs& K, const Ac
     // previous_theta), or the preferred theta of an unreachable pose (U:115-127)
     const double goal = T.ok_limits ? (T.found ? T.theta : __builtin_nan("")) : K.pref_arg[slot];
     if constexpr (PAIRS) {
-        st_pair(K.gw, t * K.n + i, goal, K.epoch);  // (the wrapped form is the theta loader's business there)
+        // ONE store: the goal and, in its tag, the flags and the state code — the joints phase, which gets them back with the
+        // theta, writes the run's flag / state / reachable rows (the wrapped goal is the theta loader's business there)
+        st_pair(K.gw, t * K.n + i, goal, pair_tag(K.epoch, T.code, (T.ok_limits ? 1 : 0) | (T.found ? 2 : 0) | (special ? 8 : 0)));
+        return;
     } else {
         stc_f64<COH>(&RSIK_WS(K, t, i), goal);
         // what limit_theta_to_interval makes of theta = goal before it looks at the interval (U:93-97): this phase has the
@@ -463,9 +481,18 @@ __device__ __forceinline__ void cont_joints_chunk(const ContRunArgs& K, SharedTa
         for (int k = 9; k < 12; k++) m[k] = src[k * n];
     }
     double theta;
-    if constexpr (PAIRS) theta = pair_value(K, K.ws, tt, ii, true, K.theta_hint + (grp >> 3), (unsigned)((c + 1) * kJointChunk < K.T ? (c + 1) * kJointChunk : K.T));  // (waits for the theta wave, if it has to)
-    else theta = ldc_f64<COH>(&RSIK_WS(K, tt, ii));
-    const int flag = ldc_u8<COH>(&K.flags[tt * n + ii]);
+    int flag, state_code = 0;
+    if constexpr (PAIRS) {
+        // (waits for the theta wave, if it has to)
+        const f64x2p p = pair_value(K, K.ws, tt, ii, true, K.theta_hint + (grp >> 3), (unsigned)((c + 1) * kJointChunk < K.T ? (c + 1) * kJointChunk : K.T));
+        theta = p.x;
+        const int low = pair_tag_low(p.y, K.epoch);
+        flag = low & 15;
+        state_code = (low >> 4) & 15;
+    } else {
+        theta = ldc_f64<COH>(&RSIK_WS(K, tt, ii));
+        flag = ldc_u8<COH>(&K.flags[tt * n + ii]);
+    }
     const bool special = (flag & 8) != 0;
     if (RSIK_RARE(special)) {
         const double* src = K.m12_steps + (K.t0 + tt) * 12 * n + ii;
@@ -537,7 +564,15 @@ __device__ __forceinline__ void cont_joints_chunk(const ContRunArgs& K, SharedTa
         const double o = (k == 0 || k == 2 || k == 4 || k == 6) ? fma(turn[k], kTwoPi, jv[k]) : jv[k];
         out[k] = sing ? __builtin_nan("") : o;  // (singular: needs previous_sol, phase 4 recomputes the step — flag bit 2)
     }
-    if (live && sing) stc_u8<COH>(&K.flags[t * n + i], (uint8_t)(flag | 4));
+    if constexpr (PAIRS) {
+        if (live) {
+            stc_u8<COH>(&K.flags[t * n + i], (uint8_t)(flag | (sing ? 4 : 0)));
+            if (K.state) stc_u8<COH>(&K.state[(K.t0 + t) * n + i], (uint8_t)state_code);
+            if (K.reachable) stc_u8<COH>(&K.reachable[(K.t0 + t) * n + i], (flag & 3) == 3 ? 1 : 0);
+        }
+    } else {
+        if (live && sing) stc_u8<COH>(&K.flags[t * n + i], (uint8_t)(flag | 4));
+    }
     // one event byte per (chunk, trajectory): OR over the chunk's steps
     const unsigned long long evm = __ballot(ev && live);
     if (live && sl == 0) stc_u8<COH>(&K.chunk_event[c * n + i], ((evm >> tl) & 0x0101010101010101ull) != 0 ? 1 : 0);

@@ -52,7 +52,7 @@ struct rsik_ctx {
     int can_wait_value;              // hipDeviceAttributeCanUseStreamWaitValue
     double flags_epoch;              // the flag-synchronised form's run counter (the tag of its (value, tag) pairs)
     bool flags_ws_clean;             // the current workspace has been zeroed since it was allocated (no stale tags in it)
-    hipStream_t side[3];             // the pipeline's own streams (prepare / joints / chain), created on first use
+    hipStream_t side[4];             // the pipeline's own streams (prepare / joints / chain; the flag-synchronised form's fourth), created on first use
     std::vector<hipEvent_t> events;  // reusable, timing disabled
     bool have_side;
     std::string err;
@@ -608,6 +608,34 @@ static int cont_resources(rsik_ctx* ctx, const char* who, size_t need, bool want
     return RSIK_OK;
 }
 
+#ifdef RSIK_PIPE_TIMING
+// diagnostic builds: the phase kernels' first-start / last-end stamps of the PREVIOUS run are printed (RSIK_PIPE_TIMING_PRINT), the
+// stamp area cleared for this one
+static unsigned long long* pipe_timing_begin(rsik_ctx* ctx, int64_t n_blocks) {
+    static unsigned long long* pipe_t = nullptr;  // [2][5 * 64]: min stamps, then max stamps
+    static int64_t pipe_prev_blocks = 0;
+    if (!pipe_t) { if (hipMalloc(&pipe_t, 2 * 320 * sizeof(unsigned long long)) != hipSuccess) pipe_t = nullptr; }
+    if (pipe_t && getenv("RSIK_PIPE_TIMING_PRINT") && pipe_prev_blocks > 0) {  // (that run has been synchronised by now)
+        unsigned long long h[640];
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(h, pipe_t, sizeof h, hipMemcpyDeviceToHost);
+        unsigned long long base = ~0ull;
+        for (int k = 0; k < 320; k++) if (h[k] < base) base = h[k];
+        static const char* names[5] = {"prepare", "theta", "joints", "chain", "turns"};
+        for (int64_t b = 0; b < pipe_prev_blocks && b < 64; b++)
+            for (int ph = 0; ph < 5; ph++)
+                if (h[b * 5 + ph] != ~0ull)
+                    fprintf(stderr, "[pipe] %-8s(%lld) %8.2f -> %8.2f us\n", names[ph], (long long)b, (h[b * 5 + ph] - base) / 100.0, (h[320 + b * 5 + ph] - base) / 100.0);
+    }
+    if (pipe_t) {
+        (void)hipMemsetAsync(pipe_t, 0xff, 320 * sizeof(unsigned long long), ctx->stream);
+        (void)hipMemsetAsync(pipe_t + 320, 0, 320 * sizeof(unsigned long long), ctx->stream);
+    }
+    pipe_prev_blocks = n_blocks;
+    return pipe_t;
+}
+#endif
+
 // The single-launch form of a run (rsik_kernel_fused.hpp): how it is cut, what it needs, whether it qualifies.
 struct FusedPlan {
     int S, Sp, L, CL, B, G, PI, CH, JQ, Jh, theta_wgs, chain_waves, grid;
@@ -651,7 +679,7 @@ static bool fused_plan(const rsik_ctx* ctx, int64_t n, int64_t n_steps, FusedPla
     P.off_events = P.off_flags + up(cells);
     P.off_scratch = P.off_events + up((size_t)B * P.CH * (size_t)n);
     P.off_sync = P.off_scratch + up((size_t)n * sizeof(double));
-    P.sync_words = (size_t)rsik::kSyncArrays + 2 * (size_t)B * G + (size_t)G;
+    P.sync_words = (size_t)rsik::kSyncArrays + 2 * (size_t)B * G + (size_t)G + (size_t)B;  // pdone, jdone, tprog, tdone
     P.need = P.off_sync + up(P.sync_words * sizeof(unsigned));
     if (P.need > ((size_t)6 << 30)) return no("workspace above 6 GB");
     long long workers = (tickets + rsik::kFusedWaves - 1) / rsik::kFusedWaves;
@@ -847,41 +875,71 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
                 // ---- the flag-synchronised form (rsik_kernel_flags.hpp).  The two persistent kernels fork off first — the
                 // (re)initialisation, which only the theta waves' start depends on, ahead of them on their stream — then the two
                 // chip-filling kernels back to back on the caller's stream, which joins the other two at the end.
-                hipStream_t s_main = ctx->stream, s_theta = ctx->side[0], s_chain = ctx->side[1];
-                RSIK_HIP(ctx, hipEventRecord(ctx->events[0], s_main));
-                RSIK_HIP(ctx, hipStreamWaitEvent(s_theta, ctx->events[0], 0));
-                RSIK_HIP(ctx, hipStreamWaitEvent(s_chain, ctx->events[0], 0));
-                // the theta workgroups first: each needs a compute unit to itself and must be running before the chip-filling
-                // kernels take the chip (a joints workgroup polls for its thetas: with the theta workgroups still waiting for a
-                // compute unit behind a chip full of such workgroups, nobody would move) — the caller's stream waits for their
-                // count in device memory before it goes on
+                hipStream_t s_main = ctx->stream, s_theta = ctx->side[0], s_ja = ctx->side[1], s_jb = ctx->side[2];
+                // words that tie the streams (device memory of the context's, values only ever grow: this run's sequence number):
+                // 0 the run's start, 1 the (re)initialisation done, 2 the theta kernel done, 3 + b the chain launch of block b done
+                const size_t need_words = 3 + (size_t)FP.B;
+                if (ctx->edge_count < need_words) {
+                    if (ctx->edge_words) { RSIK_HIP(ctx, hipDeviceSynchronize()); RSIK_HIP(ctx, hipFree(ctx->edge_words)); ctx->edge_words = nullptr; }
+                    RSIK_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->edge_words), need_words * 2 * sizeof(unsigned)));
+                    RSIK_HIP(ctx, hipMemset(ctx->edge_words, 0, need_words * 2 * sizeof(unsigned)));
+                    ctx->edge_count = need_words * 2;
+                    ctx->edge_seq = 0;
+                }
+                const unsigned seq = ++ctx->edge_seq;
+                unsigned* const W = ctx->edge_words;
+#ifdef RSIK_PIPE_TIMING
+                {
+                    unsigned long long* const pipe_t = pipe_timing_begin(ctx, FP.B);
+                    R.tmin = pipe_t; R.tmax = pipe_t ? pipe_t + 320 : nullptr;
+                }
+#endif
+                F.init_word = W + 1;
+                F.init_seq = seq;
+                F.jwords = W + 3;
+                unsigned* const tdone = F.sync + rsik::kSyncArrays + 2 * (size_t)FP.B * FP.G + FP.G;
+                RSIK_HIP(ctx, hipStreamWriteValue32(s_main, W + 0, seq, 0));  // (behind the sync area's memset)
+                RSIK_HIP(ctx, hipStreamWaitValue32(s_theta, W + 0, seq, hipStreamWaitValueGte, 0xffffffffu));
+                RSIK_HIP(ctx, hipStreamWaitValue32(s_ja, W + 0, seq, hipStreamWaitValueGte, 0xffffffffu));
+                RSIK_HIP(ctx, hipStreamWaitValue32(s_jb, W + 0, seq, hipStreamWaitValueGte, 0xffffffffu));
+                // the theta workgroups first: each needs a compute unit to itself, and must be running before the chip-filling
+                // kernels take the chip — the caller's stream waits for their count before the prepare kernel
                 if (arm) hipLaunchKernelGGL(rsik::flags_theta_kernel<true>, dim3((unsigned)FP.theta_wgs), dim3(768), 0, s_theta, F);
                 else hipLaunchKernelGGL(rsik::flags_theta_kernel<false>, dim3((unsigned)FP.theta_wgs), dim3(768), 0, s_theta, F);
-                RSIK_HIP(ctx, hipEventRecord(ctx->events[1], s_theta));
-                // (the chain waves are small and many: let loose first, they would sit on every compute unit and leave the theta
-                // workgroups none to themselves)
-                RSIK_HIP(ctx, hipStreamWaitValue32(s_chain, F.sync + rsik::kSyncAlive, (uint32_t)FP.theta_wgs, hipStreamWaitValueGte, 0xffffffffu));
-                if (arm) hipLaunchKernelGGL(rsik::flags_chain_kernel<true>, dim3((unsigned)FP.G * 8u), dim3(64), 0, s_chain, F);
-                else hipLaunchKernelGGL(rsik::flags_chain_kernel<false>, dim3((unsigned)FP.G * 8u), dim3(64), 0, s_chain, F);
-                RSIK_HIP(ctx, hipEventRecord(ctx->events[2], s_chain));
+                RSIK_HIP(ctx, hipStreamWriteValue32(s_theta, W + 2, seq, 0));
+                // the (re)initialisation beside it (C:296-325; only the theta walkers' first step and the first chain launch need it)
                 {
                     const bool pair = !singularity_plane_binds(K0.arms);
                     dim3 grid_init = grid;
                     if (pair && (rc = launch_dims(ctx, n * 2, &grid_init, who)) != RSIK_OK) return rc;
-                    if (arm) { if (pair) hipLaunchKernelGGL((rsik::cont_init_kernel<true, true>), grid_init, block, 0, s_main, K0); else hipLaunchKernelGGL((rsik::cont_init_kernel<true, false>), grid_init, block, 0, s_main, K0); }
-                    else { if (pair) hipLaunchKernelGGL((rsik::cont_init_kernel<false, true>), grid_init, block, 0, s_main, K0); else hipLaunchKernelGGL((rsik::cont_init_kernel<false, false>), grid_init, block, 0, s_main, K0); }
+                    if (arm) { if (pair) hipLaunchKernelGGL((rsik::cont_init_kernel<true, true>), grid_init, block, 0, s_ja, K0); else hipLaunchKernelGGL((rsik::cont_init_kernel<true, false>), grid_init, block, 0, s_ja, K0); }
+                    else { if (pair) hipLaunchKernelGGL((rsik::cont_init_kernel<false, true>), grid_init, block, 0, s_ja, K0); else hipLaunchKernelGGL((rsik::cont_init_kernel<false, false>), grid_init, block, 0, s_ja, K0); }
                 }
-                if (!getenv("RSIK_FLAGS_NO_WAITVALUE"))
-                    RSIK_HIP(ctx, hipStreamWaitValue32(s_main, F.sync + rsik::kSyncAlive, (uint32_t)FP.theta_wgs, hipStreamWaitValueGte, 0xffffffffu));
+                RSIK_HIP(ctx, hipStreamWriteValue32(s_ja, W + 1, seq, 0));
+                RSIK_HIP(ctx, hipStreamWaitValue32(s_main, F.sync + rsik::kSyncAlive, (uint32_t)FP.theta_wgs, hipStreamWaitValueGte, 0xffffffffu));
                 const bool pb = singularity_plane_binds(R.arms);
                 const dim3 pgrid(grid.x, (unsigned)n_steps);
+                const unsigned chain_wgs = (unsigned)((n * 8 + rsik::kChainBlock - 1) / rsik::kChainBlock);
                 if (arm) { if (pb) hipLaunchKernelGGL((rsik::flags_prepare_kernel<true, true>), pgrid, block, 0, s_main, F); else hipLaunchKernelGGL((rsik::flags_prepare_kernel<true, false>), pgrid, block, 0, s_main, F); }
                 else { if (pb) hipLaunchKernelGGL((rsik::flags_prepare_kernel<false, true>), pgrid, block, 0, s_main, F); else hipLaunchKernelGGL((rsik::flags_prepare_kernel<false, false>), pgrid, block, 0, s_main, F); }
-                const dim3 jgrid((unsigned)((n + 31) / 32), (unsigned)((n_steps + rsik::kJointChunk - 1) / rsik::kJointChunk));
-                if (arm) hipLaunchKernelGGL(rsik::flags_joints_kernel<true>, jgrid, block, 0, s_main, F);
-                else hipLaunchKernelGGL(rsik::flags_joints_kernel<false>, jgrid, block, 0, s_main, F);
-                RSIK_HIP(ctx, hipStreamWaitEvent(s_main, ctx->events[1], 0));
-                RSIK_HIP(ctx, hipStreamWaitEvent(s_main, ctx->events[2], 0));
+                for (int b = 0; b < FP.B; b++) {
+                    const int64_t t0 = (int64_t)b * FP.S;
+                    const int64_t Tb = (n_steps - t0) < FP.S ? (n_steps - t0) : (int64_t)FP.S;
+                    // joints(b): once every theta wave has counted itself through the block; the blocks take the two streams in turn
+                    hipStream_t sj = (b & 1) ? s_jb : s_ja;
+                    RSIK_HIP(ctx, hipStreamWaitValue32(sj, tdone + b, (uint32_t)FP.G, hipStreamWaitValueGte, 0xffffffffu));
+                    const dim3 jgrid((unsigned)((n + 31) / 32), (unsigned)((Tb + rsik::kJointChunk - 1) / rsik::kJointChunk));
+                    if (arm) hipLaunchKernelGGL(rsik::flags_joints_kernel<true>, jgrid, block, 0, sj, F, (int64_t)(t0 / rsik::kJointChunk));
+                    else hipLaunchKernelGGL(rsik::flags_joints_kernel<false>, jgrid, block, 0, sj, F, (int64_t)(t0 / rsik::kJointChunk));
+                    // chain(b): right behind joints(b) on the same stream (a kernel boundary: the rows are in memory), once the
+                    // chain launch of the block before — on the other stream — has completed (block 0: the (re)initialisation)
+                    RSIK_HIP(ctx, hipStreamWaitValue32(sj, b == 0 ? W + 1 : W + 3 + (b - 1), seq, hipStreamWaitValueGte, 0xffffffffu));
+                    if (arm) hipLaunchKernelGGL(rsik::flags_chain_kernel<true>, dim3(chain_wgs), dim3(rsik::kChainBlock), 0, sj, F, t0, Tb, (int)(b == FP.B - 1));
+                    else hipLaunchKernelGGL(rsik::flags_chain_kernel<false>, dim3(chain_wgs), dim3(rsik::kChainBlock), 0, sj, F, t0, Tb, (int)(b == FP.B - 1));
+                    RSIK_HIP(ctx, hipStreamWriteValue32(sj, W + 3 + b, seq, 0));
+                }
+                RSIK_HIP(ctx, hipStreamWaitValue32(s_main, W + 3 + (FP.B - 1), seq, hipStreamWaitValueGte, 0xffffffffu));
+                RSIK_HIP(ctx, hipStreamWaitValue32(s_main, W + 2, seq, hipStreamWaitValueGte, 0xffffffffu));
                 RSIK_HIP(ctx, hipGetLastError());
                 if (capturing) ctx->ws_captured = true;
                 ctx->fused_sync = F.sync;
@@ -933,26 +991,7 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     const int slots = P.slots;
     (void)carry_bytes;
 #ifdef RSIK_PIPE_TIMING
-    static unsigned long long* pipe_t = nullptr;  // [2][5 * 64]: min stamps, then max stamps
-    static std::vector<unsigned long long> pipe_prev;
-    static int64_t pipe_prev_blocks = 0;
-    if (!pipe_t) { if (hipMalloc(&pipe_t, 2 * 320 * sizeof(unsigned long long)) != hipSuccess) pipe_t = nullptr; }
-    if (pipe_t && getenv("RSIK_PIPE_TIMING_PRINT") && pipe_prev_blocks > 0) {  // the PREVIOUS run's stamps (that run has been synchronised by now)
-        unsigned long long h[640];
-        (void)hipDeviceSynchronize();
-        (void)hipMemcpy(h, pipe_t, sizeof h, hipMemcpyDeviceToHost);
-        unsigned long long base = ~0ull;
-        for (int k = 0; k < 320; k++) if (h[k] < base) base = h[k];
-        static const char* names[5] = {"prepare", "theta", "joints", "chain", "turns"};
-        for (int64_t b = 0; b < pipe_prev_blocks && b < 64; b++)
-            for (int ph = 0; ph < 5; ph++)
-                if (h[b * 5 + ph] != ~0ull)
-                    fprintf(stderr, "[pipe] %-8s(%lld) %8.2f -> %8.2f us\n", names[ph], (long long)b, (h[b * 5 + ph] - base) / 100.0, (h[320 + b * 5 + ph] - base) / 100.0);
-    }
-    if (pipe_t) {
-        (void)hipMemsetAsync(pipe_t, 0xff, 320 * sizeof(unsigned long long), ctx->stream);
-        (void)hipMemsetAsync(pipe_t + 320, 0, 320 * sizeof(unsigned long long), ctx->stream);
-    }
+    unsigned long long* const pipe_t = pipe_timing_begin(ctx, n_blocks);
 #endif
     hipStream_t s_main = ctx->stream, s_theta = ctx->stream, s_prep = ctx->side[0], s_joints = ctx->side[1], s_chain = ctx->side[2];
     // Dependencies between the streams.  Recorded into a hipGraph they are events (the only form a capture takes).  Issued
@@ -1032,7 +1071,6 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     if (!arm) snap_kind = theta_snap_plan(R.lim[0][0], R.lim[0][1], d_theta_max, &R.snap_tdag);
 #ifdef RSIK_PIPE_TIMING
     R.tmin = pipe_t; R.tmax = pipe_t ? pipe_t + 320 : nullptr;
-    pipe_prev_blocks = n_blocks;
 #endif
     auto set_block = [&](int64_t b) {
 #ifdef RSIK_PIPE_TIMING
