@@ -45,7 +45,7 @@ struct rsik_ctx {
     std::vector<void*> retired_ws;   // outgrown workspaces a captured hipGraph may still point into: kept until rsik_destroy / _release
     unsigned long long* trace;       // RSIK_OPT_CONT_TRACE: the single launch's item records (device), or NULL
     size_t trace_cap;
-    unsigned* fused_sync;            // sync area of the last single-launch run (inside ws): its abort word is read by rsik_sync
+    unsigned* fused_sync;            // the abort words (raised, which wait, wanted, was) of the last run with bounded in-kernel waits: read by rsik_sync
     unsigned* edge_words;            // the phased pipeline's dependency words (device): see cont_edges
     size_t edge_count;
     unsigned edge_seq;               // runs issued with them: the value a word must reach
@@ -155,7 +155,7 @@ int rsik_sync(rsik_ctx* ctx) {
     if (ctx->fused_sync) {
         // the single-launch continuous run bounds every wait inside the kernel; a wait that ran out left its mark here
         unsigned aborted[4] = {0, 0, 0, 0};
-        RSIK_HIP(ctx, hipMemcpy(aborted, ctx->fused_sync + rsik::kSyncAbort, sizeof aborted, hipMemcpyDeviceToHost));
+        RSIK_HIP(ctx, hipMemcpy(aborted, ctx->fused_sync, sizeof aborted, hipMemcpyDeviceToHost));
         ctx->fused_sync = nullptr;
         if (aborted[0] != 0)
             return fail(ctx, RSIK_E_HIP, "rsik_control_continuous_run: a wait inside the pipeline ran out (3 s; sync word " + std::to_string(aborted[1]) +
@@ -177,7 +177,7 @@ int rsik_set_arm(rsik_ctx* ctx, int arm, const double* consts_host, int count) {
 int rsik_set_option(rsik_ctx* ctx, int option, int value) {
     if (!ctx) return RSIK_E_INVALID;
     if (option < 0 || option >= RSIK_OPT_COUNT) return fail(ctx, RSIK_E_INVALID, "rsik_set_option: unknown option");
-    static const int max_value[RSIK_OPT_COUNT] = {RSIK_EULER_NEVER, 2, 1, 1, RSIK_CONT_RUN_FLAGS, 65535, 64, 64, 1024, 64, 8};
+    static const int max_value[RSIK_OPT_COUNT] = {RSIK_EULER_NEVER, 2, 1, 1, RSIK_CONT_RUN_FLAGS, 65535, 64, 64, 1024, 64, 8, 7};
     if (value < 0 || value > max_value[option]) return fail(ctx, RSIK_E_INVALID, "rsik_set_option: value out of range");
     ctx->options[option] = value;
     return RSIK_OK;
@@ -942,7 +942,7 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
                 RSIK_HIP(ctx, hipStreamWaitValue32(s_main, W + 2, seq, hipStreamWaitValueGte, 0xffffffffu));
                 RSIK_HIP(ctx, hipGetLastError());
                 if (capturing) ctx->ws_captured = true;
-                ctx->fused_sync = F.sync;
+                ctx->fused_sync = F.sync + rsik::kSyncAbort;
                 return RSIK_OK;
             }
             {
@@ -958,7 +958,7 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
             else { if (pb) hipLaunchKernelGGL((rsik::cont_fused_kernel<false, true>), fgrid, fblock, 0, ctx->stream, F); else hipLaunchKernelGGL((rsik::cont_fused_kernel<false, false>), fgrid, fblock, 0, ctx->stream, F); }
             RSIK_HIP(ctx, hipGetLastError());
             if (capturing) ctx->ws_captured = true;
-            ctx->fused_sync = F.sync;
+            ctx->fused_sync = F.sync + rsik::kSyncAbort;
             return RSIK_OK;
         }
     }
@@ -999,9 +999,10 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     // kernel (hipStreamWriteValue32), the consumer's stream waits for the word to reach it (hipStreamWaitValue32) — measured
     // on an otherwise idle chip (scripts/probes/edge_probe.hip): the dependent kernel starts 3.8 us after its parent's end,
     // against 10.6 us behind an event (15-55 us inside a pass).  Words are per (kind, block) and only ever grow.
-    const bool by_value = !capturing && ctx->can_wait_value != 0 && !getenv("RSIK_EDGES_BY_EVENT");
+    const int variant = ctx->options[RSIK_OPT_CONT_PHASED_VARIANT];
+    const bool by_value = !capturing && ctx->can_wait_value != 0 && !(variant & RSIK_PHASED_EDGES_BY_EVENT);
     if (by_value) {
-        const size_t need_words = P.n_events;
+        const size_t need_words = P.n_events + 2 * (size_t)n_blocks + 8;  // (+ per block: "theta(b) has started", the theta run's count; + alive, abort)
         if (ctx->edge_count < need_words) {
             if (ctx->edge_words) { RSIK_HIP(ctx, hipDeviceSynchronize()); RSIK_HIP(ctx, hipFree(ctx->edge_words)); ctx->edge_words = nullptr; }
             RSIK_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->edge_words), need_words * 2 * sizeof(unsigned)));
@@ -1026,19 +1027,34 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     // the trajectory state: its stream forks off BEFORE the initialisation (behind whatever the caller queued ahead of
     // this call), so prepare(0) runs beside it and theta(0) starts when both are done; the joints and chain streams fork
     // behind it.
+    // Launch by launch the theta phase is ONE persistent launch (cont_theta_run_kernel), issued first and resident for the
+    // whole run: the prepare kernels are held until its last workgroup has said that it runs.
+    const bool theta_run = by_value && (variant & RSIK_PHASED_THETA_RUN) != 0;
+    unsigned* const run_words = by_value ? ctx->edge_words + P.n_events + (size_t)n_blocks : nullptr;  // [n_blocks] counts, then alive, abort
     RSIK_HIP(ctx, signal(s_main, 1));
     RSIK_HIP(ctx, wait_for(s_prep, 1));
+    if (theta_run) {
+        RSIK_HIP(ctx, hipMemsetAsync(run_words, 0, ((size_t)n_blocks + 8) * sizeof(unsigned), s_main));
+        RSIK_HIP(ctx, wait_for(s_chain, 1));
+    }
     {
         // two lanes per trajectory where get_joints cannot move the solver's state (no elbow projection possible)
+        // (with the persistent theta launch on the caller's stream, the (re)initialisation goes to the chain stream: ahead of
+        // the chain launches, which need it, and beside everything else)
+        hipStream_t s_init = theta_run ? s_chain : s_main;
         const bool pair = !singularity_plane_binds(K0.arms);
         dim3 grid_init = grid;
         if (pair && (rc = launch_dims(ctx, n * 2, &grid_init, who)) != RSIK_OK) return rc;
-        if (arm) { if (pair) hipLaunchKernelGGL((rsik::cont_init_kernel<true, true>), grid_init, block, 0, s_main, K0); else hipLaunchKernelGGL((rsik::cont_init_kernel<true, false>), grid_init, block, 0, s_main, K0); }
-        else { if (pair) hipLaunchKernelGGL((rsik::cont_init_kernel<false, true>), grid_init, block, 0, s_main, K0); else hipLaunchKernelGGL((rsik::cont_init_kernel<false, false>), grid_init, block, 0, s_main, K0); }
+        if (arm) { if (pair) hipLaunchKernelGGL((rsik::cont_init_kernel<true, true>), grid_init, block, 0, s_init, K0); else hipLaunchKernelGGL((rsik::cont_init_kernel<true, false>), grid_init, block, 0, s_init, K0); }
+        else { if (pair) hipLaunchKernelGGL((rsik::cont_init_kernel<false, true>), grid_init, block, 0, s_init, K0); else hipLaunchKernelGGL((rsik::cont_init_kernel<false, false>), grid_init, block, 0, s_init, K0); }
+        RSIK_HIP(ctx, signal(s_init, 0));
     }
-    RSIK_HIP(ctx, signal(s_main, 0));
-    RSIK_HIP(ctx, wait_for(s_joints, 0));
-    RSIK_HIP(ctx, wait_for(s_chain, 0));
+    if (theta_run) {
+        RSIK_HIP(ctx, wait_for(s_joints, 1));
+    } else {
+        RSIK_HIP(ctx, wait_for(s_joints, 0));
+        RSIK_HIP(ctx, wait_for(s_chain, 0));
+    }
     rsik::ContRunArgs R;
     std::memset(&R, 0, sizeof R);
     R.n = n;
@@ -1072,6 +1088,32 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
 #ifdef RSIK_PIPE_TIMING
     R.tmin = pipe_t; R.tmax = pipe_t ? pipe_t + 320 : nullptr;
 #endif
+    if (theta_run) {
+        rsik::ThetaRunArgs TA;
+        std::memset(&TA, 0, sizeof TA);
+        TA.K = R;
+        TA.ws_base = static_cast<char*>(ctx->ws);
+        TA.slot_bytes = slot_bytes;
+        TA.slots = slots;
+        TA.n_blocks = (int)n_blocks;
+        TA.block_steps = P.T;
+        TA.n_steps = n_steps;
+        TA.prep_words = ctx->edge_words + edge_id(0, 0);
+        TA.theta_words = ctx->edge_words + edge_id(1, 0);
+        TA.init_word = ctx->edge_words + 0;
+        TA.theta_counts = run_words;
+        TA.alive_word = run_words + n_blocks;
+        TA.abort_word = run_words + n_blocks + 1;
+        TA.seq = seq;
+        const dim3 grid_t((unsigned)((n + rsik::kThetaBlock - 1) / rsik::kThetaBlock)), block_t(rsik::kThetaBlock);
+        if (arm) hipLaunchKernelGGL((rsik::cont_theta_run_kernel<true, rsik::kSnapGeneric>), grid_t, block_t, 0, s_main, TA);
+        else if (snap_kind == rsik::kSnapInner) hipLaunchKernelGGL((rsik::cont_theta_run_kernel<false, rsik::kSnapInner>), grid_t, block_t, 0, s_main, TA);
+        else if (snap_kind == rsik::kSnapWrap) hipLaunchKernelGGL((rsik::cont_theta_run_kernel<false, rsik::kSnapWrap>), grid_t, block_t, 0, s_main, TA);
+        else hipLaunchKernelGGL((rsik::cont_theta_run_kernel<false, rsik::kSnapGeneric>), grid_t, block_t, 0, s_main, TA);
+        // the prepare kernels only once every theta wave has its SIMD
+        RSIK_HIP(ctx, hipStreamWaitValue32(s_prep, run_words + n_blocks, seq, hipStreamWaitValueGte, 0xffffffffu));
+        ctx->fused_sync = run_words + n_blocks + 1;
+    }
     auto set_block = [&](int64_t b) {
 #ifdef RSIK_PIPE_TIMING
         R.tslot = (int)(b < 64 ? b : 63);
@@ -1085,6 +1127,7 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         R.flags = reinterpret_cast<uint8_t*>(R.gw + (size_t)R.T * (size_t)n);
         R.chunk_event = R.flags + (size_t)R.T * (size_t)n;
     };
+    const int64_t head = n_blocks < slots ? n_blocks : slots;  // blocks with a workspace slot of their own: issued phase by phase
     auto issue_prepare = [&](int64_t b) -> int {
         set_block(b);
         const dim3 grid2(grid.x, (unsigned)R.T);
@@ -1095,7 +1138,11 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         return RSIK_OK;
     };
     auto issue_theta = [&](int64_t b) -> int {
+        if (theta_run) return RSIK_OK;  // (the persistent launch takes the blocks as their goals arrive)
         set_block(b);
+        // (launch by launch: the kernel says when it has started — the joints kernel of the block before is held until then)
+        R.started_word = by_value ? ctx->edge_words + P.n_events + (size_t)b : nullptr;
+        R.started_seq = seq;
         RSIK_HIP(ctx, wait_for(s_theta, edge_id(0, b)));
         const dim3 grid_t((unsigned)((n + rsik::kThetaBlock - 1) / rsik::kThetaBlock)), block_t(rsik::kThetaBlock);
         if (arm) hipLaunchKernelGGL((rsik::cont_theta_kernel<true, rsik::kSnapGeneric>), grid_t, block_t, 0, s_theta, R);
@@ -1109,17 +1156,35 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         set_block(b);
         // (a wave = 8 trajectories x 8 steps: n / 8 groups, 4 per workgroup)
         const dim3 grid2((unsigned)((n + 8 * (rsik::kBlock / 64) - 1) / (8 * (rsik::kBlock / 64))), (unsigned)((R.T + rsik::kJointChunk - 1) / rsik::kJointChunk));
-        RSIK_HIP(ctx, wait_for(s_joints, edge_id(1, b)));
+        // joints(b) needs theta(b).  Launch by launch it is held a little longer: until theta(b + 1) has STARTED (which is after
+        // theta(b)'s end: same stream).  The theta kernel's lone waves want 276 registers each — a SIMD that holds six waves of a
+        // chip-filling kernel has none to give — so a theta kernel that becomes ready together with a joints kernel and loses the
+        // race for the chip only gets in when that kernel drains: theta(b + 1) ran behind joints(b), not beside it (measured with
+        // in-kernel stamps: a third of a pass).  Let in first, it has its SIMDs before the chip fills up.
+        // (measured and not kept, beside the persistent theta launch: the first joints kernel held until the last prepare kernel has
+        // completed, so that the prepare kernels — which every later phase of a block waits for — have the chip to themselves:
+        // 0.424 against 0.371 ms per pass, the joints kernels then run one behind the other with a stream operation's ~15 us
+        // between them; higher stream priority for the prepare and chain streams: no difference)
+        // (only where theta(b + 1) has been ISSUED before this wait: streams can share a hardware queue, and a wait that sat in one
+        // ahead of the launch it waits for would wait for ever — true for the blocks that have workspace slots of their own)
+        if (by_value && !theta_run && !(variant & RSIK_PHASED_NO_THETA_FIRST) && b + 1 < head)
+            RSIK_HIP(ctx, hipStreamWaitValue32(s_joints, ctx->edge_words + P.n_events + (size_t)(b + 1), seq, hipStreamWaitValueGte, 0xffffffffu));
+        else
+            RSIK_HIP(ctx, wait_for(s_joints, edge_id(1, b)));
         if (arm) hipLaunchKernelGGL(rsik::cont_joints_kernel<true>, grid2, block, 0, s_joints, R);
         else hipLaunchKernelGGL(rsik::cont_joints_kernel<false>, grid2, block, 0, s_joints, R);
         RSIK_HIP(ctx, signal(s_joints, edge_id(2, b)));
         RSIK_HIP(ctx, wait_for(s_chain, edge_id(2, b)));
-        if (arm) hipLaunchKernelGGL(rsik::cont_chain_kernel<true>, grid8, dim3(rsik::kChainBlock), 0, s_chain, R);
-        else hipLaunchKernelGGL(rsik::cont_chain_kernel<false>, grid8, dim3(rsik::kChainBlock), 0, s_chain, R);
+        if (theta_run) {  // (beside chip-filling kernels all the time: the form that gets in)
+            if (arm) hipLaunchKernelGGL(rsik::cont_chain_small_kernel<true>, grid8, dim3(rsik::kChainBlock), 0, s_chain, R);
+            else hipLaunchKernelGGL(rsik::cont_chain_small_kernel<false>, grid8, dim3(rsik::kChainBlock), 0, s_chain, R);
+        } else {
+            if (arm) hipLaunchKernelGGL(rsik::cont_chain_kernel<true>, grid8, dim3(rsik::kChainBlock), 0, s_chain, R);
+            else hipLaunchKernelGGL(rsik::cont_chain_kernel<false>, grid8, dim3(rsik::kChainBlock), 0, s_chain, R);
+        }
         RSIK_HIP(ctx, signal(s_chain, edge_id(3, b)));
         return RSIK_OK;
     };
-    const int64_t head = n_blocks < slots ? n_blocks : slots;
     // Issue order of the blocks that have a workspace slot of their own (it is also the order of the nodes in a captured
     // graph): prepare(0), theta(0), then the other prepares back to back, the other thetas, then joints + chain of
     // every block.  Measured on graph replays of 4096 x 1000 steps against three other orders (prepare / theta

@@ -1,7 +1,8 @@
 #!/bin/bash
-# config-5 passes of the phased pipeline, issued launch by launch, for several block sizes; RSIK_EDGES_BY_EVENT=1: the old edges
+# config-5 passes of the phased pipeline, issued launch by launch, for several block sizes; VARIANT = RSIK_OPT_CONT_PHASED_VARIANT bits
+# (1 edges by event, 2 no theta-first, 4 persistent theta launch)
 for blk in "$@"; do
-  echo "== block steps $blk  (events: ${RSIK_EDGES_BY_EVENT:-0})"
+  echo "== block steps $blk  (variant: ${VARIANT:-0})"
   timeout -k 10 200 python - "$blk" <<'PY'
 import os, sys, time, torch
 sys.path.insert(0, os.getcwd())
@@ -15,6 +16,7 @@ traj = bench.make_config5_trajectories(n, N, device=0)
 cont0 = ctrl.new_continuous_state("r_arm", n)
 hs.set_option(A.OPT_CONT_RUN_MODE, A.CONT_RUN_PHASED)
 hs.set_option(A.OPT_CONT_BLOCK_STEPS, blk)
+hs.set_option(A.OPT_CONT_PHASED_VARIANT, int(os.environ.get("VARIANT", "0")))
 st = cont0.clone()
 out = None
 def one():
