@@ -18,6 +18,10 @@
  *     by the caller unless the name ends in `_host`.  The library never frees or retains them.
  *   - Work is enqueued on the context's HIP stream (rsik_set_stream) and is asynchronous;
  *     rsik_sync waits for it.
+ *   - Streams: calls of one context may be issued on different streams (rsik_set_stream between them).  The continuous run keeps
+ *     a workspace, dependency words and side streams in the context: a run issued on another stream than the run before it
+ *     waits for that run's end first.  hipGraphs recorded from ONE context's continuous runs share that workspace: replay
+ *     them one at a time (or record them from different contexts).
  *   - Threads: a context is NOT thread-safe (it holds the stream, the arm constants, the options and the
  *     continuous pipeline's workspace that the next call uses; the reference's objects are not re-entrant either,
  *     symbolic_ik.py:143-144,185).  Use it from one thread at a time; several contexts — one per thread, per stream or

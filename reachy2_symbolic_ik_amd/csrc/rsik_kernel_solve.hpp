@@ -379,9 +379,12 @@ __device__ __forceinline__ void goal_from_m12(const double (&m)[12], Rot& Rg, V3
 #pragma unroll
     for (int k = 0; k < 9; k++) Rg.m[k] = m[k];
     if (special) {
-        // row 2 against row 0 x row 1, entry by entry (1e-9: far above rounding, far below anything the solver resolves)
+        // row 2 against row 0 x row 1, entry by entry, to 1e-14: a few roundings of the entries themselves.  (A looser test — 1e-9
+        // until round 4 — let the joints phase rebuild the third row of a matrix that is NOT orthonormal to rounding, and where
+        // the arm is stretched out the elbow-yaw / wrist-yaw split amplifies such a difference 2e4 times and more: the pipeline
+        // and the step kernel could then differ by ~1e-5 rad under RSIK_EULER_NEVER.  Anything else re-reads the three entries.)
         const double c6 = fma(m[1], m[5], -(m[2] * m[4])), c7 = fma(m[2], m[3], -(m[0] * m[5])), c8 = fma(m[0], m[4], -(m[1] * m[3]));
-        *special = !(fabs(c6 - m[6]) <= 1e-9 && fabs(c7 - m[7]) <= 1e-9 && fabs(c8 - m[8]) <= 1e-9);
+        *special = !(fabs(c6 - m[6]) <= 1e-14 && fabs(c7 - m[7]) <= 1e-14 && fabs(c8 - m[8]) <= 1e-14);
     }
     // np.allclose(R, I) needs all nine entries close; R00 alone rules it out for nearly every goal
     bool eye = RSIK_RARE(np_isclose(Rg.m[0], 1.0));

@@ -46,6 +46,9 @@ struct rsik_ctx {
     unsigned long long* trace;       // RSIK_OPT_CONT_TRACE: the single launch's item records (device), or NULL
     size_t trace_cap;
     unsigned* fused_sync;            // the abort words (raised, which wait, wanted, was) of the last run with bounded in-kernel waits: read by rsik_sync
+    hipEvent_t run_done;             // recorded behind every continuous run issued launch by launch: the next run, if it comes on
+    hipStream_t run_stream;          // ANOTHER stream, waits for it (the workspace, the words and the side streams are the context's)
+    bool have_run_done;
     unsigned* edge_words;            // the phased pipeline's dependency words (device): see cont_edges
     size_t edge_count;
     unsigned edge_seq;               // runs issued with them: the value a word must reach
@@ -115,6 +118,8 @@ int rsik_create(int device_id, rsik_ctx** out) {
     c->fused_sync = nullptr;
     c->flags_epoch = 0.0;
     c->flags_ws_clean = false;
+    c->have_run_done = false;
+    c->run_stream = nullptr;
     c->edge_words = nullptr;
     c->edge_count = 0;
     c->edge_seq = 0;
@@ -131,6 +136,7 @@ int rsik_destroy(rsik_ctx* ctx) {
         if (ctx->ws) (void)hipFree(ctx->ws);
         if (ctx->trace) (void)hipFree(ctx->trace);
         if (ctx->edge_words) (void)hipFree(ctx->edge_words);
+        if (ctx->have_run_done) (void)hipEventDestroy(ctx->run_done);
         for (void* w : ctx->retired_ws) (void)hipFree(w);
         for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
         if (ctx->have_side)
@@ -750,6 +756,25 @@ int rsik_control_continuous_trace(rsik_ctx* ctx, unsigned long long* records_hos
     return RSIK_OK;
 }
 
+// Two runs of one context share its workspace, words and side streams: a run issued on another stream than the one before it
+// waits for that one's end (runs on one stream are ordered by the stream; hipGraphs recorded from one context must not be
+// replayed concurrently: include/rsik.h).
+static int cont_run_begin(rsik_ctx* ctx, bool capturing) {
+    if (capturing || !ctx->have_run_done || ctx->run_stream == ctx->stream) return RSIK_OK;
+    RSIK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->run_done, 0));
+    return RSIK_OK;
+}
+static int cont_run_end(rsik_ctx* ctx, bool capturing) {
+    if (capturing) return RSIK_OK;
+    if (!ctx->have_run_done) {
+        RSIK_HIP(ctx, hipEventCreateWithFlags(&ctx->run_done, hipEventDisableTiming));
+        ctx->have_run_done = true;
+    }
+    RSIK_HIP(ctx, hipEventRecord(ctx->run_done, ctx->stream));
+    ctx->run_stream = ctx->stream;
+    return RSIK_OK;
+}
+
 // The whole trajectory batch: the phased pipeline (include/rsik.h), or — RSIK_CONT_RUN_STEPS — one launch of the step
 // kernel per control step.
 int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const double* m12_steps,
@@ -804,6 +829,7 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         capturing = hipStreamIsCapturing(ctx->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
     }
+    if ((rc = cont_run_begin(ctx, capturing)) != RSIK_OK) return rc;
     // ---- the single self-scheduling launch (rsik_kernel_fused.hpp), where the run qualifies
     {
         FusedPlan FP;
@@ -943,7 +969,7 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
                 RSIK_HIP(ctx, hipGetLastError());
                 if (capturing) ctx->ws_captured = true;
                 ctx->fused_sync = F.sync + rsik::kSyncAbort;
-                return RSIK_OK;
+                return cont_run_end(ctx, capturing);
             }
             {
                 const bool pair = !singularity_plane_binds(K0.arms);
@@ -959,7 +985,7 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
             RSIK_HIP(ctx, hipGetLastError());
             if (capturing) ctx->ws_captured = true;
             ctx->fused_sync = F.sync + rsik::kSyncAbort;
-            return RSIK_OK;
+            return cont_run_end(ctx, capturing);
         }
     }
     // ---- phased pipeline.  The four phases of a block run on four streams (theta on the caller's, the others on the
@@ -1206,7 +1232,7 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     // the caller's stream continues once the last chain (hence every phase of every block) is done
     RSIK_HIP(ctx, wait_for(s_main, edge_id(3, n_blocks - 1)));
     RSIK_HIP(ctx, hipGetLastError());
-    return RSIK_OK;
+    return cont_run_end(ctx, capturing);
 }
 
 int rsik_matrix_to_pose(rsik_ctx* ctx, int64_t n, const double* const m12_soa[12], int identity_shortcut,

@@ -1101,6 +1101,110 @@ def test_continuous_pipeline_block_sizes_agree(torch_mod):
     c._solver.set_option(A.OPT_CONT_BLOCK_STEPS, 0)
 
 
+@pytest.mark.parametrize("euler_mode", ["auto", "never"])
+def test_continuous_pipeline_takes_slightly_skewed_matrices_as_they_are(torch_mod, euler_mode):
+    """The pipeline's joints phase rebuilds a goal rotation's third row as row 0 x row 1 only where the prepare phase found the
+    two equal to 1e-14.  A matrix whose third row is off by 1e-10 — through SciPy's nearest-rotation round trip under
+    RSIK_EULER_AUTO, taken as it is under RSIK_EULER_NEVER — must go through every form with the entries it has: the
+    pipeline forms and the step kernel agree to 1e-9 (where the arm is stretched out a rebuilt row would differ by more)."""
+    from bench import make_config5_trajectories
+
+    A = _abi_mod()
+    n_traj, n_steps = 500, 96
+    traj = make_config5_trajectories(n_traj, n_steps, seed=4242).clone()
+    g = torch_mod.Generator(device="cpu").manual_seed(5)
+    traj[:, 6:9, :] += (torch_mod.rand((n_steps, 3, n_traj), generator=g, dtype=torch_mod.float64).to(traj.device) - 0.5) * 2e-10
+    c = make_control()
+    hs = c._solver
+    hs.set_option(A.OPT_EULER_ROUNDTRIP, A.EULER_NEVER if euler_mode == "never" else A.EULER_AUTO)
+    ref = None
+    for run_mode in (A.CONT_RUN_STEPS, A.CONT_RUN_PHASED, A.CONT_RUN_FUSED, A.CONT_RUN_FLAGS):
+        hs.set_option(A.OPT_CONT_RUN_MODE, run_mode)
+        st = c.new_continuous_state("r_arm", n_traj)
+        res = c.run_continuous_trajectories("r_arm", traj, st, first_step_timed_out=True, current_pose=traj[0])
+        hs.synchronize()
+        got = {k: v.clone() for k, v in res.items()}
+        got["cont_state"] = st[:11].clone()
+        if ref is None:
+            ref = got
+        else:
+            _same_run(torch_mod, ref, got, (euler_mode, run_mode), joint_tol=1e-9)
+    hs.set_option(A.OPT_CONT_RUN_MODE, A.CONT_RUN_AUTO)
+    hs.set_option(A.OPT_EULER_ROUNDTRIP, A.EULER_AUTO)
+
+
+def _eventful_trajectories(torch, n_traj, n_steps, seed, arm):
+    """[n_steps, 12, n_traj] goal matrices: config 5's sinusoids plus, per trajectory, one of: a jump of the goal, a winding
+    wrist (reaches the +-6 pi limit), a stretch far out of reach, a run of exact repeats ("stay" steps) — what makes the
+    sequential phases take their rare paths (scripts/soak_pipeline.py's generator, smaller)."""
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    r = lambda *sh: torch.rand(*sh, generator=g, dtype=torch.float64).to(dev)  # noqa: E731
+    k = torch.arange(n_steps, dtype=torch.float64, device=dev)[:, None]
+    t = k / 60.0 + 11.0 + r(n_traj)[None, :] * 40.0
+    c0 = [0.45, -0.2 if arm == "r_arm" else 0.2, -0.1, 0.0, -np.pi / 2, 0.0]
+    amp = [0.3, 0.3, 0.3, np.pi / 4, np.pi / 4, np.pi / 4]
+    freq = [0.6, 0.34, 0.78, 0.18, 0.31, 0.47]
+    v = [c + a * torch.sin(f * t) for c, a, f in zip(c0, amp, freq)]
+    kind = (r(n_traj) * 6).floor()
+    at = (r(n_traj) * max(n_steps - 20, 1) + 5).floor()
+    after = (k >= at[None, :]).double()
+    v[0] = v[0] + after * (kind < 2).double()[None, :] * 0.25 * (r(n_traj)[None, :] - 0.5)
+    v[5] = v[5] + (kind == 2).double()[None, :] * k * 0.12 + (kind == 3).double()[None, :] * k * -0.2
+    far = ((k >= at[None, :]) & (k < at[None, :] + 25)).double() * (kind == 4).double()[None, :]
+    v[0] = v[0] + far * 2.0
+    hold = ((k >= at[None, :]) & (k < at[None, :] + 6)).double() * (kind == 5).double()[None, :]
+    idx = torch.where(hold.bool(), at[None, :].expand(n_steps, -1), k.expand(-1, n_traj)).long().clamp(max=n_steps - 1)
+    v = [torch.gather(x, 0, idx) for x in v]
+    ca, sa, cb, sb, cc, sc = torch.cos(v[3]), torch.sin(v[3]), torch.cos(v[4]), torch.sin(v[4]), torch.cos(v[5]), torch.sin(v[5])
+    rows = [cc * cb, cc * sb * sa - sc * ca, cc * sb * ca + sc * sa, sc * cb, sc * sb * sa + cc * ca, sc * sb * ca - cc * sa,
+            -sb, cb * sa, cb * ca, v[0], v[1], v[2]]
+    return torch.stack(rows, dim=1).contiguous()
+
+
+@pytest.mark.parametrize("n_traj,n_steps,arm,mode,dmax", [(1, 300, "r_arm", "unconstrained", 0.01), (7, 129, "l_arm", "low_elbow", 0.3),
+                                                         (65, 33, "r_arm", "low_elbow", 0.01), (600, 203, "l_arm", "unconstrained", 0.3),
+                                                         (4099, 40, "r_arm", "unconstrained", 0.01)])
+def test_continuous_run_forms_are_bit_identical(torch_mod, n_traj, n_steps, arm, mode, dmax):
+    """rsik_control_continuous_run has several forms of issuing the same four bodies (include/rsik.h: the phased pipeline, its
+    variants — events instead of stream value words, no theta-first hold, the persistent theta launch —, the single
+    self-scheduling launch, the flag-synchronised form).  They run the same device code on the same data: every output and
+    the carried state must be the same BITS, on eventful trajectories (jumps, wound wrists, unreachable stretches, repeats)
+    that take the sequential phases through their rare paths; the step kernel, launch per step, bounds them all (_same_run)."""
+    A = _abi_mod()
+    traj = _eventful_trajectories(torch_mod, n_traj, n_steps, 7000 + n_traj, arm)
+    c = make_control()
+    hs = c._solver
+    forms = [("steps", A.CONT_RUN_STEPS, 0, 0), ("phased", A.CONT_RUN_PHASED, 0, 0), ("phased, events", A.CONT_RUN_PHASED, A.PHASED_EDGES_BY_EVENT, 0),
+             ("phased, no theta-first", A.CONT_RUN_PHASED, A.PHASED_NO_THETA_FIRST, 0), ("phased, persistent theta", A.CONT_RUN_PHASED, A.PHASED_THETA_RUN, 0),
+             ("phased, persistent theta, blocks of 48", A.CONT_RUN_PHASED, A.PHASED_THETA_RUN, 48), ("fused", A.CONT_RUN_FUSED, 0, 0),
+             ("fused, blocks of 24", A.CONT_RUN_FUSED, 0, 24), ("flags", A.CONT_RUN_FLAGS, 0, 0), ("flags, blocks of 40", A.CONT_RUN_FLAGS, 0, 40)]
+    got = {}
+    for name, run_mode, variant, blk in forms:
+        hs.set_option(A.OPT_CONT_RUN_MODE, run_mode)
+        hs.set_option(A.OPT_CONT_PHASED_VARIANT, variant)
+        hs.set_option(A.OPT_CONT_BLOCK_STEPS, blk)
+        st = c.new_continuous_state(arm, n_traj)
+        res = c.run_continuous_trajectories(arm, traj, st, first_step_timed_out=True, current_pose=traj[0], constrained_mode=mode,
+                                            d_theta_max=dmax)
+        hs.synchronize()  # (also reports a wait that ran out inside one of the launches)
+        got[name] = {k: v.clone() for k, v in res.items()}
+        got[name]["cont_state"] = st.clone()
+    hs.set_option(A.OPT_CONT_RUN_MODE, A.CONT_RUN_AUTO)
+    hs.set_option(A.OPT_CONT_PHASED_VARIANT, 0)
+    hs.set_option(A.OPT_CONT_BLOCK_STEPS, 0)
+    ref = got["phased"]
+    _same_run(torch_mod, {k: (v[:11] if k == "cont_state" else v) for k, v in got["steps"].items()},
+              {k: (v[:11] if k == "cont_state" else v) for k, v in ref.items()}, "steps vs phased")
+    for name, _, _, blk in forms[2:]:
+        for k, v in ref.items():
+            a, b = v, got[name][k]
+            same = torch_mod.equal(a.view(torch_mod.uint8), b.view(torch_mod.uint8))
+            assert same, (name, k, float((a.double() - b.double()).abs().nan_to_num().max()))
+    if n_traj >= 600:
+        assert float((ref["cont_state"][9] != 0).float().mean()) > 0.02, "no trajectory latched: the rare paths were not exercised"
+
+
 @pytest.mark.parametrize("mode,d_theta_max,preferred", [("unconstrained", 0.01, -4 * np.pi / 6), ("low_elbow", 0.05, 0.5)])
 def test_config5_full_size_against_checker(torch_mod, orc, mode, d_theta_max, preferred):
     """BASELINE config 5 at its stated size: 4096 trajectories x 1000 control steps in one rsik_control_continuous_run
