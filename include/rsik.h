@@ -61,6 +61,32 @@ extern "C" {
 #define RSIK_STATE_NOT_REACHABLE_NO_LIMITS 9 /* continuous mode: is_reachable_no_limits failed, where the reference raises
                                               * RuntimeError("Pose not reachable in symbolic IK. ...") control_ik.py:385-387.
                                               * Joints NaN, trajectory state untouched.  Needs projection_margin <= 0. */
+#define RSIK_STATE_INVALID_INPUT 10       /* the row's goal (pose or matrix) holds a NaN or an infinity: see "Rows that are not
+                                          * numbers" below.  Where the reference raises numpy.linalg.LinAlgError
+                                          * (symbolic_ik.py:580, reached through the comparisons of :284-307, which are all
+                                          * false for a NaN) or ValueError (scipy's Rotation.from_matrix, control_ik.py:215). */
+
+/* ---- Rows that are not numbers ----
+ * A batch is data: a row with a NaN or an infinity in it is answered in that row, never with an error code, never by stalling,
+ * and it changes nothing in any other row — every other row's outputs (and, in the continuous entry points, its trajectory
+ * state) are bit for bit those of a run in which the bad row held an ordinary goal.
+ *
+ *  the goal — the six pose entries of rsik_solve / rsik_reach_state, the twelve matrix entries (rotation and translation) of
+ *  rsik_control_discrete / rsik_control_continuous_step / rsik_control_continuous_run — holds a NaN or +-infinity:
+ *      state RSIK_STATE_INVALID_INPUT, reachable 0, joints / elbow / interval NaN, emergency 0; rsik_reach_state leaves the
+ *      solver-state row's geometry as it was.  (The reference raises for a NaN anywhere and for an infinite angle; for an
+ *      infinite POSITION its is_reachable returns "Pose out of reach" / "Backward pose" with a projected pose that is itself
+ *      NaN, symbolic_ik.py:292-307, and the control entry points raise on it a few lines later: one code for all of them.)
+ *      Continuous mode, a step with such a goal: the latch comes first as always (a latched trajectory reports
+ *      RSIK_STATE_EMERGENCY and previous_sol); otherwise the step reports the code and NaN joints, previous_sol / init / the
+ *      latch stay as they were — the next good step is judged against the last good one — and previous_theta takes the step
+ *      of a search that found nothing (utils.py:252-264 with goal = previous_theta, then limit_theta_to_interval: it stays
+ *      where it is once inside the control interval).  The start-up branch of a timed-out step (control_ik.py:296-325) does
+ *      not read the goal and runs before this.
+ *  anything else that is not a number — theta_in, previous_joints, current_joints, current_pose, a row of cont_state or of a
+ *  solver state: IEEE arithmetic as the reference would do it: the outputs of THAT row which depend on the value are NaN or
+ *  what comparisons that are all false select (a NaN never trips an emergency stop, a NaN previous_theta stays NaN); the state
+ *  code is one of the codes above.  A poisoned cont_state row stays poisoned until the caller re-initialises it (timed_out). */
 
 /* ---- why an emergency stop tripped: one bit per message the reference appends to ControlIK.emergency_state
  * (utils.multiturn_safety_check utils.py:544-566, utils.continuity_check utils.py:584-586) ---- */

@@ -934,6 +934,151 @@ def gen_continuous_modes(out, n_steps=160):
     np.savez_compressed(os.path.join(out, "g12_control_continuous_modes.npz"), **data)
 
 
+# ----------------------------------------------------------------------------------------
+# G13: goals that are not numbers — what the reference does with a NaN / an infinity in the pose or the matrix
+# (include/rsik.h "Rows that are not numbers": where it raises, the build reports RSIK_STATE_INVALID_INPUT)
+# ----------------------------------------------------------------------------------------
+OUTCOME_RETURNED, OUTCOME_LINALG, OUTCOME_VALUE, OUTCOME_OTHER, OUTCOME_HANGS = 0, 1, 2, 3, 4
+
+
+def _outcome(fn, forked=False, limit=8.0):
+    """(outcome code, whatever fn returned or None).  LAPACK prints its own complaints about NaN arguments to the C stderr: not
+    silenced, harmless.  forked: the call is made in a forked child with a time limit — for an infinite entry in the rotation
+    scipy's Rotation.from_matrix may never come back from LAPACK (observed: R[0,0] = +inf), which no Python signal interrupts."""
+    import warnings
+
+    def run():
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                return OUTCOME_RETURNED, quiet(fn)
+        except np.linalg.LinAlgError:
+            return OUTCOME_LINALG, None
+        except ValueError:
+            return OUTCOME_VALUE, None
+        except Exception:  # noqa: BLE001
+            return OUTCOME_OTHER, None
+
+    if not forked:
+        return run()
+    import multiprocessing as mp
+
+    ctx = mp.get_context("fork")
+    rx, tx = ctx.Pipe(duplex=False)
+
+    def child():
+        tx.send(run())
+        tx.close()
+
+    proc = ctx.Process(target=child)
+    proc.start()
+    got = rx.recv() if rx.poll(limit) else (OUTCOME_HANGS, None)
+    if proc.is_alive() and got[0] == OUTCOME_HANGS:
+        proc.kill()
+    proc.join()
+    return got
+
+
+def gen_hostile(out, n_steps=48):
+    poisons = [NAN, float("inf"), float("-inf")]
+    bases = [([0.55, -0.3, -0.15], [0.0, -np.pi / 2, 0.0]), ([0.38, -0.2, -0.28], [0.3, -1.2, 0.2]),
+             ([0.1, -0.2, 0.1], [0.0, -np.pi / 2, 0.0]), ([0.9, -0.2, 0.0], [0.0, -np.pi / 2, 0.0])]
+    data = {}
+    # (a) SymbolicIK.is_reachable (+ get_joints(interval[0]) when it says reachable)
+    rows = {k: [] for k in ("arm", "pos", "eul", "outcome", "state", "reachable")}
+    for ai, arm in enumerate(ARMS):
+        solver = make_solver(arm)
+        for bp, be in bases:
+            if arm == "l_arm":
+                bp, be = mirror_pose(np.array(bp), np.array(be))
+            for comp in range(6):
+                for v in poisons:
+                    pos, eul = np.array(bp, dtype=float), np.array(be, dtype=float)
+                    (pos if comp < 3 else eul)[comp % 3] = v
+
+                    def call(pos=pos, eul=eul):
+                        ok, interval, fn, state = solver.is_reachable(np.array([pos, eul]))
+                        if ok:
+                            fn(interval[0])
+                        return bool(ok), state
+
+                    oc, ret = _outcome(call, forked=True)
+                    rows["arm"].append(ai)
+                    rows["pos"].append(pos)
+                    rows["eul"].append(eul)
+                    rows["outcome"].append(oc)
+                    rows["state"].append(STATE_CODES[ret[1]] if ret else 255)
+                    rows["reachable"].append(int(ret[0]) if ret else 0)
+    data["sym_arm"] = np.array(rows["arm"], dtype=np.uint8)
+    data["sym_pos"], data["sym_eul"] = np.array(rows["pos"]), np.array(rows["eul"])
+    data["sym_outcome"] = np.array(rows["outcome"], dtype=np.uint8)
+    data["sym_state"] = np.array(rows["state"], dtype=np.uint8)
+    data["sym_reachable"] = np.array(rows["reachable"], dtype=np.uint8)
+    # (b) ControlIK discrete: every one of the twelve entries of the goal matrix, NaN / +inf / -inf
+    Ms, ocs, sts, arms = [], [], [], []
+    for ai, arm in enumerate(ARMS):
+        for bp, be in bases[:2]:
+            if arm == "l_arm":
+                bp, be = mirror_pose(np.array(bp), np.array(be))
+            for r_ in range(3):
+                for c_ in range(4):
+                    for v in poisons:
+                        M = pose_to_matrix(np.array(bp, dtype=float), np.array(be, dtype=float))
+                        M[r_, c_] = v
+                        ctrl = quiet(ControlIK, urdf_path="../config_files/reachy2.urdf")
+                        oc, ret = _outcome(lambda M=M, ctrl=ctrl: ctrl.symbolic_inverse_kinematics(arm, M, "discrete"), forked=True)
+                        Ms.append(M)
+                        ocs.append(oc)
+                        sts.append(STATE_CODES.get(ret[2], 255) if ret else 255)
+                        # (an infinite translation: "Pose out of reach" / "Backward pose" and current_joints, no exception)
+                        arms.append(ai)
+    data["disc_arm"] = np.array(arms, dtype=np.uint8)
+    data["disc_M"] = np.array(Ms)
+    data["disc_outcome"] = np.array(ocs, dtype=np.uint8)
+    data["disc_state"] = np.array(sts, dtype=np.uint8)
+    # (c) ControlIK continuous: a trajectory with some goals that are not numbers; the caller catches the exception and goes on
+    # with the next goal, as a control loop would.  Recorded: what every call did, and previous_theta / previous_sol after it.
+    real_time = ref_control_mod.time
+    # (only goals on which the reference raises whatever the arm: a NaN anywhere, -inf on the rotation's diagonal (ValueError).
+    # Other infinities it may answer — an infinite translation with "Pose out of reach" and NaN joints that then ARE its
+    # previous_sol, an infinite rotation entry with the solution for whatever rotation scipy's nearest-rotation step makes of it,
+    # or not at all — section (b).)
+    bad_steps = {7: (0, 3, NAN), 19: (1, 1, float("-inf")), 20: (2, 2, NAN), 21: (1, 2, NAN), 40: (0, 0, NAN)}
+    for arm in ARMS:
+        Mt = np.zeros((n_steps, 4, 4))
+        J = np.full((n_steps, 7), NAN)
+        OC = np.zeros(n_steps, dtype=np.uint8)
+        F = np.zeros(n_steps, dtype=np.uint8)
+        S = np.full(n_steps, 255, dtype=np.uint8)
+        TH = np.zeros(n_steps)
+        PS = np.zeros((n_steps, 7))
+        clock = FakeClock()
+        ref_control_mod.time = clock
+        try:
+            ctrl = quiet(ControlIK, urdf_path="../config_files/reachy2.urdf")
+            for i in range(n_steps):
+                pos, eul = trajectory_pose(i / 120.0 + 13.0, arm)
+                M = pose_to_matrix(pos, eul)
+                if i in bad_steps:
+                    r_, c_, v = bad_steps[i]
+                    M[r_, c_] = v
+                Mt[i] = M
+                clock.t += 1.0 / 120.0
+                oc, ret = _outcome(lambda M=M: ctrl.symbolic_inverse_kinematics(arm, M, "continuous", d_theta_max=0.01))
+                OC[i] = oc
+                if ret:
+                    J[i], F[i], S[i] = np.array(ret[0], dtype=float), bool(ret[1]), STATE_CODES.get(ret[2], 255)
+                TH[i] = ctrl.previous_theta[arm]
+                PS[i] = np.array(ctrl.previous_sol[arm], dtype=float) if len(ctrl.previous_sol[arm]) == 7 else NAN
+                assert not ctrl.emergency_stop and (oc != OUTCOME_RETURNED) == (i in bad_steps)
+        finally:
+            ref_control_mod.time = real_time
+        data[f"cont_{arm}_M"], data[f"cont_{arm}_outcome"] = Mt, OC
+        data[f"cont_{arm}_joints"], data[f"cont_{arm}_reachable"], data[f"cont_{arm}_state"] = J, F, S
+        data[f"cont_{arm}_previous_theta"], data[f"cont_{arm}_previous_sol"] = TH, PS
+    np.savez_compressed(os.path.join(out, "g13_hostile.npz"), **data)
+
+
 def ref_default_joints(k):
     return [[0.0, 0.2617993877991494, -0.17453292519943295, 0.0, 0.0, 0.0, 0.0],
             [0.0, -0.2617993877991494, 0.17453292519943295, 0.0, 0.0, 0.0, 0.0]][k]
@@ -942,21 +1087,50 @@ def ref_default_joints(k):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
-    ap.add_argument("--only", default="")
+    ap.add_argument("--only", default="", help="comma-separated set names (g1,g6,...): exact names")
+    ap.add_argument("--check", action="store_true",
+                    help="regenerate into a temporary directory and compare, array by array and byte for byte, with the fixtures "
+                         "committed under --out; exit status 1 on any difference (nothing is written to --out)")
     args = ap.parse_args()
     out = os.path.abspath(args.out)
+    if args.check:
+        import tempfile
+
+        committed = out
+        tmp = tempfile.TemporaryDirectory(prefix="rsik_golden_check_")
+        out = tmp.name
     os.makedirs(out, exist_ok=True)
     steps = [("g0", gen_constants), ("g1", gen_catalogue), ("g2", gen_sweep), ("g3", gen_reachable),
              ("g4", gen_control), ("g5", gen_helpers), ("g6", gen_continuous),
              ("g7", gen_continuous_start), ("g8", gen_matrix_edges),
              ("g9", gen_custom_geometry), ("g10", gen_custom_urdf_control), ("g11", gen_emergency),
-             ("g12", gen_continuous_modes)]
+             ("g12", gen_continuous_modes), ("g13", gen_hostile)]
+    bad = 0
     for name, fn in steps:
         if args.only and name not in args.only.split(","):  # exact names: "g1" does not select "g12"
             continue
         t0 = _time.time()
         fn(out)
         print(f"{name}: done in {_time.time() - t0:.1f}s", flush=True)
+        if args.check:
+            # the set's file(s) just written, against the committed ones: same arrays, same dtypes and shapes, same bytes
+            # (the .npz containers themselves may differ in zip metadata: the arrays are what is pinned)
+            for fname in sorted(f for f in os.listdir(out) if f.startswith(name + "_")):
+                new_path, old_path = os.path.join(out, fname), os.path.join(committed, fname)
+                if not os.path.exists(old_path):
+                    print(f"CHECK {fname}: not committed under {committed}")
+                    bad += 1
+                    continue
+                a, b = np.load(new_path), np.load(old_path)
+                diffs = [k for k in sorted(set(a.files) | set(b.files))
+                         if k not in a.files or k not in b.files or a[k].dtype != b[k].dtype or a[k].shape != b[k].shape
+                         or a[k].tobytes() != b[k].tobytes()]
+                print(f"CHECK {fname}: " + ("identical (%d arrays)" % len(a.files) if not diffs else "DIFFERS in " + ", ".join(diffs)))
+                bad += 1 if diffs else 0
+                os.remove(new_path)
+    if args.check:
+        tmp.cleanup()
+        sys.exit(1 if bad else 0)
 
 
 if __name__ == "__main__":

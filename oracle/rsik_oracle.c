@@ -572,11 +572,24 @@ static int are_circles_linked(const orc_arm_t *arm, const orc_solver_t *sv, cons
 }
 
 /* S:121-282 */
+/* include/rsik.h "Rows that are not numbers": the convention for what the reference answers with an exception */
+static int all_finite(const double *v, int n) {
+    for (int i = 0; i < n; i++)
+        if (!isfinite(v[i])) return 0;
+    return 1;
+}
+static int matrix_is_numbers(const double M[16]) { /* the rotation and the translation: what C:212-216 reads */
+    for (int r = 0; r < 3; r++)
+        if (!all_finite(&M[4 * r], 4)) return 0;
+    return 1;
+}
+
 int orc_is_reachable(const orc_arm_t *arm, orc_solver_t *sv, const double pos[3], const double eul[3], int *reachable,
                      double interval[2]) {
     double goal[3];
     *reachable = 0;
     interval[0] = NAN; interval[1] = NAN;
+    if (!all_finite(pos, 3) || !all_finite(eul, 3)) return ORC_STATE_INVALID_INPUT; /* self.* untouched */
     int st = is_pose_in_robot_reach(arm, pos, goal);
     if (st != ORC_STATE_REACHABLE) return st; /* S:130-132: self.* untouched */
     memcpy(sv->goal_pos, goal, sizeof goal);
@@ -900,6 +913,12 @@ int orc_control_discrete(const orc_arm_t *arm, const double M[16], int nb, doubl
                          const double previous_sol[7], const double current_joints[7], double previous_theta,
                          double orbita3d_max_angle, double joints[7], int *reachable, int *emergency_stop) {
     double pos[3], eul[3], lim[2];
+    if (!matrix_is_numbers(M)) { /* the reference raises (C:215 / S:580): no joints, no verdict on them */
+        for (int i = 0; i < 7; i++) joints[i] = NAN;
+        *reachable = 0;
+        *emergency_stop = 0;
+        return ORC_STATE_INVALID_INPUT;
+    }
     matrix_to_pose(M, pos, eul);
     interval_limit_for(arm, constrained_mode, lim, &preferred_theta);
     orc_solver_t sv;
@@ -997,7 +1016,8 @@ int orc_control_continuous_step(const orc_arm_t *arm, orc_cont_state_t *cs, cons
         return ORC_STATE_EMERGENCY;
     }
     double pos[3], eul[3], lim[2];
-    matrix_to_pose(M, pos, eul);
+    const int numbers = matrix_is_numbers(M);
+    if (numbers) matrix_to_pose(M, pos, eul);
     double pref = preferred_theta_arg;
     interval_limit_for(arm, constrained_mode, lim, &pref);
     int state = ORC_STATE_EMPTY;
@@ -1011,6 +1031,15 @@ int orc_control_continuous_step(const orc_arm_t *arm, orc_cont_state_t *cs, cons
         matrix_to_pose(current_pose, cpos, ceul);
         orc_is_reachable_no_limits(arm, &sv, cpos, ceul);
         cs->previous_theta = orc_get_best_theta_to_current_joints(arm, &sv, current_joints, 7, pref);
+    }
+    if (!numbers) {
+        /* include/rsik.h "Rows that are not numbers" (the start-up branch above does not read the goal and has run): no joints;
+         * previous_sol, init and the latch stay; previous_theta takes the step of a search that found nothing (U:252-264 with
+         * goal = previous_theta, then U:93-112) */
+        cs->previous_theta = orc_limit_theta_to_interval(cs->previous_theta, cs->previous_theta, lim);
+        for (int i = 0; i < 7; i++) joints[i] = NAN;
+        *reachable = 0;
+        return ORC_STATE_INVALID_INPUT;
     }
     double interval[2];
     int ok;

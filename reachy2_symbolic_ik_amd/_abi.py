@@ -84,7 +84,7 @@ CONT_RUN_AUTO, CONT_RUN_PHASED, CONT_RUN_STEPS, CONT_RUN_FUSED, CONT_RUN_FLAGS =
 EMERGENCY_SHOULDER_PITCH, EMERGENCY_ELBOW_YAW, EMERGENCY_WRIST_YAW, EMERGENCY_CONTINUITY = 1, 2, 4, 8
 EULER_AUTO, EULER_ALWAYS, EULER_NEVER = 0, 1, 2
 
-STATE_EMERGENCY, STATE_NOT_REACHABLE_NO_LIMITS = 8, 9
+STATE_EMERGENCY, STATE_NOT_REACHABLE_NO_LIMITS, STATE_INVALID_INPUT = 8, 9, 10
 SOLVER_STATE_STRIDE = 32
 CONT_STATE_ROWS = 19
 

@@ -35,6 +35,7 @@ STATE_STRINGS = (
     "",
     "emergency stop",
     "not reachable without limits",  # RSIK_STATE_NOT_REACHABLE_NO_LIMITS: where the reference raises (control_ik.py:385-387)
+    "invalid input",  # RSIK_STATE_INVALID_INPUT: the goal holds a NaN / an infinity — where the reference raises LinAlgError (symbolic_ik.py:580)
 )
 
 

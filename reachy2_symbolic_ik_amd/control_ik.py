@@ -262,6 +262,8 @@ class ControlIK:
                 float(self.orbita3D_max_angle), io["joints"], io["reachable"], io["code"], io["emergency"]))
             torch.cuda.current_stream(sv.device).synchronize()
         flags = io["h_bytes"][8 * self._IO_B: 8 * self._IO_B + 4]
+        if int(flags[1]) == _abi.STATE_INVALID_INPUT:  # rsik.h "Rows that are not numbers": the scalar drop-in raises like the reference
+            raise np.linalg.LinAlgError("SVD did not converge")
         return hn[self._IO_J: self._IO_J + 7].tolist(), bool(flags[0]), STATE_STRINGS[int(flags[1])], int(flags[2])
 
     # ------------------------------------------------------------------ reference API
@@ -350,6 +352,8 @@ class ControlIK:
         flags = io["h_bytes"][8 * self._IO_B: 8 * self._IO_B + 2]
         self.previous_theta[name] = float(back[0])
         self.init = bool(back[8])
+        if int(flags[1]) == _abi.STATE_INVALID_INPUT:  # rsik.h "Rows that are not numbers" (previous_sol, init, the latch: untouched)
+            raise np.linalg.LinAlgError("SVD did not converge")
         if int(flags[1]) == _abi.STATE_NOT_REACHABLE_NO_LIMITS:
             # control_ik.py:385-387: is_reachable_no_limits failed (a solver with a non-positive projection_margin).  The
             # reference has by now (re)initialised previous_sol / previous_theta if the call timed out, and nothing else.
@@ -499,31 +503,68 @@ class ControlIK:
             d_theta_max=float(d_theta_max), current_joints=current_joints, current_pose_m12=cp,
             orbita3d_max_angle=float(self.orbita3D_max_angle), out=out)
 
-    def capture_continuous_trajectories(self, name: Any, M_steps: Any, cont_state: torch.Tensor, **kwargs: Any):
+    def capture_continuous_trajectories(
+        self,
+        name: Any,
+        M_steps: Any,
+        cont_state: torch.Tensor,
+        first_step_timed_out: bool = True,
+        current_joints: Any = None,
+        current_pose: Any = None,
+        constrained_mode: str = "unconstrained",
+        d_theta_max: float = 0.01,
+        preferred_theta: float = -4 * np.pi / 6,
+        out: Optional[Dict[str, torch.Tensor]] = None,
+    ):
         """run_continuous_trajectories recorded once into a hipGraph: returns (graph, out) — `graph.replay()` re-runs the whole
         run on the buffers it was captured with (M_steps, cont_state and `out` are read / written in place: refill M_steps and
-        reset or keep cont_state between replays as the caller needs).  A replay costs less than issuing the pipeline's launches
-        one by one (4096 trajectories x 1000 steps: 0.375 against 0.43 ms) — what a caller that solves batch after batch of the
-        same shape should use.  The capture needs nothing created: the workspace, side streams and events are reserved first."""
+        reset or keep cont_state between replays as the caller needs).  What a caller that solves batch after batch of the same
+        shape may use when the host thread is the bottleneck; issued eagerly the pipeline ties its launches with stream value
+        waits, which a capture cannot hold, and is as fast (DESIGN.md "Continuous runs").  The capture needs nothing created: the
+        workspace, side streams and events are reserved first, and every per-trajectory argument (a tensor of arm ids,
+        current_joints, current_pose) is brought to the device BEFORE the capture begins — a host array converted inside it would
+        be a copy on the capturing stream from memory the graph does not own.  Those device copies are kept alive on the returned
+        graph object (`graph.rsik_inputs`): refill them in place to replay with other values.  The scalars (first_step_timed_out,
+        constrained_mode, d_theta_max, preferred_theta, this object's per-arm preferred_theta and the arm parameters as uploaded
+        now) are frozen into the graph: a run with other values is another capture."""
+        if constrained_mode not in _abi.MODES:
+            raise UnboundLocalError("local variable 'interval_limit' referenced before assignment")
         dev = self._solver.device
         t = M_steps if isinstance(M_steps, torch.Tensor) else torch.as_tensor(np.asarray(M_steps, dtype=np.float64))
         if not (t.dim() == 3 and t.shape[1] == 12 and t.dtype == torch.float64 and t.device == dev and t.is_contiguous()):
             raise ValueError("capture_continuous_trajectories: M_steps must be a contiguous float64 [n_steps, 12, n] tensor on the device "
                              "(the graph reads it in place)")
         n_steps, _, n = (int(v) for v in t.shape)
-        out = kwargs.pop("out", None)
+        held: Dict[str, torch.Tensor] = {}
+        if not isinstance(name, str):
+            name = held["arm"] = self._solver._dev_u8(name, n, "arm")
+        if current_joints is not None:
+            current_joints = held["current_joints"] = self._solver._dev_f64(current_joints, (n, 7), "current_joints")
+        if current_pose is not None:
+            current_pose = held["current_pose"] = matrices_to_m12_soa(current_pose, dev)
         if out is None:
             out = {"joints": torch.empty((n_steps, n, 7), dtype=torch.float64, device=dev),
                    "reachable": torch.empty((n_steps, n), dtype=torch.uint8, device=dev),
                    "state": torch.empty((n_steps, n), dtype=torch.uint8, device=dev)}
+        else:
+            for key, shape, dt in (("joints", (n_steps, n, 7), torch.float64), ("reachable", (n_steps, n), torch.uint8),
+                                   ("state", (n_steps, n), torch.uint8)):
+                o = out.get(key)
+                if o is None or tuple(o.shape) != shape or o.dtype != dt or o.device != dev or not o.is_contiguous():
+                    raise ValueError(f"capture_continuous_trajectories: out[{key!r}] must be a contiguous {dt} {list(shape)} tensor on the device")
         self._upload_arms()
         self._solver.control_continuous_reserve(n, n_steps)
+        torch.cuda.synchronize(dev)  # the conversions above are done before anything is recorded
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.stream(side):
             with torch.cuda.graph(graph, stream=side):
-                self.run_continuous_trajectories(name, t, cont_state, out=out, **kwargs)
+                self.run_continuous_trajectories(name, t, cont_state, first_step_timed_out=first_step_timed_out,
+                                                 current_joints=current_joints, current_pose=current_pose,
+                                                 constrained_mode=constrained_mode, d_theta_max=d_theta_max,
+                                                 preferred_theta=preferred_theta, out=out)
         torch.cuda.current_stream(dev).wait_stream(side)
+        graph.rsik_inputs = held
         return graph, out
 

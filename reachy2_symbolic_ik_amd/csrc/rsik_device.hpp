@@ -71,6 +71,15 @@ __device__ __forceinline__ V3 normalized(V3 a) {
 
 // numpy.isclose(a, b), default rtol/atol: |a-b| <= 1e-8 + 1e-5*|b|
 __device__ __forceinline__ bool np_isclose(double a, double b) { return fabs(a - b) <= (1e-8 + 1e-5 * fabs(b)); }
+// include/rsik.h "Rows that are not numbers": a goal (pose or matrix) with a NaN or an infinity in it is RSIK_STATE_INVALID_INPUT.
+// One compare per entry (|x| < inf is false for both), the lanes' answers meet on the scalar side.
+template <int N>
+__device__ __forceinline__ bool all_finite(const double (&v)[N]) {
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < N; k++) ok = ok && (fabs(v[k]) < __builtin_inf());
+    return ok;
+}
 
 // Python float modulo `a % (2*pi)` (result in [0, 2pi)).  CPython computes fmod(a, b) (exact) and adds b
 // when the signs differ.  For the small quotients on this path a - q*2pi is exactly representable, so one

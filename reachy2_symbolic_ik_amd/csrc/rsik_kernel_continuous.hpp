@@ -147,7 +147,11 @@ __global__ __launch_bounds__(kBlock) void control_continuous_kernel(const Contin
     } else {
         Rot Rg;
         V3 pos;
-        load_m12(K.in, ii, Rg, pos, K.euler_roundtrip);
+        double m[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) m[k] = K.in[k][ii];
+        const bool invalid = !all_finite(m);
+        goal_from_m12(m, Rg, pos, K.euler_roundtrip);
         if (K.first_timed_out || (K.timed_out && K.timed_out[ii])) { has_prev = false; init = true; }  // C:298-304
         if (!has_prev) {  // C:306-325
             has_prev = true;
@@ -156,7 +160,14 @@ __global__ __launch_bounds__(kBlock) void control_continuous_kernel(const Contin
         const Goal G = make_goal(A, Rg);
         Reach r;
         const ThetaTarget T = continuous_target<PLANE>(A, pos, G.woff, K.pref_self[slot], K.pref_self_cs[slot], K.pref_self_sn[slot], r);
-        if (RSIK_RARE(!T.ok_limits && !r.ok)) {
+        if (RSIK_RARE(invalid)) {
+            // rsik.h "Rows that are not numbers": no joints; previous_sol, init and the latch stay as they are; previous_theta goes
+            // through the step of a search that found nothing (U:252-264 with goal = previous_theta, then U:93-112)
+#pragma unroll
+            for (int k = 0; k < 7; k++) jv[k] = __builtin_nan("");
+            st_code = RSIK_STATE_INVALID_INPUT;
+            prev_theta = continuous_next_theta(true, false, 0.0, K.pref_arg[slot], prev_theta, K.d_theta_max, K.lim[slot][0], K.lim[slot][1]);
+        } else if (RSIK_RARE(!T.ok_limits && !r.ok)) {
             // C:385-387: is_reachable_no_limits came back false (only a solver whose projection_margin lets the pulled-back
             // wrist land beyond u + f can do that, S:343-345) and the reference raises RuntimeError — before it touches
             // previous_theta, previous_sol or init.  Reported as data: NaN joints, RSIK_STATE_NOT_REACHABLE_NO_LIMITS.

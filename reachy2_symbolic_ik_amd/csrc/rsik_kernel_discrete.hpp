@@ -166,6 +166,7 @@ __global__ __launch_bounds__(kDiscBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR voi
     const int slot = MIXED ? (A.isl ? 1 : 0) : 0;
 
     // C:212-217: M -> pose (see goal_from_m12)
+    const bool invalid = !all_finite(m12);  // rsik.h "Rows that are not numbers" (judged while the twelve values are at hand)
     Rot Rg;
     V3 pos;
     goal_from_m12(m12, Rg, pos, K.euler_roundtrip);
@@ -181,6 +182,7 @@ __global__ __launch_bounds__(kDiscBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR voi
     RSIK_MARK("disc_reach");
     RSIK_DISC_PRIO(3);
     Reach r = reach_g<false, false>(A, pos, G.woff);
+    if (RSIK_RARE(invalid)) { r.ok = false; r.state = RSIK_STATE_INVALID_INPUT; }
     RSIK_MARK("disc_shortcut");
     const double pref = K.pref[slot];
     bool found = false;
@@ -289,7 +291,12 @@ __global__ __launch_bounds__(kDiscBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR voi
     }
     RSIK_MARK("disc_safety");
     RSIK_DISC_PRIO(0);
-    const int em = safety_checks(A.utab, jv, c4, s4, c5, s5, c6, s6, prev, K.max_angle, K.cos_max, K.sin_max);
+    int em = safety_checks(A.utab, jv, c4, s4, c5, s5, c6, s6, prev, K.max_angle, K.cos_max, K.sin_max);
+    if (RSIK_RARE(invalid)) {  // no joints, no verdict on them (the reference has raised, C:215 / S:580)
+#pragma unroll
+        for (int k = 0; k < 7; k++) jv[k] = __builtin_nan("");
+        em = 0;
+    }
     RSIK_MARK("disc_store");
     RSIK_DISC_PROBE(4);
     store_rows<7>(K.joints, wave_base, K.n, lane, &lds_slab[wave][0][0], jv);

@@ -200,14 +200,18 @@ __device__ __forceinline__ f64x2p pair_value(const ContRunArgs& K, const double*
 template <bool MIXED, bool PLANE, bool COH, bool PAIRS = false>
 __device__ __forceinline__ void cont_prepare_step(const ContRunArgs& K, const Acc<MIXED>& A, int slot, const double (&m)[12], int64_t t,
                                                   int64_t t_abs, int64_t i, bool live) {
+    const bool invalid = !all_finite(m);  // (judged while the twelve values are at hand)
     Rot Rg;
     V3 pos;
     bool special;
     goal_from_m12(m, Rg, pos, K.euler_roundtrip, &special);
     const Goal G = make_goal(A, Rg);
     Reach r;
-    const ThetaTarget T = continuous_target<PLANE, false>(A, pos, G.woff, K.pref_self[slot], K.pref_self_cs[slot], K.pref_self_sn[slot], r);
+    ThetaTarget T = continuous_target<PLANE, false>(A, pos, G.woff, K.pref_self[slot], K.pref_self_cs[slot], K.pref_self_sn[slot], r);
     if (!live) return;
+    // rsik.h "Rows that are not numbers": for the theta phase a step whose search found nothing ("stay"); the joints phase writes no
+    // joints for it and the chain phase steps over it (flag bit 4; the paired layout carries it as the state code)
+    if (RSIK_RARE(invalid)) { T.ok_limits = true; T.found = false; T.code = RSIK_STATE_INVALID_INPUT; }
     // the step's goal for the theta phase: the search's theta, NaN = nothing found, stay (U:252-264 with goal =
     // previous_theta), or the preferred theta of an unreachable pose (U:115-127)
     const double goal = T.ok_limits ? (T.found ? T.theta : __builtin_nan("")) : K.pref_arg[slot];
@@ -222,7 +226,7 @@ __device__ __forceinline__ void cont_prepare_step(const ContRunArgs& K, const Ac
         // issue slots for it, the theta phase (a lone wave per SIMD) has not
         stc_f64<COH>(&K.gw[t * K.n + i], wrap_theta_to_pi(goal));
     }
-    stc_u8<COH>(&K.flags[t * K.n + i], (uint8_t)((T.ok_limits ? 1 : 0) | (T.found ? 2 : 0) | (special ? 8 : 0)));
+    stc_u8<COH>(&K.flags[t * K.n + i], (uint8_t)((T.ok_limits ? 1 : 0) | (T.found ? 2 : 0) | (special ? 8 : 0) | (invalid ? 16 : 0)));
     if (K.state) stc_u8<COH>(&K.state[t_abs * K.n + i], (uint8_t)T.code);
     if (K.reachable) stc_u8<COH>(&K.reachable[t_abs * K.n + i], (T.ok_limits && T.found) ? 1 : 0);
 }
@@ -579,6 +583,7 @@ __device__ __forceinline__ void cont_joints_chunk(const ContRunArgs& K, SharedTa
         const int low = pair_tag_low(p.y, K.epoch);
         flag = low & 15;
         state_code = (low >> 4) & 15;
+        if (RSIK_RARE(state_code == RSIK_STATE_INVALID_INPUT)) flag |= 16;  // (the tag has four flag bits: this one rides on the code)
     } else {
         theta = ldc_f64<COH>(&RSIK_WS(K, tt, ii));
         flag = ldc_u8<COH>(&K.flags[tt * n + ii]);
@@ -603,6 +608,9 @@ __device__ __forceinline__ void cont_joints_chunk(const ContRunArgs& K, SharedTa
     double jv[7];
     bool sing;
     step_joints(A, K, r, G, theta, zeros, jv, sing);
+    // a step without joints: singular (phase 4 recomputes it with previous_sol), or its goal is not numbers (flag bit 4: it stays
+    // without, and phase 4 steps over it — rsik.h "Rows that are not numbers")
+    const bool dead = sing || (flag & 16) != 0;
     // Steps relative to the step before (lane - 8; none for the chunk's first step, which phase 4 judges).  Whole turns
     // only for the four joints whose raw angle has a branch cut to cross — shoulder pitch, elbow yaw, wrist roll, wrist yaw
     // (atan2 values, S:751-786, 815-848 / U:508-519); shoulder roll is atan2(q_y, q_x >= 0), elbow pitch is clamped to
@@ -630,9 +638,9 @@ __device__ __forceinline__ void cont_joints_chunk(const ContRunArgs& K, SharedTa
         else worst_b = __builtin_fmax(worst_b, fabs(x));
     }
     // a singular step (NaN joints, here or in the lane below) is an event too: fmax drops NaNs, so it is told by the flags
-    const unsigned long long sing_mask = __ballot(sing);
+    const unsigned long long sing_mask = __ballot(dead);
     const bool sing_below = sl > 0 && ((sing_mask >> (lane - 8)) & 1ull) != 0;
-    const bool ev = sing || sing_below || !(worst_a <= 0.5 - 1e-9) || !(worst_b <= 1.0 - 1e-9) || !(fabs(packed) < 4.0e9);
+    const bool ev = dead || sing_below || !(worst_a <= 0.5 - 1e-9) || !(worst_b <= 1.0 - 1e-9) || !(fabs(packed) < 4.0e9);
     unsigned word = (unsigned)packed;  // (garbage for a NaN: the chunk is an event then)
 #pragma unroll
     for (int step = 1; step < 8; step *= 2) {  // inclusive prefix sum over the chunk's steps (lane stride 8)
@@ -652,7 +660,7 @@ __device__ __forceinline__ void cont_joints_chunk(const ContRunArgs& K, SharedTa
 #pragma unroll
     for (int k = 0; k < 7; k++) {
         const double o = (k == 0 || k == 2 || k == 4 || k == 6) ? fma(turn[k], kTwoPi, jv[k]) : jv[k];
-        out[k] = sing ? __builtin_nan("") : o;  // (singular: needs previous_sol, phase 4 recomputes the step — flag bit 2)
+        out[k] = dead ? __builtin_nan("") : o;  // (singular: needs previous_sol, phase 4 recomputes the step — flag bit 2)
     }
     if constexpr (PAIRS) {
         if (live) {
@@ -750,7 +758,8 @@ __device__ __forceinline__ void cont_chain_walk(const ContRunArgs& K, SharedTabl
     const unsigned jstride = (unsigned)(n * 7 * sizeof(double)), fstride = (unsigned)n;
     int64_t t_abs = t_abs0;
     auto one = [&](double cur, int f, int64_t t, unsigned jrow) {  // step t of the block; this lane's joint of it at (jbuf, joff, jrow)
-        if (RSIK_RARE((f & 4) != 0 && !emergency)) {  // the same byte in all 8 lanes of the trajectory
+        const bool inv = (f & 16) != 0;  // the goal is not numbers: NaN joints out, the trajectory's state as it was
+        if (RSIK_RARE((f & 4) != 0 && !emergency && !inv)) {  // the same byte in all 8 lanes of the trajectory
             // exact singularity in get_joints: the step is recomputed with the real previous_sol (every lane of the
             // group computes all seven joints and keeps its own)
             double pv[7];
@@ -777,8 +786,8 @@ __device__ __forceinline__ void cont_chain_walk(const ContRunArgs& K, SharedTabl
         const bool disc = !init && (code & 16) != 0;
         const int cause = (code & 7) | (disc ? RSIK_EMERGENCY_CONTINUITY : 0);
         const double accepted = disc ? prev : clamped;
-        const bool trips = cause != 0 && !emergency;
-        const double result = emergency ? prev : accepted;                    // latched (C:205-210): previous_sol
+        const bool trips = cause != 0 && !emergency && !inv;
+        const double result = emergency ? prev : (inv ? __builtin_nan("") : accepted);  // latched (C:205-210): previous_sol
         if (owner) st_row_f64<AUX>(jbuf, joff, jrow, result);
         if (RSIK_RARE(emergency || trips) && live) {
             if (emergency) {
@@ -793,8 +802,8 @@ __device__ __forceinline__ void cont_chain_walk(const ContRunArgs& K, SharedTabl
                 stc_f64<COH>(&K.st[(12 + j) * n + i], clamped);       // the joints that failed the check
             }
         }
-        prev = (emergency || trips) ? prev : accepted;
-        init = emergency ? init : false;
+        prev = (emergency || trips || inv) ? prev : accepted;
+        init = (emergency || inv) ? init : false;
         emergency = emergency || trips;
         t_abs += 1;
     };
@@ -863,6 +872,34 @@ __device__ __forceinline__ void cont_chain_walk(const ContRunArgs& K, SharedTabl
     // faster within a pass either.
     double* const jcol = K.joints + (t_abs0 * n + ii) * 7 + jj;
     const int64_t row_doubles = n * 7;
+    // (the whole turns of a quiet chunk, added to its rows)
+    auto add_turns = [&](int64_t c, double sh) {
+        double* p = jcol + c * kJointChunk * row_doubles;
+        const int len = (int)chunk_len(c);
+        // (written as an instruction: the compiler counts the memory operations a wave has in flight — one counter for
+        // loads, stores and atomics, in issue order — to wait for exactly the loads it needs, and a data-dependent number
+        // of atomics among them would make it wait for everything, the operands just requested for the next batch
+        // included.  Atomics it does not see only prolong a wait where they really are still in flight.)
+#pragma unroll
+        for (int q = 0; q < kJointChunk; q++)
+            if (q < len) asm volatile("global_atomic_add_f64 %0, %1, off" : : "v"(p + q * row_doubles), "v"(sh) : "memory");
+    };
+    // Where the walk stops, the chunk that did not stand for the WAVE may well stand for this lane's trajectory (eight lanes): that
+    // trajectory takes it like any quiet chunk, only the eventful ones go step by step — so what a trajectory gets never depends on
+    // the seven others that happen to share its wave (rsik.h "Rows that are not numbers": neighbours bit for bit).
+    // (judged again from the chunk's operands, fetched again: nothing of this is carried through the walk, whose registers are scarce)
+    auto stands_alone = [&](int64_t c, double& sh, double& last) -> bool {
+        const unsigned r_first = (unsigned)(c * kJointChunk) * jstride;
+        const double first = ld_row_f64<AUX>(jbuf, joff, r_first);
+        last = ld_row_f64<AUX>(jbuf, joff, r_first + (unsigned)(chunk_len(c) - 1) * jstride);
+        const int ev = ld_row_u8<AUX>(ebuf, foff, (unsigned)c * fstride);
+        const double turns = -rint((first - prev) * 0.15915494309189535);
+        sh = turns * kTwoPi;
+        const double f2 = first + sh;
+        const bool quiet = !emergency && !init && ev == 0 && (fabs(f2 - prev) <= thr_short) && (fabs(turns) <= 100.0) &&
+                           (!limited || fabs(f2) <= clear_of_limit);
+        return group_or(quiet ? 0 : 1) == 0;
+    };
     auto walk = [&](const Operands& o, int64_t c0) -> int {
         int stop = BATCH;
 #pragma unroll
@@ -878,17 +915,7 @@ __device__ __forceinline__ void cont_chain_walk(const ContRunArgs& K, SharedTabl
             if (stop == BATCH && !stands) stop = u;
             if (taken) prev = o.last[u] + sh;
             // (a chunk that goes through `one` instead is rewritten there: no turns to add)
-            if (RSIK_RARE(taken && turns != 0.0) && owner) {
-                double* p = jcol + (c0 + u) * kJointChunk * row_doubles;
-                const int len = (int)chunk_len(c0 + u);
-                // (written as an instruction: the compiler counts the memory operations a wave has in flight — one counter for
-                // loads, stores and atomics, in issue order — to wait for exactly the loads it needs, and a data-dependent number
-                // of atomics among them would make it wait for everything, the operands just requested for the next batch
-                // included.  Atomics it does not see only prolong a wait where they really are still in flight.)
-#pragma unroll
-                for (int q = 0; q < kJointChunk; q++)
-                    if (q < len) asm volatile("global_atomic_add_f64 %0, %1, off" : : "v"(p + q * row_doubles), "v"(sh) : "memory");
-            }
+            if (RSIK_RARE(taken && turns != 0.0) && owner) add_turns(c0 + u, sh);
         }
         return stop;
     };
@@ -906,7 +933,13 @@ __device__ __forceinline__ void cont_chain_walk(const ContRunArgs& K, SharedTabl
             const int stop = walk(oa, c0);
             if (RSIK_RARE(c0 + stop < n_chunks && stop < BATCH)) {
                 // an eventful chunk: the reference's own sequence of operations for its steps, then the walk resumes behind it
-                stepwise((c0 + stop) * kJointChunk, chunk_len(c0 + stop));
+                double sh, last_row;
+                if (stands_alone(c0 + stop, sh, last_row)) {
+                    prev = last_row + sh;
+                    if (RSIK_RARE(sh != 0.0) && owner) add_turns(c0 + stop, sh);
+                } else {
+                    stepwise((c0 + stop) * kJointChunk, chunk_len(c0 + stop));
+                }
                 c0 += stop + 1;
                 if (c0 < n_chunks) fetch(oa, c0);
             } else {

@@ -274,6 +274,8 @@ __global__ __launch_bounds__(kBlock, RSIK_SOLVE_MIN_WAVES) void solve_kernel(con
                         (LdsConst)lds_tab.arm[(MIXED != 0 && K.arm[tile0 + tt] != 0) ? 1 : 0], (UnitAtanTab)&lds_tab.utab[0][0]};
     double* lds_wave = lds[wave];
 
+    // rsik.h "Rows that are not numbers": judged here, while the six values are at hand (further down it would keep them all alive)
+    const bool invalid = !all_finite(in);
     const V3 pos = {in[0], in[1], in[2]};
     Goal G;
     if constexpr (TIPZ) {
@@ -286,6 +288,11 @@ __global__ __launch_bounds__(kBlock, RSIK_SOLVE_MIN_WAVES) void solve_kernel(con
     }
     RSIK_MARK("reach_start");
     Reach r = reach_g<false, false>(A, pos, G.woff);
+    if (RSIK_RARE(invalid)) {  // where the reference raises (S:580) or projects an infinity
+        r.ok = false;
+        r.state = RSIK_STATE_INVALID_INPUT;
+        r.i0 = r.i1 = __builtin_nan("");
+    }
     RSIK_MARK("after_reach");
 
     // joints [64,7] and elbow [64,3] of the wave are staged in LDS (row-major, as they go to HBM) by whichever branch

@@ -37,8 +37,13 @@ __global__ __launch_bounds__(kBlock) void reach_state_kernel(const StateArgs K) 
     const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[i] != 0) : false, lds_tab);
     V3 pos = {K.in[0][i], K.in[1][i], K.in[2][i]};
     double e0 = K.in[3][i], e1 = K.in[4][i], e2 = K.in[5][i];
+    const double in6[6] = {pos.x, pos.y, pos.z, e0, e1, e2};
+    const bool invalid = !all_finite(in6);
     Rot Rg = rot_from_euler(e0, e1, e2);
     Reach r = K.no_limits ? reach<true>(A, pos, Rg) : reach<false>(A, pos, Rg);
+    if (RSIK_RARE(invalid)) {  // rsik.h "Rows that are not numbers": the solver object stays as it was
+        r.ok = false; r.state = RSIK_STATE_INVALID_INPUT; r.stage = 0; r.i0 = r.i1 = __builtin_nan("");
+    }
     double* S = K.solver_state + i * RSIK_SOLVER_STATE_STRIDE;
     if (r.stage >= 1) {
         S[0] = r.pos.x; S[1] = r.pos.y; S[2] = r.pos.z; S[3] = e0; S[4] = e1; S[5] = e2;

@@ -131,6 +131,10 @@ class SymbolicIK:
             sv._check(sv.lib.rsik_reach_state(sv._h, 1, io["cols"], None, self.arm_id, 1 if no_limits else 0, io["state"],
                                               None, None, None))
             s = self._finish(io)
+        if int(s[23]) == _abi.STATE_INVALID_INPUT:
+            # include/rsik.h "Rows that are not numbers": the batch API reports the row; the scalar drop-in does what the reference
+            # does with a NaN in the pose (symbolic_ik.py:580, np.linalg.lstsq on a system full of NaN) — the solver object is untouched
+            raise np.linalg.LinAlgError("SVD did not converge in Linear Least Squares")
         return bool(s[22] != 0.0), s[20:22].copy(), int(s[23])
 
     def is_reachable(self, goal_pose: npt.NDArray[np.float64]) -> Tuple[bool, npt.NDArray[np.float64], Optional[Any], str]:

@@ -41,7 +41,7 @@ def test_header_constants_match_python(lib):
                   ("C_PROJ_RADIUS", "RSIK_C_PROJ_RADIUS"), ("C_TIP_Z", "RSIK_C_TIP_Z"), ("C_WRIST_AX", "RSIK_C_WRIST_AX")):
         assert getattr(constants, py) == enum[c]
     states = dict((int(v), k) for k, v in re.findall(r"#define (RSIK_STATE_[A-Z_]+) (\d+)", hdr))
-    assert len(states) == 10 and len(constants.STATE_STRINGS) == 10
+    assert len(states) == 11 and len(constants.STATE_STRINGS) == 11
     assert states[_abi.STATE_EMERGENCY] == "RSIK_STATE_EMERGENCY" and states[_abi.STATE_NOT_REACHABLE_NO_LIMITS] == "RSIK_STATE_NOT_REACHABLE_NO_LIMITS"
     assert int(re.search(r"#define RSIK_SOLVER_STATE_STRIDE (\d+)", hdr).group(1)) == _abi.SOLVER_STATE_STRIDE
     assert lib.rsik_abi_version() == int(re.search(r"#define RSIK_ABI_VERSION (\d+)", hdr).group(1))

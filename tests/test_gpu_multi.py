@@ -46,10 +46,19 @@ def _check_two_rank_line(d, gather):
     assert all(r["pid"] > 0 and r["name"] for r in g["ranks"]) and g["collective_timeout_s"] > 0
     assert m["n1_same_config"]["solves_per_s"] > 0
     eff = m["scaling_efficiency_vs_n1_same_config"]
-    assert eff["kernel_only"] == 1.0 and 0 < eff["end_to_end"] <= 1.0 + 1e-9
+    assert eff["kernel_only"] is None and eff["kernel_only_note"] and 0 < eff["end_to_end"] <= 1.0 + 1e-9
+    # beside `value` at the top level of the line: the efficiency against one GPU on this config, and the north star's job shape
+    # (K sharded steps + ONE all-gather of the final joints) end to end
+    assert d["scaling_efficiency_vs_n1_same_config"] == eff
     if gather != "none":
         assert m["gather_final"]["solves_per_s"] > 0 and m["gather_step"]["solves_per_s"] > 0
         assert m["gather_final"]["ms_for_K_steps_plus_one_gather"] > m["gather_final"]["one_all_gather_ms"] > 0
+        top = d["gather_final"]
+        assert top["solves_per_s"] == m["gather_final"]["solves_per_s"] and 0 < top["efficiency_vs_n1_same_config"] <= 1.0 + 1e-9
+        assert d["cpu_baseline"]["workload_filter"]["rows_the_checker_calls_reachable"] == d["cpu_baseline"]["workload_filter"]["rows"]
+        assert d["cpu_baseline"]["reference_numpy"]["static"] is True
+    else:
+        assert "gather_final" not in d
 
 
 @pytest.mark.parametrize("gather", ["step", "final", "none"])
@@ -66,6 +75,20 @@ def test_bench_two_ranks_gloo_config3_and_config5():
     assert d["n_gpus"] == 2 and d["cpu_baseline"]["parity_on_sample"]["max_abs_joint_error_rad"] < 1e-6
     d = _bench("--gpus", "2", "--backend", "gloo", "--single-device", "--config", "5", "--poses", "256", "--steps", "1", "--warmup", "1")
     assert d["n_gpus"] == 2 and d["unit"] == "steps/s" and d["config"]["collective"] == "none"
+
+
+def test_bench_config5_line_carries_both_protocols():
+    """Config 5 on one GPU: the line's value is the protocol asked for (W warm-up passes, K timed), issued eagerly; `steady_state`
+    holds the same K passes after 60 more untimed ones, in both launch forms; the CPU leg carries the static reference figures."""
+    d = _bench("--config", "5", "--poses", "256", "--steps", "3", "--warmup", "2", "--cpu-seconds", "2")
+    assert d["unit"] == "steps/s" and d["steps"] == 3 and d["warmup"] == 2 and d["launch"].startswith("eager")
+    ss = d["steady_state"]
+    assert ss["launch"] == "eager" and ss["steps"] == 3 and ss["after_untimed_passes"] == 65
+    assert ss["launch_forms_ms"]["eager"] > 0 and ss["launch_forms_ms"]["graph"] > 0 and ss["value"] > 0
+    assert d["cpu_baseline"]["parity_on_sample"]["flags_and_states"] == "bit-exact"
+    assert d["cpu_baseline"]["reference_numpy"]["config5_steps_per_s_per_core"] > 0
+    g = _bench("--config", "5", "--poses", "256", "--steps", "2", "--warmup", "1", "--launch", "graph", "--no-cpu-baseline")
+    assert g["launch"].startswith("K replays") and g["steady_state"]["launch"] == "graph" and g["steady_state"]["launch_forms_ms"]["eager"] > 0
 
 
 def test_bench_rank_without_a_device_fails_the_launcher():

@@ -869,6 +869,40 @@ def test_capture_continuous_trajectories_convenience(torch_mod):
     assert torch_mod.equal(st.view(torch_mod.uint8), st2.view(torch_mod.uint8))
 
 
+def test_capture_continuous_trajectories_takes_host_arguments(torch_mod):
+    """Per-trajectory arguments handed over as host arrays (arm ids, current_joints, current_pose as [n,4,4] numpy) are brought
+    to the device before the capture begins and kept alive on the graph; a wrong `out` buffer or an unknown argument is
+    refused before anything is recorded (and the context stays usable)."""
+    from bench import make_config5_trajectories
+
+    n_traj, n_steps = 130, 40
+    traj = make_config5_trajectories(n_traj, n_steps, seed=5)
+    arm = (np.arange(n_traj) % 2).astype(np.uint8)
+    cj = np.zeros((n_traj, 7))
+    first = traj[0].T.cpu().numpy()
+    pose = np.tile(np.eye(4), (n_traj, 1, 1))
+    pose[:, :3, :3] = first[:, :9].reshape(n_traj, 3, 3)
+    pose[:, :3, 3] = first[:, 9:]
+    eager = make_control()
+    st0 = eager.new_continuous_state("r_arm", n_traj)
+    st = st0.clone()
+    ref = eager.run_continuous_trajectories(torch_mod.as_tensor(arm).cuda(), traj, st, current_joints=cj, current_pose=pose)
+    torch_mod.cuda.synchronize()
+    c = make_control()
+    st2 = st0.clone()
+    with pytest.raises(TypeError):
+        c.capture_continuous_trajectories(arm, traj, st2, no_such_argument=1)
+    with pytest.raises(ValueError):
+        c.capture_continuous_trajectories(arm, traj, st2, out={"joints": torch_mod.empty((1,), device="cuda")})
+    graph, out = c.capture_continuous_trajectories(arm, traj, st2, current_joints=cj, current_pose=pose)
+    assert set(graph.rsik_inputs) == {"arm", "current_joints", "current_pose"}
+    graph.replay()
+    torch_mod.cuda.synchronize()
+    for k in ref:
+        assert torch_mod.equal(ref[k].view(torch_mod.uint8), out[k].view(torch_mod.uint8)), k
+    assert torch_mod.equal(st.view(torch_mod.uint8), st2.view(torch_mod.uint8))
+
+
 def test_two_threads_two_contexts(torch_mod, orc):
     """include/rsik.h: a context is used by one thread at a time; contexts are independent.  Two threads, each with a
     context and a stream of its own, solve different batches concurrently (rsik_solve and the continuous pipeline, whose

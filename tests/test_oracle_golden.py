@@ -497,3 +497,91 @@ def test_continuous_batch_driver_equals_the_step_driver():
                                                     current_joints=cs.previous_sol, current_pose=M[0, k])
             assert np.array_equal(j, res["joints"][i, k]) and ok == bool(res["reachable"][i, k]) and code == res["state"][i, k]
         assert np.array_equal(cs.buf, st[k])
+
+
+# ------------------------------------------------------------------------------------------ goals that are not numbers (G13)
+def test_hostile_goals_symbolic_and_discrete(golden_dir, arms):
+    """G13 (a), (b): a NaN / +-inf in one entry of the pose or of the goal matrix.  The reference raises (LinAlgError / ValueError),
+    does not come back at all (an infinity in the rotation's first column), or — for some infinities and where an early exit fires
+    before the entry is read — answers with numbers derived from it.  The checker's convention (include/rsik.h "Rows that are not
+    numbers") is one code for all of them: RSIK_STATE_INVALID_INPUT, unreachable, NaN outputs; never an exception, never a hang."""
+    g = load(golden_dir, "g13_hostile.npz")
+    ar, al = arms[("r_arm", 0.03)], arms[("l_arm", 0.03)]
+    res = orc.solve_batch(ar, al, g["sym_pos"], g["sym_eul"], arm_id=g["sym_arm"])
+    assert (res["state"] == 10).all() and (res["reachable"] == 0).all()
+    assert np.isnan(res["joints"]).all() and np.isnan(res["interval"]).all()
+    oc, pos, eul = g["sym_outcome"], g["sym_pos"], g["sym_eul"]
+    no_answer = oc != 0
+    assert no_answer.sum() >= 70 and set(oc.tolist()) <= {0, 1, 2, 4}
+    # where the reference does answer: an infinite position (projected onto the reach sphere, S:292-307), or a pose whose position
+    # alone takes an early exit before the poisoned entry is read — never a NaN position, never a bad angle on a pose within reach
+    ret = oc == 0
+    in_reach_base = np.repeat(np.tile(np.array([True, True, False, False]), 2), 18)
+    assert not (ret & np.isnan(pos).any(axis=1)).any()
+    assert not (ret & in_reach_base & ~np.isfinite(eul).all(axis=1)).any()
+    assert set(g["sym_state"][ret].tolist()) <= {1, 2} and (g["sym_reachable"][ret] == 0).all()
+    car, cal = _ctrl_arms()
+    M, doc = g["disc_M"], g["disc_outcome"]
+    rd = orc.control_discrete_batch(car, cal, M, arm_id=g["disc_arm"], nb_search_points=20)
+    assert (rd["state"] == 10).all() and (rd["reachable"] == 0).all() and np.isnan(rd["joints"]).all() and (rd["emergency"] == 0).all()
+    assert (doc == 4).sum() >= 1 and (doc != 0).sum() >= 100   # the hang is on record; most entries have no answer
+    assert not ((doc == 0) & np.isnan(M[:, :3, :]).any(axis=(1, 2))).any()  # a NaN never gets an answer
+    # ... and a clean neighbour is what it is alone
+    clean = np.tile(np.eye(4), (3, 1, 1))
+    clean[:, :3, 3] = [0.4, -0.25, -0.2]
+    mixed = np.concatenate([clean[:1], M[:5], clean[1:]])
+    a_id = np.zeros(len(mixed), dtype=np.uint8)
+    r1 = orc.control_discrete_batch(car, cal, mixed, arm_id=a_id, nb_search_points=20)
+    r0 = orc.control_discrete_batch(car, cal, clean, arm_id=a_id[:3], nb_search_points=20)
+    keep = [0, 6, 7]
+    for k in r0:
+        assert np.array_equal(r1[k][keep], r0[k], equal_nan=True), k
+
+
+def test_hostile_goals_continuous(golden_dir):
+    """G13 (c): a trajectory in which five goals are not numbers; the caller of the reference catches the exception and goes on with
+    the next goal.  The reference's state is untouched by the failed call; the checker reports the step (code 10, NaN joints), keeps
+    previous_sol / init / the latch and lets previous_theta take the step of a search that found nothing — inside the control
+    interval that leaves it where it is, to the rounding of limit_theta_to_interval's own modulo (utils.py:93-97).  Every good step
+    must then agree with the reference: flags and states exact, joints 1e-9, previous_theta 1e-12."""
+    g = load(golden_dir, "g13_hostile.npz")
+    g0 = load(golden_dir, "g0_constants.npz")
+    for arm, y in (("r_arm", -0.2), ("l_arm", 0.2)):
+        a = orc.Arm(arm, -1.01)
+        Ms, OC = g[f"cont_{arm}_M"], g[f"cont_{arm}_outcome"]
+        J, F, S, TH, PS = (g[f"cont_{arm}_{k}"] for k in ("joints", "reachable", "state", "previous_theta", "previous_sol"))
+        cs = orc.ContinuousState(g0[f"{arm}_urdf_previous_theta_init"], g0[f"{arm}_urdf_previous_sol"])
+        pose0 = np.eye(4); pose0[:3, 3] = [0, y, -0.66]
+        assert (OC != 0).sum() == 5 and OC[0] == 0
+        for i in range(len(Ms)):
+            before = (cs.previous_theta, cs.previous_sol.copy())
+            j, ok, st = orc.control_continuous_step(a, cs, Ms[i], timed_out=(i == 0), preferred_theta_arg=-4 * np.pi / 6,
+                                                    preferred_theta_self=g0[f"{arm}_urdf_preferred_theta"], constrained_mode=0,
+                                                    current_joints=cs.previous_sol, current_pose=pose0)
+            if OC[i] != 0:
+                assert st == 10 and not ok and np.isnan(j).all(), (arm, i)
+                assert abs(cs.previous_theta - before[0]) < 1e-15 and np.array_equal(cs.previous_sol, before[1]), (arm, i)
+            else:
+                assert ok == bool(F[i]) and st == S[i], (arm, i)
+                assert np.max(np.abs(j - J[i])) < 1e-9, (arm, i)
+            assert abs(cs.previous_theta - TH[i]) < 1e-12 and np.max(np.abs(cs.previous_sol - PS[i])) < 1e-9, (arm, i)
+        assert not cs.emergency_stop
+
+
+# ------------------------------------------------------------------------------------------ the pin itself
+def test_golden_fixtures_reproduce_from_the_reference():
+    """`oracle/gen_golden.py --check`: the committed fixtures are what the reference, imported from /root/reference, produces today —
+    regenerated into a temporary directory and compared array by array, byte for byte.  Here G1 (the catalogue: SymbolicIK and
+    ControlIK discrete) and G6 (ControlIK continuous trajectories); `--check` without `--only` does all fourteen sets (~6 min).
+    Skipped where the reference is not mounted (the GPU box: it never travels)."""
+    import subprocess
+    import sys
+
+    if not os.path.isdir("/root/reference/src/reachy2_symbolic_ik"):
+        pytest.skip("/root/reference is not mounted here")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    p = subprocess.run([sys.executable, os.path.join(root, "oracle", "gen_golden.py"), "--check", "--only", "g1,g6"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "CHECK g1_catalogue.npz: identical" in p.stdout and "CHECK g6_control_continuous.npz: identical" in p.stdout
