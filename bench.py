@@ -413,6 +413,9 @@ def parse_args(argv):
     ap.add_argument("--poses", type=int, default=0, help="poses per GPU (default: the BASELINE size)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stages", action="store_true",
+                    help="add per-stage device figures for configs 2 and 3 (scripts/stage_timers.py, a child process after the timed "
+                         "region: launch differences with this library, per-wave stamps with a -DRSIK_TIMELINE_PROBE build)")
     ap.add_argument("--no-valu-calibration", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the cold-HBM, sustained-clock and calibration phases (A/B timing)")
     ap.add_argument("--gather", choices=["step", "final", "none"], default="step",
@@ -724,9 +727,10 @@ def main(argv=None, return_line=False):
     # capture through the events the run records) and is replayed K times, same bits (scripts/c5_graph.py).
     # Round 4: issued eagerly the pipeline ties its launches with stream value waits (hipStreamWriteValue32 / WaitValue32, ~4 us an edge
     # against ~11 for an event) and starts each block's theta walk before the previous block's joints fill the chip, which a capture
-    # cannot hold: eager 0.370 against 0.375-0.39 ms replayed, so `auto` issues config 5 eagerly; both forms are timed below
-    # (`steady_state.launch_forms_ms`).
-    use_graph = world == 1 and (args.launch == "graph" or (args.launch == "auto" and cfg != 5 and (args.steps <= 32 or args.steps >= 200)))
+    # cannot hold — 0.41 -> 0.37-0.39 ms eager; the replayed graph is still 1-3 % ahead and steadier (same box, alternating processes,
+    # W = 5 / K = 20: 0.380-0.386 against 0.387-0.391; after 60 more passes 0.363-0.373 against 0.369-0.390), so `auto` replays;
+    # both forms are timed below (`steady_state.launch_forms_ms`).
+    use_graph = world == 1 and (args.launch == "graph" or (args.launch == "auto" and (cfg == 5 or args.steps <= 32 or args.steps >= 200)))
     graph = None
     graph_replays = 1
     if use_graph:
@@ -1064,6 +1068,13 @@ def main(argv=None, return_line=False):
             line["cpu_baseline"] = cpu_baseline(cfg, sample, args.cpu_seconds, gpu=gpu_rows)
         if return_line:
             return line
+        if args.stages and world == 1:
+            import subprocess
+
+            sp = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts", "stage_timers.py")],
+                                capture_output=True, text=True, timeout=900)
+            got = [ln for ln in sp.stdout.splitlines() if ln.startswith("{")]
+            line["stages"] = json.loads(got[-1]) if sp.returncode == 0 and got else {"error": (sp.stderr or sp.stdout)[-600:]}
         if world == 1 and args.config == 0 and not args.no_other_configs:
             line["other_configs"] = other_configs_section(cfg)
         print(json.dumps(line), flush=True)

@@ -338,7 +338,17 @@ int rsik_control_continuous_step(rsik_ctx *ctx, int64_t n, const double *const m
  *                sequence of operations (also: steps whose get_joints hit an exact singularity)
  * A run is cut into blocks of steps: four when it is issued launch by launch, two when it is being captured into a
  * hipGraph (RSIK_OPT_CONT_BLOCK_STEPS overrides); the results do not depend on the cut.
- * The phases of neighbouring blocks overlap on four streams (the caller's and three of the context's).  The workspace
+ * The phases of neighbouring blocks overlap on four streams (the caller's and three of the context's).  Issued launch by
+ * launch the streams are tied by words in device memory (hipStreamWriteValue32 behind the producer, hipStreamWaitValue32
+ * ahead of the consumer: a third of an event's latency) and a block's joints kernel is held until the NEXT block's theta
+ * kernel has started (its lone 276-register waves cannot get onto a chip that a chip-filling kernel holds); while the
+ * caller's stream is capturing, by events, which is all a capture takes.  Two more forms of the same run exist, selectable
+ * with RSIK_OPT_CONT_RUN_MODE and never chosen by the library (same results bit for bit, slower: docs/experiments.md A.1,
+ * A.2): RSIK_CONT_RUN_FUSED, the whole run as ONE self-scheduling launch (persistent workgroups that claim roles, a ticket
+ * queue in dependency order, hand-over through self-validating 16-byte pairs written through the XCDs' L2s), and
+ * RSIK_CONT_RUN_FLAGS, a persistent theta kernel fed by flags beside per-block joints / chain launches.  Their waits are
+ * bounded (three seconds): a run that could not make progress raises a word that the next rsik_sync reports as RSIK_E_HIP.
+ * The workspace
  * (17 bytes per step and trajectory + 1 per 8-step chunk, of up to eight blocks in flight), the side streams and the
  * events belong to the context: they are created by the first call that needs them, or ahead of time by
  * rsik_control_continuous_reserve.  A call can be captured into a hipGraph (the side streams join the capture through
@@ -347,6 +357,7 @@ int rsik_control_continuous_step(rsik_ctx *ctx, int64_t n, const double *const m
  * stays valid after later, larger calls (an outgrown workspace is kept until rsik_destroy).  A solver whose
  * projection_margin is not positive (RSIK_STATE_NOT_REACHABLE_NO_LIMITS possible) is run step by step.  At most 30 Mi
  * trajectories per call.  4096 trajectories x 1000 steps: see DESIGN.md section 4.
+ * A goal that is not numbers: see "Rows that are not numbers" above (the step is reported, the trajectory goes on).
  *   m12_steps        device [n_steps][12][n]: the goal matrices of every step
  *   current_pose_m12_soa / current_joints   used by the first step only (see rsik_control_continuous_step)
  *   first_step_timed_out  non-zero: every trajectory (re)initialises on the first step (the reference's behaviour for

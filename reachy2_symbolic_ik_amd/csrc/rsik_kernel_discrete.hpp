@@ -145,7 +145,7 @@ __global__ __launch_bounds__(kDiscBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR voi
     const int64_t ii = live ? i : (K.n - 1);
 
 #ifdef RSIK_TIMELINE_PROBE
-    uint64_t probe_t[6];
+    uint64_t probe_t[7];  // (6: joints done, safety_checks not yet — the stage timers' extra stamp)
     probe_t[0] = __builtin_amdgcn_s_memrealtime();
 #define RSIK_DISC_PROBE(k) do { __builtin_amdgcn_sched_barrier(0); probe_t[k] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
@@ -290,6 +290,7 @@ __global__ __launch_bounds__(kDiscBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR voi
         c6 = K.prev_cs[slot][2]; s6 = K.prev_sn[slot][2];
     }
     RSIK_MARK("disc_safety");
+    RSIK_DISC_PROBE(6);
     RSIK_DISC_PRIO(0);
     int em = safety_checks(A.utab, jv, c4, s4, c5, s5, c6, s6, prev, K.max_angle, K.cos_max, K.sin_max);
     if (RSIK_RARE(invalid)) {  // no joints, no verdict on them (the reference has raised, C:215 / S:580)
@@ -299,6 +300,11 @@ __global__ __launch_bounds__(kDiscBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR voi
     }
     RSIK_MARK("disc_store");
     RSIK_DISC_PROBE(4);
+#ifdef RSIK_DISC_CLASS_PROBE
+    // diagnostic build only (scripts/probes/disc_sorted_bound.py): the pose's path through the kernel instead of the emergency bits —
+    // 16 the grid search was needed (the preferred-theta shortcut failed), 32 a theta was found, 64 it took the cooperative sweep
+    em = (need ? 16 : 0) | (found ? 32 : 0) | (coop ? 64 : 0);
+#endif
     store_rows<7>(K.joints, wave_base, K.n, lane, &lds_slab[wave][0][0], jv);
     if (live) {
         if (K.reachable) K.reachable[i] = found ? 1 : 0;
@@ -316,7 +322,10 @@ __global__ __launch_bounds__(kDiscBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR voi
         for (int k = 0; k < 6; k++) K.joints[i * 7 + k] = (double)probe_t[k];
         K.joints[i * 7 + 6] = (double)hw;
     }
-    if (live && lane == 1) K.joints[i * 7] = (double)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
+    if (live && lane == 1) {
+        K.joints[i * 7] = (double)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
+        K.joints[i * 7 + 1] = (double)probe_t[6];
+    }
 #endif
 }
 

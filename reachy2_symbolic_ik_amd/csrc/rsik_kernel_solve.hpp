@@ -268,7 +268,10 @@ __global__ __launch_bounds__(kBlock, RSIK_SOLVE_MIN_WAVES) void solve_kernel(con
     stage_tables<(MIXED != 0)>(lds_tab, K.arms);
 #ifdef RSIK_TIMELINE_PROBE
     const uint64_t probe_t1 = __builtin_amdgcn_s_memrealtime();
-    uint64_t probe_mid = 0;
+    uint64_t probe_mid = 0, probe_goal = 0, probe_reach = 0;
+#define RSIK_SOLVE_PROBE(v) do { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define RSIK_SOLVE_PROBE(v) do { } while (0)
 #endif
     const AccK<MIXED> A{(KConst)&((const __attribute__((address_space(4))) SolveArgs*)__builtin_amdgcn_kernarg_segment_ptr())->arms[0].v[0],
                         (LdsConst)lds_tab.arm[(MIXED != 0 && K.arm[tile0 + tt] != 0) ? 1 : 0], (UnitAtanTab)&lds_tab.utab[0][0]};
@@ -287,7 +290,9 @@ __global__ __launch_bounds__(kBlock, RSIK_SOLVE_MIN_WAVES) void solve_kernel(con
         G = make_goal(A, Rg);
     }
     RSIK_MARK("reach_start");
+    RSIK_SOLVE_PROBE(probe_goal);
     Reach r = reach_g<false, false>(A, pos, G.woff);
+    RSIK_SOLVE_PROBE(probe_reach);
     if (RSIK_RARE(invalid)) {  // where the reference raises (S:580) or projects an infinity
         r.ok = false;
         r.state = RSIK_STATE_INVALID_INPUT;
@@ -348,7 +353,7 @@ __global__ __launch_bounds__(kBlock, RSIK_SOLVE_MIN_WAVES) void solve_kernel(con
 #ifdef RSIK_TIMELINE_PROBE
     // diagnostic build only (scripts/timeline_probe.py): lanes 0-2 of every wave overwrite their interval rows with
     // (start, tables staged), (outputs staged, stores issued), (HW_ID, XCC_ID)
-    if (lane < 3 && K.interval && live) {
+    if (lane < 4 && K.interval && live) {
         __builtin_amdgcn_s_waitcnt(0);
         const uint64_t t3 = __builtin_amdgcn_s_memrealtime();
         const uint32_t hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
@@ -356,7 +361,8 @@ __global__ __launch_bounds__(kBlock, RSIK_SOLVE_MIN_WAVES) void solve_kernel(con
         double2 iv;
         if (lane == 0) iv = {(double)probe_t0, (double)probe_t1};
         else if (lane == 1) iv = {(double)probe_mid, (double)t3};
-        else iv = {(double)hw, (double)xcc};
+        else if (lane == 2) iv = {(double)hw, (double)xcc};
+        else iv = {(double)probe_goal, (double)probe_reach};  // (the stage timers' extra stamps: goal vectors done, is_reachable done)
         reinterpret_cast<double2*>(K.interval)[tile0 + t] = iv;
     }
 #endif

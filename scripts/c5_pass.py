@@ -11,6 +11,9 @@ if len(sys.argv) > 1 and sys.argv[1] != "-":
     _abi.use_library(os.path.abspath(sys.argv[1]))
 n, n_steps = 4096, 1000
 traj = bench.make_config5_trajectories(n, n_steps, seed=20250204, device=0)
+if os.environ.get("C5_COHERENT"):  # every trajectory a copy of one of them: all lanes of a wave take the same path (a bound for what
+    # making the waves coherent could win; C5_COHERENT = which trajectory)
+    traj = traj[:, :, int(os.environ["C5_COHERENT"]):int(os.environ["C5_COHERENT"]) + 1].expand(-1, -1, n).contiguous()
 ctrl = bench._quiet(ControlIK, urdf_path=bench.URDF, device=0)
 cont0 = ctrl.new_continuous_state("r_arm", n)
 ctrl._solver.set_option(_abi.OPT_CONT_BLOCK_STEPS, blk)

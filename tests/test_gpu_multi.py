@@ -78,17 +78,18 @@ def test_bench_two_ranks_gloo_config3_and_config5():
 
 
 def test_bench_config5_line_carries_both_protocols():
-    """Config 5 on one GPU: the line's value is the protocol asked for (W warm-up passes, K timed), issued eagerly; `steady_state`
-    holds the same K passes after 60 more untimed ones, in both launch forms; the CPU leg carries the static reference figures."""
+    """Config 5 on one GPU: the line's value is the protocol asked for (W warm-up passes, K timed; one captured pass replayed);
+    `steady_state` holds the same K passes after 60 more untimed ones, in both launch forms; the CPU leg carries the static
+    reference figures."""
     d = _bench("--config", "5", "--poses", "256", "--steps", "3", "--warmup", "2", "--cpu-seconds", "2")
-    assert d["unit"] == "steps/s" and d["steps"] == 3 and d["warmup"] == 2 and d["launch"].startswith("eager")
+    assert d["unit"] == "steps/s" and d["steps"] == 3 and d["warmup"] == 2 and d["launch"].startswith("K replays")
     ss = d["steady_state"]
-    assert ss["launch"] == "eager" and ss["steps"] == 3 and ss["after_untimed_passes"] == 65
+    assert ss["launch"] == "graph" and ss["steps"] == 3 and ss["after_untimed_passes"] == 65
     assert ss["launch_forms_ms"]["eager"] > 0 and ss["launch_forms_ms"]["graph"] > 0 and ss["value"] > 0
     assert d["cpu_baseline"]["parity_on_sample"]["flags_and_states"] == "bit-exact"
     assert d["cpu_baseline"]["reference_numpy"]["config5_steps_per_s_per_core"] > 0
-    g = _bench("--config", "5", "--poses", "256", "--steps", "2", "--warmup", "1", "--launch", "graph", "--no-cpu-baseline")
-    assert g["launch"].startswith("K replays") and g["steady_state"]["launch"] == "graph" and g["steady_state"]["launch_forms_ms"]["eager"] > 0
+    g = _bench("--config", "5", "--poses", "256", "--steps", "2", "--warmup", "1", "--launch", "eager", "--no-cpu-baseline")
+    assert g["launch"].startswith("eager") and g["steady_state"]["launch"] == "eager" and g["steady_state"]["launch_forms_ms"]["graph"] > 0
 
 
 def test_bench_rank_without_a_device_fails_the_launcher():
