@@ -49,7 +49,7 @@ BYTES_PER_STEP_STATE_ROUND_TRIP = 96 + 58 + 2 * 66
 GATHER_BYTES_PER_POSE = 56 + 1  # joints [7] f64 + state u8 (reachable == (state == 0) for rsik_solve)
 URDF = "config_files/reachy2_ik_minimal.urdf"
 SHOULDER_R = np.array([0.0, -0.2, 0.0])
-PROFILE_COUNTERS = os.path.join(ROOT, "profiles", "r03", "counters.json")
+PROFILE_COUNTERS = os.path.join(ROOT, "profiles", "r04", "counters.json")
 
 
 def _quiet(fn, *a, **k):
@@ -344,7 +344,7 @@ def committed_counters(cfg, n, build_id):
         t = doc.get(str(cfg))
         if t and t["poses_per_gpu"] == n and doc.get("build_id") == build_id:
             return t
-        return {"stale": f"profiles/r03/counters.json was collected with another build or size (library {build_id})"}
+        return {"stale": f"profiles/r04/counters.json was collected with another build or size (library {build_id})"}
     except (OSError, ValueError, KeyError):
         return None
 
@@ -413,6 +413,12 @@ def parse_args(argv):
     ap.add_argument("--poses", type=int, default=0, help="poses per GPU (default: the BASELINE size)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--phased-variant", type=int, default=0,
+                    help="config 5: RSIK_OPT_CONT_PHASED_VARIANT for the run (1 = streams tied by events also when issued launch by launch: "
+                         "what the PMC passes of scripts/profile.sh use — a profiler that serialises dispatches deadlocks on a replayed "
+                         "multi-stream graph, and device-word waits are not its business either)")
+    ap.add_argument("--no-steady-state", action="store_true",
+                    help="config 5: skip the second timing after 60 more passes and the other launch form (profiler runs: only the timed form's kernels)")
     ap.add_argument("--stages", action="store_true",
                     help="add per-stage device figures for configs 2 and 3 (scripts/stage_timers.py, a child process after the timed "
                          "region: launch differences with this library, per-wave stamps with a -DRSIK_TIMELINE_PROBE build)")
@@ -671,6 +677,10 @@ def main(argv=None, return_line=False):
         traj = make_config5_trajectories(n_traj, n_steps, seed=20250204 + rank, device=local_rank)
         ctrl = _quiet(ControlIK, urdf_path=URDF, device=local_rank)
         hs = ctrl._solver
+        if args.phased_variant:
+            from reachy2_symbolic_ik_amd import _abi as _A
+
+            hs.set_option(_A.OPT_CONT_PHASED_VARIANT, args.phased_variant)
         cont = ctrl.new_continuous_state("r_arm", n_traj)
         cont0 = cont.clone()
         out = {"joints": torch.empty((n_steps, n_traj, 7), dtype=f64, device=dev),
@@ -769,7 +779,7 @@ def main(argv=None, return_line=False):
     # ---- config 5: the same K passes again after 60 more untimed ones (the clock has settled: the driver's W = 5 protocol above is the
     # headline, this is the steady state), in the form timed above and in the other one (eager <-> one captured pass replayed)
     steady = None
-    if cfg == 5 and world == 1:
+    if cfg == 5 and world == 1 and not args.no_steady_state:
         def timed_passes(fn, w, k):
             for _ in range(w):
                 fn()
@@ -1003,7 +1013,7 @@ def main(argv=None, return_line=False):
         cnt = committed_counters(cfg, n, build_id)
         if cnt and "bytes" in cnt:
             line["roofline"]["traffic"] = cnt["bytes"]
-            line["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) / WRITE_SIZE of this build (profiles/r03/counters.json)"
+            line["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) / WRITE_SIZE of this build (profiles/r04/counters.json)"
             if "bytes_per_pass_by_kernel" in cnt:  # config 5: `traffic` is per control step like `achieved`; the pass by kernel:
                 line["roofline"]["traffic_per_pass_by_kernel"] = cnt["bytes_per_pass_by_kernel"]
         elif cnt and "stale" in cnt:

@@ -222,16 +222,10 @@ int rsik_set_arm(rsik_ctx *ctx, int arm, const double *consts_host, int count);
 /*   RSIK_OPT_CONT_PHASED_VARIANT  phased pipeline issued launch by launch, a bit mask (0 = the default form; results do not depend on it):
  *                              1  its streams tied by hipEvents (as a run recorded into a hipGraph always is) instead of by
  *                                 hipStreamWriteValue32 / hipStreamWaitValue32 on words in device memory
- *                              2  the joints kernel of a block NOT held until the theta kernel of the next block has started
- *                              4  experimental: the theta phase as ONE persistent launch that is resident for the whole run and
- *                                 takes the blocks as their goals arrive (+ a chain kernel of at most 128 registers).  It holds
- *                                 compute resources while it waits for kernels issued behind it on other streams: only for
- *                                 processes whose streams do not outnumber the hardware queues (GPU_MAX_HW_QUEUES, 4 by
- *                                 default) — a wait that runs out (3 s) fails the run, rsik_sync reports it */
+ *                              2  the joints kernel of a block NOT held until the theta kernel of the next block has started */
 #define RSIK_OPT_CONT_PHASED_VARIANT 11
 #define RSIK_PHASED_EDGES_BY_EVENT 1
 #define RSIK_PHASED_NO_THETA_FIRST 2
-#define RSIK_PHASED_THETA_RUN 4
 #define RSIK_OPT_COUNT 12
 int rsik_set_option(rsik_ctx *ctx, int option, int value);
 int rsik_get_option(const rsik_ctx *ctx, int option, int *value);

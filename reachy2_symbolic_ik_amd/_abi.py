@@ -79,7 +79,7 @@ PROTOTYPES = {
 GOAL_POSE6, GOAL_M12 = 0, 1
 OPT_EULER_ROUNDTRIP, OPT_SWEEP_MODE, OPT_NO_TIPZ, OPT_NO_MIRROR, OPT_CONT_RUN_MODE = 0, 1, 2, 3, 4
 OPT_CONT_BLOCK_STEPS, OPT_CONT_LOOKAHEAD, OPT_CONT_PREP_STEPS, OPT_CONT_TRACE, OPT_CONT_CHAIN_LAG, OPT_CONT_JOINT_GROUPS, OPT_CONT_PHASED_VARIANT = 5, 6, 7, 8, 9, 10, 11
-PHASED_EDGES_BY_EVENT, PHASED_NO_THETA_FIRST, PHASED_THETA_RUN = 1, 2, 4
+PHASED_EDGES_BY_EVENT, PHASED_NO_THETA_FIRST = 1, 2
 CONT_RUN_AUTO, CONT_RUN_PHASED, CONT_RUN_STEPS, CONT_RUN_FUSED, CONT_RUN_FLAGS = 0, 1, 2, 3, 4
 EMERGENCY_SHOULDER_PITCH, EMERGENCY_ELBOW_YAW, EMERGENCY_WRIST_YAW, EMERGENCY_CONTINUITY = 1, 2, 4, 8
 EULER_AUTO, EULER_ALWAYS, EULER_NEVER = 0, 1, 2

@@ -406,91 +406,6 @@ __global__ __launch_bounds__(kThetaBlock) __attribute__((amdgpu_waves_per_eu(1, 
                                                                  prev_theta, K.theta_carry + K.n);
 }
 
-// phase 2 as ONE launch for the whole run, resident from its start (rsik_control_continuous_run, launch by launch).  The
-// per-block kernel above wants 276 registers a wave: a SIMD that holds six waves of a chip-filling kernel has none to give, so
-// a theta kernel that becomes ready while a prepare or joints kernel fills the chip gets in only when that kernel drains —
-// measured with in-kernel stamps: theta(b + 1) ran behind joints(b) instead of beside it, a third of a pass, whatever the
-// streams said.  This kernel is launched FIRST (the host holds the prepare kernels until its last workgroup has said it
-// runs), keeps its SIMDs for the whole run and takes the blocks as their goals arrive:
-//   prep_words[b]  reaches `seq` once the prepare kernel of block b has completed (its stream writes it behind the kernel: a
-//                  kernel boundary, the goals are in memory); init_word the same for the (re)initialisation
-//   theta_words[b] written here once the block's thetas are in memory (written through, acknowledged): the host's joints
-//                  stream is held on it (hipStreamWaitValue32; 1.2 us from the store to the kernel's first wave on an idle chip)
-struct ThetaRunArgs {
-    ContRunArgs K;            // ws / gw / T / t0 / first_block / last_block are set per block in the kernel
-    char* ws_base;            // the workspace slots: block b uses slot b % slots
-    size_t slot_bytes;
-    int slots, n_blocks;
-    int64_t block_steps, n_steps;
-    const unsigned* prep_words;
-    const unsigned* init_word;
-    unsigned* theta_words;
-    unsigned* theta_counts;   // per block: workgroups through it (zeroed before the launch)
-    unsigned* alive_word;
-    unsigned* abort_word;
-    unsigned seq;
-};
-__device__ __forceinline__ bool theta_run_wait(const ThetaRunArgs& A, const unsigned* word) {
-    // (one lane polls, bounded: three seconds, then the run's abort word is raised and the kernel goes on with what is there)
-    if (__hip_atomic_load(const_cast<unsigned*>(word), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= A.seq) return true;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    for (;;) {
-        __builtin_amdgcn_s_sleep(8);
-        if (__hip_atomic_load(const_cast<unsigned*>(word), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= A.seq) return true;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) {
-            __hip_atomic_store(A.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            return false;
-        }
-    }
-}
-template <bool MIXED, int KIND>
-__global__ __launch_bounds__(kThetaBlock) __attribute__((amdgpu_waves_per_eu(1, 1))) void cont_theta_run_kernel(const ThetaRunArgs A) {
-    static_assert(!MIXED || KIND == kSnapGeneric, "a mixed launch has an interval per lane");
-    const ContRunArgs& K = A.K;
-    __builtin_amdgcn_s_setprio(3);
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)  // (the last workgroup runs: all of them have been placed)
-        __hip_atomic_store(A.alive_word, A.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    int64_t i = (int64_t)blockIdx.x * kThetaBlock + threadIdx.x;
-    if (i >= K.n) i = K.n - 1;  // (lanes past the end repeat the last trajectory: same values to the same addresses)
-    const int slot = MIXED ? (K.arm[i] != 0 ? 1 : 0) : 0;
-    const double l0 = K.lim[slot][0], l1 = K.lim[slot][1];
-    double prev_theta = 0.0;
-    for (int b = 0; b < A.n_blocks; b++) {
-#ifdef RSIK_PIPE_TIMING
-        const unsigned long long ts0 = __builtin_amdgcn_s_memrealtime();
-#endif
-        if (b == 0) {
-            (void)theta_run_wait(A, A.init_word);
-            prev_theta = ldc_f64<true>(&K.st[0 * K.n + i]);
-        }
-        (void)theta_run_wait(A, A.prep_words + 4 * (size_t)b);
-        asm volatile("" ::: "memory");
-        const int64_t t0 = (int64_t)b * A.block_steps;
-        const int64_t T = (A.n_steps - t0) < A.block_steps ? (A.n_steps - t0) : A.block_steps;
-        double* const ws = reinterpret_cast<double*>(A.ws_base + A.slot_bytes * (size_t)(b % A.slots));
-        double* const gw = ws + (size_t)T * (size_t)K.n;
-#ifdef RSIK_PIPE_TIMING
-        const unsigned long long ts1 = __builtin_amdgcn_s_memrealtime();
-#endif
-        prev_theta = cont_theta_walk<KIND, true, kThetaBatch>(K, i, l0, l1, ws, gw, T, b == 0, prev_theta, K.theta_carry + K.n);
-        // the block's thetas are in memory (written through; this wave's stores acknowledged) — then its count; the last wave to
-        // count tells the host's joints stream
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-        asm volatile("" ::: "memory");
-        if (threadIdx.x == 0) {
-            const unsigned arrived = __hip_atomic_fetch_add(A.theta_counts + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (arrived == gridDim.x - 1) __hip_atomic_store(A.theta_words + 4 * (size_t)b, A.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-#ifdef RSIK_PIPE_TIMING
-        if (K.tmin && threadIdx.x == 0 && (blockIdx.x & 31) == 0 && b < 64) {
-            atomicMin(K.tmin + b * 5 + 1, ts1);
-            atomicMax(K.tmax + b * 5 + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
-            (void)ts0;
-        }
-#endif
-    }
-}
-
 // What get_joints reads of a step (S:697-863), re-derived from the step's goal matrix: the goal vectors and the circle
 // is_reachable (flag bit 0 set) or is_reachable_no_limits (clear; C:371) left on the solver — the same device code the
 // step kernel runs, so the joints are the same to the last bit.  `m`: the step's twelve matrix entries.
@@ -971,20 +886,6 @@ __global__ __launch_bounds__(kChainBlock) __attribute__((amdgpu_waves_per_eu(1, 
     __shared__ SharedTables lds_tab;
         stage_tables<MIXED, (int)offsetof(ContRunArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC)), kChainBlock>(lds_tab, K.arms);
     cont_chain_walk<MIXED, false, kChainBatch>(K, lds_tab, gid >> 3, (int)(gid & 7), 0, K.t0, K.T, K.last_block != 0);
-}
-
-// phase 4 with at most 128 registers a wave (launch by launch, beside the persistent theta launch): the kernel above wants 222 and a
-// SIMD to itself, and — like the per-block theta kernel — only gets onto a chip that a chip-filling kernel holds when that kernel
-// drains (measured: chain(0) started 90 us after joints(0) had ended).  This one fits in beside two or three of a chip-filling
-// kernel's waves, so it starts as soon as a few of those retire.  Eight chunks' operands at a time instead of sixteen.
-template <bool MIXED>
-__global__ __launch_bounds__(kChainBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) void cont_chain_small_kernel(const ContRunArgs K) {
-    RSIK_PIPE_STAMP(K, 3);
-    __builtin_amdgcn_s_setprio(2);
-    const int64_t gid = (int64_t)blockIdx.x * kChainBlock + threadIdx.x;
-    __shared__ SharedTables lds_tab;
-    stage_tables<MIXED, (int)offsetof(ContRunArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC)), kChainBlock>(lds_tab, K.arms);
-    cont_chain_walk<MIXED, false, 8>(K, lds_tab, gid >> 3, (int)(gid & 7), 0, K.t0, K.T, K.last_block != 0);
 }
 
 }  // namespace rsik

@@ -183,7 +183,7 @@ int rsik_set_arm(rsik_ctx* ctx, int arm, const double* consts_host, int count) {
 int rsik_set_option(rsik_ctx* ctx, int option, int value) {
     if (!ctx) return RSIK_E_INVALID;
     if (option < 0 || option >= RSIK_OPT_COUNT) return fail(ctx, RSIK_E_INVALID, "rsik_set_option: unknown option");
-    static const int max_value[RSIK_OPT_COUNT] = {RSIK_EULER_NEVER, 2, 1, 1, RSIK_CONT_RUN_FLAGS, 65535, 64, 64, 1024, 64, 8, 7};
+    static const int max_value[RSIK_OPT_COUNT] = {RSIK_EULER_NEVER, 2, 1, 1, RSIK_CONT_RUN_FLAGS, 65535, 64, 64, 1024, 64, 8, 3};
     if (value < 0 || value > max_value[option]) return fail(ctx, RSIK_E_INVALID, "rsik_set_option: value out of range");
     ctx->options[option] = value;
     return RSIK_OK;
@@ -1053,34 +1053,19 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     // the trajectory state: its stream forks off BEFORE the initialisation (behind whatever the caller queued ahead of
     // this call), so prepare(0) runs beside it and theta(0) starts when both are done; the joints and chain streams fork
     // behind it.
-    // Launch by launch the theta phase is ONE persistent launch (cont_theta_run_kernel), issued first and resident for the
-    // whole run: the prepare kernels are held until its last workgroup has said that it runs.
-    const bool theta_run = by_value && (variant & RSIK_PHASED_THETA_RUN) != 0;
-    unsigned* const run_words = by_value ? ctx->edge_words + P.n_events + (size_t)n_blocks : nullptr;  // [n_blocks] counts, then alive, abort
     RSIK_HIP(ctx, signal(s_main, 1));
     RSIK_HIP(ctx, wait_for(s_prep, 1));
-    if (theta_run) {
-        RSIK_HIP(ctx, hipMemsetAsync(run_words, 0, ((size_t)n_blocks + 8) * sizeof(unsigned), s_main));
-        RSIK_HIP(ctx, wait_for(s_chain, 1));
-    }
     {
         // two lanes per trajectory where get_joints cannot move the solver's state (no elbow projection possible)
-        // (with the persistent theta launch on the caller's stream, the (re)initialisation goes to the chain stream: ahead of
-        // the chain launches, which need it, and beside everything else)
-        hipStream_t s_init = theta_run ? s_chain : s_main;
         const bool pair = !singularity_plane_binds(K0.arms);
         dim3 grid_init = grid;
         if (pair && (rc = launch_dims(ctx, n * 2, &grid_init, who)) != RSIK_OK) return rc;
-        if (arm) { if (pair) hipLaunchKernelGGL((rsik::cont_init_kernel<true, true>), grid_init, block, 0, s_init, K0); else hipLaunchKernelGGL((rsik::cont_init_kernel<true, false>), grid_init, block, 0, s_init, K0); }
-        else { if (pair) hipLaunchKernelGGL((rsik::cont_init_kernel<false, true>), grid_init, block, 0, s_init, K0); else hipLaunchKernelGGL((rsik::cont_init_kernel<false, false>), grid_init, block, 0, s_init, K0); }
-        RSIK_HIP(ctx, signal(s_init, 0));
+        if (arm) { if (pair) hipLaunchKernelGGL((rsik::cont_init_kernel<true, true>), grid_init, block, 0, s_main, K0); else hipLaunchKernelGGL((rsik::cont_init_kernel<true, false>), grid_init, block, 0, s_main, K0); }
+        else { if (pair) hipLaunchKernelGGL((rsik::cont_init_kernel<false, true>), grid_init, block, 0, s_main, K0); else hipLaunchKernelGGL((rsik::cont_init_kernel<false, false>), grid_init, block, 0, s_main, K0); }
+        RSIK_HIP(ctx, signal(s_main, 0));
     }
-    if (theta_run) {
-        RSIK_HIP(ctx, wait_for(s_joints, 1));
-    } else {
-        RSIK_HIP(ctx, wait_for(s_joints, 0));
-        RSIK_HIP(ctx, wait_for(s_chain, 0));
-    }
+    RSIK_HIP(ctx, wait_for(s_joints, 0));
+    RSIK_HIP(ctx, wait_for(s_chain, 0));
     rsik::ContRunArgs R;
     std::memset(&R, 0, sizeof R);
     R.n = n;
@@ -1114,32 +1099,6 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
 #ifdef RSIK_PIPE_TIMING
     R.tmin = pipe_t; R.tmax = pipe_t ? pipe_t + 320 : nullptr;
 #endif
-    if (theta_run) {
-        rsik::ThetaRunArgs TA;
-        std::memset(&TA, 0, sizeof TA);
-        TA.K = R;
-        TA.ws_base = static_cast<char*>(ctx->ws);
-        TA.slot_bytes = slot_bytes;
-        TA.slots = slots;
-        TA.n_blocks = (int)n_blocks;
-        TA.block_steps = P.T;
-        TA.n_steps = n_steps;
-        TA.prep_words = ctx->edge_words + edge_id(0, 0);
-        TA.theta_words = ctx->edge_words + edge_id(1, 0);
-        TA.init_word = ctx->edge_words + 0;
-        TA.theta_counts = run_words;
-        TA.alive_word = run_words + n_blocks;
-        TA.abort_word = run_words + n_blocks + 1;
-        TA.seq = seq;
-        const dim3 grid_t((unsigned)((n + rsik::kThetaBlock - 1) / rsik::kThetaBlock)), block_t(rsik::kThetaBlock);
-        if (arm) hipLaunchKernelGGL((rsik::cont_theta_run_kernel<true, rsik::kSnapGeneric>), grid_t, block_t, 0, s_main, TA);
-        else if (snap_kind == rsik::kSnapInner) hipLaunchKernelGGL((rsik::cont_theta_run_kernel<false, rsik::kSnapInner>), grid_t, block_t, 0, s_main, TA);
-        else if (snap_kind == rsik::kSnapWrap) hipLaunchKernelGGL((rsik::cont_theta_run_kernel<false, rsik::kSnapWrap>), grid_t, block_t, 0, s_main, TA);
-        else hipLaunchKernelGGL((rsik::cont_theta_run_kernel<false, rsik::kSnapGeneric>), grid_t, block_t, 0, s_main, TA);
-        // the prepare kernels only once every theta wave has its SIMD
-        RSIK_HIP(ctx, hipStreamWaitValue32(s_prep, run_words + n_blocks, seq, hipStreamWaitValueGte, 0xffffffffu));
-        ctx->fused_sync = run_words + n_blocks + 1;
-    }
     auto set_block = [&](int64_t b) {
 #ifdef RSIK_PIPE_TIMING
         R.tslot = (int)(b < 64 ? b : 63);
@@ -1164,7 +1123,6 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         return RSIK_OK;
     };
     auto issue_theta = [&](int64_t b) -> int {
-        if (theta_run) return RSIK_OK;  // (the persistent launch takes the blocks as their goals arrive)
         set_block(b);
         // (launch by launch: the kernel says when it has started — the joints kernel of the block before is held until then)
         R.started_word = by_value ? ctx->edge_words + P.n_events + (size_t)b : nullptr;
@@ -1187,13 +1145,13 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         // chip-filling kernel has none to give — so a theta kernel that becomes ready together with a joints kernel and loses the
         // race for the chip only gets in when that kernel drains: theta(b + 1) ran behind joints(b), not beside it (measured with
         // in-kernel stamps: a third of a pass).  Let in first, it has its SIMDs before the chip fills up.
-        // (measured and not kept, beside the persistent theta launch: the first joints kernel held until the last prepare kernel has
+        // (measured and not kept — with the theta phase as one persistent launch, docs/experiments.md A.4: the first joints kernel held until the last prepare kernel has
         // completed, so that the prepare kernels — which every later phase of a block waits for — have the chip to themselves:
         // 0.424 against 0.371 ms per pass, the joints kernels then run one behind the other with a stream operation's ~15 us
         // between them; higher stream priority for the prepare and chain streams: no difference)
         // (only where theta(b + 1) has been ISSUED before this wait: streams can share a hardware queue, and a wait that sat in one
         // ahead of the launch it waits for would wait for ever — true for the blocks that have workspace slots of their own)
-        if (by_value && !theta_run && !(variant & RSIK_PHASED_NO_THETA_FIRST) && b + 1 < head)
+        if (by_value && !(variant & RSIK_PHASED_NO_THETA_FIRST) && b + 1 < head)
             RSIK_HIP(ctx, hipStreamWaitValue32(s_joints, ctx->edge_words + P.n_events + (size_t)(b + 1), seq, hipStreamWaitValueGte, 0xffffffffu));
         else
             RSIK_HIP(ctx, wait_for(s_joints, edge_id(1, b)));
@@ -1201,13 +1159,8 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         else hipLaunchKernelGGL(rsik::cont_joints_kernel<false>, grid2, block, 0, s_joints, R);
         RSIK_HIP(ctx, signal(s_joints, edge_id(2, b)));
         RSIK_HIP(ctx, wait_for(s_chain, edge_id(2, b)));
-        if (theta_run) {  // (beside chip-filling kernels all the time: the form that gets in)
-            if (arm) hipLaunchKernelGGL(rsik::cont_chain_small_kernel<true>, grid8, dim3(rsik::kChainBlock), 0, s_chain, R);
-            else hipLaunchKernelGGL(rsik::cont_chain_small_kernel<false>, grid8, dim3(rsik::kChainBlock), 0, s_chain, R);
-        } else {
-            if (arm) hipLaunchKernelGGL(rsik::cont_chain_kernel<true>, grid8, dim3(rsik::kChainBlock), 0, s_chain, R);
-            else hipLaunchKernelGGL(rsik::cont_chain_kernel<false>, grid8, dim3(rsik::kChainBlock), 0, s_chain, R);
-        }
+        if (arm) hipLaunchKernelGGL(rsik::cont_chain_kernel<true>, grid8, dim3(rsik::kChainBlock), 0, s_chain, R);
+        else hipLaunchKernelGGL(rsik::cont_chain_kernel<false>, grid8, dim3(rsik::kChainBlock), 0, s_chain, R);
         RSIK_HIP(ctx, signal(s_chain, edge_id(3, b)));
         return RSIK_OK;
     };

@@ -1,12 +1,14 @@
 #!/bin/bash
 # GPU box: everything profiles/<round>/ holds besides the profile.sh collections, for the tree as it is.
-# usage: scripts/final_evidence.sh <tag>   -> gpurun_out/<tag>/...
+# usage: scripts/final_evidence.sh <tag> [a|b|ab]   -> gpurun_out/<tag>/...   (two parts: a call on the GPU box is limited to 20 minutes)
 set -u
 TAG=${1:-final}
+PART=${2:-ab}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
+if [[ $PART == *a* ]]; then
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_driver_flags.json 2> $OUT/bench_driver_flags.err || exit 1
 (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/drv_trace -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --no-other-configs > $OUT/drv_trace.log 2>&1) || exit 1
 cp $(find $OUT/drv_trace -name '*kernel_stats.csv' | head -1) $OUT/driver_flags_all_launches_kernel_stats.csv
@@ -34,3 +36,16 @@ python3 scripts/scalar_latency.py > $OUT/scalar_latency.txt 2>&1 || exit 1
 python3 scripts/soak_parity.py 1048576 2 > $OUT/soak_parity.txt 2>&1 || exit 1
 [ -x build/issue_probe ] && timeout -k 5 120 ./build/issue_probe > $OUT/issue_probe.txt 2>&1
 tail -3 $OUT/c5_block_sweep.txt; tail -3 $OUT/c5_graph.txt; tail -4 $OUT/scalar_latency.txt; tail -2 $OUT/soak_parity.txt
+fi
+if [[ $PART == *b* ]]; then
+# round 4: the stage timers, what an edge between streams costs, the other forms of the continuous run (bits, time, work-item trace),
+# the pass without a profiler (in-kernel stamps), the bounds, eager against replayed at the driver's protocol
+timeout -k 10 400 python3 scripts/stage_timers.py --no-build > $OUT/stage_timers.json 2> $OUT/stage_timers.err
+[ -x build/edge_probe ] && timeout -k 5 120 ./build/edge_probe > $OUT/edge_probe.txt 2>&1
+timeout -k 10 300 python3 scripts/fused_check.py 4096 1000 20 > $OUT/c5_forms_bits_time_trace.txt 2>&1
+[ -f build/variants/pipe_timing.so ] && timeout -k 10 300 python3 scripts/probes/c5_untraced_timeline.py build/variants/pipe_timing.so > $OUT/c5_untraced_timeline.txt 2>&1
+[ -f build/variants/disc_class.so ] && timeout -k 10 300 python3 scripts/probes/disc_sorted_bound.py --no-build > $OUT/disc_sorted_bound.txt 2>&1
+timeout -k 10 400 bash scripts/probes/c5_forms.sh > $OUT/c5_eager_vs_replayed_driver_protocol.txt 2>&1
+timeout -k 10 300 bash scripts/probes/c3_forms.sh > $OUT/c3_eager_vs_replayed_driver_protocol.txt 2>&1
+tail -4 $OUT/edge_probe.txt; tail -3 $OUT/c5_eager_vs_replayed_driver_protocol.txt
+fi

@@ -1,6 +1,6 @@
 #!/bin/bash
 # config-5 passes of the phased pipeline, issued launch by launch, for several block sizes; VARIANT = RSIK_OPT_CONT_PHASED_VARIANT bits
-# (1 edges by event, 2 no theta-first, 4 persistent theta launch)
+# (1 edges by event, 2 no theta-first)
 for blk in "$@"; do
   echo "== block steps $blk  (variant: ${VARIANT:-0})"
   timeout -k 10 200 python - "$blk" <<'PY'

@@ -179,7 +179,7 @@ def test_continuous_run_goals_that_are_not_numbers(torch_mod, orc, n_traj, n_ste
     st0 = c.new_continuous_state("r_arm", n_traj)
     keep = _rows_except(torch, n_traj, sorted(cases))
     forms = [("steps", A.CONT_RUN_STEPS, 0, 0), ("phased", A.CONT_RUN_PHASED, 0, 0), ("phased/events", A.CONT_RUN_PHASED, 0, A.PHASED_EDGES_BY_EVENT),
-             ("phased/blocks of 24", A.CONT_RUN_PHASED, 24, 0), ("phased/theta run", A.CONT_RUN_PHASED, 40, A.PHASED_THETA_RUN),
+             ("phased/blocks of 24", A.CONT_RUN_PHASED, 24, 0), ("phased/no theta-first", A.CONT_RUN_PHASED, 40, A.PHASED_NO_THETA_FIRST),
              ("single launch", A.CONT_RUN_FUSED, 16, 0), ("flags", A.CONT_RUN_FLAGS, 16, 0)]
     results = {}
     try:

@@ -1201,7 +1201,7 @@ def _eventful_trajectories(torch, n_traj, n_steps, seed, arm):
                                                          (4099, 40, "r_arm", "unconstrained", 0.01)])
 def test_continuous_run_forms_are_bit_identical(torch_mod, n_traj, n_steps, arm, mode, dmax):
     """rsik_control_continuous_run has several forms of issuing the same four bodies (include/rsik.h: the phased pipeline, its
-    variants — events instead of stream value words, no theta-first hold, the persistent theta launch —, the single
+    variants — events instead of stream value words, no theta-first hold, other block sizes —, the single
     self-scheduling launch, the flag-synchronised form).  They run the same device code on the same data: every output and
     the carried state must be the same BITS, on eventful trajectories (jumps, wound wrists, unreachable stretches, repeats)
     that take the sequential phases through their rare paths; the step kernel, launch per step, bounds them all (_same_run)."""
@@ -1210,8 +1210,8 @@ def test_continuous_run_forms_are_bit_identical(torch_mod, n_traj, n_steps, arm,
     c = make_control()
     hs = c._solver
     forms = [("steps", A.CONT_RUN_STEPS, 0, 0), ("phased", A.CONT_RUN_PHASED, 0, 0), ("phased, events", A.CONT_RUN_PHASED, A.PHASED_EDGES_BY_EVENT, 0),
-             ("phased, no theta-first", A.CONT_RUN_PHASED, A.PHASED_NO_THETA_FIRST, 0), ("phased, persistent theta", A.CONT_RUN_PHASED, A.PHASED_THETA_RUN, 0),
-             ("phased, persistent theta, blocks of 48", A.CONT_RUN_PHASED, A.PHASED_THETA_RUN, 48), ("fused", A.CONT_RUN_FUSED, 0, 0),
+             ("phased, no theta-first", A.CONT_RUN_PHASED, A.PHASED_NO_THETA_FIRST, 0), ("phased, events, no theta-first, blocks of 48", A.CONT_RUN_PHASED, 3, 48),
+             ("phased, blocks of 48", A.CONT_RUN_PHASED, 0, 48), ("fused", A.CONT_RUN_FUSED, 0, 0),
              ("fused, blocks of 24", A.CONT_RUN_FUSED, 0, 24), ("flags", A.CONT_RUN_FLAGS, 0, 0), ("flags, blocks of 40", A.CONT_RUN_FLAGS, 0, 40)]
     got = {}
     for name, run_mode, variant, blk in forms:
