@@ -466,9 +466,13 @@ __device__ __forceinline__ void step_joints(const Acc& A, const ContRunArgs& K, 
 // cross compute units while the kernel runs).
 // STAGE: the workgroup's tables are staged here, behind the chunk's loads (their latency overlaps the staging's round trip).
 template <bool MIXED, bool COH, bool STAGE = false, bool PAIRS = false>
-__device__ __forceinline__ void cont_joints_chunk(const ContRunArgs& K, SharedTables& lds_tab, double* lw, int64_t grp, int64_t c) {
+__device__ __forceinline__ void cont_joints_chunk(const ContRunArgs& K, SharedTables& lds_tab, double* lw, int64_t grp_in, int64_t c) {
     static_assert(kJointChunk == 8, "lane = 8 * step + trajectory");
     constexpr int AUX = COH ? 16 : 0;
+    // the group is the same for the whole wave, but derived from threadIdx (a vector register): said so, or the buffer descriptor of
+    // the rows written below sits in vector registers and each of its seven stores becomes a loop over "the lanes that agree"
+    // (4 v_readfirstlane + 2 compares + mask juggling: ~70 instructions a wave-step, 7 % of this phase).  (< 2^31 groups: n <= 30 Mi)
+    const int64_t grp = (int64_t)__builtin_amdgcn_readfirstlane((int)grp_in);
     const int lane = threadIdx.x & 63;
     const int tl = lane & 7, sl = lane >> 3;
     const int64_t n = K.n;
@@ -573,9 +577,10 @@ __device__ __forceinline__ void cont_joints_chunk(const ContRunArgs& K, SharedTa
     }
     double out[7];
 #pragma unroll
-    for (int k = 0; k < 7; k++) {
-        const double o = (k == 0 || k == 2 || k == 4 || k == 6) ? fma(turn[k], kTwoPi, jv[k]) : jv[k];
-        out[k] = dead ? __builtin_nan("") : o;  // (singular: needs previous_sol, phase 4 recomputes the step — flag bit 2)
+    for (int k = 0; k < 7; k++) out[k] = (k == 0 || k == 2 || k == 4 || k == 6) ? fma(turn[k], kTwoPi, jv[k]) : jv[k];
+    if (RSIK_RARE(sing_mask != 0)) {  // (wave-uniform: no wave of an ordinary run has such a step, and fourteen selects are 2 % of this phase)
+#pragma unroll
+        for (int k = 0; k < 7; k++) out[k] = dead ? __builtin_nan("") : out[k];  // (singular: needs previous_sol, phase 4 recomputes the step — flag bit 2)
     }
     if constexpr (PAIRS) {
         if (live) {
@@ -599,11 +604,13 @@ __device__ __forceinline__ void cont_joints_chunk(const ContRunArgs& K, SharedTa
     const int steps_left = (int)((K.T - c * kJointChunk) < kJointChunk ? (K.T - c * kJointChunk) : kJointChunk);
     const __amdgpu_buffer_rsrc_t obuf = row_buffer(K.joints + ((K.t0 + c * kJointChunk) * n + grp * 8) * 7);
     const unsigned row_bytes = (unsigned)(n * 7 * sizeof(double));
+    // one store per step: its 8 x 7 doubles are consecutive in the slab (lane = 8 step + trajectory) and in memory, so lane l < 56
+    // takes element l of every row — the slab offset is a constant per store, the memory offset a scalar: no address arithmetic per
+    // store (seven 64-lane stores across the row boundaries cost an integer division by 56 and two compares each: ~50 instructions)
+    if (lane < traj_left * 7) {
 #pragma unroll
-    for (int k = 0; k < 7; k++) {
-        const int idx = k * 64 + lane;
-        const int s_ = idx / 56, off = idx - s_ * 56;
-        if (s_ < steps_left && off < traj_left * 7) st_row_f64<AUX>(obuf, (unsigned)s_ * row_bytes + (unsigned)off * 8u, 0, lw[idx]);
+        for (int s_ = 0; s_ < kJointChunk; s_++)
+            if (s_ < steps_left) st_row_f64<AUX>(obuf, (unsigned)lane * 8u, (unsigned)s_ * row_bytes, lw[s_ * 56 + lane]);
     }
     __builtin_amdgcn_wave_barrier();  // (the wave's slab is free again)
 }
