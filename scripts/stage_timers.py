@@ -134,7 +134,9 @@ def main():
         subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "build_variant.py"), "probe_timeline", "-DRSIK_TIMELINE_PROBE"],
                        check=True, stdout=subprocess.DEVNULL)
     out = {"launches_config2": launches()}
-    if os.path.exists(probe):
+    if os.path.exists(probe) and stale(probe):
+        out["waves"] = {"error": "the probe build is not of this tree's sources (rebuild: scripts/build_variant.py probe_timeline -DRSIK_TIMELINE_PROBE)"}
+    elif os.path.exists(probe):
         p = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}, probe], capture_output=True, text=True, timeout=600)
         line = [ln for ln in p.stdout.splitlines() if ln.startswith("STAGES ")]
         if p.returncode != 0 or not line:

@@ -92,6 +92,20 @@ def test_bench_config5_line_carries_both_protocols():
     assert g["launch"].startswith("eager") and g["steady_state"]["launch"] == "eager" and g["steady_state"]["launch_forms_ms"]["graph"] > 0
 
 
+def test_stage_timers_script():
+    """SURVEY f-4: `scripts/stage_timers.py` (what `bench.py --stages` embeds) — the launch-difference figures of config 2 with the
+    product library, and, where a current -DRSIK_TIMELINE_PROBE build travels with the tree, the per-wave stage times of configs 2 / 3."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "stage_timers.py"), "--no-build"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    k = d["launches_config2"]["kernel_us"]
+    assert 0 < k["reach_only"] <= k["reach_and_interval"] * 1.1 and k["reach_and_interval"] < k["full_solve"]
+    w = d["waves"]
+    if "error" not in w:
+        assert w["config2"]["stages"] == ["head", "goal", "reach", "joints", "stores"] and min(w["config2"]["mean_us"]) > 0
+        assert w["config3"]["stages"] == ["head", "reach", "search", "joints", "safety", "stores"] and min(w["config3"]["mean_us"]) > 0
+
+
 def test_bench_rank_without_a_device_fails_the_launcher():
     """`--gpus 2` on a box with one GPU and no --single-device: rank 1 has no device of its own and fails; the launcher stops
     the other rank, exits non-zero and shows the failing rank's stderr (never a silent hang, never a shared device: ranks
