@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define RSIK_ABI_VERSION 5
+#define RSIK_ABI_VERSION 6
 
 /* ---- status codes ---- */
 #define RSIK_OK 0
@@ -169,6 +169,7 @@ int rsik_destroy(rsik_ctx *ctx);
 const char *rsik_last_error(const rsik_ctx *ctx);
 /* Use the caller's hipStream_t (e.g. torch's current stream) for all launches; NULL = default stream. */
 int rsik_set_stream(rsik_ctx *ctx, void *hip_stream);
+/* Waits for the context's stream; also frees the workspaces that continuous runs have outgrown since the last call. */
 int rsik_sync(rsik_ctx *ctx);
 /* Uploads one arm's constant block (host pointer).  Replaces SymbolicIK.__init__ (symbolic_ik.py:26-83). */
 int rsik_set_arm(rsik_ctx *ctx, int arm, const double *consts_host, int count);
@@ -193,8 +194,7 @@ int rsik_set_arm(rsik_ctx *ctx, int arm, const double *consts_host, int count);
  *   RSIK_OPT_NO_MIRROR      non-zero: mixed r/l launches read every constant per lane (no mirror-image shortcut)
  *   RSIK_OPT_CONT_RUN_MODE  rsik_control_continuous_run: 0 = chosen by the library, 1 = the phased trajectory pipeline
  *                           (kernels per block of steps on four streams), 2 = one launch of the step kernel per control
- *                           step, exactly what n_steps calls of rsik_control_continuous_step issue, 3 = the single
- *                           self-scheduling launch (see there; RSIK_E_INVALID if the run does not qualify) */
+ *                           step, exactly what n_steps calls of rsik_control_continuous_step issue */
 #define RSIK_OPT_SWEEP_MODE 1
 #define RSIK_OPT_NO_TIPZ 2
 #define RSIK_OPT_NO_MIRROR 3
@@ -202,31 +202,18 @@ int rsik_set_arm(rsik_ctx *ctx, int arm, const double *consts_host, int count);
 #define RSIK_CONT_RUN_AUTO 0
 #define RSIK_CONT_RUN_PHASED 1
 #define RSIK_CONT_RUN_STEPS 2
-#define RSIK_CONT_RUN_FUSED 3
-#define RSIK_CONT_RUN_FLAGS 4
 /* Tuning of rsik_control_continuous_run (results do not depend on it):
- *   RSIK_OPT_CONT_BLOCK_STEPS  control steps per block: 0 (default) = a quarter of the run, at least 64 (phased pipeline) /
- *                              64 (single launch); n > 0 = n (rounded up to the sequential phases' batch of steps)
- *   RSIK_OPT_CONT_LOOKAHEAD    single launch: blocks the prepare items are handed out ahead of the joints items (0 = default)
- *   RSIK_OPT_CONT_PREP_STEPS   single launch: control steps per prepare item (0 = default; a divisor of the block)
- *   RSIK_OPT_CONT_CHAIN_LAG    single launch: blocks the chain items are handed out behind the joints items (0 = default)
- *   RSIK_OPT_CONT_JOINT_GROUPS single launch: sub-groups of eight trajectories per joints item (0 = default; 1, 2, 4 or 8)
- *   RSIK_OPT_CONT_TRACE        single launch, diagnostic: non-zero = keep a record (start, ready, end, what, where) of up to
- *                              that many thousand work items per run for rsik_control_continuous_trace */
+ *   RSIK_OPT_CONT_BLOCK_STEPS  control steps per block: 0 (default) = a quarter of the run, at least 64; n > 0 = n (rounded up
+ *                              to the sequential phases' batch of steps) */
 #define RSIK_OPT_CONT_BLOCK_STEPS 5
-#define RSIK_OPT_CONT_LOOKAHEAD 6
-#define RSIK_OPT_CONT_PREP_STEPS 7
-#define RSIK_OPT_CONT_TRACE 8
-#define RSIK_OPT_CONT_CHAIN_LAG 9
-#define RSIK_OPT_CONT_JOINT_GROUPS 10
 /*   RSIK_OPT_CONT_PHASED_VARIANT  phased pipeline issued launch by launch, a bit mask (0 = the default form; results do not depend on it):
  *                              1  its streams tied by hipEvents (as a run recorded into a hipGraph always is) instead of by
  *                                 hipStreamWriteValue32 / hipStreamWaitValue32 on words in device memory
  *                              2  the joints kernel of a block NOT held until the theta kernel of the next block has started */
-#define RSIK_OPT_CONT_PHASED_VARIANT 11
+#define RSIK_OPT_CONT_PHASED_VARIANT 6
 #define RSIK_PHASED_EDGES_BY_EVENT 1
 #define RSIK_PHASED_NO_THETA_FIRST 2
-#define RSIK_OPT_COUNT 12
+#define RSIK_OPT_COUNT 7
 int rsik_set_option(rsik_ctx *ctx, int option, int value);
 int rsik_get_option(const rsik_ctx *ctx, int option, int *value);
 
@@ -336,19 +323,16 @@ int rsik_control_continuous_step(rsik_ctx *ctx, int64_t n, const double *const m
  * launch the streams are tied by words in device memory (hipStreamWriteValue32 behind the producer, hipStreamWaitValue32
  * ahead of the consumer: a third of an event's latency) and a block's joints kernel is held until the NEXT block's theta
  * kernel has started (its lone 276-register waves cannot get onto a chip that a chip-filling kernel holds); while the
- * caller's stream is capturing, by events, which is all a capture takes.  Two more forms of the same run exist, selectable
- * with RSIK_OPT_CONT_RUN_MODE and never chosen by the library (same results bit for bit, slower: docs/experiments.md A.1,
- * A.2): RSIK_CONT_RUN_FUSED, the whole run as ONE self-scheduling launch (persistent workgroups that claim roles, a ticket
- * queue in dependency order, hand-over through self-validating 16-byte pairs written through the XCDs' L2s), and
- * RSIK_CONT_RUN_FLAGS, a persistent theta kernel fed by flags beside per-block joints / chain launches.  Their waits are
- * bounded (three seconds): a run that could not make progress raises a word that the next rsik_sync reports as RSIK_E_HIP.
+ * caller's stream is capturing, by events, which is all a capture takes.
  * The workspace
  * (17 bytes per step and trajectory + 1 per 8-step chunk, of up to eight blocks in flight), the side streams and the
  * events belong to the context: they are created by the first call that needs them, or ahead of time by
  * rsik_control_continuous_reserve.  A call can be captured into a hipGraph (the side streams join the capture through
  * the events the call records) provided it has nothing to create: reserve first, or run a call of at least that size
  * first — otherwise the call fails with RSIK_E_INVALID instead of allocating inside the capture.  A captured graph
- * stays valid after later, larger calls (an outgrown workspace is kept until rsik_destroy).  A solver whose
+ * stays valid after later, larger calls (the workspace it points into is kept until rsik_destroy / _release; an
+ * outgrown workspace that only runs already issued can use is freed by the next rsik_sync).  The call never waits for
+ * the device.  A solver whose
  * projection_margin is not positive (RSIK_STATE_NOT_REACHABLE_NO_LIMITS possible) is run step by step.  At most 30 Mi
  * trajectories per call.  4096 trajectories x 1000 steps: see DESIGN.md section 4.
  * A goal that is not numbers: see "Rows that are not numbers" above (the step is reported, the trajectory goes on).
@@ -374,22 +358,11 @@ int rsik_control_continuous_reserve(rsik_ctx *ctx, int64_t n, int64_t n_steps);
 
 /*
  * rsik_control_continuous_release — waits for the device and frees everything rsik_control_continuous_run keeps in the
- * context between calls: the workspace, workspaces it has outgrown while a captured hipGraph could still point into them,
- * the diagnostic trace.  After it, hipGraphs captured from this context's continuous runs must not be replayed any more.
- * (Without a capture an outgrown workspace is freed when it is outgrown; the context then holds one, of the largest run
- * so far, grown geometrically.)
+ * context between calls: the workspace and the workspaces it has outgrown.  After it, hipGraphs captured from this
+ * context's continuous runs must not be replayed any more.  (The context otherwise holds one workspace, of the largest
+ * run so far, grown geometrically.)
  */
 int rsik_control_continuous_release(rsik_ctx *ctx);
-
-/*
- * rsik_control_continuous_trace — diagnostic (RSIK_OPT_CONT_TRACE): the work-item records of the last single-launch run,
- * four 64-bit words each: claimed, dependencies met, done (100 MHz device clock), and what / where — kind [0:3] (0 chain,
- * 1 joints, 2 prepare, 3 one block of a theta wave), block [4:19], group [20:31], sub-item [32:39], XCD [40:43], the low
- * 16 bits of the hardware id (wave, SIMD, pipe, CU, SH, SE) [44:59].  Synchronises the context's stream.
- *   records_host   host buffer for up to max_records records (may be NULL to ask for the count only)
- *   n_records      out: records copied (or available, with records_host NULL)
- */
-int rsik_control_continuous_trace(rsik_ctx *ctx, unsigned long long *records_host, size_t max_records, size_t *n_records);
 
 /*
  * Solver-state entry points: the scalar drop-in API.  A SymbolicIK object keeps self.goal_pose,

@@ -43,6 +43,9 @@ import reachy2_symbolic_ik.control_ik as ref_control_mod  # noqa: E402
 from reachy2_symbolic_ik.control_ik import ControlIK  # noqa: E402
 from reachy2_symbolic_ik.symbolic_ik import SymbolicIK  # noqa: E402
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+import scale_inputs as SCALE  # noqa: E402  (seeded input generators of G14: NumPy + libm only)
+
 # state string <-> uint8 code (shared with include/rsik.h, keep in sync)
 STATE_CODES = {
     "reachable": 0,
@@ -1079,6 +1082,109 @@ def gen_hostile(out, n_steps=48):
     np.savez_compressed(os.path.join(out, "g13_hostile.npz"), **data)
 
 
+# ----------------------------------------------------------------------------------------
+# G14: BASELINE-scale digests.  The reference itself over the seeded generators of configs 2 and 3 at their full sizes
+# (1 Mi poses per arm with every outcome; 256 Ki goal matrices through ControlIK discrete, 64-point grid): only digests,
+# per-state counts and every 64th row's numbers are committed (tests/scale_inputs.py regenerates the inputs anywhere).
+# Rows are independent (is_reachable starts from the pose; discrete mode does not carry state, C:409-462), so they are
+# spread over worker processes; the result does not depend on how.
+# ----------------------------------------------------------------------------------------
+_G14 = {}
+
+
+def _g14_solver(arm):
+    if ("s", arm) not in _G14:
+        _G14[("s", arm)] = make_solver(arm, 0.03)
+    return _G14[("s", arm)]
+
+
+def _g14_ctrl():
+    if "c" not in _G14:
+        _G14["c"] = quiet(ControlIK, urdf_path="../config_files/reachy2.urdf", is_dvt=False)
+    return _G14["c"]
+
+
+def _g14_rows_config2(job):
+    arm, pos, eul, first = job
+    solver = _g14_solver(arm)
+    reach = np.zeros(len(pos), dtype=np.uint8)
+    state = np.zeros(len(pos), dtype=np.uint8)
+    sub = []
+    for k, (p, e) in enumerate(zip(pos, eul)):
+        if (first + k) % SCALE.SUBSAMPLE == 0:
+            r = solve_symbolic(solver, p, e)  # fresh is_reachable, then get_joints(interval[0]) (Q1)
+            reach[k], state[k] = r["reachable"], r["state"]
+            sub.append((r["interval"], r["joints"]))
+        else:
+            ok, _, _, st = solver.is_reachable(np.array([p, e]))
+            reach[k], state[k] = bool(ok), STATE_CODES[st]
+    return reach, state, sub
+
+
+def _g14_filter_config3(job):
+    pos, eul = job
+    solver = _g14_ctrl().symbolic_ik_solver["r_arm"]
+    return np.array([bool(solver.is_reachable(np.array([p, e]))[0]) for p, e in zip(pos, eul)])
+
+
+def _g14_rows_config3(Ms):
+    ctrl = _g14_ctrl()
+    res = [control_call(ctrl, "r_arm", M, 64, "unconstrained") for M in Ms]
+    return (np.array([r[0] for r in res]), np.array([r[1] for r in res], dtype=np.uint8), np.array([r[2] for r in res], dtype=np.uint8))
+
+
+def gen_scale(out, workers=None):
+    import multiprocessing as mp
+
+    workers = workers or max(1, (os.cpu_count() or 2) - 1)
+    data = {"seed": np.int64(SCALE.SEED), "subsample": np.int64(SCALE.SUBSAMPLE)}
+    with mp.get_context("fork").Pool(workers) as pool:
+        # config 2's generator before its filter, both arms
+        for arm in ARMS:
+            pos, eul = SCALE.config2_unfiltered(arm)
+            piece = 4096
+            jobs = [(arm, pos[a:a + piece], eul[a:a + piece], a) for a in range(0, len(pos), piece)]
+            parts = pool.map(_g14_rows_config2, jobs)
+            reach = np.concatenate([p[0] for p in parts])
+            state = np.concatenate([p[1] for p in parts])
+            sub = [row for p in parts for row in p[2]]
+            pre = f"c2_{arm}_"
+            data[pre + "n"] = np.int64(len(pos))
+            data[pre + "input_sha256"] = np.array(SCALE.sha256(np.concatenate([pos, eul], axis=1)))
+            data[pre + "reachable_sha256"] = np.array(SCALE.sha256(reach))
+            data[pre + "state_sha256"] = np.array(SCALE.sha256(state))
+            data[pre + "state_counts"] = np.bincount(state, minlength=9).astype(np.int64)
+            data[pre + "sub_reachable"] = reach[::SCALE.SUBSAMPLE].copy()
+            data[pre + "sub_state"] = state[::SCALE.SUBSAMPLE].copy()
+            data[pre + "sub_interval"] = np.array([r[0] for r in sub])
+            data[pre + "sub_joints"] = np.array([r[1] for r in sub])
+        # config 3: the candidates' is_reachable flags (the filter), then ControlIK discrete over the kept matrices
+        kept, gen = [], SCALE.config3_candidates()
+        while sum(int(k.sum()) for k in kept) < SCALE.N_CONFIG3:
+            pos, eul = next(gen)
+            piece = 8192
+            flags = pool.map(_g14_filter_config3, [(pos[a:a + piece], eul[a:a + piece]) for a in range(0, len(pos), piece)])
+            kept.append(np.concatenate(flags))
+        kept_bits = np.packbits(np.concatenate(kept))
+        _, _, kept_mask, Ms = SCALE.config3_from_kept(kept_bits)
+        piece = 1024
+        parts = pool.map(_g14_rows_config3, [Ms[a:a + piece] for a in range(0, len(Ms), piece)])
+        joints = np.concatenate([p[0] for p in parts])
+        reach = np.concatenate([p[1] for p in parts])
+        state = np.concatenate([p[2] for p in parts])
+        data["c3_n"] = np.int64(len(Ms))
+        data["c3_candidates"] = np.int64(kept_mask.size)
+        data["c3_kept_bits"] = kept_bits
+        data["c3_input_sha256"] = np.array(SCALE.sha256(Ms))
+        data["c3_reachable_sha256"] = np.array(SCALE.sha256(reach))
+        data["c3_state_sha256"] = np.array(SCALE.sha256(state))
+        data["c3_state_counts"] = np.bincount(state, minlength=9).astype(np.int64)
+        data["c3_sub_reachable"] = reach[::SCALE.SUBSAMPLE].copy()
+        data["c3_sub_state"] = state[::SCALE.SUBSAMPLE].copy()
+        data["c3_sub_joints"] = joints[::SCALE.SUBSAMPLE].copy()
+    np.savez_compressed(os.path.join(out, "g14_scale.npz"), **data)
+
+
 def ref_default_joints(k):
     return [[0.0, 0.2617993877991494, -0.17453292519943295, 0.0, 0.0, 0.0, 0.0],
             [0.0, -0.2617993877991494, 0.17453292519943295, 0.0, 0.0, 0.0, 0.0]][k]
@@ -1104,7 +1210,7 @@ def main():
              ("g4", gen_control), ("g5", gen_helpers), ("g6", gen_continuous),
              ("g7", gen_continuous_start), ("g8", gen_matrix_edges),
              ("g9", gen_custom_geometry), ("g10", gen_custom_urdf_control), ("g11", gen_emergency),
-             ("g12", gen_continuous_modes), ("g13", gen_hostile)]
+             ("g12", gen_continuous_modes), ("g13", gen_hostile), ("g14", gen_scale)]
     bad = 0
     for name, fn in steps:
         if args.only and name not in args.only.split(","):  # exact names: "g1" does not select "g12"

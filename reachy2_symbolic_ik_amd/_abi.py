@@ -24,7 +24,7 @@ def use_library(path: str) -> None:
     LIB_PATH = os.path.abspath(path)
 
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 RSIK_OK = 0
 RSIK_E_INVALID, RSIK_E_NO_DEVICE, RSIK_E_HIP, RSIK_E_NOT_SET = -1, -2, -3, -4
 
@@ -63,7 +63,6 @@ PROTOTYPES = {
                                               C.c_int, C.c_double, _vp, C.c_double, _vp, _vp, _vp, _vp]),
     "rsik_control_continuous_reserve": (C.c_int, [_vp, C.c_int64, C.c_int64]),
     "rsik_control_continuous_release": (C.c_int, [_vp]),
-    "rsik_control_continuous_trace": (C.c_int, [_vp, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "rsik_reach_state": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp), _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "rsik_joints_from_state": (C.c_int, [_vp, C.c_int64, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     "rsik_elbow_from_state": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp]),
@@ -78,9 +77,9 @@ PROTOTYPES = {
 
 GOAL_POSE6, GOAL_M12 = 0, 1
 OPT_EULER_ROUNDTRIP, OPT_SWEEP_MODE, OPT_NO_TIPZ, OPT_NO_MIRROR, OPT_CONT_RUN_MODE = 0, 1, 2, 3, 4
-OPT_CONT_BLOCK_STEPS, OPT_CONT_LOOKAHEAD, OPT_CONT_PREP_STEPS, OPT_CONT_TRACE, OPT_CONT_CHAIN_LAG, OPT_CONT_JOINT_GROUPS, OPT_CONT_PHASED_VARIANT = 5, 6, 7, 8, 9, 10, 11
+OPT_CONT_BLOCK_STEPS, OPT_CONT_PHASED_VARIANT = 5, 6
 PHASED_EDGES_BY_EVENT, PHASED_NO_THETA_FIRST = 1, 2
-CONT_RUN_AUTO, CONT_RUN_PHASED, CONT_RUN_STEPS, CONT_RUN_FUSED, CONT_RUN_FLAGS = 0, 1, 2, 3, 4
+CONT_RUN_AUTO, CONT_RUN_PHASED, CONT_RUN_STEPS = 0, 1, 2
 EMERGENCY_SHOULDER_PITCH, EMERGENCY_ELBOW_YAW, EMERGENCY_WRIST_YAW, EMERGENCY_CONTINUITY = 1, 2, 4, 8
 EULER_AUTO, EULER_ALWAYS, EULER_NEVER = 0, 1, 2
 

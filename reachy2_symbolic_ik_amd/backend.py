@@ -95,18 +95,6 @@ class HipSolver:
         with torch.cuda.device(self.device):
             self._check(self.lib.rsik_control_continuous_release(self._h))
 
-    def control_continuous_trace(self) -> np.ndarray:
-        """Diagnostic (RSIK_OPT_CONT_TRACE): the work-item records of the last single-launch continuous run as a uint64
-        [records, 4] array — claimed, dependencies met, done (100 MHz device clock), packed what / where (include/rsik.h)."""
-        with torch.cuda.device(self.device):
-            self._bind_stream()
-            cnt = C.c_size_t(0)
-            self._check(self.lib.rsik_control_continuous_trace(self._h, None, 0, C.byref(cnt)))
-            rec = np.zeros((int(cnt.value), 4), dtype=np.uint64)
-            if cnt.value:
-                self._check(self.lib.rsik_control_continuous_trace(self._h, rec.ctypes.data_as(C.c_void_p), int(cnt.value), C.byref(cnt)))
-            return rec[: int(cnt.value)]
-
     # ------------------------------------------------------------------ checks
     def _dev_f64(self, t: torch.Tensor, shape: Sequence[int], name: str) -> torch.Tensor:
         if not isinstance(t, torch.Tensor):

@@ -23,10 +23,7 @@ namespace rsik {
 #define RSIK_CHAIN_BATCH 16  // chunks of the joints phase whose first / last rows the chain phase fetches at once
 #endif
 constexpr int kThetaBatch = RSIK_THETA_BATCH, kChainBatch = RSIK_CHAIN_BATCH;
-// analysis builds: the phased kernels with the coherent (sc1) accesses of the single-launch form / at a fixed occupancy
-#ifndef RSIK_PHASED_COH
-#define RSIK_PHASED_COH false
-#endif
+// analysis builds: the chip-filling kernels at a fixed occupancy
 #ifdef RSIK_PHASED_OCC
 #define RSIK_PHASED_OCC_ATTR __attribute__((amdgpu_waves_per_eu(RSIK_PHASED_OCC, RSIK_PHASED_OCC)))
 #else
@@ -98,9 +95,6 @@ struct ContRunArgs {
     double snap_tdag;             // phase 2, single-arm launches: see continuous_next_theta_lean (the kind is a template argument)
     double* theta_carry;          // [2][n]: previous_theta between the blocks of one run (phase 2's own state); row 1: see cont_theta_kernel
     int first_block, last_block;
-    double epoch;                 // PAIRS layout (rsik_kernel_flags.hpp): this run's tag, see ld_pair / st_pair
-    unsigned* abort_word;         // PAIRS layout: raised when a wait for a tagged value runs out (else NULL)
-    const unsigned* theta_hint;   // PAIRS layout: per group of 64 trajectories, steps whose thetas the theta wave has stored (a hint)
     unsigned* started_word;       // phased pipeline, launch by launch: the theta kernel of a block writes started_seq here when it starts
     unsigned started_seq;         // (the host holds the joints kernel of the block BEFORE on it, see rsik_control_continuous_run), or NULL
     double* st;                   // cont_state
@@ -111,93 +105,9 @@ struct ContRunArgs {
 };
 #define RSIK_WS(K, t, i) (K).ws[(int64_t)(t) * (K).n + (i)]
 
-// Accesses to data that ANOTHER compute unit produces or consumes while the same kernel runs (the single-launch form,
-// rsik_kernel_fused.hpp): the eight XCDs' L2 caches are not coherent with each other for ordinary accesses, so such data
-// is written through and read past them — relaxed agent-scope atomics, i.e. the `sc1` forms of the plain instructions.
-// COH = false (the phased kernels, where a kernel boundary does the job): ordinary accesses, the code as it was.
-template <bool COH>
-__device__ __forceinline__ double ldc_f64(const double* p) {
-    if constexpr (COH) return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<unsigned long long*>(const_cast<double*>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    else return *p;
-}
-// (RSIK_COH_PLAIN_STORES: a timing experiment — the coherent forms' stores as ordinary ones; the results are not valid)
-#ifndef RSIK_COH_PLAIN_STORES
-#define RSIK_COH_PLAIN_STORES 0
-#endif
-template <bool COH>
-__device__ __forceinline__ void stc_f64(double* p, double v) {
-    if constexpr (COH && !RSIK_COH_PLAIN_STORES) __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-}
-template <bool COH>
-__device__ __forceinline__ int ldc_u8(const uint8_t* p) {
-    if constexpr (COH) return (int)__hip_atomic_load(const_cast<uint8_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else return (int)*p;
-}
-template <bool COH>
-__device__ __forceinline__ void stc_u8(uint8_t* p, uint8_t v) {
-    if constexpr (COH && !RSIK_COH_PLAIN_STORES) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-}
-// The PAIRS layout of the flag-synchronised form: a value that one kernel hands to another while both run travels as a
-// 16-byte (value, tag) pair, written by ONE written-through store and read by ONE L2-bypassing load — a pair is valid by
-// itself: its tag is this run's epoch (the host counts runs; fresh workspace is zeroed, epochs start at 1).  Neither side
-// needs a counter, a drain or a poll: a consumer that finds an old tag loads the pair again.  Addressing: `pairs` = the
-// array (the same for every lane: one buffer descriptor in scalar registers), `cell` = the pair's index in it (per lane;
-// the array stays below 2 GB, the host sees to that).
-typedef double f64x2p __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4p __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f64x2p ld_pair(const double* pairs, int64_t cell) {
-    const __amdgpu_buffer_rsrc_t buf = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(pairs), 0, 0x7fffffff, 0x00020000);
-    return __builtin_bit_cast(f64x2p, __builtin_amdgcn_raw_buffer_load_b128(buf, (unsigned)(cell * 16), 0, 16));
-}
-__device__ __forceinline__ void st_pair(double* pairs, int64_t cell, double value, double tag) {
-    const __amdgpu_buffer_rsrc_t buf = __builtin_amdgcn_make_buffer_rsrc(pairs, 0, 0x7fffffff, 0x00020000);
-    f64x2p v;
-    v.x = value; v.y = tag;
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4p, v), buf, (unsigned)(cell * 16), 0, 16);
-}
-// A tag = 64 bits: the run's epoch (a 32-bit count, as the double K.epoch) in the high word, 16 x the step's state code + its flag
-// bits (cont_prepare_step) in the low one: whoever holds a valid pair also holds what the prepare phase found out about the
-// step, and nothing else has to cross with it.  (Integer words: a validity check is one 32-bit compare.)
-__device__ __forceinline__ double pair_tag(double epoch, int state, int flags) {
-    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)epoch << 32) | (unsigned)(state * 16 + flags));
-}
-__device__ __forceinline__ bool pair_tag_valid(double tag, double epoch) {
-    return (unsigned)(__builtin_bit_cast(unsigned long long, tag) >> 32) == (unsigned)epoch;
-}
-__device__ __forceinline__ int pair_tag_low(double tag, double epoch) {
-    (void)epoch;
-    return (int)(unsigned)__builtin_bit_cast(unsigned long long, tag);
-}
-// the value of pair (t, i) once its tag is this run's (every lane of the wave loads; `need`: this lane's pair matters).
-// A wave that finds an old tag does not keep loading pairs — thousands of waves doing that take the memory system away from
-// the producer they wait for — it polls `hint` (one word, bumped by the producer behind its stores, without waiting for
-// them: a hint, not a promise) until that reaches `want`, then loads again.  Bounded: three seconds, then the run's abort
-// word is raised and whatever is there is returned.
-__device__ __forceinline__ f64x2p pair_value(const ContRunArgs& K, const double* pairs, int64_t t, int64_t i, bool need, const unsigned* hint,
-                                             unsigned want) {
-    f64x2p p = ld_pair(pairs, t * K.n + i);
-    if (__builtin_expect(__any(need && !pair_tag_valid(p.y, K.epoch)), 0)) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        do {
-            do {
-                __builtin_amdgcn_s_sleep(16);
-            } while (__hip_atomic_load(const_cast<unsigned*>(hint), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want &&
-                     __builtin_amdgcn_s_memrealtime() - t0 <= 300000000ull);
-            p = ld_pair(pairs, t * K.n + i);
-            if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull || __hip_atomic_load(K.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                __hip_atomic_store(K.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        } while (__any(need && !pair_tag_valid(p.y, K.epoch)));
-    }
-    return p;
-}
-
 // phase 1, one (step, trajectory): `m` the step's twelve matrix entries, `t` the step's row in the workspace arrays, `t_abs`
-// its row in the run's outputs.  Shared by the phased kernel below and the single-launch form (COH, see above).
-template <bool MIXED, bool PLANE, bool COH, bool PAIRS = false>
+// its row in the run's outputs.
+template <bool MIXED, bool PLANE>
 __device__ __forceinline__ void cont_prepare_step(const ContRunArgs& K, const Acc<MIXED>& A, int slot, const double (&m)[12], int64_t t,
                                                   int64_t t_abs, int64_t i, bool live) {
     const bool invalid = !all_finite(m);  // (judged while the twelve values are at hand)
@@ -215,20 +125,13 @@ __device__ __forceinline__ void cont_prepare_step(const ContRunArgs& K, const Ac
     // the step's goal for the theta phase: the search's theta, NaN = nothing found, stay (U:252-264 with goal =
     // previous_theta), or the preferred theta of an unreachable pose (U:115-127)
     const double goal = T.ok_limits ? (T.found ? T.theta : __builtin_nan("")) : K.pref_arg[slot];
-    if constexpr (PAIRS) {
-        // ONE store: the goal and, in its tag, the flags and the state code — the joints phase, which gets them back with the
-        // theta, writes the run's flag / state / reachable rows (the wrapped goal is the theta loader's business there)
-        st_pair(K.gw, t * K.n + i, goal, pair_tag(K.epoch, T.code, (T.ok_limits ? 1 : 0) | (T.found ? 2 : 0) | (special ? 8 : 0)));
-        return;
-    } else {
-        stc_f64<COH>(&RSIK_WS(K, t, i), goal);
-        // what limit_theta_to_interval makes of theta = goal before it looks at the interval (U:93-97): this phase has the
-        // issue slots for it, the theta phase (a lone wave per SIMD) has not
-        stc_f64<COH>(&K.gw[t * K.n + i], wrap_theta_to_pi(goal));
-    }
-    stc_u8<COH>(&K.flags[t * K.n + i], (uint8_t)((T.ok_limits ? 1 : 0) | (T.found ? 2 : 0) | (special ? 8 : 0) | (invalid ? 16 : 0)));
-    if (K.state) stc_u8<COH>(&K.state[t_abs * K.n + i], (uint8_t)T.code);
-    if (K.reachable) stc_u8<COH>(&K.reachable[t_abs * K.n + i], (T.ok_limits && T.found) ? 1 : 0);
+    RSIK_WS(K, t, i) = goal;
+    // what limit_theta_to_interval makes of theta = goal before it looks at the interval (U:93-97): this phase has the
+    // issue slots for it, the theta phase (a lone wave per SIMD) has not
+    K.gw[t * K.n + i] = wrap_theta_to_pi(goal);
+    K.flags[t * K.n + i] = (uint8_t)((T.ok_limits ? 1 : 0) | (T.found ? 2 : 0) | (special ? 8 : 0) | (invalid ? 16 : 0));
+    if (K.state) K.state[t_abs * K.n + i] = (uint8_t)T.code;
+    if (K.reachable) K.reachable[t_abs * K.n + i] = (T.ok_limits && T.found) ? 1 : 0;
 }
 
 // phase 1: one thread per (trajectory, step of the block)
@@ -248,7 +151,7 @@ __global__ __launch_bounds__(kBlock) RSIK_PHASED_OCC_ATTR void cont_prepare_kern
         stage_tables<MIXED, (int)offsetof(ContRunArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>(lds_tab, K.arms);
     const Acc<MIXED> A = make_acc<MIXED>(K.arms, lane_isl, lds_tab);
     const int slot = MIXED ? (A.isl ? 1 : 0) : 0;
-    cont_prepare_step<MIXED, PLANE, RSIK_PHASED_COH>(K, A, slot, m, t, K.t0 + t, i, live);
+    cont_prepare_step<MIXED, PLANE>(K, A, slot, m, t, K.t0 + t, i, live);
 }
 
 // Row + lane addressing for the sequential phases: a step's row starts `row` bytes into the block's array (the same for
@@ -260,18 +163,14 @@ typedef unsigned RowWords2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t row_buffer(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
 }
-// (AUX = 16: the `sc1` form, for rows another compute unit writes or reads while the kernel runs — see ldc_f64)
-template <int AUX = 0>
 __device__ __forceinline__ double ld_row_f64(__amdgpu_buffer_rsrc_t buf, unsigned lane, unsigned row) {
-    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(buf, lane, row, AUX));
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(buf, lane, row, 0));
 }
-template <int AUX = 0>
 __device__ __forceinline__ void st_row_f64(__amdgpu_buffer_rsrc_t buf, unsigned lane, unsigned row, double v) {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(RowWords2, v), buf, lane, row, RSIK_COH_PLAIN_STORES ? 0 : AUX);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(RowWords2, v), buf, lane, row, 0);
 }
-template <int AUX = 0>
 __device__ __forceinline__ int ld_row_u8(__amdgpu_buffer_rsrc_t buf, unsigned lane, unsigned row) {
-    return (int)__builtin_amdgcn_raw_buffer_load_b8(buf, lane, row, AUX);
+    return (int)__builtin_amdgcn_raw_buffer_load_b8(buf, lane, row, 0);
 }
 
 // phase 2: one thread per trajectory walks the block's steps: the recurrence on previous_theta.
@@ -280,11 +179,9 @@ __device__ __forceinline__ int ld_row_u8(__amdgpu_buffer_rsrc_t buf, unsigned la
 // cont_theta_walk: T steps of one trajectory per lane; `ws` / `gw` = the rows of the first of them, `first_generic`: the first
 // step goes through the generic form (the state a run starts from is the caller's), `scratch`: n doubles nothing reads.
 // BATCH steps' operands are fetched at once, a batch ahead.  Returns previous_theta after the last step.
-// COH / COH_ST: loads / stores in the forms that cross compute units while other kernels run (see ldc_f64).
-template <int KIND, bool COH, int BATCH, bool COH_ST = COH>
+template <int KIND, int BATCH>
 __device__ __forceinline__ double cont_theta_walk(const ContRunArgs& K, int64_t i, double l0, double l1, double* ws, double* gw, int64_t T,
                                                   bool first_generic, double prev_theta, double* scratch) {
-    constexpr int AUX = COH ? 16 : 0, AUX_ST = COH_ST ? 16 : 0;
     // A lone wave per SIMD: every instruction of a step is paid in full (~4.5 cycles each, rsik_device.hpp `opaque`), and
     // the memory round trip of a step's operands would double a step, so they are fetched BATCH steps at a time,
     // one batch ahead of the one being computed, into two register sets that take turns (no copies); what is left of the
@@ -311,8 +208,8 @@ __device__ __forceinline__ double cont_theta_walk(const ContRunArgs& K, int64_t 
     if (KIND != kSnapGeneric && first_generic && left > 0) {
         // the state a run starts from is the caller's: only from the first result on is previous_theta known to lie in
         // [-pi, pi], which the specialised step relies on
-        prev_theta = generic(ld_row_f64<AUX>(wbuf, off, row));
-        st_row_f64<AUX_ST>(wbuf, off, row, prev_theta);
+        prev_theta = generic(ld_row_f64(wbuf, off, row));
+        st_row_f64(wbuf, off, row, prev_theta);
         row += stride; left -= 1;
     }
     struct Operands { double g[BATCH], gw[BATCH]; };
@@ -321,8 +218,8 @@ __device__ __forceinline__ double cont_theta_walk(const ContRunArgs& K, int64_t 
 #pragma unroll
         for (int u = 0; u < BATCH; u++) {
             const unsigned at = row + (unsigned)(ahead + (u < valid ? u : valid - 1)) * stride;
-            o.g[u] = ld_row_f64<AUX>(wbuf, off, at);
-            if constexpr (KIND != kSnapGeneric) o.gw[u] = ld_row_f64<AUX>(gbuf, off, at);
+            o.g[u] = ld_row_f64(wbuf, off, at);
+            if constexpr (KIND != kSnapGeneric) o.gw[u] = ld_row_f64(gbuf, off, at);
         }
     };
     auto compute = [&](const Operands& o, auto partial, int valid) {  // the batch at `row`; leaves `row` at the next one
@@ -341,7 +238,7 @@ __device__ __forceinline__ double cont_theta_walk(const ContRunArgs& K, int64_t 
         }
 #pragma unroll
         for (int u = 0; u < BATCH; u++) {
-            if (!kPartial || u < valid) st_row_f64<AUX_ST>(wbuf, off, r0 + (unsigned)u * stride, res[u]);
+            if (!kPartial || u < valid) st_row_f64(wbuf, off, r0 + (unsigned)u * stride, res[u]);
         }
     };
     int64_t batches = left / BATCH;
@@ -402,7 +299,7 @@ __global__ __launch_bounds__(kThetaBlock) __attribute__((amdgpu_waves_per_eu(1, 
     // alone decides what ends up in the state's row 0 — the theta of the last step, or of the step that latched the
     // emergency stop (C:205-210; what this phase computes for a latched trajectory is never looked at).
     const double prev_theta = K.first_block ? K.st[0 * K.n + i] : K.theta_carry[i];
-    K.theta_carry[i] = cont_theta_walk<KIND, false, kThetaBatch>(K, i, K.lim[slot][0], K.lim[slot][1], K.ws, K.gw, K.T, K.first_block != 0,
+    K.theta_carry[i] = cont_theta_walk<KIND, kThetaBatch>(K, i, K.lim[slot][0], K.lim[slot][1], K.ws, K.gw, K.T, K.first_block != 0,
                                                                  prev_theta, K.theta_carry + K.n);
 }
 
@@ -462,13 +359,10 @@ __device__ __forceinline__ void step_joints(const Acc& A, const ContRunArgs& K, 
 // and a quiet step's value is its raw joint plus whole turns: within 2 ulp of the reference's previous + angle_diff(raw,
 // previous), no accumulation.
 // One wave: chunk `c` (steps 8 c ... 8 c + 7 of the K arrays) of the trajectories 8 grp ... 8 grp + 7; `lw`: 64 x 7 doubles of LDS
-// of the wave's own.  Shared by the phased kernel below and the single-launch form (COH: theta, flags in; rows, events out
-// cross compute units while the kernel runs).
-// STAGE: the workgroup's tables are staged here, behind the chunk's loads (their latency overlaps the staging's round trip).
-template <bool MIXED, bool COH, bool STAGE = false, bool PAIRS = false>
+// of the wave's own.  The workgroup's tables are staged here, behind the chunk's loads (their latency overlaps the staging's round trip).
+template <bool MIXED>
 __device__ __forceinline__ void cont_joints_chunk(const ContRunArgs& K, SharedTables& lds_tab, double* lw, int64_t grp_in, int64_t c) {
     static_assert(kJointChunk == 8, "lane = 8 * step + trajectory");
-    constexpr int AUX = COH ? 16 : 0;
     // the group is the same for the whole wave, but derived from threadIdx (a vector register): said so, or the buffer descriptor of
     // the rows written below sits in vector registers and each of its seven stores becomes a loop over "the lanes that agree"
     // (4 v_readfirstlane + 2 compares + mask juggling: ~70 instructions a wave-step, 7 % of this phase).  (< 2^31 groups: n <= 30 Mi)
@@ -493,20 +387,8 @@ __device__ __forceinline__ void cont_joints_chunk(const ContRunArgs& K, SharedTa
 #pragma unroll
         for (int k = 9; k < 12; k++) m[k] = src[k * n];
     }
-    double theta;
-    int flag, state_code = 0;
-    if constexpr (PAIRS) {
-        // (waits for the theta wave, if it has to)
-        const f64x2p p = pair_value(K, K.ws, tt, ii, true, K.theta_hint + (grp >> 3), (unsigned)((c + 1) * kJointChunk < K.T ? (c + 1) * kJointChunk : K.T));
-        theta = p.x;
-        const int low = pair_tag_low(p.y, K.epoch);
-        flag = low & 15;
-        state_code = (low >> 4) & 15;
-        if (RSIK_RARE(state_code == RSIK_STATE_INVALID_INPUT)) flag |= 16;  // (the tag has four flag bits: this one rides on the code)
-    } else {
-        theta = ldc_f64<COH>(&RSIK_WS(K, tt, ii));
-        flag = ldc_u8<COH>(&K.flags[tt * n + ii]);
-    }
+    const double theta = RSIK_WS(K, tt, ii);
+    int flag = (int)K.flags[tt * n + ii];
     const bool special = (flag & 8) != 0;
     if (RSIK_RARE(special)) {
         const double* src = K.m12_steps + (K.t0 + tt) * 12 * n + ii;
@@ -518,7 +400,7 @@ __device__ __forceinline__ void cont_joints_chunk(const ContRunArgs& K, SharedTa
         m[8] = fma(m[0], m[4], -(m[1] * m[3]));
     }
     const bool lane_isl = MIXED ? (K.arm[ii] != 0) : false;
-    if constexpr (STAGE) stage_tables<MIXED, (int)offsetof(ContRunArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>(lds_tab, K.arms);
+    stage_tables<MIXED, (int)offsetof(ContRunArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>(lds_tab, K.arms);
     const Acc<MIXED> A = make_acc<MIXED>(K.arms, lane_isl, lds_tab);
     Reach r;
     Goal G;
@@ -582,18 +464,10 @@ __device__ __forceinline__ void cont_joints_chunk(const ContRunArgs& K, SharedTa
 #pragma unroll
         for (int k = 0; k < 7; k++) out[k] = dead ? __builtin_nan("") : out[k];  // (singular: needs previous_sol, phase 4 recomputes the step — flag bit 2)
     }
-    if constexpr (PAIRS) {
-        if (live) {
-            stc_u8<COH>(&K.flags[t * n + i], (uint8_t)(flag | (sing ? 4 : 0)));
-            if (K.state) stc_u8<COH>(&K.state[(K.t0 + t) * n + i], (uint8_t)state_code);
-            if (K.reachable) stc_u8<COH>(&K.reachable[(K.t0 + t) * n + i], (flag & 3) == 3 ? 1 : 0);
-        }
-    } else {
-        if (live && sing) stc_u8<COH>(&K.flags[t * n + i], (uint8_t)(flag | 4));
-    }
+    if (live && sing) K.flags[t * n + i] = (uint8_t)(flag | 4);
     // one event byte per (chunk, trajectory): OR over the chunk's steps
     const unsigned long long evm = __ballot(ev && live);
-    if (live && sl == 0) stc_u8<COH>(&K.chunk_event[c * n + i], ((evm >> tl) & 0x0101010101010101ull) != 0 ? 1 : 0);
+    if (live && sl == 0) K.chunk_event[c * n + i] = ((evm >> tl) & 0x0101010101010101ull) != 0 ? 1 : 0;
     // rows out: the wave's 64 rows are 8 runs (one per step) of 8 x 7 consecutive doubles; 32-bit offsets from the chunk's
     // first row (a block's joints stay below 2 GB, see rsik_control_continuous_run)
 #pragma unroll
@@ -610,7 +484,7 @@ __device__ __forceinline__ void cont_joints_chunk(const ContRunArgs& K, SharedTa
     if (lane < traj_left * 7) {
 #pragma unroll
         for (int s_ = 0; s_ < kJointChunk; s_++)
-            if (s_ < steps_left) st_row_f64<AUX>(obuf, (unsigned)lane * 8u, (unsigned)s_ * row_bytes, lw[s_ * 56 + lane]);
+            if (s_ < steps_left) st_row_f64(obuf, (unsigned)lane * 8u, (unsigned)s_ * row_bytes, lw[s_ * 56 + lane]);
     }
     __builtin_amdgcn_wave_barrier();  // (the wave's slab is free again)
 }
@@ -621,7 +495,7 @@ __global__ __launch_bounds__(kBlock) RSIK_PHASED_OCC_ATTR void cont_joints_kerne
     __shared__ double lds_out[kBlock / 64][64 * 7];
     __shared__ SharedTables lds_tab;
     const int wave = threadIdx.x >> 6;
-    cont_joints_chunk<MIXED, RSIK_PHASED_COH, true>(K, lds_tab, lds_out[wave], (int64_t)blockIdx.x * (kBlock / 64) + wave, (int64_t)blockIdx.y);
+    cont_joints_chunk<MIXED>(K, lds_tab, lds_out[wave], (int64_t)blockIdx.x * (kBlock / 64) + wave, (int64_t)blockIdx.y);
 }
 
 // phase 4: eight lanes per trajectory, lane j < 7 owns joint j; sequential over the block's steps: the recurrence on
@@ -629,20 +503,11 @@ __global__ __launch_bounds__(kBlock) RSIK_PHASED_OCC_ATTR void cont_joints_kerne
 // latch C:205-210, C:398-405).
 // cont_chain_walk: trajectory i, lane j of its eight (gid = 8 i + j), over T steps: rows tw0 ... of the workspace arrays (chunk rows
 // tw0 / 8 ...), steps t_abs0 ... of the run.  BATCH chunks' operands are fetched at once.  `last`: the run ends with these steps.
-// Shared by the phased kernel below and the single-launch form (COH: everything but the goal matrices crosses compute units
-// while the kernel runs — the trajectory state included, which the walk of the block before left in cont_state).
-// `carry` (the single-launch form's chain waves, which walk a run block by block): the trajectory state of this lane between two
-// calls — taken from cont_state when `first`, left in cont_state when `last`, in registers in between.
-struct ChainCarry { double prev; bool init, emergency; };
-template <bool MIXED, bool COH, int BATCH, bool PAIRS = false>
+template <bool MIXED, int BATCH>
 __device__ __forceinline__ void cont_chain_walk(const ContRunArgs& K, SharedTables& lds_tab, int64_t i, int j, int64_t tw0, int64_t t_abs0,
-                                                int64_t T, bool last, ChainCarry* carry = nullptr, bool first = true) {
-    constexpr int AUX = COH ? 16 : 0;
+                                                int64_t T, bool last) {
     // a step's theta (behind the joints phase, which has read it: it is there)
-    auto theta_at = [&](int64_t t_ws, int64_t ix) {
-        if constexpr (PAIRS) return ldc_f64<COH>(K.ws + (t_ws * K.n + ix) * 2);
-        else return ldc_f64<COH>(&RSIK_WS(K, t_ws, ix));
-    };
+    auto theta_at = [&](int64_t t_ws, int64_t ix) { return RSIK_WS(K, t_ws, ix); };
     const int lane = threadIdx.x & 63;
     const int gshift = lane & ~7;
     const bool live = i < K.n;
@@ -652,15 +517,9 @@ __device__ __forceinline__ void cont_chain_walk(const ContRunArgs& K, SharedTabl
     const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[ii] != 0) : false, lds_tab);
     const int64_t n = K.n;
     const int64_t tm0 = t_abs0 - K.t0;  // (load_step_m12 counts from K.t0)
-    double prev;
-    bool init, emergency;
-    if (carry && !first) {
-        prev = carry->prev; init = carry->init; emergency = carry->emergency;
-    } else {
-        prev = ldc_f64<COH>(&K.st[(1 + jj) * n + ii]);
-        init = ldc_f64<COH>(&K.st[8 * n + ii]) != 0.0;
-        emergency = ldc_f64<COH>(&K.st[9 * n + ii]) != 0.0;
-    }
+    double prev = K.st[(1 + jj) * n + ii];
+    bool init = K.st[8 * n + ii] != 0.0;
+    bool emergency = K.st[9 * n + ii] != 0.0;
     const double thr = jj < 4 ? 0.5 : 1.0;                                       // continuity thresholds, C:398
     const double lim = (jj == 0 || jj == 2 || jj == 6) ? 6 * kPi : __builtin_inf();  // multiturn limit of this lane's joint (U:535-568)
     const int hit_bit = jj == 0 ? RSIK_EMERGENCY_SHOULDER_PITCH : (jj == 2 ? RSIK_EMERGENCY_ELBOW_YAW : RSIK_EMERGENCY_WRIST_YAW);
@@ -710,18 +569,18 @@ __device__ __forceinline__ void cont_chain_walk(const ContRunArgs& K, SharedTabl
         const double accepted = disc ? prev : clamped;
         const bool trips = cause != 0 && !emergency && !inv;
         const double result = emergency ? prev : (inv ? __builtin_nan("") : accepted);  // latched (C:205-210): previous_sol
-        if (owner) st_row_f64<AUX>(jbuf, joff, jrow, result);
+        if (owner) st_row_f64(jbuf, joff, jrow, result);
         if (RSIK_RARE(emergency || trips) && live) {
             if (emergency) {
                 if (j == 7) {
-                    if (K.state) stc_u8<COH>(&K.state[t_abs * n + i], (uint8_t)RSIK_STATE_EMERGENCY);
-                    if (K.reachable) stc_u8<COH>(&K.reachable[t_abs * n + i], 0);
+                    if (K.state) K.state[t_abs * n + i] = (uint8_t)RSIK_STATE_EMERGENCY;
+                    if (K.reachable) K.reachable[t_abs * n + i] = 0;
                 }
             } else if (j == 7) {
-                stc_f64<COH>(&K.st[11 * n + i], (double)cause);
-                stc_f64<COH>(&K.st[0 * n + i], theta_at(tw0 + t, i));  // previous_theta of the step that tripped (phase 2 ran ahead)
+                K.st[11 * n + i] = (double)cause;
+                K.st[0 * n + i] = theta_at(tw0 + t, i);  // previous_theta of the step that tripped (phase 2 ran ahead)
             } else if (disc) {
-                stc_f64<COH>(&K.st[(12 + j) * n + i], clamped);       // the joints that failed the check
+                K.st[(12 + j) * n + i] = clamped;       // the joints that failed the check
             }
         }
         prev = (emergency || trips || inv) ? prev : accepted;
@@ -743,8 +602,8 @@ __device__ __forceinline__ void cont_chain_walk(const ContRunArgs& K, SharedTabl
         unsigned jrow = (unsigned)t_blk * jstride, frow = (unsigned)t_blk * fstride;
         t_abs = t_abs0 + t_blk;
         auto at = [&](int64_t k) { return k < count ? k : count - 1; };
-        auto raw_at = [&](int64_t k) { return ld_row_f64<AUX>(jbuf, joff, jrow + (unsigned)k * jstride); };
-        auto flag_at = [&](int64_t k) { return ld_row_u8<AUX>(fbuf, foff, frow + (unsigned)k * fstride); };
+        auto raw_at = [&](int64_t k) { return ld_row_f64(jbuf, joff, jrow + (unsigned)k * jstride); };
+        auto flag_at = [&](int64_t k) { return ld_row_u8(fbuf, foff, frow + (unsigned)k * fstride); };
         double r0 = raw_at(0), r1 = raw_at(at(1)), r2 = raw_at(at(2));
         int f0 = flag_at(0), f1 = flag_at(at(1)), f2 = flag_at(at(2));
 #pragma unroll 1
@@ -768,9 +627,9 @@ __device__ __forceinline__ void cont_chain_walk(const ContRunArgs& K, SharedTabl
         for (int u = 0; u < BATCH; u++) {
             const int64_t c = (c0 + u) < n_chunks ? (c0 + u) : (n_chunks - 1);  // (past the end: the last chunk again, skipped)
             const unsigned r_first = (unsigned)(c * kJointChunk) * jstride;
-            o.first[u] = ld_row_f64<AUX>(jbuf, joff, r_first);
-            o.last[u] = ld_row_f64<AUX>(jbuf, joff, r_first + (unsigned)(chunk_len(c) - 1) * jstride);
-            o.ev[u] = ld_row_u8<AUX>(ebuf, foff, (unsigned)c * fstride);
+            o.first[u] = ld_row_f64(jbuf, joff, r_first);
+            o.last[u] = ld_row_f64(jbuf, joff, r_first + (unsigned)(chunk_len(c) - 1) * jstride);
+            o.ev[u] = ld_row_u8(ebuf, foff, (unsigned)c * fstride);
         }
     };
     // Walks the fetched chunks until one does not stand: returns its index in the batch (BATCH: all stood).
@@ -812,9 +671,9 @@ __device__ __forceinline__ void cont_chain_walk(const ContRunArgs& K, SharedTabl
     // (judged again from the chunk's operands, fetched again: nothing of this is carried through the walk, whose registers are scarce)
     auto stands_alone = [&](int64_t c, double& sh, double& last) -> bool {
         const unsigned r_first = (unsigned)(c * kJointChunk) * jstride;
-        const double first = ld_row_f64<AUX>(jbuf, joff, r_first);
-        last = ld_row_f64<AUX>(jbuf, joff, r_first + (unsigned)(chunk_len(c) - 1) * jstride);
-        const int ev = ld_row_u8<AUX>(ebuf, foff, (unsigned)c * fstride);
+        const double first = ld_row_f64(jbuf, joff, r_first);
+        last = ld_row_f64(jbuf, joff, r_first + (unsigned)(chunk_len(c) - 1) * jstride);
+        const int ev = ld_row_u8(ebuf, foff, (unsigned)c * fstride);
         const double turns = -rint((first - prev) * 0.15915494309189535);
         sh = turns * kTwoPi;
         const double f2 = first + sh;
@@ -870,15 +729,11 @@ __device__ __forceinline__ void cont_chain_walk(const ContRunArgs& K, SharedTabl
             }
         }
     }
-    if (carry) {
-        carry->prev = prev; carry->init = init; carry->emergency = emergency;
-        if (!last) return;
-    }
-    if (owner) stc_f64<COH>(&K.st[(1 + j) * n + i], prev);
+    if (owner) K.st[(1 + j) * n + i] = prev;
     if (live && j == 7) {
-        stc_f64<COH>(&K.st[8 * n + i], init ? 1.0 : 0.0);
-        stc_f64<COH>(&K.st[9 * n + i], emergency ? 1.0 : 0.0);
-        if (last && !emergency) stc_f64<COH>(&K.st[0 * n + i], theta_at(tw0 + T - 1, i));  // previous_theta after the last step
+        K.st[8 * n + i] = init ? 1.0 : 0.0;
+        K.st[9 * n + i] = emergency ? 1.0 : 0.0;
+        if (last && !emergency) K.st[0 * n + i] = theta_at(tw0 + T - 1, i);  // previous_theta after the last step
     }
 }
 
@@ -892,7 +747,7 @@ __global__ __launch_bounds__(kChainBlock) __attribute__((amdgpu_waves_per_eu(1, 
     const int64_t gid = (int64_t)blockIdx.x * kChainBlock + threadIdx.x;
     __shared__ SharedTables lds_tab;
         stage_tables<MIXED, (int)offsetof(ContRunArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC)), kChainBlock>(lds_tab, K.arms);
-    cont_chain_walk<MIXED, false, kChainBatch>(K, lds_tab, gid >> 3, (int)(gid & 7), 0, K.t0, K.T, K.last_block != 0);
+    cont_chain_walk<MIXED, kChainBatch>(K, lds_tab, gid >> 3, (int)(gid & 7), 0, K.t0, K.T, K.last_block != 0);
 }
 
 }  // namespace rsik

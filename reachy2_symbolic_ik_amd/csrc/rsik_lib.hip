@@ -25,8 +25,6 @@
 #include "rsik_kernel_discrete.hpp"
 #include "rsik_kernel_continuous.hpp"
 #include "rsik_kernel_pipeline.hpp"
-#include "rsik_kernel_fused.hpp"
-#include "rsik_kernel_flags.hpp"
 #include "rsik_kernel_state.hpp"
 
 // =====================================================================================
@@ -39,13 +37,11 @@ struct rsik_ctx {
     bool have_arm[2];
     rsik::ArmC arms[2];
     int options[RSIK_OPT_COUNT];
-    void* ws;          // workspace of rsik_control_continuous_run (device: the phased pipeline's slots, or the single launch's arrays), grown on demand
+    void* ws;          // workspace of rsik_control_continuous_run (device: the pipeline's block slots), grown on demand
     size_t ws_bytes;
     bool ws_captured;                // a run recorded into a hipGraph points into the current workspace
     std::vector<void*> retired_ws;   // outgrown workspaces a captured hipGraph may still point into: kept until rsik_destroy / _release
-    unsigned long long* trace;       // RSIK_OPT_CONT_TRACE: the single launch's item records (device), or NULL
-    size_t trace_cap;
-    unsigned* fused_sync;            // the abort words (raised, which wait, wanted, was) of the last run with bounded in-kernel waits: read by rsik_sync
+    std::vector<void*> outgrown_ws;  // outgrown workspaces only runs already issued can use: freed by the next rsik_sync / _release / rsik_destroy
     hipEvent_t run_done;             // recorded behind every continuous run issued launch by launch: the next run, if it comes on
     hipStream_t run_stream;          // ANOTHER stream, waits for it (the workspace, the words and the side streams are the context's)
     bool have_run_done;
@@ -53,9 +49,7 @@ struct rsik_ctx {
     size_t edge_count;
     unsigned edge_seq;               // runs issued with them: the value a word must reach
     int can_wait_value;              // hipDeviceAttributeCanUseStreamWaitValue
-    double flags_epoch;              // the flag-synchronised form's run counter (the tag of its (value, tag) pairs)
-    bool flags_ws_clean;             // the current workspace has been zeroed since it was allocated (no stale tags in it)
-    hipStream_t side[4];             // the pipeline's own streams (prepare / joints / chain; the flag-synchronised form's fourth), created on first use
+    hipStream_t side[3];             // the pipeline's own streams (prepare / joints / chain), created on first use
     std::vector<hipEvent_t> events;  // reusable, timing disabled
     bool have_side;
     std::string err;
@@ -113,11 +107,6 @@ int rsik_create(int device_id, rsik_ctx** out) {
     c->ws = nullptr;
     c->ws_bytes = 0;
     c->ws_captured = false;
-    c->trace = nullptr;
-    c->trace_cap = 0;
-    c->fused_sync = nullptr;
-    c->flags_epoch = 0.0;
-    c->flags_ws_clean = false;
     c->have_run_done = false;
     c->run_stream = nullptr;
     c->edge_words = nullptr;
@@ -134,10 +123,10 @@ int rsik_create(int device_id, rsik_ctx** out) {
 int rsik_destroy(rsik_ctx* ctx) {
     if (ctx && hipSetDevice(ctx->device) == hipSuccess) {
         if (ctx->ws) (void)hipFree(ctx->ws);
-        if (ctx->trace) (void)hipFree(ctx->trace);
         if (ctx->edge_words) (void)hipFree(ctx->edge_words);
         if (ctx->have_run_done) (void)hipEventDestroy(ctx->run_done);
         for (void* w : ctx->retired_ws) (void)hipFree(w);
+        for (void* w : ctx->outgrown_ws) (void)hipFree(w);
         for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
         if (ctx->have_side)
             for (hipStream_t st : ctx->side) (void)hipStreamDestroy(st);
@@ -158,14 +147,11 @@ int rsik_sync(rsik_ctx* ctx) {
     if (!ctx) return RSIK_E_INVALID;
     RSIK_HIP(ctx, hipSetDevice(ctx->device));
     RSIK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->fused_sync) {
-        // the single-launch continuous run bounds every wait inside the kernel; a wait that ran out left its mark here
-        unsigned aborted[4] = {0, 0, 0, 0};
-        RSIK_HIP(ctx, hipMemcpy(aborted, ctx->fused_sync, sizeof aborted, hipMemcpyDeviceToHost));
-        ctx->fused_sync = nullptr;
-        if (aborted[0] != 0)
-            return fail(ctx, RSIK_E_HIP, "rsik_control_continuous_run: a wait inside the pipeline ran out (3 s; sync word " + std::to_string(aborted[1]) +
-                        " wanted " + std::to_string(aborted[2]) + ", was " + std::to_string(aborted[3]) + "); the run's outputs are incomplete");
+    // workspaces that continuous runs outgrew: whatever was issued into them has finished now
+    if (!ctx->outgrown_ws.empty()) {
+        if (ctx->have_run_done) RSIK_HIP(ctx, hipEventSynchronize(ctx->run_done));
+        for (void* w : ctx->outgrown_ws) (void)hipFree(w);
+        ctx->outgrown_ws.clear();
     }
     return RSIK_OK;
 }
@@ -183,7 +169,7 @@ int rsik_set_arm(rsik_ctx* ctx, int arm, const double* consts_host, int count) {
 int rsik_set_option(rsik_ctx* ctx, int option, int value) {
     if (!ctx) return RSIK_E_INVALID;
     if (option < 0 || option >= RSIK_OPT_COUNT) return fail(ctx, RSIK_E_INVALID, "rsik_set_option: unknown option");
-    static const int max_value[RSIK_OPT_COUNT] = {RSIK_EULER_NEVER, 2, 1, 1, RSIK_CONT_RUN_FLAGS, 65535, 64, 64, 1024, 64, 8, 3};
+    static const int max_value[RSIK_OPT_COUNT] = {RSIK_EULER_NEVER, 2, 1, 1, RSIK_CONT_RUN_STEPS, 65535, 3};
     if (value < 0 || value > max_value[option]) return fail(ctx, RSIK_E_INVALID, "rsik_set_option: value out of range");
     ctx->options[option] = value;
     return RSIK_OK;
@@ -589,16 +575,15 @@ static int cont_resources(rsik_ctx* ctx, const char* who, size_t need, bool want
                 // rsik_control_continuous_release
                 ctx->retired_ws.push_back(ctx->ws);
             } else {
-                // nothing but runs already issued can use it: wait for them, free it
-                RSIK_HIP(ctx, hipDeviceSynchronize());
-                RSIK_HIP(ctx, hipFree(ctx->ws));
+                // nothing but runs already issued can use it: freed once they are known to have finished (rsik_sync, _release,
+                // rsik_destroy) — not here: a device-wide wait and a free inside an asynchronous call would stall every stream of
+                // the process and invalidate a capture some other thread has open
+                ctx->outgrown_ws.push_back(ctx->ws);
             }
         }
         ctx->ws = fresh;
         ctx->ws_bytes = want;
         ctx->ws_captured = false;
-        ctx->fused_sync = nullptr;
-        ctx->flags_ws_clean = false;
     }
     if (streams) {
         for (auto& st : ctx->side) RSIK_HIP(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -642,67 +627,6 @@ static unsigned long long* pipe_timing_begin(rsik_ctx* ctx, int64_t n_blocks) {
 }
 #endif
 
-// The single-launch form of a run (rsik_kernel_fused.hpp): how it is cut, what it needs, whether it qualifies.
-struct FusedPlan {
-    int S, Sp, L, CL, B, G, PI, CH, JQ, Jh, theta_wgs, chain_waves, grid;
-    unsigned tickets;
-    size_t off_gw, off_flags, off_events, off_scratch, off_sync, sync_words, need;
-    bool flags_ok;  // the run also fits the flag-synchronised form (rsik_kernel_flags.hpp): its grids are (tiles, steps)
-};
-static bool fused_plan(const rsik_ctx* ctx, int64_t n, int64_t n_steps, FusedPlan& P, std::string* why) {
-    auto no = [&](const char* msg) { if (why) *why = msg; return false; };
-    const int64_t G = (n + 63) / 64;
-    const int64_t theta_wgs = (G + 3) / 4;
-    // theta workgroups own a compute unit each: at most a quarter of the chip (16 384 trajectories on 256 compute units);
-    // beyond that the sequential phases fill the chip by themselves and the phased pipeline is the better form
-    if (theta_wgs * 4 > ctx->compute_units || ctx->compute_units - theta_wgs < 1) return no("too many trajectories for the theta workgroups (a quarter of the compute units at most)");
-    int S = ctx->options[RSIK_OPT_CONT_BLOCK_STEPS] > 0 ? ctx->options[RSIK_OPT_CONT_BLOCK_STEPS] : 64;
-    S = (S + 7) / 8 * 8;
-    if (S > 4096) S = 4096;
-    int Sp = ctx->options[RSIK_OPT_CONT_PREP_STEPS] > 0 ? ctx->options[RSIK_OPT_CONT_PREP_STEPS] : 4;
-    if (Sp > S) Sp = S;
-    while (S % Sp != 0) Sp--;
-    const int64_t B = (n_steps + S - 1) / S;
-    P.S = S; P.Sp = Sp; P.PI = S / Sp; P.CH = S / 8;
-    P.L = ctx->options[RSIK_OPT_CONT_LOOKAHEAD] > 0 ? ctx->options[RSIK_OPT_CONT_LOOKAHEAD] : 6;
-    P.CL = ctx->options[RSIK_OPT_CONT_CHAIN_LAG] > 0 ? ctx->options[RSIK_OPT_CONT_CHAIN_LAG] : 2;
-    P.Jh = ctx->options[RSIK_OPT_CONT_JOINT_GROUPS] > 0 ? ctx->options[RSIK_OPT_CONT_JOINT_GROUPS] : 2;
-    while (8 % P.Jh != 0) P.Jh--;
-    P.JQ = 8 / P.Jh;
-    P.G = (int)G; P.theta_wgs = (int)theta_wgs;
-    if (B > 1000000) return no("too many blocks");
-    P.B = (int)B;
-    const long long tickets = (long long)G * B * (P.PI + P.CH * P.JQ);
-    if (tickets >= (1ll << 31)) return no("too many work items");
-    P.tickets = (unsigned)tickets;
-    // a block's rows are addressed through 2 GB buffer windows: S steps of n x 7 doubles
-    if ((long long)S * n * 56 >= (1ll << 31)) return no("block too large for a buffer window");
-    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
-    const size_t cells = (size_t)n * (size_t)n_steps;
-    // (goal and theta arrays sized for the flag-synchronised form's 16-byte pairs; the single launch uses half of each)
-    P.off_gw = up(cells * 2 * sizeof(double));
-    P.off_flags = P.off_gw + up(cells * 2 * sizeof(double));
-    P.off_events = P.off_flags + up(cells);
-    P.off_scratch = P.off_events + up((size_t)B * P.CH * (size_t)n);
-    P.off_sync = P.off_scratch + up((size_t)n * sizeof(double));
-    P.sync_words = (size_t)rsik::kSyncArrays + 2 * (size_t)B * G + (size_t)G + (size_t)B;  // pdone, jdone, tprog, tdone
-    P.need = P.off_sync + up(P.sync_words * sizeof(unsigned));
-    if (P.need > ((size_t)6 << 30)) return no("workspace above 6 GB");
-    long long workers = (tickets + rsik::kFusedWaves - 1) / rsik::kFusedWaves;
-    if (workers > ctx->compute_units - theta_wgs) workers = ctx->compute_units - theta_wgs;
-    if (workers < 1) workers = 1;
-    P.grid = (int)(theta_wgs + workers);
-    // the chain sub-groups (eight trajectories each) go to the last waves of the worker workgroups: enough of them per
-    // workgroup for all sub-groups, at most half of a workgroup's waves
-    P.chain_waves = (int)((G * 8 + workers - 1) / workers);
-    P.flags_ok = n_steps <= 65535 && cells * 16 < ((size_t)1 << 31);  // (grids of (tiles, steps); pair arrays below 2 GB)
-    if (P.chain_waves > rsik::kFusedWaves / 2) {
-        if (ctx->options[RSIK_OPT_CONT_RUN_MODE] == RSIK_CONT_RUN_FUSED) return no("too many trajectories for the chain waves (half of the worker waves at most)");
-        P.chain_waves = rsik::kFusedWaves / 2;  // (only the single launch uses them)
-    }
-    return true;
-}
-
 int rsik_control_continuous_reserve(rsik_ctx* ctx, int64_t n, int64_t n_steps) {
     const char* who = "rsik_control_continuous_reserve";
     if (!ctx) return RSIK_E_INVALID;
@@ -716,11 +640,6 @@ int rsik_control_continuous_reserve(rsik_ctx* ctx, int64_t n, int64_t n_steps) {
     if ((rc = cont_plan(ctx, who, n, n_steps, true, Pc)) != RSIK_OK) return rc;
     if (Pc.need > P.need) P.need = Pc.need;
     if (Pc.n_events > P.n_events) P.n_events = Pc.n_events;
-    // ... and what the single launch needs, if the run qualifies for it
-    FusedPlan F;
-    const int mode = ctx->options[RSIK_OPT_CONT_RUN_MODE];
-    const bool fused_ok = fused_plan(ctx, n, n_steps, F, nullptr);
-    if ((mode == RSIK_CONT_RUN_FUSED || mode == RSIK_CONT_RUN_FLAGS) && fused_ok) return cont_resources(ctx, who, F.need, mode == RSIK_CONT_RUN_FLAGS, 3);
     return cont_resources(ctx, who, P.need, true, P.n_events);
 }
 
@@ -730,29 +649,12 @@ int rsik_control_continuous_release(rsik_ctx* ctx) {
     RSIK_HIP(ctx, hipDeviceSynchronize());
     for (void* w : ctx->retired_ws) (void)hipFree(w);
     ctx->retired_ws.clear();
+    for (void* w : ctx->outgrown_ws) (void)hipFree(w);
+    ctx->outgrown_ws.clear();
     if (ctx->ws) (void)hipFree(ctx->ws);
     ctx->ws = nullptr;
     ctx->ws_bytes = 0;
     ctx->ws_captured = false;
-    ctx->fused_sync = nullptr;
-    if (ctx->trace) (void)hipFree(ctx->trace);
-    ctx->trace = nullptr;
-    ctx->trace_cap = 0;
-    return RSIK_OK;
-}
-
-int rsik_control_continuous_trace(rsik_ctx* ctx, unsigned long long* records_host, size_t max_records, size_t* n_records) {
-    if (!ctx || !n_records) return RSIK_E_INVALID;
-    *n_records = 0;
-    if (!ctx->trace) return RSIK_OK;
-    RSIK_HIP(ctx, hipSetDevice(ctx->device));
-    RSIK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    unsigned long long count = 0;
-    RSIK_HIP(ctx, hipMemcpy(&count, ctx->trace, sizeof count, hipMemcpyDeviceToHost));
-    if (count > ctx->trace_cap) count = ctx->trace_cap;
-    if (records_host && count > max_records) count = max_records;
-    if (count > 0 && records_host) RSIK_HIP(ctx, hipMemcpy(records_host, ctx->trace + 4, (size_t)count * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    *n_records = (size_t)count;
     return RSIK_OK;
 }
 
@@ -830,164 +732,6 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         capturing = hipStreamIsCapturing(ctx->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
     }
     if ((rc = cont_run_begin(ctx, capturing)) != RSIK_OK) return rc;
-    // ---- the single self-scheduling launch (rsik_kernel_fused.hpp), where the run qualifies
-    {
-        FusedPlan FP;
-        std::string why;
-        const int mode = ctx->options[RSIK_OPT_CONT_RUN_MODE];
-        const bool qualifies = fused_plan(ctx, n, n_steps, FP, &why);
-        if (mode == RSIK_CONT_RUN_FUSED && !qualifies) return fail(ctx, RSIK_E_INVALID, std::string(who) + ": RSIK_CONT_RUN_FUSED: " + why);
-        if (mode == RSIK_CONT_RUN_FLAGS && !(qualifies && FP.flags_ok))
-            return fail(ctx, RSIK_E_INVALID, std::string(who) + ": RSIK_CONT_RUN_FLAGS: " + (qualifies ? std::string("more than 65535 steps") : why));
-        // (the flag-synchronised form holds the caller's stream on a value in device memory, which a hipGraph capture does not take)
-        if (mode == RSIK_CONT_RUN_FLAGS && capturing) return fail(ctx, RSIK_E_INVALID, std::string(who) + ": RSIK_CONT_RUN_FLAGS cannot be captured into a hipGraph");
-        // (RSIK_CONT_RUN_AUTO: the phased pipeline, until one of the two newer forms has proven faster on every size — DESIGN.md section 4)
-        const bool as_flags = qualifies && FP.flags_ok && !capturing && mode == RSIK_CONT_RUN_FLAGS;
-        if (qualifies && (mode == RSIK_CONT_RUN_FUSED || as_flags)) {
-            if ((rc = cont_resources(ctx, who, FP.need, as_flags, as_flags ? 3 : 0)) != RSIK_OK) return rc;
-            const int trace_k = ctx->options[RSIK_OPT_CONT_TRACE];
-            if (trace_k > 0 && !capturing && ctx->trace_cap < (size_t)trace_k * 1000) {
-                if (ctx->trace) { RSIK_HIP(ctx, hipDeviceSynchronize()); (void)hipFree(ctx->trace); ctx->trace = nullptr; ctx->trace_cap = 0; }
-                RSIK_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->trace), (4 + (size_t)trace_k * 1000 * 4) * sizeof(unsigned long long)));
-                ctx->trace_cap = (size_t)trace_k * 1000;
-            }
-            char* base = static_cast<char*>(ctx->ws);
-            rsik::FusedArgs F;
-            std::memset(&F, 0, sizeof F);
-            rsik::ContRunArgs& R = F.R;
-            R.n = n; R.t0 = 0; R.T = n_steps;
-            R.m12_steps = m12_steps;
-            R.arm = arm;
-            R.euler_roundtrip = K0.euler_roundtrip;
-            for (int slot = 0; slot < 2; slot++) {
-                R.pref_arg[slot] = K0.pref_arg[slot]; R.pref_self[slot] = K0.pref_self[slot];
-                R.pref_self_cs[slot] = K0.pref_self_cs[slot]; R.pref_self_sn[slot] = K0.pref_self_sn[slot];
-                R.lim[slot][0] = K0.lim[slot][0]; R.lim[slot][1] = K0.lim[slot][1];
-                R.arms[slot] = K0.arms[slot];
-            }
-            R.d_theta_max = d_theta_max;
-            R.max_angle = K0.max_angle; R.cos_max = K0.cos_max; R.sin_max = K0.sin_max;
-            R.ws = reinterpret_cast<double*>(base);
-            R.gw = reinterpret_cast<double*>(base + FP.off_gw);
-            R.flags = reinterpret_cast<uint8_t*>(base + FP.off_flags);
-            R.chunk_event = reinterpret_cast<uint8_t*>(base + FP.off_events);
-            R.first_block = 1; R.last_block = 1;
-            R.st = cont_state; R.joints = joints_steps; R.reachable = reachable_steps; R.state = state_steps;
-            F.sync = reinterpret_cast<unsigned*>(base + FP.off_sync);
-            F.scratch = reinterpret_cast<double*>(base + FP.off_scratch);
-            F.trace = (trace_k > 0 && ctx->trace) ? ctx->trace : nullptr;
-            F.trace_cap = (unsigned)ctx->trace_cap;
-            F.S = FP.S; F.Sp = FP.Sp; F.L = FP.L; F.CL = FP.CL; F.B = FP.B; F.G = FP.G; F.PI = FP.PI; F.CH = FP.CH; F.JQ = FP.JQ; F.Jh = FP.Jh;
-            F.theta_wgs = FP.theta_wgs; F.chain_waves = FP.chain_waves; F.tickets = FP.tickets;
-            F.flags_mode = as_flags ? 1 : 0;
-            if (as_flags) {
-                // tagged pairs: a workspace that has not been zeroed since it was allocated could hold anything, this run's tag included
-                if (!ctx->flags_ws_clean) {
-                    RSIK_HIP(ctx, hipMemsetAsync(base, 0, FP.off_flags, ctx->stream));
-                    ctx->flags_ws_clean = true;
-                }
-                ctx->flags_epoch += 1.0;
-                R.epoch = ctx->flags_epoch;
-                R.abort_word = reinterpret_cast<unsigned*>(base + FP.off_sync) + rsik::kSyncAbort;
-                R.theta_hint = reinterpret_cast<unsigned*>(base + FP.off_sync) + rsik::kSyncArrays + 2 * (size_t)FP.B * FP.G;  // (= tprog)
-            }
-            F.snap_kind = rsik::kSnapGeneric;
-            if (!arm) F.snap_kind = theta_snap_plan(R.lim[0][0], R.lim[0][1], d_theta_max, &R.snap_tdag);
-            // the sync area starts every run at zero; the (re)initialisation of the trajectories that start here
-            // (C:296-325) runs first, then the one launch
-            RSIK_HIP(ctx, hipMemsetAsync(F.sync, 0, FP.sync_words * sizeof(unsigned), ctx->stream));
-            if (F.trace) RSIK_HIP(ctx, hipMemsetAsync(F.trace, 0, 4 * sizeof(unsigned long long), ctx->stream));
-            if (as_flags) {
-                // ---- the flag-synchronised form (rsik_kernel_flags.hpp).  The two persistent kernels fork off first — the
-                // (re)initialisation, which only the theta waves' start depends on, ahead of them on their stream — then the two
-                // chip-filling kernels back to back on the caller's stream, which joins the other two at the end.
-                hipStream_t s_main = ctx->stream, s_theta = ctx->side[0], s_ja = ctx->side[1], s_jb = ctx->side[2];
-                // words that tie the streams (device memory of the context's, values only ever grow: this run's sequence number):
-                // 0 the run's start, 1 the (re)initialisation done, 2 the theta kernel done, 3 + b the chain launch of block b done
-                const size_t need_words = 3 + (size_t)FP.B;
-                if (ctx->edge_count < need_words) {
-                    if (ctx->edge_words) { RSIK_HIP(ctx, hipDeviceSynchronize()); RSIK_HIP(ctx, hipFree(ctx->edge_words)); ctx->edge_words = nullptr; }
-                    RSIK_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->edge_words), need_words * 2 * sizeof(unsigned)));
-                    RSIK_HIP(ctx, hipMemset(ctx->edge_words, 0, need_words * 2 * sizeof(unsigned)));
-                    ctx->edge_count = need_words * 2;
-                    ctx->edge_seq = 0;
-                }
-                const unsigned seq = ++ctx->edge_seq;
-                unsigned* const W = ctx->edge_words;
-#ifdef RSIK_PIPE_TIMING
-                {
-                    unsigned long long* const pipe_t = pipe_timing_begin(ctx, FP.B);
-                    R.tmin = pipe_t; R.tmax = pipe_t ? pipe_t + 320 : nullptr;
-                }
-#endif
-                F.init_word = W + 1;
-                F.init_seq = seq;
-                F.jwords = W + 3;
-                unsigned* const tdone = F.sync + rsik::kSyncArrays + 2 * (size_t)FP.B * FP.G + FP.G;
-                RSIK_HIP(ctx, hipStreamWriteValue32(s_main, W + 0, seq, 0));  // (behind the sync area's memset)
-                RSIK_HIP(ctx, hipStreamWaitValue32(s_theta, W + 0, seq, hipStreamWaitValueGte, 0xffffffffu));
-                RSIK_HIP(ctx, hipStreamWaitValue32(s_ja, W + 0, seq, hipStreamWaitValueGte, 0xffffffffu));
-                RSIK_HIP(ctx, hipStreamWaitValue32(s_jb, W + 0, seq, hipStreamWaitValueGte, 0xffffffffu));
-                // the theta workgroups first: each needs a compute unit to itself, and must be running before the chip-filling
-                // kernels take the chip — the caller's stream waits for their count before the prepare kernel
-                if (arm) hipLaunchKernelGGL(rsik::flags_theta_kernel<true>, dim3((unsigned)FP.theta_wgs), dim3(768), 0, s_theta, F);
-                else hipLaunchKernelGGL(rsik::flags_theta_kernel<false>, dim3((unsigned)FP.theta_wgs), dim3(768), 0, s_theta, F);
-                RSIK_HIP(ctx, hipStreamWriteValue32(s_theta, W + 2, seq, 0));
-                // the (re)initialisation beside it (C:296-325; only the theta walkers' first step and the first chain launch need it)
-                {
-                    const bool pair = !singularity_plane_binds(K0.arms);
-                    dim3 grid_init = grid;
-                    if (pair && (rc = launch_dims(ctx, n * 2, &grid_init, who)) != RSIK_OK) return rc;
-                    if (arm) { if (pair) hipLaunchKernelGGL((rsik::cont_init_kernel<true, true>), grid_init, block, 0, s_ja, K0); else hipLaunchKernelGGL((rsik::cont_init_kernel<true, false>), grid_init, block, 0, s_ja, K0); }
-                    else { if (pair) hipLaunchKernelGGL((rsik::cont_init_kernel<false, true>), grid_init, block, 0, s_ja, K0); else hipLaunchKernelGGL((rsik::cont_init_kernel<false, false>), grid_init, block, 0, s_ja, K0); }
-                }
-                RSIK_HIP(ctx, hipStreamWriteValue32(s_ja, W + 1, seq, 0));
-                RSIK_HIP(ctx, hipStreamWaitValue32(s_main, F.sync + rsik::kSyncAlive, (uint32_t)FP.theta_wgs, hipStreamWaitValueGte, 0xffffffffu));
-                const bool pb = singularity_plane_binds(R.arms);
-                const dim3 pgrid(grid.x, (unsigned)n_steps);
-                const unsigned chain_wgs = (unsigned)((n * 8 + rsik::kChainBlock - 1) / rsik::kChainBlock);
-                if (arm) { if (pb) hipLaunchKernelGGL((rsik::flags_prepare_kernel<true, true>), pgrid, block, 0, s_main, F); else hipLaunchKernelGGL((rsik::flags_prepare_kernel<true, false>), pgrid, block, 0, s_main, F); }
-                else { if (pb) hipLaunchKernelGGL((rsik::flags_prepare_kernel<false, true>), pgrid, block, 0, s_main, F); else hipLaunchKernelGGL((rsik::flags_prepare_kernel<false, false>), pgrid, block, 0, s_main, F); }
-                for (int b = 0; b < FP.B; b++) {
-                    const int64_t t0 = (int64_t)b * FP.S;
-                    const int64_t Tb = (n_steps - t0) < FP.S ? (n_steps - t0) : (int64_t)FP.S;
-                    // joints(b): once every theta wave has counted itself through the block; the blocks take the two streams in turn
-                    hipStream_t sj = (b & 1) ? s_jb : s_ja;
-                    RSIK_HIP(ctx, hipStreamWaitValue32(sj, tdone + b, (uint32_t)FP.G, hipStreamWaitValueGte, 0xffffffffu));
-                    const dim3 jgrid((unsigned)((n + 31) / 32), (unsigned)((Tb + rsik::kJointChunk - 1) / rsik::kJointChunk));
-                    if (arm) hipLaunchKernelGGL(rsik::flags_joints_kernel<true>, jgrid, block, 0, sj, F, (int64_t)(t0 / rsik::kJointChunk));
-                    else hipLaunchKernelGGL(rsik::flags_joints_kernel<false>, jgrid, block, 0, sj, F, (int64_t)(t0 / rsik::kJointChunk));
-                    // chain(b): right behind joints(b) on the same stream (a kernel boundary: the rows are in memory), once the
-                    // chain launch of the block before — on the other stream — has completed (block 0: the (re)initialisation)
-                    RSIK_HIP(ctx, hipStreamWaitValue32(sj, b == 0 ? W + 1 : W + 3 + (b - 1), seq, hipStreamWaitValueGte, 0xffffffffu));
-                    if (arm) hipLaunchKernelGGL(rsik::flags_chain_kernel<true>, dim3(chain_wgs), dim3(rsik::kChainBlock), 0, sj, F, t0, Tb, (int)(b == FP.B - 1));
-                    else hipLaunchKernelGGL(rsik::flags_chain_kernel<false>, dim3(chain_wgs), dim3(rsik::kChainBlock), 0, sj, F, t0, Tb, (int)(b == FP.B - 1));
-                    RSIK_HIP(ctx, hipStreamWriteValue32(sj, W + 3 + b, seq, 0));
-                }
-                RSIK_HIP(ctx, hipStreamWaitValue32(s_main, W + 3 + (FP.B - 1), seq, hipStreamWaitValueGte, 0xffffffffu));
-                RSIK_HIP(ctx, hipStreamWaitValue32(s_main, W + 2, seq, hipStreamWaitValueGte, 0xffffffffu));
-                RSIK_HIP(ctx, hipGetLastError());
-                if (capturing) ctx->ws_captured = true;
-                ctx->fused_sync = F.sync + rsik::kSyncAbort;
-                return cont_run_end(ctx, capturing);
-            }
-            {
-                const bool pair = !singularity_plane_binds(K0.arms);
-                dim3 grid_init = grid;
-                if (pair && (rc = launch_dims(ctx, n * 2, &grid_init, who)) != RSIK_OK) return rc;
-                if (arm) { if (pair) hipLaunchKernelGGL((rsik::cont_init_kernel<true, true>), grid_init, block, 0, ctx->stream, K0); else hipLaunchKernelGGL((rsik::cont_init_kernel<true, false>), grid_init, block, 0, ctx->stream, K0); }
-                else { if (pair) hipLaunchKernelGGL((rsik::cont_init_kernel<false, true>), grid_init, block, 0, ctx->stream, K0); else hipLaunchKernelGGL((rsik::cont_init_kernel<false, false>), grid_init, block, 0, ctx->stream, K0); }
-            }
-            const dim3 fgrid((unsigned)FP.grid), fblock(rsik::kFusedThreads);
-            const bool pb = singularity_plane_binds(R.arms);
-            if (arm) { if (pb) hipLaunchKernelGGL((rsik::cont_fused_kernel<true, true>), fgrid, fblock, 0, ctx->stream, F); else hipLaunchKernelGGL((rsik::cont_fused_kernel<true, false>), fgrid, fblock, 0, ctx->stream, F); }
-            else { if (pb) hipLaunchKernelGGL((rsik::cont_fused_kernel<false, true>), fgrid, fblock, 0, ctx->stream, F); else hipLaunchKernelGGL((rsik::cont_fused_kernel<false, false>), fgrid, fblock, 0, ctx->stream, F); }
-            RSIK_HIP(ctx, hipGetLastError());
-            if (capturing) ctx->ws_captured = true;
-            ctx->fused_sync = F.sync + rsik::kSyncAbort;
-            return cont_run_end(ctx, capturing);
-        }
-    }
     // ---- phased pipeline.  The four phases of a block run on four streams (theta on the caller's, the others on the
     // context's own), ordered by events: prepare(b) -> theta(b) -> joints(b) -> chain(b), theta(b) after theta(b-1),
     // chain(b) after chain(b-1).  The two sequential phases (a lone wave per SIMD on a few CUs) then run beside each other
@@ -1010,7 +754,6 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         if ((rc = cont_resources(ctx, who, both.need, true, both.n_events)) != RSIK_OK) return rc;
     }
     if (capturing) ctx->ws_captured = true;
-    ctx->fused_sync = nullptr;
     const std::vector<int64_t>&block_t0 = P.block_t0, &block_T = P.block_T;
     const int64_t n_blocks = (int64_t)block_t0.size();
     const size_t slot_bytes = P.slot_bytes, carry_bytes = P.carry_bytes, chunks_per_block = P.chunks_per_block;
@@ -1028,9 +771,10 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     const int variant = ctx->options[RSIK_OPT_CONT_PHASED_VARIANT];
     const bool by_value = !capturing && ctx->can_wait_value != 0 && !(variant & RSIK_PHASED_EDGES_BY_EVENT);
     if (by_value) {
-        const size_t need_words = P.n_events + 2 * (size_t)n_blocks + 8;  // (+ per block: "theta(b) has started", the theta run's count; + alive, abort)
+        const size_t need_words = P.n_events + (size_t)n_blocks;  // (+ per block: "theta(b) has started")
         if (ctx->edge_count < need_words) {
-            if (ctx->edge_words) { RSIK_HIP(ctx, hipDeviceSynchronize()); RSIK_HIP(ctx, hipFree(ctx->edge_words)); ctx->edge_words = nullptr; }
+            // (the old words: runs already issued still wait on them and write them — freed like an outgrown workspace)
+            if (ctx->edge_words) { ctx->outgrown_ws.push_back(ctx->edge_words); ctx->edge_words = nullptr; ctx->edge_count = 0; }
             RSIK_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->edge_words), need_words * 2 * sizeof(unsigned)));
             RSIK_HIP(ctx, hipMemset(ctx->edge_words, 0, need_words * 2 * sizeof(unsigned)));
             ctx->edge_count = need_words * 2;
@@ -1048,24 +792,6 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         if (by_value) return hipStreamWaitValue32(st, ctx->edge_words + id, seq, hipStreamWaitValueGte, 0xffffffffu);
         return hipStreamWaitEvent(st, ctx->events[id], 0);
     };
-    // (Re)initialisation of the trajectories that start here (C:296-325: the start-up search for previous_theta, ~55 us
-    // of lone waves), then the pipeline's streams join in.  The prepare phase depends on the goal matrices alone, not on
-    // the trajectory state: its stream forks off BEFORE the initialisation (behind whatever the caller queued ahead of
-    // this call), so prepare(0) runs beside it and theta(0) starts when both are done; the joints and chain streams fork
-    // behind it.
-    RSIK_HIP(ctx, signal(s_main, 1));
-    RSIK_HIP(ctx, wait_for(s_prep, 1));
-    {
-        // two lanes per trajectory where get_joints cannot move the solver's state (no elbow projection possible)
-        const bool pair = !singularity_plane_binds(K0.arms);
-        dim3 grid_init = grid;
-        if (pair && (rc = launch_dims(ctx, n * 2, &grid_init, who)) != RSIK_OK) return rc;
-        if (arm) { if (pair) hipLaunchKernelGGL((rsik::cont_init_kernel<true, true>), grid_init, block, 0, s_main, K0); else hipLaunchKernelGGL((rsik::cont_init_kernel<true, false>), grid_init, block, 0, s_main, K0); }
-        else { if (pair) hipLaunchKernelGGL((rsik::cont_init_kernel<false, true>), grid_init, block, 0, s_main, K0); else hipLaunchKernelGGL((rsik::cont_init_kernel<false, false>), grid_init, block, 0, s_main, K0); }
-        RSIK_HIP(ctx, signal(s_main, 0));
-    }
-    RSIK_HIP(ctx, wait_for(s_joints, 0));
-    RSIK_HIP(ctx, wait_for(s_chain, 0));
     rsik::ContRunArgs R;
     std::memset(&R, 0, sizeof R);
     R.n = n;
@@ -1151,10 +877,9 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         // between them; higher stream priority for the prepare and chain streams: no difference)
         // (only where theta(b + 1) has been ISSUED before this wait: streams can share a hardware queue, and a wait that sat in one
         // ahead of the launch it waits for would wait for ever — true for the blocks that have workspace slots of their own)
+        RSIK_HIP(ctx, wait_for(s_joints, edge_id(1, b)));
         if (by_value && !(variant & RSIK_PHASED_NO_THETA_FIRST) && b + 1 < head)
             RSIK_HIP(ctx, hipStreamWaitValue32(s_joints, ctx->edge_words + P.n_events + (size_t)(b + 1), seq, hipStreamWaitValueGte, 0xffffffffu));
-        else
-            RSIK_HIP(ctx, wait_for(s_joints, edge_id(1, b)));
         if (arm) hipLaunchKernelGGL(rsik::cont_joints_kernel<true>, grid2, block, 0, s_joints, R);
         else hipLaunchKernelGGL(rsik::cont_joints_kernel<false>, grid2, block, 0, s_joints, R);
         RSIK_HIP(ctx, signal(s_joints, edge_id(2, b)));
@@ -1164,27 +889,72 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         RSIK_HIP(ctx, signal(s_chain, edge_id(3, b)));
         return RSIK_OK;
     };
+    // (Re)initialisation of the trajectories that start here (C:296-325: the start-up search for previous_theta, ~55 us
+    // of lone waves), then the pipeline's streams join in.  The prepare phase depends on the goal matrices alone, not on
+    // the trajectory state: its stream forks off BEFORE the initialisation (behind whatever the caller queued ahead of
+    // this call), so prepare(0) runs beside it and theta(0) starts when both are done; the joints and chain streams fork
+    // behind it.
+    auto issue_start = [&]() -> int {
+        RSIK_HIP(ctx, signal(s_main, 1));
+        RSIK_HIP(ctx, wait_for(s_prep, 1));
+        {
+            // two lanes per trajectory where get_joints cannot move the solver's state (no elbow projection possible)
+            const bool pair = !singularity_plane_binds(K0.arms);
+            dim3 grid_init = grid;
+            int rc_ = RSIK_OK;
+            if (pair && (rc_ = launch_dims(ctx, n * 2, &grid_init, who)) != RSIK_OK) return rc_;
+            if (arm) { if (pair) hipLaunchKernelGGL((rsik::cont_init_kernel<true, true>), grid_init, block, 0, s_main, K0); else hipLaunchKernelGGL((rsik::cont_init_kernel<true, false>), grid_init, block, 0, s_main, K0); }
+            else { if (pair) hipLaunchKernelGGL((rsik::cont_init_kernel<false, true>), grid_init, block, 0, s_main, K0); else hipLaunchKernelGGL((rsik::cont_init_kernel<false, false>), grid_init, block, 0, s_main, K0); }
+            RSIK_HIP(ctx, signal(s_main, 0));
+        }
+        RSIK_HIP(ctx, wait_for(s_joints, 0));
+        RSIK_HIP(ctx, wait_for(s_chain, 0));
+        return RSIK_OK;
+    };
     // Issue order of the blocks that have a workspace slot of their own (it is also the order of the nodes in a captured
     // graph): prepare(0), theta(0), then the other prepares back to back, the other thetas, then joints + chain of
     // every block.  Measured on graph replays of 4096 x 1000 steps against three other orders (prepare / theta
     // alternating: 0.394-0.411 ms; all prepares, all thetas: 0.398-0.401; thetas and backs alternating: 0.414-0.416):
     // 0.387-0.392 ms.
-    if ((rc = issue_prepare(0)) != RSIK_OK) return rc;
-    if ((rc = issue_theta(0)) != RSIK_OK) return rc;
-    for (int64_t b = 1; b < head; b++)
-        if ((rc = issue_prepare(b)) != RSIK_OK) return rc;
-    for (int64_t b = 1; b < head; b++)
-        if ((rc = issue_theta(b)) != RSIK_OK) return rc;
-    for (int64_t b = 0; b < head; b++)
-        if ((rc = issue_back(b)) != RSIK_OK) return rc;
-    for (int64_t b = head; b < n_blocks; b++) {
-        if ((rc = issue_prepare(b)) != RSIK_OK) return rc;
-        if ((rc = issue_theta(b)) != RSIK_OK) return rc;
-        if ((rc = issue_back(b)) != RSIK_OK) return rc;
+    auto issue_all = [&]() -> int {
+        int rc_ = issue_start();
+        if (rc_ != RSIK_OK) return rc_;
+        if ((rc_ = issue_prepare(0)) != RSIK_OK) return rc_;
+        if ((rc_ = issue_theta(0)) != RSIK_OK) return rc_;
+        for (int64_t b = 1; b < head; b++)
+            if ((rc_ = issue_prepare(b)) != RSIK_OK) return rc_;
+        for (int64_t b = 1; b < head; b++)
+            if ((rc_ = issue_theta(b)) != RSIK_OK) return rc_;
+        for (int64_t b = 0; b < head; b++)
+            if ((rc_ = issue_back(b)) != RSIK_OK) return rc_;
+        for (int64_t b = head; b < n_blocks; b++) {
+            if ((rc_ = issue_prepare(b)) != RSIK_OK) return rc_;
+            if ((rc_ = issue_theta(b)) != RSIK_OK) return rc_;
+            if ((rc_ = issue_back(b)) != RSIK_OK) return rc_;
+        }
+        // the caller's stream continues once the last chain (hence every phase of every block) is done
+        RSIK_HIP(ctx, wait_for(s_main, edge_id(3, n_blocks - 1)));
+        RSIK_HIP(ctx, hipGetLastError());
+        return RSIK_OK;
+    };
+    if ((rc = issue_all()) != RSIK_OK) {
+        // A failure part-way leaves value waits queued on the context's streams whose words nobody is going to write (an event
+        // that was never recorded is no wait at all; a word is one).  Every word of the context is raised to this run's number
+        // from a stream of its own, so that the streams drain and no later call (rsik_sync, _release, rsik_destroy) hangs on
+        // them; the run's outputs are unspecified, the error is the caller's to see.
+        if (by_value) {
+            const std::string first_error = ctx->err;
+            hipStream_t fresh = nullptr;
+            if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) == hipSuccess) {
+                (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->edge_words), (int)seq, ctx->edge_count, fresh);
+                (void)hipStreamSynchronize(fresh);
+                (void)hipStreamDestroy(fresh);
+            }
+            (void)hipGetLastError();
+            ctx->err = first_error;
+        }
+        return rc;
     }
-    // the caller's stream continues once the last chain (hence every phase of every block) is done
-    RSIK_HIP(ctx, wait_for(s_main, edge_id(3, n_blocks - 1)));
-    RSIK_HIP(ctx, hipGetLastError());
     return cont_run_end(ctx, capturing);
 }
 

@@ -42,7 +42,6 @@ if [[ $PART == *b* ]]; then
 # the pass without a profiler (in-kernel stamps), the bounds, eager against replayed at the driver's protocol
 timeout -k 10 400 python3 scripts/stage_timers.py --no-build > $OUT/stage_timers.json 2> $OUT/stage_timers.err
 [ -x build/edge_probe ] && timeout -k 5 120 ./build/edge_probe > $OUT/edge_probe.txt 2>&1
-timeout -k 10 300 python3 scripts/fused_check.py 4096 1000 20 > $OUT/c5_forms_bits_time_trace.txt 2>&1
 [ -f build/variants/pipe_timing.so ] && timeout -k 10 300 python3 scripts/probes/c5_untraced_timeline.py build/variants/pipe_timing.so > $OUT/c5_untraced_timeline.txt 2>&1
 [ -f build/variants/disc_class.so ] && timeout -k 10 300 python3 scripts/probes/disc_sorted_bound.py --no-build > $OUT/disc_sorted_bound.txt 2>&1
 timeout -k 10 400 bash scripts/probes/c5_forms.sh > $OUT/c5_eager_vs_replayed_driver_protocol.txt 2>&1

@@ -75,7 +75,7 @@ tp[50, 9, bad_t[0]] = float("nan")       # tx at step 50
 tp[0, 0, bad_t[1]] = float("inf")        # R00 at step 0
 tp[120:, 11, bad_t[2]] = float("nan")    # tz from step 120 on
 tp[199, 4, bad_t[3]] = float("-inf")     # last step
-for name, mode in (("steps", A.CONT_RUN_STEPS), ("phased", A.CONT_RUN_PHASED), ("fused", A.CONT_RUN_FUSED), ("flags", A.CONT_RUN_FLAGS)):
+for name, mode in (("steps", A.CONT_RUN_STEPS), ("phased", A.CONT_RUN_PHASED)):
     hs.set_option(A.OPT_CONT_RUN_MODE, mode)
     res = {}
     for tag, T in (("clean", traj), ("bad", tp)):

@@ -164,10 +164,9 @@ def _m12_to_matrices(m12):
 
 @pytest.mark.parametrize("n_traj,n_steps", [(300, 200), (9, 131), (1, 64)])
 def test_continuous_run_goals_that_are_not_numbers(torch_mod, orc, n_traj, n_steps):
-    """rsik_control_continuous_run, every form (the step kernel launch by launch, the phased pipeline with its edge kinds, the
-    single launch, the flag-synchronised form): poisoned trajectories are reported step by step as the checker reports them, end
-    in the state the checker ends in, and every other trajectory — outputs and carried state — is bit for bit that of a clean run
-    of the same form.  A run that stalled would fail rsik_sync (bounded waits) or the test's time limit."""
+    """rsik_control_continuous_run, every form (the step kernel launch by launch, the phased pipeline with its edge kinds and
+    block sizes): poisoned trajectories are reported step by step as the checker reports them, end in the state the checker ends
+    in, and every other trajectory — outputs and carried state — is bit for bit that of a clean run of the same form."""
     torch = torch_mod
     from bench import make_config5_trajectories
 
@@ -179,8 +178,7 @@ def test_continuous_run_goals_that_are_not_numbers(torch_mod, orc, n_traj, n_ste
     st0 = c.new_continuous_state("r_arm", n_traj)
     keep = _rows_except(torch, n_traj, sorted(cases))
     forms = [("steps", A.CONT_RUN_STEPS, 0, 0), ("phased", A.CONT_RUN_PHASED, 0, 0), ("phased/events", A.CONT_RUN_PHASED, 0, A.PHASED_EDGES_BY_EVENT),
-             ("phased/blocks of 24", A.CONT_RUN_PHASED, 24, 0), ("phased/no theta-first", A.CONT_RUN_PHASED, 40, A.PHASED_NO_THETA_FIRST),
-             ("single launch", A.CONT_RUN_FUSED, 16, 0), ("flags", A.CONT_RUN_FLAGS, 16, 0)]
+             ("phased/blocks of 24", A.CONT_RUN_PHASED, 24, 0), ("phased/no theta-first", A.CONT_RUN_PHASED, 40, A.PHASED_NO_THETA_FIRST)]
     results = {}
     try:
         for name, mode, block, variant in forms:

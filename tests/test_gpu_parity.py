@@ -1152,7 +1152,7 @@ def test_continuous_pipeline_takes_slightly_skewed_matrices_as_they_are(torch_mo
     hs = c._solver
     hs.set_option(A.OPT_EULER_ROUNDTRIP, A.EULER_NEVER if euler_mode == "never" else A.EULER_AUTO)
     ref = None
-    for run_mode in (A.CONT_RUN_STEPS, A.CONT_RUN_PHASED, A.CONT_RUN_FUSED, A.CONT_RUN_FLAGS):
+    for run_mode in (A.CONT_RUN_STEPS, A.CONT_RUN_PHASED):
         hs.set_option(A.OPT_CONT_RUN_MODE, run_mode)
         st = c.new_continuous_state("r_arm", n_traj)
         res = c.run_continuous_trajectories("r_arm", traj, st, first_step_timed_out=True, current_pose=traj[0])
@@ -1200,9 +1200,9 @@ def _eventful_trajectories(torch, n_traj, n_steps, seed, arm):
                                                          (65, 33, "r_arm", "low_elbow", 0.01), (600, 203, "l_arm", "unconstrained", 0.3),
                                                          (4099, 40, "r_arm", "unconstrained", 0.01)])
 def test_continuous_run_forms_are_bit_identical(torch_mod, n_traj, n_steps, arm, mode, dmax):
-    """rsik_control_continuous_run has several forms of issuing the same four bodies (include/rsik.h: the phased pipeline, its
-    variants — events instead of stream value words, no theta-first hold, other block sizes —, the single
-    self-scheduling launch, the flag-synchronised form).  They run the same device code on the same data: every output and
+    """rsik_control_continuous_run has several forms of issuing the same four bodies (include/rsik.h: the phased pipeline and
+    its variants — events instead of stream value words, no theta-first hold, other block sizes).  They run the same device
+    code on the same data: every output and
     the carried state must be the same BITS, on eventful trajectories (jumps, wound wrists, unreachable stretches, repeats)
     that take the sequential phases through their rare paths; the step kernel, launch per step, bounds them all (_same_run)."""
     A = _abi_mod()
@@ -1211,8 +1211,7 @@ def test_continuous_run_forms_are_bit_identical(torch_mod, n_traj, n_steps, arm,
     hs = c._solver
     forms = [("steps", A.CONT_RUN_STEPS, 0, 0), ("phased", A.CONT_RUN_PHASED, 0, 0), ("phased, events", A.CONT_RUN_PHASED, A.PHASED_EDGES_BY_EVENT, 0),
              ("phased, no theta-first", A.CONT_RUN_PHASED, A.PHASED_NO_THETA_FIRST, 0), ("phased, events, no theta-first, blocks of 48", A.CONT_RUN_PHASED, 3, 48),
-             ("phased, blocks of 48", A.CONT_RUN_PHASED, 0, 48), ("fused", A.CONT_RUN_FUSED, 0, 0),
-             ("fused, blocks of 24", A.CONT_RUN_FUSED, 0, 24), ("flags", A.CONT_RUN_FLAGS, 0, 0), ("flags, blocks of 40", A.CONT_RUN_FLAGS, 0, 40)]
+             ("phased, blocks of 48", A.CONT_RUN_PHASED, 0, 48), ("phased, blocks of 16", A.CONT_RUN_PHASED, 0, 16)]
     got = {}
     for name, run_mode, variant, blk in forms:
         hs.set_option(A.OPT_CONT_RUN_MODE, run_mode)
@@ -1221,7 +1220,7 @@ def test_continuous_run_forms_are_bit_identical(torch_mod, n_traj, n_steps, arm,
         st = c.new_continuous_state(arm, n_traj)
         res = c.run_continuous_trajectories(arm, traj, st, first_step_timed_out=True, current_pose=traj[0], constrained_mode=mode,
                                             d_theta_max=dmax)
-        hs.synchronize()  # (also reports a wait that ran out inside one of the launches)
+        hs.synchronize()
         got[name] = {k: v.clone() for k, v in res.items()}
         got[name]["cont_state"] = st.clone()
     hs.set_option(A.OPT_CONT_RUN_MODE, A.CONT_RUN_AUTO)
