@@ -424,8 +424,10 @@ def parse_args(argv):
                          "region: launch differences with this library, per-wave stamps with a -DRSIK_TIMELINE_PROBE build)")
     ap.add_argument("--no-valu-calibration", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the cold-HBM, sustained-clock and calibration phases (A/B timing)")
-    ap.add_argument("--gather", choices=["step", "final", "none"], default="step",
-                    help="N > 1: all-gather joints + state inside every timed step (default), once after them, or never")
+    ap.add_argument("--gather", choices=["step", "final", "none"], default="final",
+                    help="N > 1: final (default) = K sharded steps, then ONE all-gather of joints + state inside the timed region — the "
+                         "north star's job shape; step = an all-gather inside every timed step; none = never.  The line carries the "
+                         "kernel-only, gather-only and both end-to-end figures whichever is timed")
     ap.add_argument("--gather-every-step", action="store_true", help="same as --gather step")
     ap.add_argument("--chunks", type=int, default=4,
                     help="N > 1 with --gather step: stripes per shard; stripe c's all-gather travels while stripe c + 1 is solved")
@@ -489,36 +491,97 @@ def rendezvous_only(args, world, rank):
 
 
 # ------------------------------------------------------------------------------------------ one rank
-def other_configs_section(headline_cfg):
-    """Configs 3, 4 (one GPU's shard) and 5 timed briefly in the same process after the headline config: K = 20 steps
-    with the same launch policy (W = 5 warm-up steps; config 5 carries its steady state beside that), the CPU checker on a sample of each.  Headline `config` / `value` are untouched; these are
-    the driver-timed figures for the other BASELINE configs."""
-    section = {}
-    for oc in (3, 4, 5):
-        if oc == headline_cfg:
-            continue
+def other_config_entry(oc, sub, wall_s):
+    """What the default line carries for one of the other BASELINE configs (its own driver-protocol leg: W = 5, K = 20)."""
+    r = sub["roofline"]
+    e = {
+        "workload": sub["config"]["workload"], "metric": sub["metric"], "value": sub["value"], "unit": sub["unit"],
+        "steps": sub["steps"], "warmup": sub["warmup"], "ms_per_step": sub["ms_per_step"], "kernel_ms": r["kernel_ms"], "launch": sub["launch"],
+        "algorithmic_bytes_per_pose": r["algorithmic_bytes_per_pose"], "achieved_GBs": r["achieved"], "frac": r["frac"],
+        "traffic": r.get("traffic"),
+        "parity_on_sample": sub.get("cpu_baseline", {}).get("parity_on_sample"),
+        "cpu_baseline": {k: sub.get("cpu_baseline", {}).get(k) for k in ("value", "unit", "cores", "kind", "single_thread", "workload_filter")},
+        "wall_s": wall_s,
+    }
+    if oc == 5:
+        # a bench "step" of config 5 is one PASS (4096 trajectories x 1000 control steps): ms_per_step above is per pass; the
+        # kernel time and the traffic are carried in both units, labelled
+        e.pop("kernel_ms")
+        e.pop("traffic")
+        e["ms_per_pass"] = sub["ms_per_step"]
+        e["kernel_ms_per_pass"] = r["kernel_ms"] * 1000
+        e["kernel_ms_per_control_step_of_4096_trajectories"] = r["kernel_ms"]
+        e["traffic_bytes_per_pass"] = (r["traffic"] * 1000) if r.get("traffic") else None
+        e["traffic_bytes_per_control_step_of_4096_trajectories"] = r.get("traffic")
+        e["frac_at_286_bytes_state_round_trip_per_step"] = r.get("frac_at_286_bytes_state_round_trip_per_step")
+        e["steady_state"] = sub.get("steady_state")
+    return e
+
+
+def run_default_protocol(make_leg, headline_cfg, others=(3, 4, 5), log=None):
+    """The default run (N = 1, no --config): the headline config and the other BASELINE configs in ONE protocol —
+        1. every config's synthetic workload is generated and made resident (no timing yet),
+        2. the GPU legs back to back: the headline's warm-up + K timed steps (+ its extras), then each other config's W = 5 / K = 20,
+        3. only then the CPU-baseline legs (seconds of host work during which the GPU idles and clocks down),
+    so that no config is timed on a chip that sat idle behind another one's CPU leg.  `make_leg(cfg)` returns a generator that
+    yields "ready" after its set-up and "timed" after its GPU legs and returns its line (bench._run); a config other than the
+    headline that fails is reported in its entry and dropped.  Returns (headline line, {cfg: line | {"error": ...}}, order)."""
+    order, t_start = [], time.perf_counter()
+
+    def note(what, cfg):
+        order.append([what, cfg, round(time.perf_counter() - t_start, 3)])
+        if log:
+            log(what, cfg)
+
+    legs, failed, wall = {}, {}, {}
+
+    def advance(cfg, want):
         t0 = time.perf_counter()
         try:
-            # (config 5: the entry's headline is the driver's protocol, W = 5 / K = 20; the same K passes after 60 more untimed ones are
-            # carried beside it as `steady_state`, with both launch forms)
-            sub = main(["--config", str(oc), "--steps", "20", "--warmup", "5", "--no-extras", "--no-valu-calibration", "--no-other-configs",
-                        "--cpu-seconds", "2"], return_line=True)
-            r = sub["roofline"]
-            section[str(oc)] = {
-                "workload": sub["config"]["workload"], "metric": sub["metric"], "value": sub["value"], "unit": sub["unit"],
-                "steps": sub["steps"], "warmup": sub["warmup"], "ms_per_step": sub["ms_per_step"], "kernel_ms": r["kernel_ms"], "launch": sub["launch"],
-                "algorithmic_bytes_per_pose": r["algorithmic_bytes_per_pose"], "achieved_GBs": r["achieved"], "frac": r["frac"],
-                "traffic": r.get("traffic"),
-                "parity_on_sample": sub.get("cpu_baseline", {}).get("parity_on_sample"),
-                "cpu_baseline": {k: sub.get("cpu_baseline", {}).get(k) for k in ("value", "unit", "cores", "kind", "single_thread", "workload_filter")},
-                "wall_s": time.perf_counter() - t0,
-            }
-            if oc == 5:
-                section["5"]["frac_at_286_bytes_state_round_trip_per_step"] = r.get("frac_at_286_bytes_state_round_trip_per_step")
-                section["5"]["steady_state"] = sub.get("steady_state")
-        except Exception as e:  # the headline line must not be lost to a secondary measurement
-            section[str(oc)] = {"error": f"{type(e).__name__}: {e}"}
-    return section
+            got = next(legs[cfg])
+            assert got == want, (got, want)
+        except Exception as e:  # (StopIteration included: a leg that ends early is an error too)
+            if cfg == headline_cfg:
+                raise
+            failed[cfg] = {"error": f"{type(e).__name__}: {e}"}
+            legs.pop(cfg, None)
+        wall[cfg] = wall.get(cfg, 0.0) + time.perf_counter() - t0
+
+    for cfg in (headline_cfg,) + tuple(c for c in others if c != headline_cfg):
+        legs[cfg] = make_leg(cfg)
+        advance(cfg, "ready")
+        note("setup", cfg)
+    for cfg in list(legs):
+        advance(cfg, "timed")
+        note("gpu", cfg)
+    lines = {}
+    for cfg in list(legs):
+        t0 = time.perf_counter()
+        try:
+            while True:
+                next(legs[cfg])
+        except StopIteration as stop:
+            lines[cfg] = stop.value
+        except Exception as e:
+            if cfg == headline_cfg:
+                raise
+            failed[cfg] = {"error": f"{type(e).__name__}: {e}"}
+        wall[cfg] = wall.get(cfg, 0.0) + time.perf_counter() - t0
+        note("cpu", cfg)
+    out = {}
+    for cfg in others:
+        if cfg == headline_cfg:
+            continue
+        out[cfg] = failed[cfg] if cfg in failed else other_config_entry(cfg, lines[cfg], wall.get(cfg, 0.0))
+    return lines[headline_cfg], out, order
+
+
+def _drain(gen):
+    try:
+        while True:
+            next(gen)
+    except StopIteration as stop:
+        return stop.value
 
 
 def main(argv=None, return_line=False):
@@ -528,13 +591,44 @@ def main(argv=None, return_line=False):
     if not in_group and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus, argv))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.config == 0 and not args.no_other_configs and not args.rendezvous_only:
+        others_argv = ["--steps", "20", "--warmup", "5", "--no-extras", "--no-valu-calibration", "--no-other-configs", "--cpu-seconds", "2"]
+        if args.lib:
+            others_argv += ["--lib", args.lib]
+        line, others, order = run_default_protocol(
+            lambda cfg: _run(argv + ["--config", "2"]) if cfg == 2 else _run(["--config", str(cfg)] + others_argv), 2)
+        line["other_configs"] = {str(k): v for k, v in others.items()}
+        line["protocol"] = {"order": order,
+                            "what": "[phase, config, seconds since start]: every workload resident first, then the GPU legs back to back "
+                                    "(headline first), then the CPU-baseline legs"}
+    else:
+        line = _drain(_run(argv))
+    if return_line:
+        return line
+    if line is not None:
+        if args.stages and world == 1:
+            import subprocess
+
+            sp = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts", "stage_timers.py")],
+                                capture_output=True, text=True, timeout=900)
+            got = [ln for ln in sp.stdout.splitlines() if ln.startswith("{")]
+            line["stages"] = json.loads(got[-1]) if sp.returncode == 0 and got else {"error": (sp.stderr or sp.stdout)[-600:]}
+        print(json.dumps(line), flush=True)
+
+
+def _run(argv):
+    """One config on one rank, as a generator: yields "ready" once the workload is resident and the launches are bound, "timed" once
+    every GPU leg is done, and returns the line (rank 0; None on the other ranks) after the CPU-baseline leg."""
+    args = parse_args(argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if args.single_device else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
                          f"(or without torchrun: bench.py starts the ranks itself)")
     if args.rendezvous_only:
-        return rendezvous_only(args, world, rank)
+        rendezvous_only(args, world, rank)
+        return None
 
     cfg = args.config or (4 if world > 1 else 2)
     if not args.steps:
@@ -542,7 +636,8 @@ def main(argv=None, return_line=False):
     if args.lib:
         from reachy2_symbolic_ik_amd import _abi
 
-        _abi.use_library(args.lib)
+        if _abi.LIB_PATH != os.path.abspath(args.lib):  # (the legs of a default run share the process and the library)
+            _abi.use_library(args.lib)
 
     import torch
 
@@ -724,6 +819,7 @@ def main(argv=None, return_line=False):
             dist.barrier()
         torch.cuda.synchronize()
 
+    yield "ready"
     for _ in range(args.warmup):
         step()
     fence()
@@ -771,6 +867,9 @@ def main(argv=None, return_line=False):
     else:
         for _ in range(args.steps):
             step()
+        if gather_mode == "final":  # the job's one exchange: the last result travels to every rank, inside the timed region
+            for w in gather_all():
+                w.wait()
     e1.record()
     fence()
     elapsed = time.perf_counter() - t0
@@ -814,7 +913,7 @@ def main(argv=None, return_line=False):
             fence()
 
     # ---- kernel-only and gather-only legs (N > 1), each on its own: same buffers, same launches
-    kernel_ms, gather_ms, final_gather_ms = step_ms_events, 0.0, None
+    kernel_ms, gather_ms = step_ms_events, 0.0
     if world > 1:
         k2 = max(5, min(args.steps, 50))
         fence()
@@ -835,8 +934,6 @@ def main(argv=None, return_line=False):
             e1.record()
             fence()
             gather_ms = e0.elapsed_time(e1) / k2
-            if gather_mode == "final":
-                final_gather_ms = gather_ms
             # every rank's rows must have arrived where the partition says: a checksum of checksums over the ranks
             launch_all()
             for w in gather_all():
@@ -899,6 +996,7 @@ def main(argv=None, return_line=False):
             rows = torch.as_tensor(np.concatenate([plan.piece(r, 0)[0] + np.arange(per) for r in range(world)])).to(dev)
             gpu_rows = {k: bufs.full[k][rows].cpu().numpy() for k in gathered_names}
 
+    line = None
     if rank == 0:
         total = units * world * args.steps
         value = total / elapsed
@@ -908,7 +1006,8 @@ def main(argv=None, return_line=False):
         if world > 1:
             collective = {"step": f"RCCL all-gather of joints [n,7] f64 + state u8 inside every step, {chunks} stripes per shard, "
                                   "stripe c in flight while stripe c + 1 is solved",
-                          "final": "none in the timed steps; one final RCCL all-gather of joints [n,7] f64 + state u8 (timed separately)",
+                          "final": "none in the K sharded steps; ONE RCCL all-gather of joints [n,7] f64 + state u8 after the last of them, "
+                                   "inside the timed region",
                           "none": "none"}[gather_mode]
             if args.backend != "nccl" and gather_mode != "none":
                 collective += f" [backend {args.backend}: rehearsal, not RCCL]"
@@ -955,9 +1054,11 @@ def main(argv=None, return_line=False):
                 "kernel_only_solves_per_s": units * world / (kernel_ms * 1e-3),
                 "gather_only_ms": gather_ms if gather_mode != "none" else None,
                 "gather_only_solves_per_s": (units * world / (gather_ms * 1e-3)) if gather_ms > 0 else None,
-                "end_to_end_ms_per_step": (elapsed / args.steps * 1e3) if gather_mode == "step" else (kernel_ms + (final_gather_ms or 0.0)),
-                "end_to_end_solves_per_s": value if gather_mode == "step" else units * world / ((kernel_ms + (final_gather_ms or 0.0)) * 1e-3),
-                "value_is": "end-to-end (solve + all-gather in every step)" if gather_mode == "step" else "kernel-only steps (no collective in the timed region)",
+                "end_to_end_ms_per_step": elapsed / args.steps * 1e3,
+                "end_to_end_solves_per_s": value,
+                "value_is": {"step": "end to end, an all-gather inside every step: n x world x K / (K x (solve + all-gather, overlapped stripe by stripe))",
+                             "final": "end to end, the north star's job shape: n x world x K / (K sharded solve steps + ONE all-gather of the final joints + state)",
+                             "none": "kernel-only steps (no collective anywhere)"}[gather_mode],
                 "gather_bytes_received_per_gpu": recv,
                 "xgmi": {"achieved": (recv / (gather_ms * 1e-3) / 1e9) if gather_ms > 0 else None, "unit": "GB/s received per GPU",
                          "peak": links * XGMI_LINK_GBS, "links_usable": links,
@@ -982,12 +1083,17 @@ def main(argv=None, return_line=False):
             mg["scaling_efficiency_vs_n1_same_config"] = eff
             if gather_mode != "none" and gather_ms > 0:
                 # north star: "all-gather ... only for the final joint array": K sharded steps, ONE all-gather of the last result
-                total_final_ms = kernel_ms * args.steps + gather_ms
-                mg["gather_final"] = {"ms_for_K_steps_plus_one_gather": total_final_ms, "solves_per_s": units * world * args.steps / (total_final_ms * 1e-3),
-                                      "one_all_gather_ms": gather_ms, "from": "the kernel-only and gather-only legs of this run"}
-                mg["gather_step"] = {"ms_per_step": kernel_ms + gather_ms if gather_mode != "step" else elapsed / args.steps * 1e3,
-                                     "solves_per_s": (value if gather_mode == "step" else units * world / ((kernel_ms + gather_ms) * 1e-3)),
-                                     "overlapped": gather_mode == "step"}
+                if gather_mode == "final":
+                    mg["gather_final"] = {"ms_for_K_steps_plus_one_gather": elapsed * 1e3, "solves_per_s": value, "one_all_gather_ms": gather_ms,
+                                          "from": "the timed region itself (= value)"}
+                    mg["gather_step"] = {"ms_per_step": kernel_ms + gather_ms, "solves_per_s": units * world / ((kernel_ms + gather_ms) * 1e-3),
+                                         "overlapped": False, "from": "the kernel-only and gather-only legs of this run, one after the other (--gather step times the overlapped form)"}
+                else:
+                    total_final_ms = kernel_ms * args.steps + gather_ms
+                    mg["gather_final"] = {"ms_for_K_steps_plus_one_gather": total_final_ms, "solves_per_s": units * world * args.steps / (total_final_ms * 1e-3),
+                                          "one_all_gather_ms": gather_ms, "from": "the kernel-only and gather-only legs of this run"}
+                    mg["gather_step"] = {"ms_per_step": elapsed / args.steps * 1e3, "solves_per_s": value, "overlapped": True,
+                                         "from": "the timed region itself (= value)"}
             mg["group"] = group_info
             # beside `value`: the north star's own job shape (K sharded steps, ONE all-gather of the final joints) end to end, and the
             # efficiency against one GPU on this same config
@@ -1074,23 +1180,13 @@ def main(argv=None, return_line=False):
                     comp["ratio_to_fma_only_rate"] = ach / fma
                 line["roofline"]["compute"] = comp
             line["extras"] = extras
-        if sample is not None:
-            line["cpu_baseline"] = cpu_baseline(cfg, sample, args.cpu_seconds, gpu=gpu_rows)
-        if return_line:
-            return line
-        if args.stages and world == 1:
-            import subprocess
-
-            sp = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts", "stage_timers.py")],
-                                capture_output=True, text=True, timeout=900)
-            got = [ln for ln in sp.stdout.splitlines() if ln.startswith("{")]
-            line["stages"] = json.loads(got[-1]) if sp.returncode == 0 and got else {"error": (sp.stderr or sp.stdout)[-600:]}
-        if world == 1 and args.config == 0 and not args.no_other_configs:
-            line["other_configs"] = other_configs_section(cfg)
-        print(json.dumps(line), flush=True)
+    yield "timed"
+    if rank == 0 and sample is not None:
+        line["cpu_baseline"] = cpu_baseline(cfg, sample, args.cpu_seconds, gpu=gpu_rows)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return line
 
 
 if __name__ == "__main__":

@@ -67,13 +67,15 @@ struct ThetaTarget {
     double theta;     // the search's theta (found only)
     int code;         // state code the step reports
 };
-// FALLBACK_GEOMETRY = false (the pipeline's prepare phase): the unreachable side's is_reachable_no_limits is left to
-// the phase that needs its circle.
+// FALLBACK_GEOMETRY = false (the pipeline's prepare phase): of the unreachable side's is_reachable_no_limits only the
+// wrist position is worked out (reach_with_wrist: one pass for every outcome), which is what the joints phase builds the
+// circle from; r.w holds the wrist get_joints will see, whatever the outcome.
 template <bool PLANE, bool FALLBACK_GEOMETRY = true, class Acc>
 __device__ __forceinline__ ThetaTarget continuous_target(const Acc& A, V3 pos, const V3 woff, double pref_self, double pref_cs,
                                                          double pref_sn, Reach& r) {
     ThetaTarget T;
-    r = reach_g<false, false>(A, pos, woff);
+    if constexpr (FALLBACK_GEOMETRY) r = reach_g<false, false>(A, pos, woff);
+    else r = reach_with_wrist(A, pos, woff);
     T.ok_limits = r.ok;
     T.found = false;
     T.theta = 0.0;

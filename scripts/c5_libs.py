@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Config 5 (4096 trajectories x 1000 control steps per pass) with several builds of the library, one process each
-(scripts/c5_libs.py libA.so libB.so ...): ms per pass and steps/s."""
+(scripts/c5_libs.py libA.so libB.so ...): ms per pass and steps/s, two rounds; then every library's results against the
+first one's: flags, state codes and the carried state bit for bit, the largest difference between joints."""
 import os
 import subprocess
 import sys
@@ -30,8 +31,22 @@ for rep in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(20): one()
     torch.cuda.synchronize(); best = min(best, (time.perf_counter() - t0) / 20 * 1e3)
-print(f"{sys.argv[1]}: {best:.3f} ms per pass, {n*n_steps/best/1e6:.2f} G steps/s, checksum {float(out['joints'].sum()):.12e}")
+print(f"{sys.argv[1]}: {best:.3f} ms per pass, {n*n_steps/best/1e6:.2f} G steps/s, checksum {float(out['joints'].sum()):.12e}", flush=True)
+if len(sys.argv) > 2:
+    torch.save({"joints": out["joints"].cpu(), "reachable": out["reachable"].cpu(), "state": out["state"].cpu(), "cont": cont.cpu()}, sys.argv[2])
 ''' % HERE
+libs = sys.argv[1:]
 for round_ in range(2):
-    for lib in sys.argv[1:]:
-        subprocess.run([sys.executable, "-c", CHILD, lib], check=False)
+    for k, lib in enumerate(libs):
+        subprocess.run([sys.executable, "-c", CHILD, lib] + ([f"/tmp/c5_libs_{k}.pt"] if round_ == 1 else []), check=False)
+import torch  # noqa: E402
+
+ref = torch.load("/tmp/c5_libs_0.pt")
+for k, lib in enumerate(libs[1:], start=1):
+    got = torch.load(f"/tmp/c5_libs_{k}.pt")
+    bits = {name: bool(torch.equal(ref[name].view(torch.uint8), got[name].view(torch.uint8))) for name in ("reachable", "state", "cont")}
+    dj = (ref["joints"] - got["joints"]).abs()
+    nan_same = bool(torch.equal(ref["joints"].isnan(), got["joints"].isnan()))
+    print(f"{lib} vs {libs[0]}: bit-identical {bits}, carried theta identical {bool(torch.equal(ref['cont'][0], got['cont'][0]))}, "
+          f"max |joints difference| {float(dj.nan_to_num().max()):.3e} rad (NaN pattern identical: {nan_same}), "
+          f"joints bit-identical in {float((dj == 0).double().mean()) * 100:.2f} % of the entries")

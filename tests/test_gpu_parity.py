@@ -436,6 +436,32 @@ def test_config3_full_size_against_checker(torch_mod, orc, mode):
     assert frac[0] > 0.5 and frac[6] > 0.1  # both the sweep-hit and the sweep-miss populations are large
 
 
+def test_scale_digests_of_the_reference(golden_dir, torch_mod):
+    """G14 — the reference ITSELF at BASELINE sizes, no checker in between: digests (SHA-256) of its `reachable` and `state`
+    arrays over config 2's generator before filtering (1 Mi poses per arm, every outcome), over the 6.3 M candidates config 3's
+    filter looked at, and over config 3's 256 Ki goal matrices through ControlIK discrete (64-point grid), plus every 64th row's
+    interval and joints (oracle/gen_golden.py gen_scale; tests/scale_inputs.py regenerates the inputs from their seeds and proves
+    it by their digest).  Flags and state codes bit-exact at 8.6 M poses, joints <= 1e-9 on the subsample."""
+    from tests import scale_inputs as SC
+    from tests.test_oracle_golden import _check_scale_set
+
+    g = load(golden_dir, "g14_scale.npz")
+    _, r, l = make_symbolic(0.03)
+    for arm, ik in (("r_arm", r), ("l_arm", l)):
+        pos, eul = SC.config2_unfiltered(arm)
+        assert SC.sha256(np.concatenate([pos, eul], axis=1)) == str(g[f"c2_{arm}_input_sha256"]), "the seeded inputs did not regenerate"
+        res = to_np(ik.solve_batch(soa(pos, eul, torch_mod)))
+        _check_scale_set(g, f"c2_{arm}_", res, SC.N_CONFIG2)
+    pos, eul, kept, M = SC.config3_from_kept(g["c3_kept_bits"])
+    assert kept.size == int(g["c3_candidates"]) and SC.sha256(M) == str(g["c3_input_sha256"]), "the seeded inputs did not regenerate"
+    c = make_control()
+    flt = to_np(c.symbolic_ik_solver["r_arm"].is_reachable_batch(soa(pos, eul, torch_mod)))
+    np.testing.assert_array_equal(flt["reachable"].astype(bool), kept)
+    c.nb_search_points = 64
+    res = to_np(c.symbolic_inverse_kinematics_batch("r_arm", M))
+    _check_scale_set(g, "c3_", res, SC.N_CONFIG3)
+
+
 def test_config4_full_size_mixed_arms_against_checker(torch_mod, orc):
     """BASELINE config 4 on one GPU: 1 048 576 poses with a per-pose arm byte (l poses = mirrored r poses),
     the mixed-launch kernel against the CPU checker pose by pose."""

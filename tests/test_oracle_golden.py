@@ -568,6 +568,59 @@ def test_hostile_goals_continuous(golden_dir):
         assert not cs.emergency_stop
 
 
+# ------------------------------------------------------------------------------------------ G14: BASELINE sizes
+def _check_scale_set(g, pre, res, n, joints_key="joints", tol=1e-9):
+    """A G14 set against results over the same n inputs: flags and state codes by SHA-256 (and by per-state counts, which say
+    where a difference lies), every 64th row's numbers to `tol`."""
+    from tests import scale_inputs as SC
+
+    assert len(res["reachable"]) == n == int(g[pre + "n"])
+    counts = np.bincount(res["state"], minlength=9)
+    assert counts.tolist() == g[pre + "state_counts"].tolist(), (pre, counts.tolist(), g[pre + "state_counts"].tolist())
+    assert SC.sha256(res["reachable"]) == str(g[pre + "reachable_sha256"]), pre + "reachable"
+    assert SC.sha256(res["state"]) == str(g[pre + "state_sha256"]), pre + "state"
+    sub = slice(None, None, SC.SUBSAMPLE)
+    np.testing.assert_array_equal(res["reachable"][sub], g[pre + "sub_reachable"])
+    np.testing.assert_array_equal(res["state"][sub], g[pre + "sub_state"])
+    worst = 0.0
+    for key in ("interval", joints_key):
+        if pre + "sub_" + key not in g.files:
+            continue
+        want, got = g[pre + "sub_" + key], res[key][sub]
+        m = ~np.isnan(want).any(axis=1)
+        if key == "interval":
+            assert np.array_equal(m, g[pre + "sub_reachable"].astype(bool))
+        # the fully stretched arm's elbow-yaw / wrist-yaw split is atan2 of two 1e-17 numbers in the reference itself (Q23): j2 + j6
+        ok = m & ~(np.abs(want[:, 3]) < 1e-12) if key == joints_key else m
+        worst = max(worst, float(np.max(np.abs(got[ok] - want[ok]))))
+    assert worst < tol, (pre, worst)
+    return worst
+
+
+def test_scale_digests_checker_against_reference(golden_dir):
+    """G14: the reference itself over configs 2 and 3 at BASELINE size (2 x 1 Mi poses with every outcome; 6.3 M candidates of
+    config 3's filter; 256 Ki goal matrices through ControlIK discrete with a 64-point grid) — digests of its flags and state
+    codes, every 64th row's joints.  The checker over the regenerated inputs must reproduce every digest: 'flags bit-exact'
+    first-hand at 8.6 M poses, which is what lets the checker stand in for the reference at these sizes."""
+    from tests import scale_inputs as SC
+
+    g = load(golden_dir, "g14_scale.npz")
+    nt = max(1, os.cpu_count() or 1)
+    ar, al = orc.Arm("r_arm", 0.03), orc.Arm("l_arm", 0.03)
+    for i, arm in enumerate(("r_arm", "l_arm")):
+        pos, eul = SC.config2_unfiltered(arm)
+        assert SC.sha256(np.concatenate([pos, eul], axis=1)) == str(g[f"c2_{arm}_input_sha256"]), "the seeded inputs did not regenerate"
+        res = orc.solve_batch(ar, al, pos, eul, arm_id=np.full(len(pos), i, dtype=np.uint8), nthreads=nt)
+        _check_scale_set(g, f"c2_{arm}_", res, SC.N_CONFIG2)
+    cr, cl = _ctrl_arms()
+    pos, eul, kept, M = SC.config3_from_kept(g["c3_kept_bits"])
+    assert kept.size == int(g["c3_candidates"]) and SC.sha256(M) == str(g["c3_input_sha256"]), "the seeded inputs did not regenerate"
+    flt = orc.solve_batch(cr, cl, pos, eul, nthreads=nt)
+    np.testing.assert_array_equal(flt["reachable"].astype(bool), kept)
+    res = orc.control_discrete_batch(cr, cl, M, nb_search_points=64, nthreads=nt)
+    _check_scale_set(g, "c3_", res, SC.N_CONFIG3)
+
+
 # ------------------------------------------------------------------------------------------ the pin itself
 def test_golden_fixtures_reproduce_from_the_reference():
     """`oracle/gen_golden.py --check`: the committed fixtures are what the reference, imported from /root/reference, produces today —
