@@ -305,13 +305,11 @@ int rsik_control_continuous_step(rsik_ctx *ctx, int64_t n, const double *const m
  * is_reachable_no_limits and the 10-point search for the target theta (control_ik.py:327-388 up to the rate limiter)
  * are functions of the pose alone — so the batch is solved in four phases per block of steps:
  *   1. prepare   one thread per (step, trajectory), chip-filling: is_reachable + the search for the target theta; the
- *                step's goal for the rate limiter (the search's theta / the preferred theta / "stay") and the wrist
- *                position get_joints will work with (is_reachable's, or is_reachable_no_limits' for an unreachable
- *                goal: one pass gives either) -> workspace
+ *                step's goal for the rate limiter (the search's theta / the preferred theta / "stay") -> workspace
  *   2. theta     one thread per trajectory, sequential over steps: the d_theta_max rate limiter and
  *                limit_theta_to_interval (the only recurrence on previous_theta)
  *   3. joints    one thread per (step, trajectory), a wave = 8 consecutive steps of 8 trajectories: the circle of
- *                is_reachable / is_reachable_no_limits rebuilt from the wrist position, get_joints at the limited theta,
+ *                is_reachable / is_reachable_no_limits re-derived from the goal matrix, get_joints at the limited theta,
  *                the Orbita3D cone clamp, and allow_multiturn INSIDE the 8-step chunk (whole turns relative to the step
  *                before, a shuffle prefix sum); continuity / limit / singularity events are detected, not decided
  *   4. chain     eight lanes per trajectory (one per joint), sequential over CHUNKS: checks each chunk's first step
@@ -327,7 +325,7 @@ int rsik_control_continuous_step(rsik_ctx *ctx, int64_t n, const double *const m
  * kernel has started (its lone 276-register waves cannot get onto a chip that a chip-filling kernel holds); while the
  * caller's stream is capturing, by events, which is all a capture takes.
  * The workspace
- * (41 bytes per step and trajectory + 1 per 8-step chunk, of up to eight blocks in flight), the side streams and the
+ * (17 bytes per step and trajectory + 1 per 8-step chunk, of up to eight blocks in flight), the side streams and the
  * events belong to the context: they are created by the first call that needs them, or ahead of time by
  * rsik_control_continuous_reserve.  A call can be captured into a hipGraph (the side streams join the capture through
  * the events the call records) provided it has nothing to create: reserve first, or run a call of at least that size

@@ -358,15 +358,9 @@ template <bool V>
 struct BoolC {
     __device__ __forceinline__ constexpr operator bool() const { return V; }
 };
-// WRIST_ON (the prepare phase of the continuous-mode pipeline; with NO_LIMITS = false, KEEP = false): a pose that fails a
-// reach test does not leave at once — it goes on under is_reachable_no_limits' rules (S:85-119: no early exit, the wrist
-// pulled back onto the sphere of radius u + f) as far as the wrist position, which is all get_joints' circle depends on, and
-// leaves with r.ok = false, its state code and r.w = the wrist ControlIK's fallback (C:371) would work with.  The lanes of a
-// wave are a mix of outcomes there anyway: the few extra instructions replace a second pass over the pose.
-template <bool KEEP, bool GEOM_ONLY, bool WRIST_ON, class NL, class Acc>
-__device__ Reach reach_core(const Acc& A, V3 pos_in, const V3 woff, const NL no_limits_v) {
+template <bool KEEP, bool GEOM_ONLY, class NL, class Acc>
+__device__ Reach reach_impl(const Acc& A, V3 pos_in, const V3 woff, const NL no_limits_v) {
     const bool NO_LIMITS = no_limits_v;
-    bool failed = false;  // (WRIST_ON) a reach test has failed: no-limits rules from here on
     Reach r;
     r.ok = false;
     r.i0 = r.i1 = __builtin_nan("");
@@ -393,10 +387,7 @@ __device__ Reach reach_core(const Acc& A, V3 pos_in, const V3 woff, const NL no_
     r.state = st;
     r.stage = 0;
     if (KEEP) { r.pos = gp; r.w = gp; r.c2 = gp; r.n2 = gp; r.a1 = gp; r.a2 = gp; r.r2 = 0.0; r.ct0 = 1.0; r.st0 = 0.0; r.ct1 = 1.0; r.st1 = 0.0; }
-    if (!NO_LIMITS && st != RSIK_STATE_REACHABLE) {
-        if constexpr (!WRIST_ON) return r;
-        failed = true;
-    }
+    if (!NO_LIMITS && st != RSIK_STATE_REACHABLE) return r;
     r.stage = 1;
 
     RSIK_MARK("reach_wrist");
@@ -406,7 +397,6 @@ __device__ Reach reach_core(const Acc& A, V3 pos_in, const V3 woff, const NL no_
         double diff = bl - w.x;
         gp.x = gp.x + diff;
         if (NO_LIMITS) w = wrist_position(woff, gp);
-        else if constexpr (WRIST_ON) w.x = failed ? (woff.x + gp.x) : (w.x + diff);  // (S:97 recomputes the wrist, S:150 shifts it)
         else w.x = w.x + diff;
     }
     V3 P = w - s;
@@ -425,16 +415,9 @@ __device__ Reach reach_core(const Acc& A, V3 pos_in, const V3 woff, const NL no_
         }
     } else {
         if (RSIK_RARE(dsw > upf)) {  // [D] S:157-161
-            if constexpr (!WRIST_ON) {
-                r.state = RSIK_STATE_WRIST_OUT_OF_RANGE;
-                if (KEEP) { r.pos = gp; r.w = w; }
-                return r;
-            } else {
-                // (a pose that failed S:284-307 never gets here in the reference: it keeps that state)
-                if (!failed) r.state = RSIK_STATE_WRIST_OUT_OF_RANGE;
-                failed = true;
-                w = madd((w - s) * fast_rcp(fabs(dsw) + pm), upf, s);  // S:102-105, as in the NO_LIMITS branch above
-            }
+            r.state = RSIK_STATE_WRIST_OUT_OF_RANGE;
+            if (KEEP) { r.pos = gp; r.w = w; }
+            return r;
         }
     }
     if (RSIK_RARE(dsw < A(RSIK_C_MIN_DIST))) {  // [D] S:166-171 / S:107-112
@@ -454,10 +437,6 @@ __device__ Reach reach_core(const Acc& A, V3 pos_in, const V3 woff, const NL no_
         inv_d = inv_d * (t * A(RSIK_C_INV_MIN_DIST));
     }
 
-    if constexpr (WRIST_ON) {
-        // (the pulled-back wrist is not pushed out again: S:107 tests the distance it had before, which was beyond u + f)
-        if (failed) { r.w = w; return r; }
-    }
     RSIK_MARK("reach_circle");
     // S:366-399 intersection circle of the shoulder sphere (radius u) and the wrist sphere (radius f)
     if (RSIK_RARE(d > upf)) {  // [D] S:374
@@ -670,40 +649,9 @@ __device__ Reach reach_core(const Acc& A, V3 pos_in, const V3 woff, const NL no_
     return r;
 }
 
-template <bool KEEP, bool GEOM_ONLY, class NL, class Acc>
-__device__ __forceinline__ Reach reach_impl(const Acc& A, V3 pos_in, const V3 woff, const NL no_limits_v) {
-    return reach_core<KEEP, GEOM_ONLY, false>(A, pos_in, woff, no_limits_v);
-}
 template <bool NO_LIMITS, bool KEEP = true, class Acc>
 __device__ __forceinline__ Reach reach_g(const Acc& A, V3 pos_in, const V3 woff) {
     return reach_impl<KEEP, false>(A, pos_in, woff, BoolC<NO_LIMITS>{});
-}
-// is_reachable that leaves every pose's wrist behind, reachable or not (see WRIST_ON above)
-template <class Acc>
-__device__ __forceinline__ Reach reach_with_wrist(const Acc& A, V3 pos_in, const V3 woff) {
-    return reach_core<false, false, true>(A, pos_in, woff, BoolC<false>{});
-}
-
-// S:366-399 for get_joints alone: the intersection circle (centre, radius, frame axes) from the wrist position — the same
-// arithmetic as reach_core's, which derives it from the same wrist (identical bits unless the wrist was pushed out to the
-// minimum distance there, where reach_core scales its vector instead of measuring it again: a rounding of difference).
-template <class Acc>
-__device__ __forceinline__ void circle_from_wrist(const Acc& A, V3 w, Reach& r) {
-    const V3 s = cvec(A, RSIK_C_SHOULDER);
-    const double u = A(RSIK_C_UPPER_ARM), f = A(RSIK_C_FOREARM);
-    const V3 P = w - s;
-    double d, inv_d;
-    sqrt_rsqrt(dot_d(P, P), d, inv_d);
-    const V3 n2 = P * inv_d;
-    const double d2 = d * d, k = d2 - f * f + u * u;
-    const double rad = 4 * d2 * (u * u) - k * k;
-    const double irad = (rad != 0.0) ? rsqrt_fast(rad) : 0.0;
-    const double hid = 0.5 * inv_d;
-    const Frame F2 = frame_from_unit(n2);
-    r.w = w;
-    r.r2 = hid * (rad * irad);
-    r.c2 = s + n2 * (k * hid);
-    r.n2 = n2; r.a1 = F2.c1; r.a2 = F2.c2;
 }
 
 template <bool NO_LIMITS, bool KEEP = true, class Acc>

@@ -17,6 +17,7 @@ struct ContinuousArgs {
     const double* cur_pose[12];   // current_pose of a (re)initialising trajectory, NULL columns => goal matrix itself
     const uint8_t* arm;
     const uint8_t* timed_out;     // NULL => nobody timed out
+    uint8_t* latched0;            // rsik_control_continuous_run: [n], out — the trajectory's emergency stop was latched when the run began (else NULL)
     int euler_roundtrip;          // RSIK_OPT_EULER_ROUNDTRIP
     int first_timed_out;          // non-zero: every trajectory (re)initialises
     double pref_arg[2];           // preferred_theta argument per arm slot (mirrored for l)
@@ -67,15 +68,13 @@ struct ThetaTarget {
     double theta;     // the search's theta (found only)
     int code;         // state code the step reports
 };
-// FALLBACK_GEOMETRY = false (the pipeline's prepare phase): of the unreachable side's is_reachable_no_limits only the
-// wrist position is worked out (reach_with_wrist: one pass for every outcome), which is what the joints phase builds the
-// circle from; r.w holds the wrist get_joints will see, whatever the outcome.
+// FALLBACK_GEOMETRY = false (the pipeline's prepare phase): the unreachable side's is_reachable_no_limits is left to
+// the phase that needs its circle.
 template <bool PLANE, bool FALLBACK_GEOMETRY = true, class Acc>
 __device__ __forceinline__ ThetaTarget continuous_target(const Acc& A, V3 pos, const V3 woff, double pref_self, double pref_cs,
                                                          double pref_sn, Reach& r) {
     ThetaTarget T;
-    if constexpr (FALLBACK_GEOMETRY) r = reach_g<false, false>(A, pos, woff);
-    else r = reach_with_wrist(A, pos, woff);
+    r = reach_g<false, false>(A, pos, woff);
     T.ok_limits = r.ok;
     T.found = false;
     T.theta = 0.0;
@@ -238,7 +237,12 @@ __global__ __launch_bounds__(kBlock) void cont_init_kernel(const ContinuousArgs 
     const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[ii] != 0) : false, lds_tab);
     const int slot = MIXED ? (A.isl ? 1 : 0) : 0;
     const int64_t n = K.n;
-    if (!live || K.st[9 * n + i] != 0.0) return;  // emergency latched: nothing is touched (C:205-210)
+    if (!live) return;
+    // emergency latched: nothing is touched (C:205-210).  A trajectory that is latched when a run begins stays so to its end
+    // (only "unfreeze" releases it): the run's later phases are told, and fill its steps in without walking them
+    const bool latched = K.st[9 * n + i] != 0.0;
+    if (K.latched0 && half == 0) K.latched0[i] = latched ? 1 : 0;
+    if (latched) return;
     const bool timed_out = K.first_timed_out || (K.timed_out && K.timed_out[i]);
     if (!timed_out && K.st[10 * n + i] != 0.0) return;
     double prev_theta = K.st[0 * n + i];

@@ -7,16 +7,12 @@ namespace rsik {
 // ------------------------------------------------------------------------------------------
 // rsik_control_continuous_run: the phased trajectory pipeline (include/rsik.h).  Workspace of one block of T steps:
 //   ws[t][n] doubles  the step's goal for the theta recurrence (phase 1) -> the step's theta (phase 2)
-//   gw[t][n] doubles  that goal after limit_theta_to_interval's wrap (phase 1 -> phase 2)
-//   wr[t][3][n] doubles  the wrist position get_joints works with (phase 1 -> phase 3): is_reachable's (S:121-282) where that
-//                     succeeded, is_reachable_no_limits' (S:85-119) where it did not — one pass over the pose in phase 1 gives
-//                     either (reach_with_wrist).  The intersection circle is a function of the wrist alone (S:366-399): phase 3
-//                     rebuilds it from these 24 bytes (~60 instructions) instead of going through the reach tests again (~240,
-//                     a third of that phase), and reads two columns of the goal rotation instead of two rows and the position
 //   flags[t][n] bytes bit 0 is_reachable succeeded, bit 1 the grid search found a theta; (phase 3) bit 2: get_joints hit an
-//                     exact singularity and needs previous_sol (recomputed in phase 4); bit 3: the rotation get_joints sees is
-//                     not the goal matrix's as it stands (identity shortcut C:212-214, Euler round trip: goal_from_m12): phase
-//                     3 derives it again; bit 4: the goal is not numbers
+//                     exact singularity and needs previous_sol (recomputed in phase 4); bit 3: the goal matrix is not a
+//                     plain proper rotation (goal_from_m12's `special`): phase 3 reads all of it
+// Nothing else travels between the phases: the pipeline is bound by HBM traffic, not by arithmetic, so the joint phase
+// re-derives the circle it needs from the goal matrix (the geometric half of is_reachable, ~150 instructions) instead
+// of reading 22 doubles per trajectory-step that the prepare phase would have to write (652 -> 400 B per step).
 // ------------------------------------------------------------------------------------------
 // steps whose operands the sequential phases fetch at once, one batch ahead of the one being computed (blocks are multiples
 // of both; measured on 4096 x 1000 steps: theta batches of 8 / 16 / 32 steps 0.544 / 0.525 / 0.552 ms per pass)
@@ -94,11 +90,11 @@ struct ContRunArgs {
     double max_angle, cos_max, sin_max;
     double* ws;                   // [T][n]: the step's theta goal (phase 1), overwritten by the step's theta (phase 2)
     double* gw;                   // [T][n]: the goal after limit_theta_to_interval's wrap (phase 1 -> phase 2)
-    double* wr;                   // [T][3][n]: the wrist position get_joints works with (phase 1 -> phase 3)
     uint8_t* flags;               // [T][n]
     uint8_t* chunk_event;         // [ceil(T / kJointChunk)][n]: phase 3 -> phase 4, see cont_joints_kernel
     double snap_tdag;             // phase 2, single-arm launches: see continuous_next_theta_lean (the kind is a template argument)
     double* theta_carry;          // [2][n]: previous_theta between the blocks of one run (phase 2's own state); row 1: see cont_theta_kernel
+    const uint8_t* latched0;      // [n]: the trajectory's emergency stop was latched when the run began (cont_init_kernel): C:205-210 for all its steps
     int first_block, last_block;
     unsigned* started_word;       // phased pipeline, launch by launch: the theta kernel of a block writes started_seq here when it starts
     unsigned started_seq;         // (the host holds the joints kernel of the block BEFORE on it, see rsik_control_continuous_run), or NULL
@@ -119,7 +115,7 @@ __device__ __forceinline__ void cont_prepare_step(const ContRunArgs& K, const Ac
     Rot Rg;
     V3 pos;
     bool special;
-    goal_from_m12(m, Rg, pos, K.euler_roundtrip, &special, false);
+    goal_from_m12(m, Rg, pos, K.euler_roundtrip, &special);
     const Goal G = make_goal(A, Rg);
     Reach r;
     ThetaTarget T = continuous_target<PLANE, false>(A, pos, G.woff, K.pref_self[slot], K.pref_self_cs[slot], K.pref_self_sn[slot], r);
@@ -134,10 +130,6 @@ __device__ __forceinline__ void cont_prepare_step(const ContRunArgs& K, const Ac
     // what limit_theta_to_interval makes of theta = goal before it looks at the interval (U:93-97): this phase has the
     // issue slots for it, the theta phase (a lone wave per SIMD) has not
     K.gw[t * K.n + i] = wrap_theta_to_pi(goal);
-    {
-        double* const wr = K.wr + t * 3 * K.n + i;
-        wr[0] = r.w.x; wr[K.n] = r.w.y; wr[2 * K.n] = r.w.z;
-    }
     K.flags[t * K.n + i] = (uint8_t)((T.ok_limits ? 1 : 0) | (T.found ? 2 : 0) | (special ? 8 : 0) | (invalid ? 16 : 0));
     if (K.state) K.state[t_abs * K.n + i] = (uint8_t)T.code;
     if (K.reachable) K.reachable[t_abs * K.n + i] = (T.ok_limits && T.found) ? 1 : 0;
@@ -312,15 +304,22 @@ __global__ __launch_bounds__(kThetaBlock) __attribute__((amdgpu_waves_per_eu(1, 
                                                                  prev_theta, K.theta_carry + K.n);
 }
 
-// What get_joints reads of a step (S:697-863), derived from the step's goal matrix alone: the goal vectors and the circle
-// is_reachable (flag bit 0 set) or is_reachable_no_limits (clear; C:371) left on the solver — the step kernel's device code.
-// The chain phase's way to a step it has to recompute with previous_sol (an exact singularity); the joints phase gets the wrist
-// from the prepare phase instead (cont_joints_chunk).  `m`: the step's twelve matrix entries.
+// What get_joints reads of a step (S:697-863), re-derived from the step's goal matrix: the goal vectors and the circle
+// is_reachable (flag bit 0 set) or is_reachable_no_limits (clear; C:371) left on the solver — the same device code the
+// step kernel runs, so the joints are the same to the last bit.  `m`: the step's twelve matrix entries.
+// `plain`: the prepare phase found the matrix a plain proper rotation (no identity shortcut, no Euler round trip): taken as it is.
 template <class Acc>
-__device__ __forceinline__ void step_geometry(const Acc& A, const double (&m)[12], int euler_roundtrip, bool no_limits, Reach& r, Goal& G) {
+__device__ __forceinline__ void step_geometry(const Acc& A, const double (&m)[12], int euler_roundtrip, bool no_limits, Reach& r, Goal& G,
+                                              bool plain = false) {
     Rot Rg;
     V3 pos;
-    goal_from_m12(m, Rg, pos, euler_roundtrip);
+    if (plain) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) Rg.m[k] = m[k];
+        pos = {m[9], m[10], m[11]};
+    } else {
+        goal_from_m12(m, Rg, pos, euler_roundtrip);
+    }
     G = make_goal(A, Rg);
     r = reach_impl<false, true>(A, pos, G.woff, no_limits);
 }
@@ -377,49 +376,60 @@ __device__ __forceinline__ void cont_joints_chunk(const ContRunArgs& K, SharedTa
     const bool live = i < n && t < K.T;
     const int64_t ii = i < n ? i : (n - 1);
     const int64_t tt = t < K.T ? t : (K.T - 1);
-    // loads first: their latency overlaps the table staging.  Of the goal matrix the first and the third column of the
-    // rotation (get_joints reads nothing else of it: Goal::xg, Goal::tw), and the wrist the prepare phase left.
-    double c0[3], c2[3], wv[3];
+    // loads first: their latency overlaps the table staging.  Of the goal matrix the first two rows of the rotation and
+    // the translation: for a proper rotation, which the prepare phase has checked (flag bit 3 clear), the third row is their
+    // cross product — to 1e-16, the rounding of the entries themselves — and 24 of the 161 bytes this phase moves per step
+    // need not be read.
+    double m[12];
     {
         const double* src = K.m12_steps + (K.t0 + tt) * 12 * n + ii;
 #pragma unroll
-        for (int k = 0; k < 3; k++) { c0[k] = src[(3 * k) * n]; c2[k] = src[(3 * k + 2) * n]; }
-        const double* wsrc = K.wr + tt * 3 * n + ii;
+        for (int k = 0; k < 6; k++) m[k] = src[k * n];
 #pragma unroll
-        for (int k = 0; k < 3; k++) wv[k] = wsrc[k * n];
+        for (int k = 9; k < 12; k++) m[k] = src[k * n];
     }
     const double theta = RSIK_WS(K, tt, ii);
-    const int flag = (int)K.flags[tt * n + ii];
+    int flag = (int)K.flags[tt * n + ii];
+    const bool special = (flag & 8) != 0;
+    if (RSIK_RARE(special)) {
+        const double* src = K.m12_steps + (K.t0 + tt) * 12 * n + ii;
+#pragma unroll
+        for (int k = 6; k < 9; k++) m[k] = src[k * n];
+    } else {
+        m[6] = fma(m[1], m[5], -(m[2] * m[4]));
+        m[7] = fma(m[2], m[3], -(m[0] * m[5]));
+        m[8] = fma(m[0], m[4], -(m[1] * m[3]));
+    }
     const bool lane_isl = MIXED ? (K.arm[ii] != 0) : false;
     stage_tables<MIXED, (int)offsetof(ContRunArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>(lds_tab, K.arms);
     const Acc<MIXED> A = make_acc<MIXED>(K.arms, lane_isl, lds_tab);
-    // (behind the staging: the Euler round trip reads the workgroup's sine / cosine table)
-    if (RSIK_RARE((flag & 8) != 0)) {
-        // the rotation get_joints sees is not the matrix as it stands: derived again, as the prepare phase derived it
-        double m[12];
-        load_step_m12(K, tt, ii, m);
-        Rot Rg;
-        V3 pos_;
-        goal_from_m12(m, Rg, pos_, K.euler_roundtrip);
-#pragma unroll
-        for (int k = 0; k < 3; k++) { c0[k] = Rg.m[3 * k]; c2[k] = Rg.m[3 * k + 2]; }
-    }
-    Reach r;
-    circle_from_wrist(A, V3{wv[0], wv[1], wv[2]}, r);
-    Goal G;
-    {
-        const double tz = A(RSIK_C_TIPL + 2);
-        G.xg = {c0[0], c0[1], c0[2]};
-        G.tw = {-(c2[0] * tz), -(c2[1] * tz), -(c2[2] * tz)};  // (make_goal's, entry by entry)
-        G.woff = G.toff = {0.0, 0.0, 0.0};                    // (not read: the wrist is given, get_joints<FRESH> works relative to it)
-    }
     const double zeros[7] = {0, 0, 0, 0, 0, 0, 0};
     double jv[7];
-    bool sing;
-    step_joints(A, K, r, G, theta, zeros, jv, sing);
+    bool sing = false;
+    // A trajectory whose emergency stop was latched when the run began (C:205-210) answers previous_sol at every step, whatever the
+    // goal: its rows are filled in here, eight steps at a go, and stand for the chain phase like any quiet chunk's (first row = last row
+    // = previous_sol: no event, no turn) — it never walks them.  Waves of such trajectories only skip the geometry altogether; an
+    // ordinary run has none (one byte per lane and a wave-uniform branch).
+    const bool frozen = K.latched0[ii] != 0;
+    const unsigned long long frozen_mask = __ballot(frozen);
+    if (!RSIK_RARE(frozen_mask == ~0ull)) {
+        Reach r;
+        Goal G;
+        step_geometry(A, m, K.euler_roundtrip, (flag & 1) == 0, r, G, !special);
+        step_joints(A, K, r, G, theta, zeros, jv, sing);
+    }
+    if (RSIK_RARE(frozen_mask != 0)) {
+#pragma unroll
+        for (int k = 0; k < 7; k++) jv[k] = frozen ? K.st[(1 + k) * n + ii] : jv[k];
+        sing = sing && !frozen;
+        if (frozen && live) {
+            if (K.state) K.state[(K.t0 + t) * n + i] = (uint8_t)RSIK_STATE_EMERGENCY;
+            if (K.reachable) K.reachable[(K.t0 + t) * n + i] = 0;
+        }
+    }
     // a step without joints: singular (phase 4 recomputes it with previous_sol), or its goal is not numbers (flag bit 4: it stays
     // without, and phase 4 steps over it — rsik.h "Rows that are not numbers")
-    const bool dead = sing || (flag & 16) != 0;
+    const bool dead = (sing || (flag & 16) != 0) && !frozen;
     // Steps relative to the step before (lane - 8; none for the chunk's first step, which phase 4 judges).  Whole turns
     // only for the four joints whose raw angle has a branch cut to cross — shoulder pitch, elbow yaw, wrist roll, wrist yaw
     // (atan2 values, S:751-786, 815-848 / U:508-519); shoulder roll is atan2(q_y, q_x >= 0), elbow pitch is clamped to
@@ -528,6 +538,9 @@ __device__ __forceinline__ void cont_chain_walk(const ContRunArgs& K, SharedTabl
     double prev = K.st[(1 + jj) * n + ii];
     bool init = K.st[8 * n + ii] != 0.0;
     bool emergency = K.st[9 * n + ii] != 0.0;
+    // latched when the run began: the joints phase has filled every step in with previous_sol and the emergency state (see there);
+    // each of its chunks stands as written
+    const bool frozen = K.latched0[ii] != 0;
     const double thr = jj < 4 ? 0.5 : 1.0;                                       // continuity thresholds, C:398
     const double lim = (jj == 0 || jj == 2 || jj == 6) ? 6 * kPi : __builtin_inf();  // multiturn limit of this lane's joint (U:535-568)
     const int hit_bit = jj == 0 ? RSIK_EMERGENCY_SHOULDER_PITCH : (jj == 2 ? RSIK_EMERGENCY_ELBOW_YAW : RSIK_EMERGENCY_WRIST_YAW);
@@ -685,8 +698,8 @@ __device__ __forceinline__ void cont_chain_walk(const ContRunArgs& K, SharedTabl
         const double turns = -rint((first - prev) * 0.15915494309189535);
         sh = turns * kTwoPi;
         const double f2 = first + sh;
-        const bool quiet = !emergency && !init && ev == 0 && (fabs(f2 - prev) <= thr_short) && (fabs(turns) <= 100.0) &&
-                           (!limited || fabs(f2) <= clear_of_limit);
+        const bool quiet = frozen || (!emergency && !init && ev == 0 && (fabs(f2 - prev) <= thr_short) && (fabs(turns) <= 100.0) &&
+                                      (!limited || fabs(f2) <= clear_of_limit));
         return group_or(quiet ? 0 : 1) == 0;
     };
     auto walk = [&](const Operands& o, int64_t c0) -> int {
@@ -696,8 +709,8 @@ __device__ __forceinline__ void cont_chain_walk(const ContRunArgs& K, SharedTabl
             const double turns = -rint((o.first[u] - prev) * 0.15915494309189535);
             const double sh = turns * kTwoPi;
             const double f2 = o.first[u] + sh;
-            const bool quiet = !emergency && !init && o.ev[u] == 0 && (fabs(f2 - prev) <= thr_short) && (fabs(turns) <= 100.0) &&
-                               (!limited || fabs(f2) <= clear_of_limit);
+            const bool quiet = frozen || (!emergency && !init && o.ev[u] == 0 && (fabs(f2 - prev) <= thr_short) && (fabs(turns) <= 100.0) &&
+                                          (!limited || fabs(f2) <= clear_of_limit));
             const bool inside = c0 + u < n_chunks;
             const bool stands = !__any(!quiet) && inside;  // (wave-uniform)
             const bool taken = stop == BATCH && stands;

@@ -385,14 +385,13 @@ __global__ __launch_bounds__(kBlock, RSIK_SOLVE_MIN_WAVES) void solve_kernel(con
 //   - the pitch is within ~1e-5 of +-pi/2 (inside 1e-7 of the lock SciPy sets yaw := 0, which moves the joints by up
 //     to ~4e-6 rad: measured on the G8 goldens).
 // mode (RSIK_OPT_EULER_ROUNDTRIP): 0 = as above, 1 = always, 2 = never.
-// `special` (out, optional): the rotation handed back is not the matrix's own nine entries (identity shortcut, Euler round
-// trip: the trajectory pipeline's joints phase derives it again only for those, cont_joints_kernel) — or, with `third_row`,
-// its third row is not the cross product of the other two to 1e-14.
-__device__ __forceinline__ void goal_from_m12(const double (&m)[12], Rot& Rg, V3& pos, int mode, bool* special = nullptr, bool third_row = true) {
+// `special` (optional): set when the matrix did not go through as it came — the identity shortcut, the Euler round trip —
+// or is not a proper rotation whose third row is the cross product of the other two: the trajectory pipeline's joints
+// phase re-reads all twelve entries only for those (cont_joints_kernel).
+__device__ __forceinline__ void goal_from_m12(const double (&m)[12], Rot& Rg, V3& pos, int mode, bool* special = nullptr) {
 #pragma unroll
     for (int k = 0; k < 9; k++) Rg.m[k] = m[k];
-    if (special) *special = false;
-    if (special && third_row) {
+    if (special) {
         // row 2 against row 0 x row 1, entry by entry, to 1e-14: a few roundings of the entries themselves.  (A looser test — 1e-9
         // until round 4 — let the joints phase rebuild the third row of a matrix that is NOT orthonormal to rounding, and where
         // the arm is stretched out the elbow-yaw / wrist-yaw split amplifies such a difference 2e4 times and more: the pipeline

@@ -516,12 +516,11 @@ constexpr int kContSlots = 8;  // workspace slots in flight (block b + 8 reuses 
 // 0.383 with three, 0.395 with four); launched eagerly four blocks are best (0.43 against 0.46 with two: more overlap for
 // the same host-side issue cost).
 static int cont_plan(rsik_ctx* ctx, const char* who, int64_t n, int64_t n_steps, bool capturing, ContPlan& P) {
-    // (the sequential phases address a block's arrays through 2 GB buffer windows: rows of n * 56 bytes, blocks of <= 926 MB
-    // of workspace — 41 bytes per trajectory-step — i.e. <= 1.3 GB of joints; every block costs the host four launches, so blocks
-    // are as long as that allows)
+    // (the sequential phases address a block's arrays through 2 GB buffer windows: rows of n * 56 bytes, blocks of <= 384 MB
+    // of workspace, i.e. <= 1.3 GB of joints; every block costs the host four launches, so blocks are as long as that allows)
     if (n > (int64_t)30 << 20) return fail(ctx, RSIK_E_INVALID, std::string(who) + ": more than 30 Mi trajectories in one call");
-    P.per_step = (size_t)n * (5 * sizeof(double) + 1);  // goal / theta, wrapped goal, wrist (3), flags
-    int64_t T_max = (int64_t)((size_t)926 << 20) / (int64_t)P.per_step;
+    P.per_step = (size_t)n * (2 * sizeof(double) + 1);
+    int64_t T_max = (int64_t)((size_t)384 << 20) / (int64_t)P.per_step;
     if (T_max < 1) T_max = 1;
     if (T_max > 65535) T_max = 65535;  // gridDim.y
     // block size: a quarter of the run, half of it under capture (the phases of neighbouring blocks overlap: more blocks, shorter fill and drain;
@@ -544,7 +543,7 @@ static int cont_plan(rsik_ctx* ctx, const char* who, int64_t n, int64_t n_steps,
     P.chunks_per_block = ((size_t)T + rsik::kJointChunk - 1) / rsik::kJointChunk;
     P.slot_bytes = (((size_t)T * P.per_step + P.chunks_per_block * (size_t)n + 255) / 256) * 256;
     P.slots = n_blocks < kContSlots ? (int)n_blocks : kContSlots;
-    P.carry_bytes = (((size_t)n * 2 * sizeof(double) + 255) / 256) * 256;
+    P.carry_bytes = (((size_t)n * (2 * sizeof(double) + 1) + 255) / 256) * 256;  // theta carry + scratch rows, the latched-at-start bytes
     P.need = P.slot_bytes * P.slots + P.carry_bytes;
     P.n_events = 2 + 4 * (size_t)n_blocks;
     return RSIK_OK;
@@ -809,6 +808,8 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     R.max_angle = K0.max_angle; R.cos_max = K0.cos_max; R.sin_max = K0.sin_max;
     R.st = cont_state; R.joints = joints_steps; R.reachable = reachable_steps; R.state = state_steps;
     R.theta_carry = reinterpret_cast<double*>(static_cast<char*>(ctx->ws) + slot_bytes * slots);
+    R.latched0 = reinterpret_cast<uint8_t*>(R.theta_carry + 2 * (size_t)n);
+    K0.latched0 = const_cast<uint8_t*>(R.latched0);
     const dim3 grid8((unsigned)((n * 8 + rsik::kChainBlock - 1) / rsik::kChainBlock));  // (n <= 30 Mi: fits)
     // What a pass really looks like was measured with in-kernel stamps (a -DRSIK_PIPE_TIMING build,
     // scripts/probes/c5_untraced_timeline.py; the profiler's kernel trace delays launches and shows another schedule): a
@@ -836,8 +837,7 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         R.last_block = b == n_blocks - 1;
         R.ws = reinterpret_cast<double*>(static_cast<char*>(ctx->ws) + slot_bytes * (size_t)(b % slots));
         R.gw = R.ws + (size_t)R.T * (size_t)n;
-        R.wr = R.gw + (size_t)R.T * (size_t)n;
-        R.flags = reinterpret_cast<uint8_t*>(R.wr + 3 * (size_t)R.T * (size_t)n);
+        R.flags = reinterpret_cast<uint8_t*>(R.gw + (size_t)R.T * (size_t)n);
         R.chunk_event = R.flags + (size_t)R.T * (size_t)n;
     };
     const int64_t head = n_blocks < slots ? n_blocks : slots;  // blocks with a workspace slot of their own: issued phase by phase

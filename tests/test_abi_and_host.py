@@ -264,3 +264,45 @@ def test_integration_doc_names_every_entry_point():
     assert not missing, missing
     version = int(re.search(r"#define\s+RSIK_ABI_VERSION\s+(\d+)", header).group(1))
     assert f"ABI version ({version})" in doc
+
+
+def test_bench_default_protocol_times_every_gpu_leg_before_any_cpu_leg():
+    """bench.py's default run (N = 1, no --config): every config's workload is made resident first, then the GPU legs back to
+    back — headline first — and only then the CPU-baseline legs, during which the GPU idles and clocks down (round 4 timed
+    configs 3 / 4 / 5 behind a 3.5 s CPU leg).  run_default_protocol with stub legs: the order it drives them in, what it
+    reports, and that a failing secondary config costs its own entry only."""
+    import bench
+
+    events = []
+
+    def make_leg(cfg):
+        def leg():
+            events.append(("setup", cfg))
+            yield "ready"
+            events.append(("gpu", cfg))
+            if cfg == 4:
+                raise RuntimeError("no such luck")
+            yield "timed"
+            events.append(("cpu", cfg))
+            r = {"kernel_ms": 0.01, "algorithmic_bytes_per_pose": 154, "achieved": 1.0, "frac": 0.1, "traffic": 2.0,
+                 "frac_at_286_bytes_state_round_trip_per_step": 0.2}
+            return {"config": {"workload": f"config{cfg}"}, "metric": "m", "value": 1.0, "unit": "u", "steps": 20, "warmup": 5, "ms_per_step": 0.4,
+                    "launch": "eager", "roofline": r, "cpu_baseline": {"value": 1.0, "parity_on_sample": {"rows": 1}}, "steady_state": {"ms_per_step": 0.39}}
+        return leg()
+
+    line, others, order = bench.run_default_protocol(make_leg, 2)
+    assert [e for e in events if e[0] == "setup"] == [("setup", 2), ("setup", 3), ("setup", 4), ("setup", 5)]
+    phases = [e[0] for e in events]
+    assert phases.index("gpu") > max(i for i, p in enumerate(phases) if p == "setup")       # nothing is timed before everything is resident
+    assert min(i for i, p in enumerate(phases) if p == "cpu") > max(i for i, p in enumerate(phases) if p == "gpu")  # no CPU leg between GPU legs
+    assert [e for e in events if e[0] == "gpu"] == [("gpu", 2), ("gpu", 3), ("gpu", 4), ("gpu", 5)]
+    assert [e for e in events if e[0] == "cpu"] == [("cpu", 2), ("cpu", 3), ("cpu", 5)]
+    assert line["config"]["workload"] == "config2" and set(others) == {3, 4, 5}
+    assert "RuntimeError" in others[4]["error"] and others[3]["kernel_ms"] == 0.01
+    # config 5: a bench step is a PASS; kernel time and traffic carried in both units, labelled
+    five = others[5]
+    assert "kernel_ms" not in five and "traffic" not in five
+    assert five["ms_per_pass"] == 0.4 and five["kernel_ms_per_pass"] == 10.0 and five["kernel_ms_per_control_step_of_4096_trajectories"] == 0.01
+    assert five["traffic_bytes_per_pass"] == 2000.0 and five["traffic_bytes_per_control_step_of_4096_trajectories"] == 2.0
+    assert [o[:2] for o in order] == [["setup", 2], ["setup", 3], ["setup", 4], ["setup", 5], ["gpu", 2], ["gpu", 3], ["gpu", 4], ["gpu", 5],
+                                      ["cpu", 2], ["cpu", 3], ["cpu", 5]]

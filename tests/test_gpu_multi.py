@@ -38,8 +38,17 @@ def _check_two_rank_line(d, gather):
         # rank 0 re-solved rows taken from BOTH ranks' parts of the gathered array with the CPU checker
         par = d["cpu_baseline"]["parity_on_sample"]
         assert par["rows"] >= 2 * 1024 and par["max_abs_joint_error_rad"] < 1e-6
+    assert abs(m["end_to_end_solves_per_s"] - d["value"]) < 1e-6 * d["value"]
+    if gather == "final":
+        # the N > 1 default, the north star's job shape: K sharded steps + ONE all-gather of the final arrays inside the timed region
+        assert "ONE RCCL all-gather" in d["config"]["collective"] and "north star" in m["value_is"]
+        assert m["gather_final"]["from"].startswith("the timed region") and abs(m["gather_final"]["solves_per_s"] - d["value"]) < 1e-6 * d["value"]
+        assert m["gather_step"]["overlapped"] is False and m["gather_step"]["solves_per_s"] < m["kernel_only_solves_per_s"]
     if gather == "step":
-        assert abs(m["end_to_end_solves_per_s"] - d["value"]) < 1e-6 * d["value"]
+        assert m["gather_step"]["from"].startswith("the timed region") and m["gather_step"]["overlapped"] is True
+    if gather != "none":  # kernel-only, gather-only and both end-to-end figures are all there, whichever was timed
+        assert m["kernel_only_solves_per_s"] > 0 and m["gather_only_solves_per_s"] > 0
+        assert m["gather_final"]["solves_per_s"] > 0 and m["gather_step"]["solves_per_s"] > 0
     # what the collective library saw, and the like-for-like reference for the driver's scaling curve
     g = m["group"]
     assert g["world_size"] == 2 and len(g["ranks"]) == 2 and {r["rank"] for r in g["ranks"]} == {0, 1}
@@ -61,12 +70,14 @@ def _check_two_rank_line(d, gather):
         assert "gather_final" not in d
 
 
-@pytest.mark.parametrize("gather", ["step", "final", "none"])
+@pytest.mark.parametrize("gather", ["default", "step", "final", "none"])
 def test_bench_two_ranks_gloo_one_gpu(gather):
-    """`bench.py --gpus 2` starts its own ranks; config 4 (mixed r/l) is the N > 1 default."""
+    """`bench.py --gpus 2` starts its own ranks; config 4 (mixed r/l) is the N > 1 default, and so is `--gather final`: the
+    all-gather the north star names, once, after the K sharded steps."""
+    flags = () if gather == "default" else ("--gather", gather)
     d = _bench("--gpus", "2", "--backend", "gloo", "--single-device", "--poses", "32768", "--steps", "3", "--warmup", "1",
-               "--cpu-seconds", "2", "--gather", gather, "--chunks", "4")
-    _check_two_rank_line(d, gather)
+               "--cpu-seconds", "2", "--chunks", "4", *flags)
+    _check_two_rank_line(d, "final" if gather == "default" else gather)
 
 
 def test_bench_two_ranks_gloo_config3_and_config5():

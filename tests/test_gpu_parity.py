@@ -1193,6 +1193,51 @@ def test_continuous_pipeline_takes_slightly_skewed_matrices_as_they_are(torch_mo
     hs.set_option(A.OPT_EULER_ROUNDTRIP, A.EULER_AUTO)
 
 
+def test_continuous_pipeline_through_gimbal_lock(torch_mod):
+    """Config 5's generator swings the goal's pitch through -pi/2: within 1e-5 of the lock the control kernels make ControlIK's
+    matrix -> Euler -> matrix round trip (RSIK_EULER_AUTO), which evaluates sines and cosines from the workgroup's table in LDS —
+    in the pipeline's joints phase on a rarely taken branch.  At BASELINE size eight trajectory-steps in four million take it; here
+    every step of every trajectory sits 0 ... 2e-5 rad from the lock (both sides, the lock itself included), so a branch
+    that ran ahead of the table's staging, or derived another rotation than the prepare phase, shows: pipeline forms against the
+    step kernel, flags / states / carried theta bit for bit, joints to 1e-9."""
+    A = _abi_mod()
+    n_traj, n_steps = 777, 160
+    dev = torch_mod.device("cuda", 0)
+    g = torch_mod.Generator(device="cpu").manual_seed(99)
+    t = (torch_mod.arange(n_steps, dtype=torch_mod.float64)[:, None] / 120.0 + 11.0 + torch_mod.rand(n_traj, generator=g, dtype=torch_mod.float64)[None, :] * 40.0).to(dev)
+    c0 = [0.65, -0.2, 0.0, 0.0, -np.pi / 2, 0.0]
+    amp = [0.35, 0.35, 0.35, np.pi / 6, np.pi / 6, np.pi / 6]
+    freq = [0.6, 0.34, 0.78, 0.18, 0.31, 0.47]
+    v = [c + a * torch_mod.sin(f * t) for c, a, f in zip(c0, amp, freq)]
+    # the pitch stays within 2e-5 rad of the lock all the way (a smooth swing: no jump for the continuity check to latch on), on
+    # both sides of goal_from_m12's 1e-10 threshold on |R20|, and every eighth step sits on the lock itself
+    v[4] = -np.pi / 2 + 2e-5 * torch_mod.sin(freq[4] * 40.0 * t)
+    v[4][::8] = -np.pi / 2
+    ca, sa, cb, sb, cc, sc = (torch_mod.cos(v[3]), torch_mod.sin(v[3]), torch_mod.cos(v[4]), torch_mod.sin(v[4]), torch_mod.cos(v[5]), torch_mod.sin(v[5]))
+    rows = [cc * cb, cc * sb * sa - sc * ca, cc * sb * ca + sc * sa, sc * cb, sc * sb * sa + cc * ca, sc * sb * ca - cc * sa,
+            -sb, cb * sa, cb * ca, v[0], v[1], v[2]]
+    traj = torch_mod.stack(rows, dim=1).contiguous()
+    frac_lock = float((traj[:, 6, :].abs() > 1.0 - 1e-10).double().mean())  # (what goal_from_m12 takes for the lock)
+    assert 0.2 < frac_lock < 0.9, frac_lock
+    c = make_control()
+    hs = c._solver
+    ref = None
+    for run_mode, blk in ((A.CONT_RUN_STEPS, 0), (A.CONT_RUN_PHASED, 0), (A.CONT_RUN_PHASED, 48)):
+        hs.set_option(A.OPT_CONT_RUN_MODE, run_mode)
+        hs.set_option(A.OPT_CONT_BLOCK_STEPS, blk)
+        st = c.new_continuous_state("r_arm", n_traj)
+        res = c.run_continuous_trajectories("r_arm", traj, st, first_step_timed_out=True, current_pose=traj[0], d_theta_max=0.05)
+        hs.synchronize()
+        got = {k: v_.clone() for k, v_ in res.items()}
+        got["cont_state"] = st[:11].clone()
+        if ref is None:
+            ref = got
+        else:
+            _same_run(torch_mod, ref, got, ("gimbal lock", run_mode, blk), joint_tol=1e-9)
+    hs.set_option(A.OPT_CONT_RUN_MODE, A.CONT_RUN_AUTO)
+    hs.set_option(A.OPT_CONT_BLOCK_STEPS, 0)
+
+
 def _eventful_trajectories(torch, n_traj, n_steps, seed, arm):
     """[n_steps, 12, n_traj] goal matrices: config 5's sinusoids plus, per trajectory, one of: a jump of the goal, a winding
     wrist (reaches the +-6 pi limit), a stretch far out of reach, a run of exact repeats ("stay" steps) — what makes the
