@@ -61,7 +61,9 @@ def _check_two_rank_line(d, gather):
     assert d["scaling_efficiency_vs_n1_same_config"] == eff
     if gather != "none":
         assert m["gather_final"]["solves_per_s"] > 0 and m["gather_step"]["solves_per_s"] > 0
-        assert m["gather_final"]["ms_for_K_steps_plus_one_gather"] > m["gather_final"]["one_all_gather_ms"] > 0
+        # (no ordering between the two: under --gather final the first is the timed region itself, the second a separate leg —
+        # over gloo, on one GPU, the legs' transport times differ by multiples)
+        assert m["gather_final"]["ms_for_K_steps_plus_one_gather"] > 0 and m["gather_final"]["one_all_gather_ms"] > 0
         top = d["gather_final"]
         assert top["solves_per_s"] == m["gather_final"]["solves_per_s"] and 0 < top["efficiency_vs_n1_same_config"] <= 1.0 + 1e-9
         assert d["cpu_baseline"]["workload_filter"]["rows_the_checker_calls_reachable"] == d["cpu_baseline"]["workload_filter"]["rows"]

@@ -1309,6 +1309,50 @@ def test_continuous_run_forms_are_bit_identical(torch_mod, n_traj, n_steps, arm,
         assert float((ref["cont_state"][9] != 0).float().mean()) > 0.02, "no trajectory latched: the rare paths were not exercised"
 
 
+@pytest.mark.parametrize("timed_out", [False, True])
+def test_continuous_run_that_begins_latched(torch_mod, timed_out):
+    """ControlIK answers previous_sol, not reachable, with the emergency state for every goal once its emergency stop is latched
+    (control_ik.py:205-210), until "unfreeze".  A run whose trajectories — some of them, or all — are latched when it begins: the
+    pipeline fills their steps in without walking them (the joints phase writes previous_sol rows, the chain phase lets them stand);
+    every output and the carried state against the step kernel, launch per step; the latched trajectories' rows are previous_sol
+    bit for bit and their state rows are untouched, whether or not the caller says its first step timed out."""
+    A = _abi_mod()
+    n_traj, n_steps = 300, 120
+    c = make_control()
+    hs = c._solver
+    st = c.new_continuous_state("r_arm", n_traj)
+    first = _eventful_trajectories(torch_mod, n_traj, n_steps, 4321, "r_arm")
+    c.run_continuous_trajectories("r_arm", first, st, first_step_timed_out=True, current_pose=first[0])
+    hs.synchronize()
+    latched = st[9] != 0
+    assert 0.02 < float(latched.double().mean()) < 0.9, "the eventful trajectories should latch some trajectories, not all"
+    goals = _eventful_trajectories(torch_mod, n_traj, n_steps, 999, "r_arm")
+    everyone = st.clone()
+    everyone[9] = 1.0
+    for start, who in ((st, latched), (everyone, torch_mod.ones_like(latched))):
+        ref = None
+        for run_mode, blk in ((A.CONT_RUN_STEPS, 0), (A.CONT_RUN_PHASED, 0), (A.CONT_RUN_PHASED, 48)):
+            hs.set_option(A.OPT_CONT_RUN_MODE, run_mode)
+            hs.set_option(A.OPT_CONT_BLOCK_STEPS, blk)
+            s2 = start.clone()
+            res = c.run_continuous_trajectories("r_arm", goals, s2, first_step_timed_out=timed_out, current_pose=goals[0])
+            hs.synchronize()
+            got = {k: v.clone() for k, v in res.items()}
+            got["cont_state"] = s2[:11].clone()
+            # the latched trajectories: previous_sol at every step, bit for bit; emergency state, not reachable; nothing of their state moved
+            prev_sol = start[1:8, who].T.contiguous()                                      # [latched, 7]
+            rows = got["joints"][:, who, :]
+            assert torch_mod.equal(rows.view(torch_mod.uint8), prev_sol[None].expand_as(rows).contiguous().view(torch_mod.uint8)), (run_mode, blk)
+            assert bool((got["state"][:, who] == A.STATE_EMERGENCY).all()) and bool((got["reachable"][:, who] == 0).all())
+            assert torch_mod.equal(s2[:, who].view(torch_mod.uint8), start[:, who].contiguous().view(torch_mod.uint8)), (run_mode, blk)
+            if ref is None:
+                ref = got
+            else:
+                _same_run(torch_mod, ref, got, ("begins latched", run_mode, blk, timed_out), joint_tol=1e-9)
+    hs.set_option(A.OPT_CONT_RUN_MODE, A.CONT_RUN_AUTO)
+    hs.set_option(A.OPT_CONT_BLOCK_STEPS, 0)
+
+
 @pytest.mark.parametrize("mode,d_theta_max,preferred", [("unconstrained", 0.01, -4 * np.pi / 6), ("low_elbow", 0.05, 0.5)])
 def test_config5_full_size_against_checker(torch_mod, orc, mode, d_theta_max, preferred):
     """BASELINE config 5 at its stated size: 4096 trajectories x 1000 control steps in one rsik_control_continuous_run
