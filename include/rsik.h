@@ -365,6 +365,34 @@ int rsik_control_continuous_reserve(rsik_ctx *ctx, int64_t n, int64_t n_steps);
 int rsik_control_continuous_release(rsik_ctx *ctx);
 
 /*
+ * rsik_stage — the stages of SymbolicIK.is_reachable as the reference exposes them: public methods that take their operands
+ * as arguments (and self.wrist_position, which a caller may assign), timed one by one by src/benchmark/ik_benchmarks.py:36-130.
+ * The fused kernels never form these intermediates; this entry point does, with the reference's own sequence of operations, on
+ * whatever operands it is given.  Row-major: row i reads in[i * in_stride ...], writes out[i * out_stride ...] (device pointers,
+ * or pinned host memory the device can address); `arm`: whose constants (RSIK_ARM_R / RSIK_ARM_L).  Per row, in -> out:
+ *   RSIK_STAGE_POSE_IN_REACH        is_pose_in_robot_reach symbolic_ik.py:284-307: position 3, euler 3 -> in reach 0/1, position 3 (pulled
+ *                                   back / clamped), state code (RSIK_STATE_EMPTY = the reference's "")
+ *   RSIK_STAGE_WRIST_POSITION       get_wrist_position :418-425: position 3, euler 3 -> wrist 3
+ *   RSIK_STAGE_LIMITATION_CIRCLE    get_limitation_wrist_circle :401-416: wrist 3, goal position 3 -> centre 3, radius, normal 3 (not normalised)
+ *   RSIK_STAGE_INTERSECTION_CIRCLE  get_intersection_circle :366-399: wrist 3 -> found 0/1 (0 = None), centre 3, radius, normal 3
+ *   RSIK_STAGE_CIRCLES_LINKED       are_circles_linked :427-568: wrist 3, intersection circle (centre 3, radius, normal 3), limitation circle
+ *                                   (the same seven) -> how many numbers the returned array holds (0 or 2), the interval 2
+ *   RSIK_STAGE_NEAREST_APPROACH     points_of_nearest_approach :588-606: p1 3, normal1 3, p2 3, normal2 3 -> q found 0/1 (0 = []), q 3, v 3
+ *   RSIK_STAGE_CIRCLE_LINE          intersection_circle_line_3d_vd :608-645: centre 3, radius, direction 3, point on line 3 -> points 0/1/2, point 3, point 3
+ *   RSIK_STAGE_ROTATION_FROM_VECTOR utils.rotation_matrix_from_vector utils.py:59-81: vector 3 -> 3 x 3 row-major
+ */
+#define RSIK_STAGE_POSE_IN_REACH 0
+#define RSIK_STAGE_WRIST_POSITION 1
+#define RSIK_STAGE_LIMITATION_CIRCLE 2
+#define RSIK_STAGE_INTERSECTION_CIRCLE 3
+#define RSIK_STAGE_CIRCLES_LINKED 4
+#define RSIK_STAGE_NEAREST_APPROACH 5
+#define RSIK_STAGE_CIRCLE_LINE 6
+#define RSIK_STAGE_ROTATION_FROM_VECTOR 7
+#define RSIK_STAGE_COUNT 8
+int rsik_stage(rsik_ctx *ctx, int op, int64_t n, int arm, const double *in, int in_stride, double *out, int out_stride);
+
+/*
  * Solver-state entry points: the scalar drop-in API.  A SymbolicIK object keeps self.goal_pose,
  * self.wrist_position and self.intersection_circle between is_reachable() and the closure it returns
  * (symbolic_ik.py:143-144,185,235), and get_joints() mutates them when the elbow projection fires

@@ -1185,6 +1185,89 @@ def gen_scale(out, workers=None):
     np.savez_compressed(os.path.join(out, "g14_scale.npz"), **data)
 
 
+# ----------------------------------------------------------------------------------------
+# G15: the stages of is_reachable as the reference exposes them (public methods on explicit operands; its own harness,
+# src/benchmark/ik_benchmarks.py:36-130, times them one by one): is_pose_in_robot_reach, get_wrist_position,
+# get_limitation_wrist_circle, get_intersection_circle, are_circles_linked, points_of_nearest_approach,
+# intersection_circle_line_3d_vd, utils.rotation_matrix_from_vector — chained the way the harness chains them.
+# ----------------------------------------------------------------------------------------
+def gen_stages(out, n=1500):
+    from reachy2_symbolic_ik.utils import rotation_matrix_from_vector
+
+    rng = np.random.default_rng(15)
+    data = {}
+    for arm in ARMS:
+        solver = make_solver(arm, 0.03)
+        # every outcome: half uniformly random poses, half reachable ones (where the circles really cross)
+        pu, eu = random_poses(rng, arm, n // 2)
+        pr, er = reachable_poses(rng, solver, arm, n - n // 2)
+        pos, eul = np.concatenate([pu, pr]), np.concatenate([eu, er])
+        rows = {k: [] for k in ("reach_ok", "reach_pos", "reach_state", "wrist", "lc", "ic_found", "ic", "linked_count", "linked",
+                                "na_found", "na_q", "na_v", "cl_count", "cl_points", "rot")}
+        for p, e in zip(pos, eul):
+            pose = np.array([p, e])
+            ok, new_pose, st = solver.is_pose_in_robot_reach(pose)
+            rows["reach_ok"].append(np.uint8(bool(ok)))
+            rows["reach_pos"].append(np.array(new_pose[0], dtype=float))
+            rows["reach_state"].append(np.uint8(STATE_CODES[st]))
+            w = np.array(solver.get_wrist_position(pose), dtype=float)
+            rows["wrist"].append(w)
+            solver.wrist_position = w
+            lc = solver.get_limitation_wrist_circle(pose)
+            rows["lc"].append(np.concatenate([lc[0], [lc[1]], lc[2]]))
+            rows["rot"].append(np.array(rotation_matrix_from_vector(lc[2]), dtype=float).reshape(9))
+            ic = solver.get_intersection_circle(pose)
+            rows["ic_found"].append(np.uint8(ic is not None))
+            linked, q, v, pts = np.array([]), np.array([]), np.full(3, NAN), None
+            if ic is None:
+                rows["ic"].append(np.full(7, NAN))
+            else:
+                rows["ic"].append(np.concatenate([ic[0], [ic[1]], ic[2]]))
+                linked = np.array(solver.are_circles_linked(ic, lc), dtype=float)
+                q, v = solver.points_of_nearest_approach(lc[0], lc[2], ic[0], ic[2])
+                if len(q):
+                    pts = solver.intersection_circle_line_3d_vd(lc[0], lc[1], v, q)
+            rows["linked_count"].append(np.uint8(len(linked)))
+            rows["linked"].append(linked if len(linked) else np.full(2, NAN))
+            rows["na_found"].append(np.uint8(len(q) > 0))
+            rows["na_q"].append(np.array(q, dtype=float) if len(q) else np.full(3, NAN))
+            rows["na_v"].append(np.array(v, dtype=float))
+            k = 0 if pts is None else len(pts)
+            rows["cl_count"].append(np.uint8(k))
+            flat = np.full(6, NAN)
+            if k:
+                flat[: 3 * k] = np.array(pts, dtype=float).reshape(-1)
+            rows["cl_points"].append(flat)
+        data[f"{arm}_pos"], data[f"{arm}_eul"] = pos, eul
+        for k, v in rows.items():
+            data[f"{arm}_{k}"] = np.array(v)
+    # rotation_matrix_from_vector at and around its two colinear special cases (np.isclose's tolerances), any length
+    vs = [[1, 0, 0], [-1, 0, 0], [3, 0, 0], [1, 1e-9, 0], [1, 2e-5, 0], [-1, 0, 1e-9], [-1, 3e-5, -2e-5], [0, 1, 0], [0, 0, -2], [1e-3, 1e-3, 1e-3],
+          [1, 1.0000001e-8, 0], [1, 1e-8, 1e-8]] + rng.normal(size=(52, 3)).tolist()
+    data["rot_vectors"] = np.array(vs, dtype=float)
+    data["rot_matrices"] = np.array([np.array(rotation_matrix_from_vector(np.array(v, dtype=float)), dtype=float).reshape(9) for v in vs])
+    # are_circles_linked on circles no pose produces: parallel planes (same / opposite normals, both sides), far apart, tangent-ish
+    solver = make_solver("r_arm", 0.03)
+    cases = []
+    for trial in range(200):
+        w = rng.uniform(-0.3, 0.3, size=3)
+        n1 = rng.normal(size=3)
+        kind = trial % 5
+        n2 = n1 * (1.0 if kind == 0 else -1.0) if kind < 2 else rng.normal(size=3)
+        if kind == 2:
+            n2 = n1 + rng.normal(size=3) * 1e-8  # inside the parallel margin (after normalisation) or just outside
+        c1 = w + rng.normal(size=3) * 0.05
+        c2 = w + rng.normal(size=3) * (0.05 if kind < 4 else 0.6)
+        r1, r2 = rng.uniform(0.02, 0.2, size=2)
+        solver.wrist_position = w
+        res = np.array(solver.are_circles_linked((c2, r2, n2), (c1, r1, n1)), dtype=float)
+        cases.append((np.concatenate([w, c2, [r2], n2, c1, [r1], n1]), len(res), res if len(res) else np.full(2, NAN)))
+    data["linked_cases_in"] = np.array([c[0] for c in cases])
+    data["linked_cases_count"] = np.array([c[1] for c in cases], dtype=np.uint8)
+    data["linked_cases_interval"] = np.array([c[2] for c in cases])
+    np.savez_compressed(os.path.join(out, "g15_stages.npz"), **data)
+
+
 def ref_default_joints(k):
     return [[0.0, 0.2617993877991494, -0.17453292519943295, 0.0, 0.0, 0.0, 0.0],
             [0.0, -0.2617993877991494, 0.17453292519943295, 0.0, 0.0, 0.0, 0.0]][k]
@@ -1210,7 +1293,7 @@ def main():
              ("g4", gen_control), ("g5", gen_helpers), ("g6", gen_continuous),
              ("g7", gen_continuous_start), ("g8", gen_matrix_edges),
              ("g9", gen_custom_geometry), ("g10", gen_custom_urdf_control), ("g11", gen_emergency),
-             ("g12", gen_continuous_modes), ("g13", gen_hostile), ("g14", gen_scale)]
+             ("g12", gen_continuous_modes), ("g13", gen_hostile), ("g14", gen_scale), ("g15", gen_stages)]
     bad = 0
     for name, fn in steps:
         if args.only and name not in args.only.split(","):  # exact names: "g1" does not select "g12"

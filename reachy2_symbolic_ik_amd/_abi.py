@@ -63,6 +63,7 @@ PROTOTYPES = {
                                               C.c_int, C.c_double, _vp, C.c_double, _vp, _vp, _vp, _vp]),
     "rsik_control_continuous_reserve": (C.c_int, [_vp, C.c_int64, C.c_int64]),
     "rsik_control_continuous_release": (C.c_int, [_vp]),
+    "rsik_stage": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_int, _vp, C.c_int, _vp, C.c_int]),
     "rsik_reach_state": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp), _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "rsik_joints_from_state": (C.c_int, [_vp, C.c_int64, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     "rsik_elbow_from_state": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp]),
@@ -76,6 +77,9 @@ PROTOTYPES = {
 }
 
 GOAL_POSE6, GOAL_M12 = 0, 1
+(STAGE_POSE_IN_REACH, STAGE_WRIST_POSITION, STAGE_LIMITATION_CIRCLE, STAGE_INTERSECTION_CIRCLE, STAGE_CIRCLES_LINKED, STAGE_NEAREST_APPROACH,
+ STAGE_CIRCLE_LINE, STAGE_ROTATION_FROM_VECTOR) = range(8)
+STAGE_ROW = {0: (6, 5), 1: (6, 3), 2: (6, 7), 3: (3, 8), 4: (17, 3), 5: (12, 7), 6: (10, 7), 7: (3, 9)}  # doubles in / out per row
 OPT_EULER_ROUNDTRIP, OPT_SWEEP_MODE, OPT_NO_TIPZ, OPT_NO_MIRROR, OPT_CONT_RUN_MODE = 0, 1, 2, 3, 4
 OPT_CONT_BLOCK_STEPS, OPT_CONT_PHASED_VARIANT = 5, 6
 PHASED_EDGES_BY_EVENT, PHASED_NO_THETA_FIRST = 1, 2

@@ -415,6 +415,20 @@ class HipSolver:
             self._check(self.lib.rsik_elbow_from_state(self._h, n, _ptr(solver_state), _ptr(theta), _ptr(elbow)))
         return elbow
 
+    def stage(self, op: int, rows: torch.Tensor, arm_uniform: int = 0) -> torch.Tensor:
+        """rsik_stage: one stage of SymbolicIK.is_reachable (include/rsik.h RSIK_STAGE_*) on explicit operands, row by row.
+        rows: [n, doubles the stage reads] float64 on the device (or pinned host memory); returns [n, doubles it writes]."""
+        need_in, need_out = _abi.STAGE_ROW[int(op)]
+        if (not isinstance(rows, torch.Tensor) or rows.dtype != _F64 or rows.dim() != 2 or rows.shape[1] != need_in or not rows.is_contiguous()
+                or not (rows.device == self.device or (rows.device.type == "cpu" and rows.is_pinned()))):
+            raise ValueError(f"stage {op} takes a contiguous float64 [n, {need_in}] tensor on {self.device} (or in pinned host memory)")
+        n = int(rows.shape[0])
+        out = torch.empty((n, need_out), dtype=_F64, device=self.device)
+        with torch.cuda.device(self.device):
+            self._bind_stream()
+            self._check(self.lib.rsik_stage(self._h, int(op), n, int(arm_uniform), _ptr(rows), need_in, _ptr(out), need_out))
+        return out
+
     def _check_state(self, solver_state: torch.Tensor, n: int) -> None:
         if (not isinstance(solver_state, torch.Tensor) or solver_state.dtype != _F64 or solver_state.device != self.device
                 or tuple(solver_state.shape) != (n, _abi.SOLVER_STATE_STRIDE) or not solver_state.is_contiguous()):

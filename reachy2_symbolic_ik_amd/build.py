@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["rsik_lib.hip"]
-DEPS = ["rsik_lib.hip", "rsik_kernel_solve.hpp", "rsik_kernel_discrete.hpp", "rsik_kernel_continuous.hpp", "rsik_kernel_pipeline.hpp",
+DEPS = ["rsik_lib.hip", "rsik_kernel_solve.hpp", "rsik_kernel_discrete.hpp", "rsik_kernel_continuous.hpp", "rsik_kernel_pipeline.hpp", "rsik_kernel_stages.hpp",
         "rsik_kernel_state.hpp", "rsik_comm.hpp", "rsik_device.hpp", "rsik_math.hpp", "rsik_poly_gen.hpp",
         os.path.join("..", "..", "include", "rsik.h")]
 OUT = os.path.join(CSRC, "librsik_hip.so")

@@ -26,6 +26,7 @@
 #include "rsik_kernel_continuous.hpp"
 #include "rsik_kernel_pipeline.hpp"
 #include "rsik_kernel_state.hpp"
+#include "rsik_kernel_stages.hpp"
 
 // =====================================================================================
 // C ABI
@@ -1068,6 +1069,33 @@ int rsik_elbow_from_state(rsik_ctx* ctx, int64_t n, const double* solver_state, 
     int rc = launch_dims(ctx, n, &grid, "rsik_elbow_from_state");
     if (rc != RSIK_OK) return rc;
     hipLaunchKernelGGL(rsik::elbow_state_kernel, grid, block, 0, ctx->stream, K);
+    RSIK_HIP(ctx, hipGetLastError());
+    return RSIK_OK;
+}
+
+int rsik_stage(rsik_ctx* ctx, int op, int64_t n, int arm, const double* in, int in_stride, double* out, int out_stride) {
+    const char* who = "rsik_stage";
+    if (!ctx) return RSIK_E_INVALID;
+    // doubles a row takes and gives, by stage (include/rsik.h)
+    static const int need_in[RSIK_STAGE_COUNT] = {6, 6, 6, 3, 17, 12, 10, 3}, need_out[RSIK_STAGE_COUNT] = {5, 3, 7, 8, 3, 7, 7, 9};
+    if (op < 0 || op >= RSIK_STAGE_COUNT) return fail(ctx, RSIK_E_INVALID, std::string(who) + ": unknown stage");
+    if (n < 0) return fail(ctx, RSIK_E_INVALID, std::string(who) + ": n < 0");
+    int rc = check_arms(ctx, nullptr, arm, who);
+    if (rc != RSIK_OK) return rc;
+    if (n == 0) return RSIK_OK;
+    if (!in || !out) return fail(ctx, RSIK_E_INVALID, std::string(who) + ": NULL buffer");
+    if (in_stride < need_in[op] || out_stride < need_out[op])
+        return fail(ctx, RSIK_E_INVALID, std::string(who) + ": stage " + std::to_string(op) + " reads " + std::to_string(need_in[op]) + " and writes " +
+                    std::to_string(need_out[op]) + " doubles per row");
+    rsik::StageArgs K;
+    std::memset(&K, 0, sizeof K);
+    K.n = n; K.op = op; K.in = in; K.out = out; K.in_stride = in_stride; K.out_stride = out_stride;
+    K.arms[0] = K.arms[1] = ctx->arms[arm];
+    RSIK_HIP(ctx, hipSetDevice(ctx->device));
+    dim3 grid, block(rsik::kBlock);
+    rc = launch_dims(ctx, n, &grid, who);
+    if (rc != RSIK_OK) return rc;
+    hipLaunchKernelGGL(rsik::stage_kernel, grid, block, 0, ctx->stream, K);
     RSIK_HIP(ctx, hipGetLastError());
     return RSIK_OK;
 }

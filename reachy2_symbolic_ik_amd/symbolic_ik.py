@@ -184,13 +184,64 @@ class SymbolicIK:
         e = io["h_elbow_np"]
         return np.array([e[0], e[1], e[2], 1.0])
 
-    def get_wrist_position(self, goal_pose: npt.NDArray[np.float64]) -> npt.NDArray[np.float64]:
-        """symbolic_ik.py:418-425 (host arithmetic: a single 3x3 product, not on the solve path)."""
-        from .constants import euler_xyz_extrinsic
+    # ---- the stages of is_reachable as public methods (the reference's own harness times them one by one,
+    # src/benchmark/ik_benchmarks.py:36-130): each is one rsik_stage launch on the operands it is given — the fused kernels never
+    # form these intermediates.  `self.wrist_position` is read where the reference reads it (a caller may assign it).
+    def _stage(self, op: int, *operands: Any) -> np.ndarray:
+        need_in, need_out = _abi.STAGE_ROW[op]
+        io = getattr(self, "_stage_io", None)
+        if io is None:
+            io = self._stage_io = {"in": torch.empty((1, 17), dtype=torch.float64).pin_memory(),
+                                   "out": torch.empty((1, 9), dtype=torch.float64).pin_memory()}
+            io["in_np"], io["out_np"] = io["in"].numpy(), io["out"].numpy()
+        flat = np.concatenate([np.asarray(a, dtype=np.float64).reshape(-1) for a in operands])
+        if flat.size != need_in:
+            raise ValueError(f"stage {op} takes {need_in} numbers, got {flat.size}")
+        io["in_np"][0, :need_in] = flat
+        sv = self._solver
+        self._upload()
+        with torch.cuda.device(sv.device):
+            sv._bind_stream()
+            sv._check(sv.lib.rsik_stage(sv._h, int(op), 1, self.arm_id, io["in"].data_ptr(), 17, io["out"].data_ptr(), 9))
+            torch.cuda.current_stream(sv.device).synchronize()
+        return io["out_np"][0, :need_out].copy()
 
-        R = euler_xyz_extrinsic(np.asarray(goal_pose[1], dtype=np.float64))
-        tl = np.array([-self.tip_position[0], self.tip_position[1], self.tip_position[2]])
-        return R @ tl + np.asarray(goal_pose[0], dtype=np.float64)
+    def is_pose_in_robot_reach(self, goal_pose: npt.NDArray[np.float64]) -> Tuple[bool, npt.NDArray[np.float64], str]:
+        """symbolic_ik.py:284-307."""
+        o = self._stage(_abi.STAGE_POSE_IN_REACH, goal_pose[0], goal_pose[1])
+        code = int(o[4])
+        return bool(o[0] != 0.0), np.array([o[1:4], np.asarray(goal_pose[1], dtype=np.float64)]), STATE_STRINGS[code]
+
+    def get_wrist_position(self, goal_pose: npt.NDArray[np.float64]) -> npt.NDArray[np.float64]:
+        """symbolic_ik.py:418-425."""
+        return self._stage(_abi.STAGE_WRIST_POSITION, goal_pose[0], goal_pose[1])
+
+    def get_limitation_wrist_circle(self, goal_pose: npt.NDArray[np.float64]) -> Tuple[npt.NDArray[np.float64], float, npt.NDArray[np.float64]]:
+        """symbolic_ik.py:401-416 (reads self.wrist_position)."""
+        o = self._stage(_abi.STAGE_LIMITATION_CIRCLE, self.wrist_position, goal_pose[0])
+        return o[0:3], float(o[3]), o[4:7]
+
+    def get_intersection_circle(self, goal_pose: npt.NDArray[np.float64]) -> Optional[Tuple[npt.NDArray[np.float64], float, npt.NDArray[np.float64]]]:
+        """symbolic_ik.py:366-399 (reads self.wrist_position; the argument is not looked at, as in the reference)."""
+        o = self._stage(_abi.STAGE_INTERSECTION_CIRCLE, self.wrist_position)
+        return None if o[0] == 0.0 else (o[1:4], float(o[4]), o[5:8])
+
+    def are_circles_linked(self, intersection_circle: Any, limitation_wrist_circle: Any) -> npt.NDArray[np.float64]:
+        """symbolic_ik.py:427-509: the interval of valid elbow angles, or an empty array (reads self.wrist_position)."""
+        o = self._stage(_abi.STAGE_CIRCLES_LINKED, self.wrist_position, intersection_circle[0], [intersection_circle[1]], intersection_circle[2],
+                        limitation_wrist_circle[0], [limitation_wrist_circle[1]], limitation_wrist_circle[2])
+        return np.array([]) if o[0] == 0.0 else o[1:3]
+
+    def points_of_nearest_approach(self, p1: Any, V_torso_normal1: Any, p2: Any, V_torso_normal2: Any) -> Tuple[npt.NDArray[np.float64], npt.NDArray[np.float64]]:
+        """symbolic_ik.py:588-606: (a point of, the direction of) the line in which the two circles' planes meet."""
+        o = self._stage(_abi.STAGE_NEAREST_APPROACH, p1, V_torso_normal1, p2, V_torso_normal2)
+        return (o[1:4] if o[0] != 0.0 else np.array([])), o[4:7]
+
+    def intersection_circle_line_3d_vd(self, center: Any, radius: float, direction: Any, point_on_line: Any) -> Optional[npt.NDArray[np.float64]]:
+        """symbolic_ik.py:608-645."""
+        o = self._stage(_abi.STAGE_CIRCLE_LINE, center, [radius], direction, point_on_line)
+        k = int(o[0])
+        return None if k == 0 else (np.array([o[1:4]]) if k == 1 else np.vstack((o[1:4], o[4:7])))
 
     # ------------------------------------------------------------------ batched API (MI355X-native)
     def solve_batch(

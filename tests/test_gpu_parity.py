@@ -486,6 +486,102 @@ def test_config4_full_size_mixed_arms_against_checker(torch_mod, orc):
         assert np.max(err) < NORTH_STAR_TOL and np.quantile(err, 0.9999) < 1e-9, k
 
 
+# ------------------------------------------------------------------------------------------ rsik_stage (G15)
+def test_stage_entry_points_against_reference(golden_dir, torch_mod):
+    """rsik_stage: the stages of is_reachable on explicit operands, batched, against what the reference's own public methods returned
+    for the same operands chained the way its harness chains them (G15; src/benchmark/ik_benchmarks.py:36-130): outcomes (found / not,
+    how many points, empty or not) exact, numbers to 1e-9."""
+    A = _abi_mod()
+    g = load(golden_dir, "g15_stages.npz")
+    hs, r, l = make_symbolic(0.03)
+    T = lambda a: torch_mod.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).cuda()  # noqa: E731
+
+    def close(got, want, what, tol=1e-9):
+        m = ~np.isnan(want)
+        assert np.array_equal(np.isnan(got), ~m), what
+        assert np.max(np.abs(got[m] - want[m]), initial=0.0) < tol, (what, float(np.max(np.abs(got[m] - want[m]))))
+
+    for arm_id, (arm, ik) in enumerate((("r_arm", r), ("l_arm", l))):
+        ik._upload()
+        G = lambda k: g[f"{arm}_{k}"]  # noqa: E731
+        pose = np.concatenate([G("pos"), G("eul")], axis=1)
+        o = hs.stage(A.STAGE_POSE_IN_REACH, T(pose), arm_id).cpu().numpy()
+        np.testing.assert_array_equal(o[:, 0] != 0, G("reach_ok") != 0)
+        # (the reference's "" — nothing wrong with the pose — is RSIK_STATE_EMPTY; the golden set codes it 7 as well)
+        np.testing.assert_array_equal(o[:, 4].astype(np.uint8), G("reach_state"))
+        close(o[:, 1:4], G("reach_pos"), "reach_pos")
+        w = hs.stage(A.STAGE_WRIST_POSITION, T(pose), arm_id).cpu().numpy()
+        close(w, G("wrist"), "wrist")
+        lc = hs.stage(A.STAGE_LIMITATION_CIRCLE, T(np.concatenate([G("wrist"), G("pos")], axis=1)), arm_id).cpu().numpy()
+        close(lc, G("lc"), "limitation circle")
+        ic = hs.stage(A.STAGE_INTERSECTION_CIRCLE, T(G("wrist")), arm_id).cpu().numpy()
+        np.testing.assert_array_equal(ic[:, 0] != 0, G("ic_found") != 0)
+        close(ic[:, 1:], G("ic"), "intersection circle")
+        have = G("ic_found") != 0
+        assert 0.3 < have.mean() < 1.0
+        rows = np.concatenate([G("wrist"), G("ic"), G("lc")], axis=1)[have]
+        lk = hs.stage(A.STAGE_CIRCLES_LINKED, T(rows), arm_id).cpu().numpy()
+        np.testing.assert_array_equal(lk[:, 0].astype(np.uint8), G("linked_count")[have])
+        close(lk[:, 1:], G("linked")[have], "interval")
+        assert (G("linked_count")[have] == 2).mean() > 0.3 and (G("linked_count")[have] == 0).mean() > 0.05
+        lcg, icg = G("lc")[have], G("ic")[have]
+        na = hs.stage(A.STAGE_NEAREST_APPROACH, T(np.concatenate([lcg[:, 0:3], lcg[:, 4:7], icg[:, 0:3], icg[:, 4:7]], axis=1)), arm_id).cpu().numpy()
+        np.testing.assert_array_equal(na[:, 0] != 0, G("na_found")[have] != 0)
+        found = G("na_found")[have] != 0
+        close(na[found, 1:4], G("na_q")[have][found], "q", tol=1e-8)
+        close(na[:, 4:7], G("na_v")[have], "v")
+        cl = hs.stage(A.STAGE_CIRCLE_LINE, T(np.concatenate([lcg[found, 0:4], G("na_v")[have][found], G("na_q")[have][found]], axis=1)), arm_id).cpu().numpy()
+        np.testing.assert_array_equal(cl[:, 0].astype(np.uint8), G("cl_count")[have][found])
+        close(cl[:, 1:], G("cl_points")[have][found], "circle-line points", tol=1e-8)
+        rot = hs.stage(A.STAGE_ROTATION_FROM_VECTOR, T(G("lc")[:, 4:7]), arm_id).cpu().numpy()
+        close(rot, G("rot"), "rotation")
+    rot = hs.stage(A.STAGE_ROTATION_FROM_VECTOR, T(g["rot_vectors"]), 0).cpu().numpy()
+    close(rot, g["rot_matrices"], "rotation, special cases", tol=1e-12)
+    lk = hs.stage(A.STAGE_CIRCLES_LINKED, T(g["linked_cases_in"]), 0).cpu().numpy()
+    np.testing.assert_array_equal(lk[:, 0].astype(np.uint8), g["linked_cases_count"])
+    close(lk[:, 1:], g["linked_cases_interval"], "made-up circles")
+    assert len(set(g["linked_cases_count"].tolist())) == 2
+    with pytest.raises(Exception):
+        hs.stage(A.STAGE_CIRCLES_LINKED, T(np.zeros((2, 5))), 0)  # a row of the wrong length is refused on the host
+
+
+def test_reference_benchmark_harness_shape_runs_on_the_drop_in(golden_dir):
+    """src/benchmark/ik_benchmarks.py:12-156 in miniature: every call the reference's own per-function harness makes, made on the
+    drop-in with the harness's pose — the scalar stage methods exist, chain (each reads what the one before returned, and
+    self.wrist_position where the reference does) and agree with is_reachable on the same pose."""
+    from reachy2_symbolic_ik_amd import SymbolicIK
+    from reachy2_symbolic_ik_amd.utils import make_homogenous_matrix_from_rotation_matrix, rotation_matrix_from_vector
+
+    import contextlib
+    import io
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        ik = SymbolicIK()
+    goal_pose = np.array([[0.3, -0.1, 0.1], [np.radians(20), np.radians(-50), np.radians(20)]])
+    ok, interval, fn, state = ik.is_reachable(goal_pose)
+    joints, elbow = ik.get_joints(interval[0])
+    assert ok and state == "reachable" and joints.shape == (7,)
+    in_reach, pose2, st = ik.is_pose_in_robot_reach(goal_pose)
+    assert in_reach and st == "" and np.array_equal(pose2, goal_pose)
+    ik.wrist_position = ik.get_wrist_position(goal_pose)
+    lc = ik.get_limitation_wrist_circle(goal_pose)
+    ic = ik.get_intersection_circle(goal_pose)
+    assert ic is not None and np.allclose(ic[0], ik.intersection_circle[0], atol=1e-12) and abs(ic[1] - ik.intersection_circle[1]) < 1e-12
+    linked = ik.are_circles_linked(ic, lc)
+    assert linked.shape == (2,) and np.max(np.abs(linked - interval)) < 1e-9
+    R = rotation_matrix_from_vector(lc[2])
+    assert R.shape == (3, 3) and np.allclose(R @ R.T, np.eye(3), atol=1e-12) and np.allclose(R[:, 0], lc[2] / np.linalg.norm(lc[2]), atol=1e-12)
+    q, v = ik.points_of_nearest_approach(lc[0], lc[2], ic[0], ic[2])
+    pts = ik.intersection_circle_line_3d_vd(lc[0], lc[1], v, q)
+    assert q.shape == (3,) and abs(np.linalg.norm(v) - 1) < 1e-12 and (pts is None or pts.shape in ((1, 3), (2, 3)))
+    assert make_homogenous_matrix_from_rotation_matrix(np.array([0.3, -0.1, 0.1]), np.eye(3)).shape == (4, 4)
+    far = np.array([[2.0, -0.1, 0.1], [0.0, 0.0, 0.0]])
+    in_reach, pose2, st = ik.is_pose_in_robot_reach(far)
+    assert not in_reach and st == "Pose out of reach" and abs(np.linalg.norm(pose2[0] - ik.shoulder_position) - ik.max_arm_length) < 1e-6
+    ik.wrist_position = ik.get_wrist_position(far)
+    assert ik.get_intersection_circle(far) is None
+
+
 # ------------------------------------------------------------------------------------------ csrc/rsik_math.hpp
 def test_device_math_accuracy(torch_mod):
     """The kernels' own rcp / sqrt / rsqrt / atan2 / sincos / python-modulo against the host libm (float64)."""
