@@ -49,7 +49,7 @@ BYTES_PER_STEP_STATE_ROUND_TRIP = 96 + 58 + 2 * 66
 GATHER_BYTES_PER_POSE = 56 + 1  # joints [7] f64 + state u8 (reachable == (state == 0) for rsik_solve)
 URDF = "config_files/reachy2_ik_minimal.urdf"
 SHOULDER_R = np.array([0.0, -0.2, 0.0])
-PROFILE_COUNTERS = os.path.join(ROOT, "profiles", "r04", "counters.json")
+PROFILE_COUNTERS = os.path.join(ROOT, "profiles", "r05", "counters.json")
 
 
 def _quiet(fn, *a, **k):
@@ -344,9 +344,69 @@ def committed_counters(cfg, n, build_id):
         t = doc.get(str(cfg))
         if t and t["poses_per_gpu"] == n and doc.get("build_id") == build_id:
             return t
-        return {"stale": f"profiles/r04/counters.json was collected with another build or size (library {build_id})"}
+        return {"stale": f"profiles/r05/counters.json was collected with another build or size (library {build_id})"}
     except (OSError, ValueError, KeyError):
         return None
+
+
+def live_traffic(cfg, n, lib, timeout_s=150.0):
+    """HBM traffic of the config's kernel(s) measured NOW, in this run: two child runs of this script under `rocprofv3 --pmc`
+    (FETCH_SIZE, then WRITE_SIZE — separate passes, with --kernel-trace only, as MI355X_MICROARCH.md's HBM section prescribes; KiB
+    units; FETCH_SIZE x 2 on gfx950), a few eager launches each.  Returns {"bytes": per launch (config 5: per pass), ...} or
+    {"error": ...}: the committed counters (profiles/) then stand in, labelled."""
+    import csv
+    import glob
+    import shutil
+    import statistics
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    kernel = {2: "solve_kernel", 3: "control_discrete_kernel", 4: "solve_kernel", 5: "cont_"}[cfg]
+    child = [sys.executable, os.path.abspath(__file__), "--config", str(cfg), "--poses", str(n), "--steps", "3", "--warmup", "1", "--launch", "eager",
+             "--no-cpu-baseline", "--no-extras", "--no-other-configs", "--no-live-traffic"]
+    if cfg == 5:  # (a profiler that serialises dispatches deadlocks on device-word waits: streams tied by events)
+        child += ["--phased-variant", "1", "--no-steady-state"]
+    if lib:
+        child += ["--lib", os.path.abspath(lib)]
+    got, t0 = {}, time.perf_counter()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["TMPDIR"] = "/tmp"
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        with tempfile.TemporaryDirectory(prefix="rsik_pmc_", dir="/tmp") as d:
+            try:
+                p = subprocess.run([exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
+                                   capture_output=True, text=True, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                return {"error": f"rocprofv3 --pmc {counter}: no result within {timeout_s:.0f} s"}
+            files = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
+            if p.returncode != 0 or not files:
+                return {"error": f"rocprofv3 --pmc {counter} failed (exit {p.returncode}): {(p.stderr or p.stdout)[-300:]}"}
+            per_kernel, starts = {}, 0
+            for f in files:
+                with open(f) as fh:
+                    for r in csv.DictReader(fh):
+                        name = r["Kernel_Name"]
+                        if r["Counter_Name"] != counter or "rsik::" not in name or kernel not in name:
+                            continue
+                        if cfg != 5 and int(r.get("Grid_Size", r.get("Grid_Size_X", "0"))) != ((n + 255) // 256) * 256:
+                            continue  # (the workload generator's filter launches: other grid sizes)
+                        short = name.split("rsik::")[1].split("<")[0].split("(")[0]
+                        per_kernel.setdefault(short, []).append(float(r["Counter_Value"]))
+                        starts += 1 if "cont_init_kernel" in name else 0
+            if not per_kernel:
+                return {"error": f"rocprofv3 --pmc {counter}: no dispatch of the {kernel} kernel(s) in the counter collection"}
+            if cfg == 5:  # the pipeline's kernels of one pass together: launches seen / passes seen (one start-up kernel per pass)
+                if not starts:
+                    return {"error": "no cont_init_kernel dispatch seen"}
+                got[counter] = {k: sum(v) / starts for k, v in per_kernel.items()}
+            else:
+                got[counter] = {k: statistics.median(v) for k, v in per_kernel.items()}
+    by_kernel = {k: 2 * got["FETCH_SIZE"].get(k, 0.0) * 1024 + got["WRITE_SIZE"].get(k, 0.0) * 1024 for k in set(got["FETCH_SIZE"]) | set(got["WRITE_SIZE"])}
+    return {"bytes": sum(by_kernel.values()), "by_kernel": by_kernel, "seconds": time.perf_counter() - t0,
+            "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes with --kernel-trace, KiB units, FETCH_SIZE x 2 on "
+                      "gfx950) around child runs of this script, 4 eager launches each" + (" (config 5: per pass, streams tied by events)" if cfg == 5 else "")}
 
 
 # ------------------------------------------------------------------------------------------ launcher (N > 1 without torchrun)
@@ -441,6 +501,9 @@ def parse_args(argv):
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="ranks only meet, all-reduce their rank numbers on the CPU and print the line's skeleton (launcher self-test, no GPU)")
     ap.add_argument("--lib", default="", help="alternative build of librsik_hip.so (A/B timing, probe builds)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic in this run (two short child runs under rocprofv3 --pmc after the timed legs); the "
+                         "counters committed under profiles/ are quoted instead when they belong to this build")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="default run (N = 1, no --config): do not time configs 3, 4 and 5 after the headline config")
     args = ap.parse_args(argv)
@@ -1119,7 +1182,7 @@ def _run(argv):
         cnt = committed_counters(cfg, n, build_id)
         if cnt and "bytes" in cnt:
             line["roofline"]["traffic"] = cnt["bytes"]
-            line["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) / WRITE_SIZE of this build (profiles/r04/counters.json)"
+            line["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) / WRITE_SIZE of this build (profiles/r05/counters.json)"
             if "bytes_per_pass_by_kernel" in cnt:  # config 5: `traffic` is per control step like `achieved`; the pass by kernel:
                 line["roofline"]["traffic_per_pass_by_kernel"] = cnt["bytes_per_pass_by_kernel"]
         elif cnt and "stale" in cnt:
@@ -1183,6 +1246,20 @@ def _run(argv):
     yield "timed"
     if rank == 0 and sample is not None:
         line["cpu_baseline"] = cpu_baseline(cfg, sample, args.cpu_seconds, gpu=gpu_rows)
+    if rank == 0 and world == 1 and not args.no_live_traffic:
+        # roofline.traffic from THIS run (behind every timed leg: the children have the GPU to themselves)
+        lt = live_traffic(cfg, n, args.lib)
+        r = line["roofline"]
+        if "bytes" in lt:
+            r["traffic"] = lt["bytes"] / (1000 if cfg == 5 else 1)  # (config 5: per control step of all trajectories, like `achieved`)
+            r["traffic_source"] = lt["source"]
+            r["traffic_over_algorithmic"] = lt["bytes"] / (BYTES_PER_POSE[cfg] * units)
+            r["traffic_seconds"] = lt["seconds"]
+            r.pop("traffic_note", None)
+            if cfg == 5:
+                r["traffic_per_pass_by_kernel"] = lt["by_kernel"]
+        else:
+            r["traffic_live_error"] = lt["error"]
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -541,6 +541,9 @@ __device__ __forceinline__ void cont_chain_walk(const ContRunArgs& K, SharedTabl
     // latched when the run began: the joints phase has filled every step in with previous_sol and the emergency state (see there);
     // each of its chunks stands as written
     const bool frozen = K.latched0[ii] != 0;
+    // ... and so does every chunk behind the step at which a trajectory latches during the run, once this phase has filled them
+    // in itself (fill_rest below): `filled` = nothing of this trajectory is left to judge in this block
+    bool filled = frozen;
     const double thr = jj < 4 ? 0.5 : 1.0;                                       // continuity thresholds, C:398
     const double lim = (jj == 0 || jj == 2 || jj == 6) ? 6 * kPi : __builtin_inf();  // multiturn limit of this lane's joint (U:535-568)
     const int hit_bit = jj == 0 ? RSIK_EMERGENCY_SHOULDER_PITCH : (jj == 2 ? RSIK_EMERGENCY_ELBOW_YAW : RSIK_EMERGENCY_WRIST_YAW);
@@ -640,6 +643,24 @@ __device__ __forceinline__ void cont_chain_walk(const ContRunArgs& K, SharedTabl
             t_blk += 1;
         }
     };
+    // A trajectory that is latched (C:205-210) answers previous_sol with the emergency state whatever the goal: the steps [t_from, T)
+    // of the block written without reading anything — what `one` would store for them, step by step — for the trajectories of the
+    // wave that are latched and not yet filled in.  Called where a trajectory can have become latched: on entry (it latched in an
+    // earlier block of the run) and behind a chunk that went through `one`.  An ordinary run never gets here.
+    auto fill_rest = [&](int64_t t_from) {
+        if (emergency && !filled) {
+            unsigned jrow = (unsigned)t_from * jstride;
+            for (int64_t t = t_from; t < T; ++t) {
+                if (owner) st_row_f64(jbuf, joff, jrow, prev);
+                if (live && j == 7) {
+                    if (K.state) K.state[(t_abs0 + t) * n + i] = (uint8_t)RSIK_STATE_EMERGENCY;
+                    if (K.reachable) K.reachable[(t_abs0 + t) * n + i] = 0;
+                }
+                jrow += jstride;
+            }
+            filled = true;
+        }
+    };
     const int64_t n_chunks = (T + kJointChunk - 1) / kJointChunk;
     struct Operands { double first[BATCH], last[BATCH]; int ev[BATCH]; };
     auto chunk_len = [&](int64_t c) { return (T - c * kJointChunk) < kJointChunk ? (T - c * kJointChunk) : (int64_t)kJointChunk; };
@@ -698,7 +719,7 @@ __device__ __forceinline__ void cont_chain_walk(const ContRunArgs& K, SharedTabl
         const double turns = -rint((first - prev) * 0.15915494309189535);
         sh = turns * kTwoPi;
         const double f2 = first + sh;
-        const bool quiet = frozen || (!emergency && !init && ev == 0 && (fabs(f2 - prev) <= thr_short) && (fabs(turns) <= 100.0) &&
+        const bool quiet = filled || (!emergency && !init && ev == 0 && (fabs(f2 - prev) <= thr_short) && (fabs(turns) <= 100.0) &&
                                       (!limited || fabs(f2) <= clear_of_limit));
         return group_or(quiet ? 0 : 1) == 0;
     };
@@ -709,7 +730,7 @@ __device__ __forceinline__ void cont_chain_walk(const ContRunArgs& K, SharedTabl
             const double turns = -rint((o.first[u] - prev) * 0.15915494309189535);
             const double sh = turns * kTwoPi;
             const double f2 = o.first[u] + sh;
-            const bool quiet = frozen || (!emergency && !init && o.ev[u] == 0 && (fabs(f2 - prev) <= thr_short) && (fabs(turns) <= 100.0) &&
+            const bool quiet = filled || (!emergency && !init && o.ev[u] == 0 && (fabs(f2 - prev) <= thr_short) && (fabs(turns) <= 100.0) &&
                                           (!limited || fabs(f2) <= clear_of_limit));
             const bool inside = c0 + u < n_chunks;
             const bool stands = !__any(!quiet) && inside;  // (wave-uniform)
@@ -724,6 +745,7 @@ __device__ __forceinline__ void cont_chain_walk(const ContRunArgs& K, SharedTabl
     {
         Operands oa, ob;
         int64_t c0 = 0;
+        if (RSIK_RARE(__any(emergency && !filled))) fill_rest(0);
         fetch(oa, 0);
 #pragma unroll 1
         while (c0 < n_chunks) {
@@ -741,6 +763,7 @@ __device__ __forceinline__ void cont_chain_walk(const ContRunArgs& K, SharedTabl
                     if (RSIK_RARE(sh != 0.0) && owner) add_turns(c0 + stop, sh);
                 } else {
                     stepwise((c0 + stop) * kJointChunk, chunk_len(c0 + stop));
+                    if (RSIK_RARE(__any(emergency && !filled))) fill_rest((c0 + stop + 1) * kJointChunk);
                 }
                 c0 += stop + 1;
                 if (c0 < n_chunks) fetch(oa, c0);
