@@ -6,7 +6,7 @@ ROUNDS=${ROUNDS:-5}
 LOG=$(mktemp)
 for round in $(seq $ROUNDS); do
 for lib in "$@"; do
-  timeout 120 python3 $R/bench.py --lib $R/$lib --config ${CFG:-2} --steps ${STEPS:-400} --warmup 20 --no-cpu-baseline --no-extras ${BENCH_ARGS:-} 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$lib', round(d['roofline']['kernel_ms']*1000,2),'us', round(d['value']/1e9,2),'G/s')" | tee -a $LOG
+  timeout 120 python3 $R/bench.py --lib $R/$lib --config ${CFG:-2} --steps ${STEPS:-400} --warmup 20 --no-cpu-baseline --no-live-traffic --no-extras ${BENCH_ARGS:-} 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$lib', round(d['roofline']['kernel_ms']*1000,2),'us', round(d['value']/1e9,2),'G/s')" | tee -a $LOG
 done; done
 python3 - $LOG <<'PY'
 import sys, collections, statistics

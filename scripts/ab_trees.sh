@@ -6,7 +6,7 @@ ROUNDS=${ROUNDS:-5}
 LOG=$(mktemp)
 for round in $(seq $ROUNDS); do
 for tree in "$@"; do
-  (cd $R/$tree && timeout 120 python3 bench.py --config ${CFG:-2} --steps ${STEPS:-400} --warmup 20 --no-cpu-baseline --no-extras 2>/dev/null) | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$tree', round(d['roofline']['kernel_ms']*1000,2),'us', round(d['value']/1e9,2),'G/s')" | tee -a $LOG
+  (cd $R/$tree && timeout 120 python3 bench.py --config ${CFG:-2} --steps ${STEPS:-400} --warmup 20 --no-cpu-baseline --no-live-traffic --no-extras 2>/dev/null) | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$tree', round(d['roofline']['kernel_ms']*1000,2),'us', round(d['value']/1e9,2),'G/s')" | tee -a $LOG
 done; done
 python3 - $LOG <<'PY'
 import sys, collections, statistics

@@ -10,7 +10,7 @@ mkdir -p $OUT
 cd $R
 if [[ $PART == *a* ]]; then
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_driver_flags.json 2> $OUT/bench_driver_flags.err || exit 1
-(cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/drv_trace -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --no-other-configs > $OUT/drv_trace.log 2>&1) || exit 1
+(cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/drv_trace -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --no-other-configs --no-live-traffic > $OUT/drv_trace.log 2>&1) || exit 1
 cp $(find $OUT/drv_trace -name '*kernel_stats.csv' | head -1) $OUT/driver_flags_all_launches_kernel_stats.csv
 # the statistics of the 20 TIMED launches alone (the run also holds 5 warm-up launches and one untimed replay of the graph)
 python3 - $(find $OUT/drv_trace -name '*kernel_trace.csv' | head -1) > $OUT/driver_flags_timed20_kernel_stats.txt <<'PY'

@@ -82,6 +82,18 @@ def test_bench_two_ranks_gloo_one_gpu(gather):
     _check_two_rank_line(d, "final" if gather == "default" else gather)
 
 
+def test_bench_measures_traffic_in_its_own_run():
+    """roofline.traffic comes from THIS run, not from a file the builder committed: after the timed legs bench.py runs itself twice more
+    under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, --kernel-trace only) and reads the kernel's counters.  A
+    small config-3 batch: the figure is there, says where it came from, and is the algorithmic 154 B per pose to within a few percent
+    (tables, constants and partial lines on a batch this small)."""
+    d = _bench("--config", "3", "--poses", "65536", "--steps", "3", "--warmup", "1", "--no-extras", "--cpu-seconds", "1")
+    r = d["roofline"]
+    assert "traffic_live_error" not in r, r.get("traffic_live_error")
+    assert r["traffic_source"].startswith("measured in this run") and r["traffic_seconds"] > 0
+    assert 0.98 < r["traffic_over_algorithmic"] < 1.15 and abs(r["traffic"] - r["traffic_over_algorithmic"] * 154 * 65536) < 1.0
+
+
 def test_bench_two_ranks_gloo_config3_and_config5():
     d = _bench("--gpus", "2", "--backend", "gloo", "--single-device", "--config", "3", "--poses", "16384", "--steps", "2",
                "--warmup", "1", "--cpu-seconds", "2", "--chunks", "2")
@@ -101,7 +113,7 @@ def test_bench_config5_line_carries_both_protocols():
     assert ss["launch_forms_ms"]["eager"] > 0 and ss["launch_forms_ms"]["graph"] > 0 and ss["value"] > 0
     assert d["cpu_baseline"]["parity_on_sample"]["flags_and_states"] == "bit-exact"
     assert d["cpu_baseline"]["reference_numpy"]["config5_steps_per_s_per_core"] > 0
-    g = _bench("--config", "5", "--poses", "256", "--steps", "2", "--warmup", "1", "--launch", "eager", "--no-cpu-baseline")
+    g = _bench("--config", "5", "--poses", "256", "--steps", "2", "--warmup", "1", "--launch", "eager", "--no-cpu-baseline", "--no-live-traffic")
     assert g["launch"].startswith("eager") and g["steady_state"]["launch"] == "eager" and g["steady_state"]["launch_forms_ms"]["graph"] > 0
 
 
@@ -130,7 +142,7 @@ def test_bench_rank_without_a_device_fails_the_launcher():
         pytest.skip("on a multi-GPU box every rank gets its own device")
     # one visible GPU: LOCAL_RANK 1 has no device of its own -> the rank fails at set_device; the launcher must fail too
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--poses", "4096", "--steps", "1",
-                        "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+                        "--warmup", "1", "--no-cpu-baseline", "--no-live-traffic"], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode != 0
     assert "rank" in p.stderr and "exited with code" in p.stderr
 
