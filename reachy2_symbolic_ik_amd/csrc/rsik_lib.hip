@@ -170,7 +170,7 @@ int rsik_set_arm(rsik_ctx* ctx, int arm, const double* consts_host, int count) {
 int rsik_set_option(rsik_ctx* ctx, int option, int value) {
     if (!ctx) return RSIK_E_INVALID;
     if (option < 0 || option >= RSIK_OPT_COUNT) return fail(ctx, RSIK_E_INVALID, "rsik_set_option: unknown option");
-    static const int max_value[RSIK_OPT_COUNT] = {RSIK_EULER_NEVER, 2, 1, 1, RSIK_CONT_RUN_STEPS, 65535, 15};
+    static const int max_value[RSIK_OPT_COUNT] = {RSIK_EULER_NEVER, 2, 1, 1, RSIK_CONT_RUN_STEPS, 65535, 3};
     if (value < 0 || value > max_value[option]) return fail(ctx, RSIK_E_INVALID, "rsik_set_option: value out of range");
     ctx->options[option] = value;
     return RSIK_OK;
@@ -539,17 +539,6 @@ static int cont_plan(rsik_ctx* ctx, const char* who, int64_t n, int64_t n_steps,
     for (int64_t t0 = 0; t0 < n_steps; t0 += T) {
         P.block_t0.push_back(t0);
         P.block_T.push_back(n_steps - t0 < T ? n_steps - t0 : T);
-    }
-    // (experiment, RSIK_OPT_CONT_PHASED_VARIANT bits 4 / 8: the last block cut in two, the last of those again — what follows the
-    // last theta kernel of a run, the joints and chain kernels of its last block, is then half / a quarter as long)
-    for (int bit = 4; bit <= 8; bit *= 2) {
-        if (!capturing && (ctx->options[RSIK_OPT_CONT_PHASED_VARIANT] & bit) && P.block_T.back() >= 4 * rsik::kSeqBatch) {
-            const int64_t whole = P.block_T.back(), t0 = P.block_t0.back();
-            const int64_t a = (whole / 2 + rsik::kSeqBatch - 1) / rsik::kSeqBatch * rsik::kSeqBatch;
-            P.block_T.back() = a;
-            P.block_t0.push_back(t0 + a);
-            P.block_T.push_back(whole - a);
-        }
     }
     const int64_t n_blocks = (int64_t)P.block_t0.size();
     P.chunks_per_block = ((size_t)T + rsik::kJointChunk - 1) / rsik::kJointChunk;
