@@ -33,6 +33,7 @@ python3 scripts/c5_graph.py > $OUT/c5_graph.txt 2>&1 || exit 1
 bash scripts/c5_trace.sh ${TAG}_tl - 0 > $OUT/c5_pipeline_timeline.txt 2>&1 || exit 1
 bash scripts/c5_trace.sh ${TAG}_tl1 - 1000 > $OUT/c5_phases_alone.txt 2>&1 || exit 1
 python3 scripts/scalar_latency.py > $OUT/scalar_latency.txt 2>&1 || exit 1
+timeout -k 10 200 python3 scripts/probes/latched_pass.py 2>&1 | grep -v amdgpu > $OUT/c5_latched_passes.txt
 python3 scripts/soak_parity.py 1048576 2 > $OUT/soak_parity.txt 2>&1 || exit 1
 [ -x build/issue_probe ] && timeout -k 5 120 ./build/issue_probe > $OUT/issue_probe.txt 2>&1
 tail -3 $OUT/c5_block_sweep.txt; tail -3 $OUT/c5_graph.txt; tail -4 $OUT/scalar_latency.txt; tail -2 $OUT/soak_parity.txt

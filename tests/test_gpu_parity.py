@@ -1405,6 +1405,37 @@ def test_continuous_run_forms_are_bit_identical(torch_mod, n_traj, n_steps, arm,
         assert float((ref["cont_state"][9] != 0).float().mean()) > 0.02, "no trajectory latched: the rare paths were not exercised"
 
 
+def test_continuous_run_outgrows_its_workspace_without_stopping_the_device(torch_mod):
+    """One context, runs of growing size issued back to back WITHOUT a synchronisation in between: the workspace (and the words that tie
+    the pipeline's streams) are outgrown while earlier runs are still in flight.  The call never waits for the device (round 4 did, a
+    hipDeviceSynchronize inside an asynchronous API): what is outgrown is parked and freed by rsik_sync.  Every run against the step kernel."""
+    from bench import make_config5_trajectories
+
+    A = _abi_mod()
+    c = make_control()
+    hs = c._solver
+    sizes = [(8, 40), (300, 100), (64, 17), (2000, 230), (9, 300)]
+    trajs = [make_config5_trajectories(n, t, seed=77 + n) for n, t in sizes]
+    hs.set_option(A.OPT_CONT_RUN_MODE, A.CONT_RUN_PHASED)
+    runs = []
+    for (n, t), traj in zip(sizes, trajs):  # (no synchronisation between these)
+        st = c.new_continuous_state("r_arm", n)
+        runs.append((c.run_continuous_trajectories("r_arm", traj, st, first_step_timed_out=True, current_pose=traj[0]), st))
+    hs.synchronize()   # rsik_sync: also frees what was outgrown
+    hs.synchronize()
+    hs.set_option(A.OPT_CONT_RUN_MODE, A.CONT_RUN_STEPS)
+    for (n, t), traj, (res, st) in zip(sizes, trajs, runs):
+        st2 = c.new_continuous_state("r_arm", n)
+        ref = c.run_continuous_trajectories("r_arm", traj, st2, first_step_timed_out=True, current_pose=traj[0])
+        hs.synchronize()
+        a = {k: v for k, v in ref.items()}
+        a["cont_state"] = st2[:11]
+        b = {k: v for k, v in res.items()}
+        b["cont_state"] = st[:11]
+        _same_run(torch_mod, a, b, ("growing", n, t))
+    hs.set_option(A.OPT_CONT_RUN_MODE, A.CONT_RUN_AUTO)
+
+
 @pytest.mark.parametrize("timed_out", [False, True])
 def test_continuous_run_that_begins_latched(torch_mod, timed_out):
     """ControlIK answers previous_sol, not reachable, with the emergency state for every goal once its emergency stop is latched
