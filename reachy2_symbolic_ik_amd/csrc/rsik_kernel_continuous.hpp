@@ -237,7 +237,11 @@ __global__ __launch_bounds__(kBlock) void cont_init_kernel(const ContinuousArgs 
     const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[ii] != 0) : false, lds_tab);
     const int slot = MIXED ? (A.isl ? 1 : 0) : 0;
     const int64_t n = K.n;
-    if (!live) return;
+    if (!live) {
+        // (the bytes up to the next multiple of eight trajectories: the joints phase reads eight at a go)
+        if (K.latched0 && half == 0 && i < ((n + 7) & ~(int64_t)7)) K.latched0[i] = 0;
+        return;
+    }
     // emergency latched: nothing is touched (C:205-210).  A trajectory that is latched when a run begins stays so to its end
     // (only "unfreeze" releases it): the run's later phases are told, and fill its steps in without walking them
     const bool latched = K.st[9 * n + i] != 0.0;

@@ -409,9 +409,15 @@ __device__ __forceinline__ void cont_joints_chunk(const ContRunArgs& K, SharedTa
     // A trajectory whose emergency stop was latched when the run began (C:205-210) answers previous_sol at every step, whatever the
     // goal: its rows are filled in here, eight steps at a go, and stand for the chain phase like any quiet chunk's (first row = last row
     // = previous_sol: no event, no turn) — it never walks them.  Waves of such trajectories only skip the geometry altogether; an
-    // ordinary run has none (one byte per lane and a wave-uniform branch).
-    const bool frozen = K.latched0[ii] != 0;
-    const unsigned long long frozen_mask = __ballot(frozen);
+    // ordinary run has none, and pays ONE scalar load and a scalar branch for it: the wave's eight trajectories are eight consecutive
+    // bytes (the start-up kernel also writes the bytes up to the next multiple of eight trajectories), and the group is wave-uniform.
+    const unsigned long long frozen_bytes = *reinterpret_cast<const unsigned long long*>(K.latched0 + grp * 8);
+    bool frozen = false;
+    unsigned long long frozen_mask = 0;
+    if (RSIK_RARE(frozen_bytes != 0)) {
+        frozen = ((frozen_bytes >> (8 * tl)) & 0xffull) != 0;
+        frozen_mask = __ballot(frozen);
+    }
     if (!RSIK_RARE(frozen_mask == ~0ull)) {
         Reach r;
         Goal G;
@@ -429,7 +435,8 @@ __device__ __forceinline__ void cont_joints_chunk(const ContRunArgs& K, SharedTa
     }
     // a step without joints: singular (phase 4 recomputes it with previous_sol), or its goal is not numbers (flag bit 4: it stays
     // without, and phase 4 steps over it — rsik.h "Rows that are not numbers")
-    const bool dead = (sing || (flag & 16) != 0) && !frozen;
+    bool dead = sing || (flag & 16) != 0;
+    if (RSIK_RARE(frozen_mask != 0)) dead = dead && !frozen;
     // Steps relative to the step before (lane - 8; none for the chunk's first step, which phase 4 judges).  Whole turns
     // only for the four joints whose raw angle has a branch cut to cross — shoulder pitch, elbow yaw, wrist roll, wrist yaw
     // (atan2 values, S:751-786, 815-848 / U:508-519); shoulder roll is atan2(q_y, q_x >= 0), elbow pitch is clamped to
