@@ -349,7 +349,10 @@ def committed_counters(cfg, n, build_id):
         return None
 
 
-def live_traffic(cfg, n, lib, timeout_s=150.0):
+_LIVE_TRAFFIC_FAILED = []  # (a first failure — no rocprofv3, a profiler that hangs — is not repeated for the other configs of the run)
+
+
+def live_traffic(cfg, n, lib, timeout_s=60.0):
     """HBM traffic of the config's kernel(s) measured NOW, in this run: two child runs of this script under `rocprofv3 --pmc`
     (FETCH_SIZE, then WRITE_SIZE — separate passes, with --kernel-trace only, as MI355X_MICROARCH.md's HBM section prescribes; KiB
     units; FETCH_SIZE x 2 on gfx950), a few eager launches each.  Returns {"bytes": per launch (config 5: per pass), ...} or
@@ -363,6 +366,11 @@ def live_traffic(cfg, n, lib, timeout_s=150.0):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return {"error": "rocprofv3 not found"}
+    if _LIVE_TRAFFIC_FAILED:
+        return {"error": "skipped: " + _LIVE_TRAFFIC_FAILED[0]}
+    if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES")) or any(
+            k.startswith("ROCPROF") for k in os.environ):
+        return {"error": "this process already runs under a profiler: no nested rocprofv3"}
     kernel = {2: "solve_kernel", 3: "control_discrete_kernel", 4: "solve_kernel", 5: "cont_"}[cfg]
     child = [sys.executable, os.path.abspath(__file__), "--config", str(cfg), "--poses", str(n), "--steps", "3", "--warmup", "1", "--launch", "eager",
              "--no-cpu-baseline", "--no-extras", "--no-other-configs", "--no-live-traffic"]
@@ -379,10 +387,12 @@ def live_traffic(cfg, n, lib, timeout_s=150.0):
                 p = subprocess.run([exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
                                    capture_output=True, text=True, timeout=timeout_s)
             except subprocess.TimeoutExpired:
-                return {"error": f"rocprofv3 --pmc {counter}: no result within {timeout_s:.0f} s"}
+                _LIVE_TRAFFIC_FAILED.append(f"rocprofv3 --pmc {counter}: no result within {timeout_s:.0f} s")
+                return {"error": _LIVE_TRAFFIC_FAILED[0]}
             files = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
             if p.returncode != 0 or not files:
-                return {"error": f"rocprofv3 --pmc {counter} failed (exit {p.returncode}): {(p.stderr or p.stdout)[-300:]}"}
+                _LIVE_TRAFFIC_FAILED.append(f"rocprofv3 --pmc {counter} failed (exit {p.returncode}): {(p.stderr or p.stdout)[-300:]}")
+                return {"error": _LIVE_TRAFFIC_FAILED[0]}
             per_kernel, starts = {}, 0
             for f in files:
                 with open(f) as fh:

@@ -21,24 +21,25 @@ def make_homogenous_matrix_from_rotation_matrix(
     return M
 
 
-_default_solver = None
+_default_ik = None
 
 
 def rotation_matrix_from_vector(vect: npt.NDArray[np.float64]) -> npt.NDArray[np.float64]:
     """The rotation that takes e_x to vect / |vect| (utils.py:59-81) — evaluated by the device's stage kernel (rsik_stage,
-    RSIK_STAGE_ROTATION_FROM_VECTOR) on a context this module creates on first use."""
-    global _default_solver
-    import torch
+    RSIK_STAGE_ROTATION_FROM_VECTOR; the stage reads no arm constant) through a solver object this module creates on first use."""
+    global _default_ik
+    if _default_ik is None:
+        import contextlib
+        import io
 
+        from . import _abi  # noqa: F401
+        from .symbolic_ik import SymbolicIK
+
+        with contextlib.redirect_stdout(io.StringIO()):
+            _default_ik = SymbolicIK()
     from . import _abi
-    from .backend import HipSolver
-    from .constants import ArmGeometry, default_ik_parameters
 
-    if _default_solver is None:
-        _default_solver = HipSolver(None)
-        _default_solver.set_arm(0, ArmGeometry("r_arm", default_ik_parameters()).pack())  # (the stage reads no arm constant)
-    rows = torch.as_tensor(np.asarray(vect, dtype=np.float64).reshape(1, 3)).to(_default_solver.device)
-    return _default_solver.stage(_abi.STAGE_ROTATION_FROM_VECTOR, rows, 0).cpu().numpy().reshape(3, 3)
+    return _default_ik._stage(_abi.STAGE_ROTATION_FROM_VECTOR, vect).reshape(3, 3)
 
 
 def get_euler_from_homogeneous_matrix(
