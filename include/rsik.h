@@ -203,7 +203,7 @@ int rsik_set_arm(rsik_ctx *ctx, int arm, const double *consts_host, int count);
 #define RSIK_CONT_RUN_PHASED 1
 #define RSIK_CONT_RUN_STEPS 2
 /* Tuning of rsik_control_continuous_run (results do not depend on it):
- *   RSIK_OPT_CONT_BLOCK_STEPS  control steps per block: 0 (default) = a quarter of the run, at least 64; n > 0 = n (rounded up
+ *   RSIK_OPT_CONT_BLOCK_STEPS  control steps per block: 0 (default) = a third of the run, at least 64; n > 0 = n (rounded up
  *                              to the sequential phases' batch of steps) */
 #define RSIK_OPT_CONT_BLOCK_STEPS 5
 /*   RSIK_OPT_CONT_PHASED_VARIANT  phased pipeline issued launch by launch, a bit mask (0 = the default form; results do not depend on it):
@@ -317,15 +317,18 @@ int rsik_control_continuous_step(rsik_ctx *ctx, int64_t n, const double *const m
  *                turns the chunk sits away from it, which it adds to the chunk's rows where they are not zero (fp64 atomic
  *                adds that nobody waits for); only a chunk with an event is walked step by step with the reference's own
  *                sequence of operations (also: steps whose get_joints hit an exact singularity)
- * A run is cut into blocks of steps: four when it is issued launch by launch, two when it is being captured into a
+ * A run is cut into blocks of steps: three when it is issued launch by launch, two when it is being captured into a
  * hipGraph (RSIK_OPT_CONT_BLOCK_STEPS overrides); the results do not depend on the cut.
  * The phases of neighbouring blocks overlap on four streams (the caller's and three of the context's).  Issued launch by
  * launch the streams are tied by words in device memory (hipStreamWriteValue32 behind the producer, hipStreamWaitValue32
  * ahead of the consumer: a third of an event's latency) and a block's joints kernel is held until the NEXT block's theta
  * kernel has started (its lone 276-register waves cannot get onto a chip that a chip-filling kernel holds); while the
  * caller's stream is capturing, by events, which is all a capture takes.
+ * A trajectory whose emergency stop is latched when the run begins (control_ik.py:205-210: previous_sol, not reachable, the
+ * emergency state for every goal until "unfreeze") is filled in by phase 3 and never walked; one that latches during the run has
+ * the rest of its block filled in at once by phase 4.
  * The workspace
- * (17 bytes per step and trajectory + 1 per 8-step chunk, of up to eight blocks in flight), the side streams and the
+ * (17 bytes per step and trajectory + 1 per 8-step chunk, of up to eight blocks in flight, + 17 per trajectory), the side streams and the
  * events belong to the context: they are created by the first call that needs them, or ahead of time by
  * rsik_control_continuous_reserve.  A call can be captured into a hipGraph (the side streams join the capture through
  * the events the call records) provided it has nothing to create: reserve first, or run a call of at least that size

@@ -1268,6 +1268,55 @@ def gen_stages(out, n=1500):
     np.savez_compressed(os.path.join(out, "g15_stages.npz"), **data)
 
 
+# ----------------------------------------------------------------------------------------
+# G16: config 5 through the reference itself at scale — 512 trajectories of the config-5 generator x 1000 control steps, each on
+# a ControlIK of its own (fresh constructor state, fake clock: no timeout after the first call): digests of the `reachable` and
+# `state` arrays, every 32nd trajectory's joints and previous_theta at every step.  Trajectories are independent: worker processes.
+# ----------------------------------------------------------------------------------------
+def _g16_walk(job):
+    Ms = job  # [n_steps, k, 4, 4]
+    n_steps, k = Ms.shape[:2]
+    J = np.zeros((n_steps, k, 7)); F = np.zeros((n_steps, k), dtype=np.uint8); S = np.zeros((n_steps, k), dtype=np.uint8)
+    TH = np.zeros((n_steps, k)); ES = np.zeros(k, dtype=np.uint8)
+    real_time = ref_control_mod.time
+    for a in range(k):
+        clock = FakeClock()
+        ref_control_mod.time = clock
+        try:
+            ctrl = quiet(ControlIK, urdf_path="../config_files/reachy2.urdf")
+            for i in range(n_steps):
+                clock.t += 1.0 / 120.0
+                j, ok, st = quiet(ctrl.symbolic_inverse_kinematics, "r_arm", Ms[i, a], "continuous", d_theta_max=0.01)
+                # (a latched ControlIK answers its emergency text, control_ik.py:205-210: RSIK_STATE_EMERGENCY = 8 in include/rsik.h)
+                J[i, a] = np.array(j, dtype=float); F[i, a] = bool(ok); TH[i, a] = ctrl.previous_theta["r_arm"]
+                S[i, a] = STATE_CODES[st] if st in STATE_CODES else (8 if ctrl.emergency_stop and st == ctrl.emergency_state else 255)
+            ES[a] = bool(ctrl.emergency_stop)
+        finally:
+            ref_control_mod.time = real_time
+    return J, F, S, TH, ES
+
+
+def gen_scale_continuous(out, workers=None):
+    import multiprocessing as mp
+
+    workers = workers or max(1, (os.cpu_count() or 2) - 1)
+    Ms = SCALE.config5_trajectories()
+    n_steps, n_traj = Ms.shape[:2]
+    piece = 4
+    with mp.get_context("fork").Pool(workers) as pool:
+        parts = pool.map(_g16_walk, [Ms[:, a:a + piece] for a in range(0, n_traj, piece)])
+    J = np.concatenate([p[0] for p in parts], axis=1); F = np.concatenate([p[1] for p in parts], axis=1)
+    S = np.concatenate([p[2] for p in parts], axis=1); TH = np.concatenate([p[3] for p in parts], axis=1)
+    ES = np.concatenate([p[4] for p in parts])
+    sub = slice(None, None, SCALE.SUBSAMPLE_TRAJ)
+    data = {"n_traj": np.int64(n_traj), "n_steps": np.int64(n_steps), "input_sha256": np.array(SCALE.sha256(Ms)),
+            "reachable_sha256": np.array(SCALE.sha256(F)), "state_sha256": np.array(SCALE.sha256(S)),
+            "state_counts": np.bincount(S.ravel(), minlength=11).astype(np.int64), "emergency_stop": ES,
+            "sub_joints": J[:, sub].copy(), "sub_previous_theta": TH[:, sub].copy(), "sub_reachable": F[:, sub].copy(), "sub_state": S[:, sub].copy(),
+            "last_previous_theta": TH[-1].copy(), "last_joints": J[-1].copy()}
+    np.savez_compressed(os.path.join(out, "g16_scale_continuous.npz"), **data)
+
+
 def ref_default_joints(k):
     return [[0.0, 0.2617993877991494, -0.17453292519943295, 0.0, 0.0, 0.0, 0.0],
             [0.0, -0.2617993877991494, 0.17453292519943295, 0.0, 0.0, 0.0, 0.0]][k]
@@ -1293,7 +1342,7 @@ def main():
              ("g4", gen_control), ("g5", gen_helpers), ("g6", gen_continuous),
              ("g7", gen_continuous_start), ("g8", gen_matrix_edges),
              ("g9", gen_custom_geometry), ("g10", gen_custom_urdf_control), ("g11", gen_emergency),
-             ("g12", gen_continuous_modes), ("g13", gen_hostile), ("g14", gen_scale), ("g15", gen_stages)]
+             ("g12", gen_continuous_modes), ("g13", gen_hostile), ("g14", gen_scale), ("g15", gen_stages), ("g16", gen_scale_continuous)]
     bad = 0
     for name, fn in steps:
         if args.only and name not in args.only.split(","):  # exact names: "g1" does not select "g12"

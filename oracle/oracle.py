@@ -78,7 +78,7 @@ def _bind(L):
     L.orc_control_discrete_batch.argtypes = [_dp, _dp, C.c_long, _dp, _u8p, C.c_int, C.c_double, C.c_int, _dp, _dp,
                                              C.c_double, _dp, _u8p, _u8p, _u8p, C.c_int]
     L.orc_control_continuous_run_batch.argtypes = [_dp, _dp, C.c_long, C.c_long, _dp, C.c_int, C.c_double, C.c_double, C.c_int,
-                                                   C.c_double, C.c_double, _dp, _u8p, _u8p, C.c_int]
+                                                   C.c_double, C.c_double, _dp, _u8p, _u8p, C.c_int, _dp]
     return L
 
 
@@ -284,9 +284,10 @@ def control_continuous_step(arm, cs, M, timed_out, preferred_theta_arg, preferre
 
 def control_continuous_run_batch(arm, states, M, first_step_timed_out=True, preferred_theta_arg=-4 * np.pi / 6,
                                  preferred_theta_self=-4 * np.pi / 6, constrained_mode=0, d_theta_max=0.01,
-                                 orbita3d_max_angle=float(np.deg2rad(42.5)), nthreads=1, L=None):
+                                 orbita3d_max_angle=float(np.deg2rad(42.5)), nthreads=1, L=None, current_pose=None):
     """M [n_steps, n_traj, 4, 4]; states [n_traj, 11] float64 (orc_cont_state_t rows: previous_theta, previous_sol[7], init,
-    emergency_stop, has_previous_sol), updated in place."""
+    emergency_stop, has_previous_sol), updated in place.  current_pose: the 4x4 pose every trajectory's first step is called with
+    (what a fresh ControlIK holds in previous_pose), or None for the trajectory's own first matrix."""
     M = np.ascontiguousarray(M, dtype=np.float64)
     n_steps, n_traj = M.shape[:2]
     assert states.shape == (n_traj, 11) and states.dtype == np.float64 and states.flags.c_contiguous
@@ -295,7 +296,7 @@ def control_continuous_run_batch(arm, states, M, first_step_timed_out=True, pref
     (L or lib()).orc_control_continuous_run_batch(_d(arm.buf), _d(states), n_traj, n_steps, _d(M.reshape(-1)), int(bool(first_step_timed_out)),
                                                   float(preferred_theta_arg), float(preferred_theta_self), int(constrained_mode),
                                                   float(d_theta_max), float(orbita3d_max_angle), _d(joints), _u8(reach), _u8(state),
-                                                  int(nthreads))
+                                                  int(nthreads), _d(None if current_pose is None else _f64(current_pose).reshape(16)))
     return dict(joints=joints, reachable=reach, state=state)
 
 

@@ -1137,13 +1137,14 @@ void orc_solve_batch(const orc_arm_t *arm_r, const orc_arm_t *arm_l, long n, con
 
 /* Trajectory batch of the continuous mode (BASELINE config 5): n_traj independent trajectories (one orc_cont_state_t
  * each, updated in place), n_steps control steps each, step s of trajectory k at M[(s * n_traj + k) * 16].  The first
- * step of every trajectory is called with `timed_out` (C:296-304) and the trajectory's own first matrix as
- * current_pose; current_joints = the state's previous_sol.  joints [n_steps][n_traj][7], reachable / state
+ * step of every trajectory is called with `timed_out` (C:296-304) and `current_pose` (16 doubles, the same for every trajectory:
+ * what a ControlIK holds in previous_pose, C:38-57, 294) or, with NULL, the trajectory's own first matrix; current_joints = the
+ * state's previous_sol.  joints [n_steps][n_traj][7], reachable / state
  * [n_steps][n_traj].  Trajectories are independent: OpenMP over k. */
 void orc_control_continuous_run_batch(const orc_arm_t *arm, orc_cont_state_t *cs, long n_traj, long n_steps, const double *M,
                                       int first_step_timed_out, double preferred_theta_arg, double preferred_theta_self,
                                       int constrained_mode, double d_theta_max, double orbita3d_max_angle, double *joints,
-                                      uint8_t *reachable, uint8_t *state, int nthreads) {
+                                      uint8_t *reachable, uint8_t *state, int nthreads, const double *current_pose) {
 #ifdef _OPENMP
     if (nthreads <= 0) nthreads = 1;
 #pragma omp parallel for num_threads(nthreads) schedule(static)
@@ -1157,7 +1158,7 @@ void orc_control_continuous_run_batch(const orc_arm_t *arm, orc_cont_state_t *cs
             memcpy(cur, cs[k].previous_sol, sizeof cur);
             int ok;
             int st = orc_control_continuous_step(arm, &cs[k], Mk, (s_ == 0 && first_step_timed_out) ? 1 : 0, preferred_theta_arg,
-                                                 preferred_theta_self, constrained_mode, cur, &M[k * 16], d_theta_max,
+                                                 preferred_theta_self, constrained_mode, cur, current_pose ? current_pose : &M[k * 16], d_theta_max,
                                                  orbita3d_max_angle, &joints[(s_ * n_traj + k) * 7], &ok);
             reachable[s_ * n_traj + k] = (uint8_t)ok;
             state[s_ * n_traj + k] = (uint8_t)st;

@@ -515,7 +515,8 @@ constexpr int kContSlots = 8;  // workspace slots in flight (block b + 8 reuses 
 // `capturing`: the call is being recorded into a hipGraph.  A replay executes the dependency DAG with 15-40 us per edge
 // whatever the streams were, so fewer, longer blocks pay there (4096 x 1000 steps replayed: 0.379 ms with two blocks,
 // 0.383 with three, 0.395 with four); launched eagerly four blocks are best (0.43 against 0.46 with two: more overlap for
-// the same host-side issue cost).
+// the same host-side issue cost).  Round 5, after the value-word edges and the theta-first hold: three blocks are level with or 1-2 %
+// ahead of four in every sweep (blocks of 256 / 352 steps: 0.370 / 0.363, 0.378 / 0.374, 0.373 / 0.367 ms on three boxes).
 static int cont_plan(rsik_ctx* ctx, const char* who, int64_t n, int64_t n_steps, bool capturing, ContPlan& P) {
     // (the sequential phases address a block's arrays through 2 GB buffer windows: rows of n * 56 bytes, blocks of <= 384 MB
     // of workspace, i.e. <= 1.3 GB of joints; every block costs the host four launches, so blocks are as long as that allows)
@@ -524,11 +525,11 @@ static int cont_plan(rsik_ctx* ctx, const char* who, int64_t n, int64_t n_steps,
     int64_t T_max = (int64_t)((size_t)384 << 20) / (int64_t)P.per_step;
     if (T_max < 1) T_max = 1;
     if (T_max > 65535) T_max = 65535;  // gridDim.y
-    // block size: a quarter of the run, half of it under capture (the phases of neighbouring blocks overlap: more blocks, shorter fill and drain;
+    // block size: a third of the run (a quarter until round 5), half of it under capture (the phases of neighbouring blocks overlap: more blocks, shorter fill and drain;
     // fewer blocks, fewer of the ~12 us hand-overs between dependent launches: 4096 x 1000 steps take 0.49 / 0.48 / 0.46 /
     // 0.48 / 0.50 ms with blocks of 128 / 192 / 256 / 512 / 1000 steps), a multiple of the theta batch and of the joint
     // chunk; RSIK_OPT_CONT_BLOCK_STEPS overrides
-    const int64_t parts = capturing ? 2 : 4;
+    const int64_t parts = capturing ? 2 : 3;
     int64_t T = ctx->options[RSIK_OPT_CONT_BLOCK_STEPS] > 0 ? ctx->options[RSIK_OPT_CONT_BLOCK_STEPS] : (n_steps + parts - 1) / parts;
     if (T < 64 && ctx->options[RSIK_OPT_CONT_BLOCK_STEPS] == 0) T = 64;
     T = (T + rsik::kSeqBatch - 1) / rsik::kSeqBatch * rsik::kSeqBatch;

@@ -18,6 +18,8 @@ N_CONFIG3 = 1 << 18                  # goal matrices whose is_reachable state is
 CHUNK_CONFIG2 = 1 << 22              # bench.make_config2_poses draws positions, then Euler angles, in chunks of this many
 CHUNK_CONFIG3 = 1 << 21              # bench.make_config3_matrices likewise
 SUBSAMPLE = 64                       # every 64th row also carries its numbers (joints, interval), not only its digest
+N_TRAJ_CONFIG5, N_STEPS_CONFIG5 = 512, 1000   # G16: trajectories of config 5's generator walked by the reference itself
+SUBSAMPLE_TRAJ = 32                  # every 32nd trajectory carries its joints and theta at every step
 
 
 def sha256(a):
@@ -72,3 +74,19 @@ def config3_from_kept(kept_bits, n=N_CONFIG3):
     idx = np.flatnonzero(kept)[:n]
     assert idx.size == n
     return pos, eul, kept, matrices_from_pose(pos[idx], eul[idx])
+
+
+def config5_trajectories(n_traj=N_TRAJ_CONFIG5, n_steps=N_STEPS_CONFIG5):
+    """Goal matrices [n_steps, n_traj, 4, 4] of config 5's task-space generator (shaped like the reference's tests/test_sdk.py:38-63, as
+    bench.make_config5_trajectories: centre (0.65, -0.2, 0; 0, -pi/2, 0), amplitudes 0.35 m / pi/6 rad, frequencies 0.6 ... 0.47,
+    t = k / 120 + 11 + phase), phases from default_rng(20250204 + 5) * 40 s, sines and cosines from libm: the same bits on every host."""
+    phase = np.random.default_rng(SEED + 5).uniform(0.0, 40.0, size=n_traj)
+    c0 = [0.65, -0.2, 0.0, 0.0, -math.pi / 2, 0.0]
+    amp = [0.35, 0.35, 0.35, math.pi / 6, math.pi / 6, math.pi / 6]
+    freq = [0.6, 0.34, 0.78, 0.18, 0.31, 0.47]
+    t = (np.arange(n_steps)[:, None] / 120.0 + 11.0) + phase[None, :]
+    flat = t.reshape(-1).tolist()
+    v = [np.array([c + a * math.sin(f * x) for x in flat]) for c, a, f in zip(c0, amp, freq)]
+    pos = np.stack(v[:3], axis=1)
+    eul = np.stack(v[3:], axis=1)
+    return matrices_from_pose(pos, eul).reshape(n_steps, n_traj, 4, 4)

@@ -1544,6 +1544,30 @@ def _same_report(a, b, tol=1e-7):
     return len(na) == len(nb) and all(abs(x - y) <= tol + 1e-7 * abs(y) for x, y in zip(na, nb))
 
 
+def test_scale_continuous_digests_of_the_reference(golden_dir, torch_mod):
+    """G16 — config 5's generator through the reference ITSELF: 512 trajectories x 1000 control steps walked by ControlIK objects in
+    the build container (oracle/gen_golden.py gen_scale_continuous), digests of the `reachable` and `state` arrays, sixteen
+    trajectories' joints and the carried theta.  The trajectory pipeline over the regenerated matrices (tests/scale_inputs.py): flags
+    and state codes bit-exact at half a million control steps, joints <= 1e-7, theta <= 1e-9 — no checker in between."""
+    from tests import scale_inputs as SC
+    from tests.test_oracle_golden import _check_scale_continuous
+
+    g = load(golden_dir, "g16_scale_continuous.npz")
+    M = SC.config5_trajectories()
+    assert SC.sha256(M) == str(g["input_sha256"]), "the seeded inputs did not regenerate"
+    n_steps, n_traj = M.shape[:2]
+    c = make_control()
+    for run_mode in (_abi_mod().CONT_RUN_PHASED, _abi_mod().CONT_RUN_STEPS):
+        c._solver.set_option(_abi_mod().OPT_CONT_RUN_MODE, run_mode)
+        st = c.new_continuous_state("r_arm", n_traj)
+        Mt = torch_mod.as_tensor(M).cuda()
+        start = np.tile(np.asarray(c.previous_pose["r_arm"], dtype=np.float64), (n_traj, 1, 1))  # (a fresh ControlIK's previous_pose)
+        res = to_np(c.run_continuous_trajectories("r_arm", Mt, st, first_step_timed_out=True, current_pose=start))
+        torch_mod.cuda.synchronize()
+        _check_scale_continuous(g, res, st[0].cpu().numpy(), st[9].cpu().numpy())
+    c._solver.set_option(_abi_mod().OPT_CONT_RUN_MODE, _abi_mod().CONT_RUN_AUTO)
+
+
 def test_emergency_reports_discrete(golden_dir, torch_mod):
     """G11: previous_sol next to the +-6 pi multiturn limit (utils.multiturn_safety_check, utils.py:535-568), every
     joint / sign / combination: the call that trips returns the clamped joints with its normal state, latches the stop

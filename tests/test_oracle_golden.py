@@ -621,6 +621,44 @@ def test_scale_digests_checker_against_reference(golden_dir):
     _check_scale_set(g, "c3_", res, SC.N_CONFIG3)
 
 
+def _check_scale_continuous(g, res, theta, latched, joints_tol=1e-7):
+    """G16 against a walk of the same trajectories: `res` = joints [n_steps, n_traj, 7], reachable, state [n_steps, n_traj]; `theta` = the
+    carried previous_theta at the end [n_traj], `latched` = the emergency stop at the end [n_traj]."""
+    from tests import scale_inputs as SC
+
+    counts = np.bincount(res["state"].ravel(), minlength=11)
+    assert counts.tolist() == g["state_counts"].tolist(), (counts.tolist(), g["state_counts"].tolist())
+    assert SC.sha256(res["reachable"]) == str(g["reachable_sha256"]) and SC.sha256(res["state"]) == str(g["state_sha256"])
+    sub = slice(None, None, SC.SUBSAMPLE_TRAJ)
+    np.testing.assert_array_equal(res["state"][:, sub], g["sub_state"])
+    err = float(np.max(np.abs(res["joints"][:, sub] - g["sub_joints"])))
+    assert err < joints_tol, err
+    assert float(np.max(np.abs(res["joints"][-1] - g["last_joints"]))) < joints_tol
+    assert float(np.max(np.abs(theta - g["last_previous_theta"]))) < 1e-9
+    # (one of the 512 trajectories trips the reference's continuity check on its way through the gimbal lock and stays latched)
+    np.testing.assert_array_equal(np.asarray(latched) != 0, g["emergency_stop"] != 0)
+    assert 0 < int(g["emergency_stop"].sum()) < 8 and int(g["state_counts"][8]) > 0 and int(g["state_counts"][9:].sum()) == 0
+    return err
+
+
+def test_scale_continuous_checker_against_reference(golden_dir):
+    """G16: 512 trajectories of config 5's generator x 1000 control steps through the reference's ControlIK itself (one object per
+    trajectory, fake clock).  The checker's state machine over the regenerated matrices reproduces the digests of its flags and state
+    codes, the recorded joints to 1e-7 (observed ~1e-12) and the carried theta to 1e-9."""
+    from tests import scale_inputs as SC
+
+    g = load(golden_dir, "g16_scale_continuous.npz")
+    M = SC.config5_trajectories()
+    assert SC.sha256(M) == str(g["input_sha256"]), "the seeded inputs did not regenerate"
+    n_steps, n_traj = M.shape[:2]
+    arm = _ctrl_arms()[0]
+    states = np.zeros((n_traj, 11))
+    states[:, 1:8] = [0.0, 0.2617993877991494, -0.17453292519943295, 0.0, 0.0, 0.0, 0.0]  # the constructor's previous_sol (control_ik.py:31-35)
+    start = np.array([[1, 0, 0, 0], [0, 1, 0, -0.2], [0, 0, 1, -0.66], [0, 0, 0, 1.0]])  # the constructor's previous_pose (control_ik.py:38-47)
+    res = orc.control_continuous_run_batch(arm, states, M, first_step_timed_out=True, nthreads=max(1, os.cpu_count() or 1), current_pose=start)
+    _check_scale_continuous(g, res, states[:, 0], states[:, 9])
+
+
 # ------------------------------------------------------------------------------------------ the pin itself
 def test_golden_fixtures_reproduce_from_the_reference():
     """`oracle/gen_golden.py --check`: the committed fixtures are what the reference, imported from /root/reference, produces today —
