@@ -324,11 +324,11 @@ int rsik_control_continuous_step(rsik_ctx *ctx, int64_t n, const double *const m
  * ahead of the consumer: a third of an event's latency) and a block's joints kernel is held until the NEXT block's theta
  * kernel has started (its lone 276-register waves cannot get onto a chip that a chip-filling kernel holds); while the
  * caller's stream is capturing, by events, which is all a capture takes.
- * A trajectory whose emergency stop is latched when the run begins (control_ik.py:205-210: previous_sol, not reachable, the
- * emergency state for every goal until "unfreeze") is filled in by phase 3 and never walked; one that latches during the run has
- * the rest of its block filled in at once by phase 4.
+ * A trajectory whose emergency stop is latched (control_ik.py:205-210: previous_sol, not reachable, the emergency state for every
+ * goal until "unfreeze") is not walked by phase 4: its steps of a block are filled in at once — on entry where it was latched before
+ * the block, behind the chunk in which it latches otherwise.
  * The workspace
- * (17 bytes per step and trajectory + 1 per 8-step chunk, of up to eight blocks in flight, + 17 per trajectory), the side streams and the
+ * (17 bytes per step and trajectory + 1 per 8-step chunk, of up to eight blocks in flight, + 16 per trajectory), the side streams and the
  * events belong to the context: they are created by the first call that needs them, or ahead of time by
  * rsik_control_continuous_reserve.  A call can be captured into a hipGraph (the side streams join the capture through
  * the events the call records) provided it has nothing to create: reserve first, or run a call of at least that size

@@ -17,7 +17,6 @@ struct ContinuousArgs {
     const double* cur_pose[12];   // current_pose of a (re)initialising trajectory, NULL columns => goal matrix itself
     const uint8_t* arm;
     const uint8_t* timed_out;     // NULL => nobody timed out
-    uint8_t* latched0;            // rsik_control_continuous_run: [n], out — the trajectory's emergency stop was latched when the run began (else NULL)
     int euler_roundtrip;          // RSIK_OPT_EULER_ROUNDTRIP
     int first_timed_out;          // non-zero: every trajectory (re)initialises
     double pref_arg[2];           // preferred_theta argument per arm slot (mirrored for l)
@@ -237,16 +236,7 @@ __global__ __launch_bounds__(kBlock) void cont_init_kernel(const ContinuousArgs 
     const Acc<MIXED> A = make_acc<MIXED>(K.arms, MIXED ? (K.arm[ii] != 0) : false, lds_tab);
     const int slot = MIXED ? (A.isl ? 1 : 0) : 0;
     const int64_t n = K.n;
-    if (!live) {
-        // (the bytes up to the next multiple of eight trajectories: the joints phase reads eight at a go)
-        if (K.latched0 && half == 0 && i < ((n + 7) & ~(int64_t)7)) K.latched0[i] = 0;
-        return;
-    }
-    // emergency latched: nothing is touched (C:205-210).  A trajectory that is latched when a run begins stays so to its end
-    // (only "unfreeze" releases it): the run's later phases are told, and fill its steps in without walking them
-    const bool latched = K.st[9 * n + i] != 0.0;
-    if (K.latched0 && half == 0) K.latched0[i] = latched ? 1 : 0;
-    if (latched) return;
+    if (!live || K.st[9 * n + i] != 0.0) return;  // emergency latched: nothing is touched (C:205-210)
     const bool timed_out = K.first_timed_out || (K.timed_out && K.timed_out[i]);
     if (!timed_out && K.st[10 * n + i] != 0.0) return;
     double prev_theta = K.st[0 * n + i];

@@ -94,7 +94,6 @@ struct ContRunArgs {
     uint8_t* chunk_event;         // [ceil(T / kJointChunk)][n]: phase 3 -> phase 4, see cont_joints_kernel
     double snap_tdag;             // phase 2, single-arm launches: see continuous_next_theta_lean (the kind is a template argument)
     double* theta_carry;          // [2][n]: previous_theta between the blocks of one run (phase 2's own state); row 1: see cont_theta_kernel
-    const uint8_t* latched0;      // [n]: the trajectory's emergency stop was latched when the run began (cont_init_kernel): C:205-210 for all its steps
     int first_block, last_block;
     unsigned* started_word;       // phased pipeline, launch by launch: the theta kernel of a block writes started_seq here when it starts
     unsigned started_seq;         // (the host holds the joints kernel of the block BEFORE on it, see rsik_control_continuous_run), or NULL
@@ -403,40 +402,16 @@ __device__ __forceinline__ void cont_joints_chunk(const ContRunArgs& K, SharedTa
     const bool lane_isl = MIXED ? (K.arm[ii] != 0) : false;
     stage_tables<MIXED, (int)offsetof(ContRunArgs, arms) + (MIXED ? 0 : (int)sizeof(ArmC))>(lds_tab, K.arms);
     const Acc<MIXED> A = make_acc<MIXED>(K.arms, lane_isl, lds_tab);
+    Reach r;
+    Goal G;
+    step_geometry(A, m, K.euler_roundtrip, (flag & 1) == 0, r, G, !special);
     const double zeros[7] = {0, 0, 0, 0, 0, 0, 0};
     double jv[7];
-    bool sing = false;
-    // A trajectory whose emergency stop was latched when the run began (C:205-210) answers previous_sol at every step, whatever the
-    // goal: its rows are filled in here, eight steps at a go, and stand for the chain phase like any quiet chunk's (first row = last row
-    // = previous_sol: no event, no turn) — it never walks them.  Waves of such trajectories only skip the geometry altogether; an
-    // ordinary run has none, and pays ONE scalar load and a scalar branch for it: the wave's eight trajectories are eight consecutive
-    // bytes (the start-up kernel also writes the bytes up to the next multiple of eight trajectories), and the group is wave-uniform.
-    const unsigned long long frozen_bytes = *reinterpret_cast<const unsigned long long*>(K.latched0 + grp * 8);
-    bool frozen = false;
-    unsigned long long frozen_mask = 0;
-    if (RSIK_RARE(frozen_bytes != 0)) {
-        frozen = ((frozen_bytes >> (8 * tl)) & 0xffull) != 0;
-        frozen_mask = __ballot(frozen);
-    }
-    if (!RSIK_RARE(frozen_mask == ~0ull)) {
-        Reach r;
-        Goal G;
-        step_geometry(A, m, K.euler_roundtrip, (flag & 1) == 0, r, G, !special);
-        step_joints(A, K, r, G, theta, zeros, jv, sing);
-    }
-    if (RSIK_RARE(frozen_mask != 0)) {
-#pragma unroll
-        for (int k = 0; k < 7; k++) jv[k] = frozen ? K.st[(1 + k) * n + ii] : jv[k];
-        sing = sing && !frozen;
-        if (frozen && live) {
-            if (K.state) K.state[(K.t0 + t) * n + i] = (uint8_t)RSIK_STATE_EMERGENCY;
-            if (K.reachable) K.reachable[(K.t0 + t) * n + i] = 0;
-        }
-    }
+    bool sing;
+    step_joints(A, K, r, G, theta, zeros, jv, sing);
     // a step without joints: singular (phase 4 recomputes it with previous_sol), or its goal is not numbers (flag bit 4: it stays
     // without, and phase 4 steps over it — rsik.h "Rows that are not numbers")
-    bool dead = sing || (flag & 16) != 0;
-    if (RSIK_RARE(frozen_mask != 0)) dead = dead && !frozen;
+    const bool dead = sing || (flag & 16) != 0;
     // Steps relative to the step before (lane - 8; none for the chunk's first step, which phase 4 judges).  Whole turns
     // only for the four joints whose raw angle has a branch cut to cross — shoulder pitch, elbow yaw, wrist roll, wrist yaw
     // (atan2 values, S:751-786, 815-848 / U:508-519); shoulder roll is atan2(q_y, q_x >= 0), elbow pitch is clamped to
@@ -545,12 +520,11 @@ __device__ __forceinline__ void cont_chain_walk(const ContRunArgs& K, SharedTabl
     double prev = K.st[(1 + jj) * n + ii];
     bool init = K.st[8 * n + ii] != 0.0;
     bool emergency = K.st[9 * n + ii] != 0.0;
-    // latched when the run began: the joints phase has filled every step in with previous_sol and the emergency state (see there);
-    // each of its chunks stands as written
-    const bool frozen = K.latched0[ii] != 0;
-    // ... and so does every chunk behind the step at which a trajectory latches during the run, once this phase has filled them
-    // in itself (fill_rest below): `filled` = nothing of this trajectory is left to judge in this block
-    bool filled = frozen;
+    // A latched trajectory (C:205-210: previous_sol, not reachable, the emergency state for every goal until "unfreeze") is not walked:
+    // its steps of the block are filled in at once (fill_rest below) — on entry where it was latched before this block, behind the
+    // chunk in which it latches otherwise — and `filled` says that nothing of it is left to judge in this block: its chunks count as
+    // standing.  An ordinary run pays one OR per chunk for it.
+    bool filled = false;
     const double thr = jj < 4 ? 0.5 : 1.0;                                       // continuity thresholds, C:398
     const double lim = (jj == 0 || jj == 2 || jj == 6) ? 6 * kPi : __builtin_inf();  // multiturn limit of this lane's joint (U:535-568)
     const int hit_bit = jj == 0 ? RSIK_EMERGENCY_SHOULDER_PITCH : (jj == 2 ? RSIK_EMERGENCY_ELBOW_YAW : RSIK_EMERGENCY_WRIST_YAW);
@@ -743,9 +717,10 @@ __device__ __forceinline__ void cont_chain_walk(const ContRunArgs& K, SharedTabl
             const bool stands = !__any(!quiet) && inside;  // (wave-uniform)
             const bool taken = stop == BATCH && stands;
             if (stop == BATCH && !stands) stop = u;
-            if (taken) prev = o.last[u] + sh;
+            // (a filled-in trajectory keeps its previous_sol whatever its rows held when they were fetched)
+            if (taken && !filled) prev = o.last[u] + sh;
             // (a chunk that goes through `one` instead is rewritten there: no turns to add)
-            if (RSIK_RARE(taken && turns != 0.0) && owner) add_turns(c0 + u, sh);
+            if (RSIK_RARE(taken && turns != 0.0 && !filled) && owner) add_turns(c0 + u, sh);
         }
         return stop;
     };
@@ -766,8 +741,8 @@ __device__ __forceinline__ void cont_chain_walk(const ContRunArgs& K, SharedTabl
                 // an eventful chunk: the reference's own sequence of operations for its steps, then the walk resumes behind it
                 double sh, last_row;
                 if (stands_alone(c0 + stop, sh, last_row)) {
-                    prev = last_row + sh;
-                    if (RSIK_RARE(sh != 0.0) && owner) add_turns(c0 + stop, sh);
+                    if (!filled) prev = last_row + sh;
+                    if (RSIK_RARE(sh != 0.0 && !filled) && owner) add_turns(c0 + stop, sh);
                 } else {
                     stepwise((c0 + stop) * kJointChunk, chunk_len(c0 + stop));
                     if (RSIK_RARE(__any(emergency && !filled))) fill_rest((c0 + stop + 1) * kJointChunk);

@@ -545,7 +545,7 @@ static int cont_plan(rsik_ctx* ctx, const char* who, int64_t n, int64_t n_steps,
     P.chunks_per_block = ((size_t)T + rsik::kJointChunk - 1) / rsik::kJointChunk;
     P.slot_bytes = (((size_t)T * P.per_step + P.chunks_per_block * (size_t)n + 255) / 256) * 256;
     P.slots = n_blocks < kContSlots ? (int)n_blocks : kContSlots;
-    P.carry_bytes = (((size_t)n * (2 * sizeof(double) + 1) + 255) / 256) * 256;  // theta carry + scratch rows, the latched-at-start bytes
+    P.carry_bytes = (((size_t)n * 2 * sizeof(double) + 255) / 256) * 256;
     P.need = P.slot_bytes * P.slots + P.carry_bytes;
     P.n_events = 2 + 4 * (size_t)n_blocks;
     return RSIK_OK;
@@ -810,8 +810,6 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     R.max_angle = K0.max_angle; R.cos_max = K0.cos_max; R.sin_max = K0.sin_max;
     R.st = cont_state; R.joints = joints_steps; R.reachable = reachable_steps; R.state = state_steps;
     R.theta_carry = reinterpret_cast<double*>(static_cast<char*>(ctx->ws) + slot_bytes * slots);
-    R.latched0 = reinterpret_cast<uint8_t*>(R.theta_carry + 2 * (size_t)n);
-    K0.latched0 = const_cast<uint8_t*>(R.latched0);
     const dim3 grid8((unsigned)((n * 8 + rsik::kChainBlock - 1) / rsik::kChainBlock));  // (n <= 30 Mi: fits)
     // What a pass really looks like was measured with in-kernel stamps (a -DRSIK_PIPE_TIMING build,
     // scripts/probes/c5_untraced_timeline.py; the profiler's kernel trace delays launches and shows another schedule): a
