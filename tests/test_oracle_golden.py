@@ -663,7 +663,8 @@ def test_scale_continuous_checker_against_reference(golden_dir):
 def test_golden_fixtures_reproduce_from_the_reference():
     """`oracle/gen_golden.py --check`: the committed fixtures are what the reference, imported from /root/reference, produces today —
     regenerated into a temporary directory and compared array by array, byte for byte.  Here G1 (the catalogue: SymbolicIK and
-    ControlIK discrete) and G6 (ControlIK continuous trajectories); `--check` without `--only` does all fourteen sets (~6 min).
+    ControlIK discrete), G6 (ControlIK continuous trajectories) and G15 (the stage methods); `--check` without `--only` does all
+    seventeen sets (~13 min: G14, the BASELINE-scale digests, takes 5 of them on 7 cores, G16 1.5).
     Skipped where the reference is not mounted (the GPU box: it never travels)."""
     import subprocess
     import sys
@@ -672,7 +673,8 @@ def test_golden_fixtures_reproduce_from_the_reference():
         pytest.skip("/root/reference is not mounted here")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
-    p = subprocess.run([sys.executable, os.path.join(root, "oracle", "gen_golden.py"), "--check", "--only", "g1,g6"],
+    p = subprocess.run([sys.executable, os.path.join(root, "oracle", "gen_golden.py"), "--check", "--only", "g1,g6,g15"],
                        capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "CHECK g1_catalogue.npz: identical" in p.stdout and "CHECK g6_control_continuous.npz: identical" in p.stdout
+    assert "CHECK g15_stages.npz: identical" in p.stdout
