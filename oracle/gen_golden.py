@@ -1317,6 +1317,71 @@ def gen_scale_continuous(out, workers=None):
     np.savez_compressed(os.path.join(out, "g16_scale_continuous.npz"), **data)
 
 
+# ----------------------------------------------------------------------------------------
+# G17: the other arm, the other modes, at scale — what G14 / G16 leave out.  (a) ControlIK discrete on the l_arm mirror images of
+# config 3's 256 Ki goal matrices, is_dvt=True (the singularity plane can bind: the kernels' PLANE variant), constrained_mode
+# "low_elbow", 20 grid points; (b) ControlIK continuous on the l_arm mirror images of G16's first 256 trajectories x 1000 steps,
+# "low_elbow", d_theta_max = 0.05.  Digests + subsamples, as there.
+# ----------------------------------------------------------------------------------------
+def _g17_rows_discrete(Ms):
+    if "cd" not in _G14:
+        _G14["cd"] = quiet(ControlIK, urdf_path="../config_files/reachy2.urdf", is_dvt=True)
+    ctrl = _G14["cd"]
+    res = [control_call(ctrl, "l_arm", M, 20, "low_elbow") for M in Ms]
+    return (np.array([r[0] for r in res]), np.array([r[1] for r in res], dtype=np.uint8), np.array([r[2] for r in res], dtype=np.uint8))
+
+
+def _g17_walk(Ms):
+    n_steps, k = Ms.shape[:2]
+    J = np.zeros((n_steps, k, 7)); F = np.zeros((n_steps, k), dtype=np.uint8); S = np.zeros((n_steps, k), dtype=np.uint8)
+    TH = np.zeros((n_steps, k)); ES = np.zeros(k, dtype=np.uint8)
+    real_time = ref_control_mod.time
+    for a in range(k):
+        clock = FakeClock()
+        ref_control_mod.time = clock
+        try:
+            ctrl = quiet(ControlIK, urdf_path="../config_files/reachy2.urdf")
+            for i in range(n_steps):
+                clock.t += 1.0 / 120.0
+                j, ok, st = quiet(ctrl.symbolic_inverse_kinematics, "l_arm", Ms[i, a], "continuous", constrained_mode="low_elbow", d_theta_max=0.05)
+                J[i, a] = np.array(j, dtype=float); F[i, a] = bool(ok); TH[i, a] = ctrl.previous_theta["l_arm"]
+                S[i, a] = STATE_CODES[st] if st in STATE_CODES else (8 if ctrl.emergency_stop and st == ctrl.emergency_state else 255)
+            ES[a] = bool(ctrl.emergency_stop)
+        finally:
+            ref_control_mod.time = real_time
+    return J, F, S, TH, ES
+
+
+def gen_scale_variants(out, workers=None):
+    import multiprocessing as mp
+
+    workers = workers or max(1, (os.cpu_count() or 2) - 1)
+    g14 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "g14_scale.npz"))
+    _, _, _, Mr = SCALE.config3_from_kept(g14["c3_kept_bits"])
+    Ml = SCALE.mirror_matrices(Mr)
+    Mt = SCALE.mirror_matrices(SCALE.config5_trajectories()[:, :256])
+    data = {}
+    with mp.get_context("fork").Pool(workers) as pool:
+        piece = 1024
+        parts = pool.map(_g17_rows_discrete, [Ml[a:a + piece] for a in range(0, len(Ml), piece)])
+        joints = np.concatenate([p[0] for p in parts]); reach = np.concatenate([p[1] for p in parts]); state = np.concatenate([p[2] for p in parts])
+        data.update({"d_n": np.int64(len(Ml)), "d_input_sha256": np.array(SCALE.sha256(Ml)), "d_reachable_sha256": np.array(SCALE.sha256(reach)),
+                     "d_state_sha256": np.array(SCALE.sha256(state)), "d_state_counts": np.bincount(state, minlength=9).astype(np.int64),
+                     "d_sub_reachable": reach[::SCALE.SUBSAMPLE].copy(), "d_sub_state": state[::SCALE.SUBSAMPLE].copy(),
+                     "d_sub_joints": joints[::SCALE.SUBSAMPLE].copy()})
+        piece = 4
+        parts = pool.map(_g17_walk, [Mt[:, a:a + piece] for a in range(0, Mt.shape[1], piece)])
+        J = np.concatenate([p[0] for p in parts], axis=1); F = np.concatenate([p[1] for p in parts], axis=1)
+        S = np.concatenate([p[2] for p in parts], axis=1); TH = np.concatenate([p[3] for p in parts], axis=1); ES = np.concatenate([p[4] for p in parts])
+        sub = slice(None, None, SCALE.SUBSAMPLE_TRAJ)
+        data.update({"n_traj": np.int64(Mt.shape[1]), "n_steps": np.int64(Mt.shape[0]), "input_sha256": np.array(SCALE.sha256(Mt)),
+                     "reachable_sha256": np.array(SCALE.sha256(F)), "state_sha256": np.array(SCALE.sha256(S)),
+                     "state_counts": np.bincount(S.ravel(), minlength=11).astype(np.int64), "emergency_stop": ES,
+                     "sub_joints": J[:, sub].copy(), "sub_previous_theta": TH[:, sub].copy(), "sub_reachable": F[:, sub].copy(), "sub_state": S[:, sub].copy(),
+                     "last_previous_theta": TH[-1].copy(), "last_joints": J[-1].copy()})
+    np.savez_compressed(os.path.join(out, "g17_scale_variants.npz"), **data)
+
+
 def ref_default_joints(k):
     return [[0.0, 0.2617993877991494, -0.17453292519943295, 0.0, 0.0, 0.0, 0.0],
             [0.0, -0.2617993877991494, 0.17453292519943295, 0.0, 0.0, 0.0, 0.0]][k]
@@ -1342,7 +1407,7 @@ def main():
              ("g4", gen_control), ("g5", gen_helpers), ("g6", gen_continuous),
              ("g7", gen_continuous_start), ("g8", gen_matrix_edges),
              ("g9", gen_custom_geometry), ("g10", gen_custom_urdf_control), ("g11", gen_emergency),
-             ("g12", gen_continuous_modes), ("g13", gen_hostile), ("g14", gen_scale), ("g15", gen_stages), ("g16", gen_scale_continuous)]
+             ("g12", gen_continuous_modes), ("g13", gen_hostile), ("g14", gen_scale), ("g15", gen_stages), ("g16", gen_scale_continuous), ("g17", gen_scale_variants)]
     bad = 0
     for name, fn in steps:
         if args.only and name not in args.only.split(","):  # exact names: "g1" does not select "g12"

@@ -90,3 +90,10 @@ def config5_trajectories(n_traj=N_TRAJ_CONFIG5, n_steps=N_STEPS_CONFIG5):
     pos = np.stack(v[:3], axis=1)
     eul = np.stack(v[3:], axis=1)
     return matrices_from_pose(pos, eul).reshape(n_steps, n_traj, 4, 4)
+
+
+def mirror_matrices(M):
+    """The l_arm goals that mirror r_arm goals (pose_l = (x, -y, z; -roll, pitch, -yaw), the reference's
+    test_random_reachability.py:156-166 rule): M_l = S M S with S = diag(1, -1, 1, 1) — sign flips only, exact."""
+    s = np.array([1.0, -1.0, 1.0, 1.0])
+    return M * (s[:, None] * s[None, :])

@@ -1565,7 +1565,40 @@ def test_scale_continuous_digests_of_the_reference(golden_dir, torch_mod):
         res = to_np(c.run_continuous_trajectories("r_arm", Mt, st, first_step_timed_out=True, current_pose=start))
         torch_mod.cuda.synchronize()
         _check_scale_continuous(g, res, st[0].cpu().numpy(), st[9].cpu().numpy())
+    assert 0 < int(g["emergency_stop"].sum()) < 8  # (one trajectory trips the reference's continuity check at the gimbal lock and stays latched)
     c._solver.set_option(_abi_mod().OPT_CONT_RUN_MODE, _abi_mod().CONT_RUN_AUTO)
+
+
+def test_scale_variants_digests_of_the_reference(golden_dir, torch_mod):
+    """G17 — the other arm, the other modes, at scale, against the reference itself: ControlIK discrete on the l_arm mirror images of
+    config 3's 256 Ki goal matrices with is_dvt=True (the kernels' singularity-plane variant), "low_elbow", 20 grid points; ControlIK
+    continuous on the l_arm mirror images of 256 of G16's trajectories x 1000 steps, "low_elbow", d_theta_max = 0.05 (pipeline and
+    step kernel).  Flags and state codes by digest, joints on the subsamples."""
+    from tests import scale_inputs as SC
+    from tests.test_oracle_golden import _check_scale_continuous, _check_scale_set
+
+    A = _abi_mod()
+    g = load(golden_dir, "g17_scale_variants.npz")
+    _, _, _, Mr = SC.config3_from_kept(load(golden_dir, "g14_scale.npz")["c3_kept_bits"])
+    Ml = SC.mirror_matrices(Mr)
+    assert SC.sha256(Ml) == str(g["d_input_sha256"]), "the seeded inputs did not regenerate"
+    c = make_control(is_dvt=True)
+    c.nb_search_points = 20
+    res = to_np(c.symbolic_inverse_kinematics_batch("l_arm", Ml, constrained_mode="low_elbow"))
+    _check_scale_set(g, "d_", res, len(Ml))
+    Mt = SC.mirror_matrices(SC.config5_trajectories()[:, :256])
+    assert SC.sha256(Mt) == str(g["input_sha256"]), "the seeded inputs did not regenerate"
+    n_traj = Mt.shape[1]
+    c = make_control()
+    for run_mode in (A.CONT_RUN_PHASED, A.CONT_RUN_STEPS):
+        c._solver.set_option(A.OPT_CONT_RUN_MODE, run_mode)
+        st = c.new_continuous_state("l_arm", n_traj)
+        start = np.tile(np.asarray(c.previous_pose["l_arm"], dtype=np.float64), (n_traj, 1, 1))
+        res = to_np(c.run_continuous_trajectories("l_arm", torch_mod.as_tensor(Mt).cuda(), st, first_step_timed_out=True, current_pose=start,
+                                                  constrained_mode="low_elbow", d_theta_max=0.05))
+        torch_mod.cuda.synchronize()
+        _check_scale_continuous(g, res, st[0].cpu().numpy(), st[9].cpu().numpy())
+    c._solver.set_option(A.OPT_CONT_RUN_MODE, A.CONT_RUN_AUTO)
 
 
 def test_emergency_reports_discrete(golden_dir, torch_mod):
