@@ -692,7 +692,7 @@ def test_golden_fixtures_reproduce_from_the_reference():
     """`oracle/gen_golden.py --check`: the committed fixtures are what the reference, imported from /root/reference, produces today —
     regenerated into a temporary directory and compared array by array, byte for byte.  Here G1 (the catalogue: SymbolicIK and
     ControlIK discrete), G6 (ControlIK continuous trajectories) and G15 (the stage methods); `--check` without `--only` does all
-    seventeen sets (~13 min: G14, the BASELINE-scale digests, takes 5 of them on 7 cores, G16 1.5).
+    eighteen sets (~15 min: G14, the BASELINE-scale digests, takes 5 of them on 7 cores, G16 1.5, G17 2.5).
     Skipped where the reference is not mounted (the GPU box: it never travels)."""
     import subprocess
     import sys
