@@ -1402,6 +1402,11 @@ def main():
         committed = out
         tmp = tempfile.TemporaryDirectory(prefix="rsik_golden_check_")
         out = tmp.name
+        # (G10 reads its made-up URDF from the fixture directory: an input written for this repo, not a product of the reference)
+        import shutil
+
+        if os.path.exists(os.path.join(committed, "custom_arm.urdf")):
+            shutil.copy(os.path.join(committed, "custom_arm.urdf"), os.path.join(out, "custom_arm.urdf"))
     os.makedirs(out, exist_ok=True)
     steps = [("g0", gen_constants), ("g1", gen_catalogue), ("g2", gen_sweep), ("g3", gen_reachable),
              ("g4", gen_control), ("g5", gen_helpers), ("g6", gen_continuous),
