@@ -168,6 +168,28 @@ def make_config5_trajectories(n_traj, n_steps, seed=20250204, device=0):
 
 
 # ------------------------------------------------------------------------------------------ CPU baseline leg (+ parity check)
+def host_facts():
+    """The host the CPU-baseline leg runs on: CPUs this process may use (affinity mask), logical CPUs of the machine, CPU model."""
+    try:
+        visible = len(os.sched_getaffinity(0))
+    except AttributeError:
+        visible = os.cpu_count() or 1
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.lower().startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    if not model:
+        import platform
+
+        model = platform.processor() or platform.machine() or "unknown"
+    return {"cores_visible": max(1, visible), "logical_cpus": os.cpu_count() or visible, "cpu_model": model}
+
+
 def cpu_baseline(config, sample, seconds, gpu=None):
     """Times the CPU checker (oracle/, a C restatement of the reference path = kind "port") on the host cores, on a
     bounded sample of the SAME workload: once as the portable build that travels with the repo (gcc -O2, baseline
@@ -177,11 +199,8 @@ def cpu_baseline(config, sample, seconds, gpu=None):
     rank's part of the all-gathered arrays."""
     from oracle import oracle as orc
 
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    avail = max(1, min(avail, orc.lib().orc_max_threads()))
+    host = host_facts()
+    avail = max(1, min(host["cores_visible"], orc.lib().orc_max_threads()))
     if config in (2, 4):
         pos, eul = np.ascontiguousarray(sample["pos"]), np.ascontiguousarray(sample["eul"])
         m = len(pos)
@@ -224,6 +243,11 @@ def cpu_baseline(config, sample, seconds, gpu=None):
     value, passes, el = rate(best, left / 2)
     base = {
         "value": value, "unit": "steps/s" if config == 5 else "solves/s", "cores": best, "kind": "port", "single_thread": probe[1],
+        # the host ("core count and CPU model printed"): `cores` / `threads_used` = the OpenMP threads `value` was
+        # measured with (the best of a short probe over thread counts, so two configs of one run may differ in it), `cores_visible` = the
+        # CPUs this process may run on (its affinity mask), `cpu_model` from /proc/cpuinfo — the same in every entry of one run
+        "threads_used": best, "cores_visible": host["cores_visible"], "logical_cpus": host["logical_cpus"], "cpu_model": host["cpu_model"],
+        "threads_probed": {str(c): probe[c] for c in cands},
         "portable_build": {"value": value, "flags": "gcc -O2 -ffp-contract=off (built in the build container, travels with the repo)",
                            "single_thread": probe[1]},
         "sample": f"{m} {'trajectory-steps' if config == 5 else 'poses'} of the workload x {passes} passes ({el:.1f} s) with OpenMP {best} threads "
@@ -373,9 +397,9 @@ def live_traffic(cfg, n, lib, timeout_s=60.0):
         return {"error": "this process already runs under a profiler: no nested rocprofv3"}
     kernel = {2: "solve_kernel", 3: "control_discrete_kernel", 4: "solve_kernel", 5: "cont_"}[cfg]
     child = [sys.executable, os.path.abspath(__file__), "--config", str(cfg), "--poses", str(n), "--steps", "3", "--warmup", "1", "--launch", "eager",
-             "--no-cpu-baseline", "--no-extras", "--no-other-configs", "--no-live-traffic"]
+             "--no-cpu-baseline", "--no-extras", "--no-other-configs", "--no-live-traffic", "--no-steady-state"]
     if cfg == 5:  # (a profiler that serialises dispatches deadlocks on device-word waits: streams tied by events)
-        child += ["--phased-variant", "1", "--no-steady-state"]
+        child += ["--phased-variant", "1"]
     if lib:
         child += ["--lib", os.path.abspath(lib)]
     got, t0 = {}, time.perf_counter()
@@ -488,7 +512,10 @@ def parse_args(argv):
                          "what the PMC passes of scripts/profile.sh use — a profiler that serialises dispatches deadlocks on a replayed "
                          "multi-stream graph, and device-word waits are not its business either)")
     ap.add_argument("--no-steady-state", action="store_true",
-                    help="config 5: skip the second timing after 60 more passes and the other launch form (profiler runs: only the timed form's kernels)")
+                    help="skip the second timing (config 5: after 60 more passes, and the other launch form; configs 2-4: after --settle-ms of "
+                         "untimed launches) — profiler runs: only the timed form's kernels")
+    ap.add_argument("--settle-ms", type=float, default=50.0,
+                    help="configs 2-4, N = 1: milliseconds of untimed back-to-back launches ahead of the `steady_state` leg (0 = no such leg)")
     ap.add_argument("--stages", action="store_true",
                     help="add per-stage device figures for configs 2 and 3 (scripts/stage_timers.py, a child process after the timed "
                          "region: launch differences with this library, per-wave stamps with a -DRSIK_TIMELINE_PROBE build)")
@@ -573,7 +600,8 @@ def other_config_entry(oc, sub, wall_s):
         "algorithmic_bytes_per_pose": r["algorithmic_bytes_per_pose"], "achieved_GBs": r["achieved"], "frac": r["frac"],
         "traffic": r.get("traffic"),
         "parity_on_sample": sub.get("cpu_baseline", {}).get("parity_on_sample"),
-        "cpu_baseline": {k: sub.get("cpu_baseline", {}).get(k) for k in ("value", "unit", "cores", "kind", "single_thread", "workload_filter")},
+        "cpu_baseline": {k: sub.get("cpu_baseline", {}).get(k) for k in ("value", "unit", "cores", "threads_used", "cores_visible", "logical_cpus",
+                                                                          "cpu_model", "kind", "single_thread", "sample", "workload_filter")},
         "wall_s": wall_s,
     }
     if oc == 5:
@@ -587,7 +615,7 @@ def other_config_entry(oc, sub, wall_s):
         e["traffic_bytes_per_pass"] = (r["traffic"] * 1000) if r.get("traffic") else None
         e["traffic_bytes_per_control_step_of_4096_trajectories"] = r.get("traffic")
         e["frac_at_286_bytes_state_round_trip_per_step"] = r.get("frac_at_286_bytes_state_round_trip_per_step")
-        e["steady_state"] = sub.get("steady_state")
+    e["steady_state"] = sub.get("steady_state")
     return e
 
 
@@ -985,6 +1013,37 @@ def _run(argv):
             step()
             fence()
 
+    # ---- configs 2-4 on one GPU: the same K steps again behind >= `--settle-ms` of untimed launches of the same kind (round 6: the
+    # first ~25 launches of a process run below the sustained clock — docs/experiments.md A.5 — so the driver's W = 5 / K = 20 figure of a
+    # 14 us kernel reads 10 % under what profiles/ and a longer run show; this leg lets the driver's own run witness the settled figure,
+    # next to the headline it does not replace)
+    if cfg != 5 and world == 1 and not args.no_steady_state and args.settle_ms > 0:
+        per_round_ms = max(step_ms_events * args.steps, 1e-3)
+        rounds = max(1, int(np.ceil(args.settle_ms / per_round_ms)))
+
+        def k_steps():
+            if graph is not None:
+                graph.replay()
+            else:
+                for _ in range(args.steps):
+                    step()
+
+        fence()
+        for _ in range(rounds):
+            k_steps()
+        e0.record()
+        k_steps()
+        e1.record()
+        fence()
+        s_ms = e0.elapsed_time(e1) / args.steps
+        steady = {"after_untimed_launches": args.warmup + args.steps * (1 + rounds) + (args.steps if graph is not None else 0),
+                  "untimed_ms_target": args.settle_ms, "untimed_rounds_of_K": rounds, "steps": args.steps, "ms_per_step": s_ms, "kernel_ms": s_ms,
+                  "value": units / (s_ms * 1e-3), "unit": "solves/s", "launch": "graph" if graph is not None else "eager",
+                  "achieved_GBs": BYTES_PER_POSE[cfg] * units / (s_ms * 1e-3) / 1e9,
+                  "frac": BYTES_PER_POSE[cfg] * units / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                  "what": f"the same K = {args.steps} launches timed again (HIP events, one pair) directly behind {rounds} untimed rounds of K "
+                          f"(>= {args.settle_ms:g} ms of back-to-back launches): the kernel at the clock the chip settles to"}
+
     # ---- kernel-only and gather-only legs (N > 1), each on its own: same buffers, same launches
     kernel_ms, gather_ms = step_ms_events, 0.0
     if world > 1:
@@ -1183,8 +1242,8 @@ def _run(argv):
                 "between the steps of a pass (SURVEY 8d's persistent-loop figure)")
             line["roofline"]["frac_at_286_bytes_state_round_trip_per_step"] = (
                 BYTES_PER_STEP_STATE_ROUND_TRIP * units / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
-            if steady is not None:
-                line["steady_state"] = steady
+        if steady is not None:
+            line["steady_state"] = steady
 
         # ---- what bounds the kernel: counters committed with this build, live clock, cold-HBM run
         build_id = hs.build_id()

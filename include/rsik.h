@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define RSIK_ABI_VERSION 6
+#define RSIK_ABI_VERSION 7
 
 /* ---- status codes ---- */
 #define RSIK_OK 0
@@ -203,8 +203,8 @@ int rsik_set_arm(rsik_ctx *ctx, int arm, const double *consts_host, int count);
 #define RSIK_CONT_RUN_PHASED 1
 #define RSIK_CONT_RUN_STEPS 2
 /* Tuning of rsik_control_continuous_run (results do not depend on it):
- *   RSIK_OPT_CONT_BLOCK_STEPS  control steps per block: 0 (default) = a third of the run, at least 64; n > 0 = n (rounded up
- *                              to the sequential phases' batch of steps) */
+ *   RSIK_OPT_CONT_BLOCK_STEPS  control steps per block: 0 (default) = a third of the run, at least 64 and — launch by launch — at most
+ *                              512 (half of the run under capture); n > 0 = n (rounded up to the sequential phases' batch of steps) */
 #define RSIK_OPT_CONT_BLOCK_STEPS 5
 /*   RSIK_OPT_CONT_PHASED_VARIANT  phased pipeline issued launch by launch, a bit mask (0 = the default form; results do not depend on it):
  *                              1  its streams tied by hipEvents (as a run recorded into a hipGraph always is) instead of by
@@ -213,7 +213,22 @@ int rsik_set_arm(rsik_ctx *ctx, int arm, const double *consts_host, int count);
 #define RSIK_OPT_CONT_PHASED_VARIANT 6
 #define RSIK_PHASED_EDGES_BY_EVENT 1
 #define RSIK_PHASED_NO_THETA_FIRST 2
-#define RSIK_OPT_COUNT 7
+/*   RSIK_OPT_CONT_GOALS_RESIDENT  rsik_control_continuous_run issued launch by launch, run after run on one stream (results do not
+ *                              depend on it).  0 (default): every run's four streams meet at its start and at its end — a run begins
+ *                              when everything queued ahead of it, the previous run included, has finished.  1: a PROMISE by the caller
+ *                              that lets consecutive runs of one shape overlap: the goal matrices `m12_steps` (and `arm`) handed to a
+ *                              run were complete before the PREVIOUS continuous run of this context was issued, and nothing the caller
+ *                              queued on the stream since that call reads or writes this run's `reachable_steps` / `state_steps` (they
+ *                              may be the previous run's own buffers: each block's rows are then written behind that run's chain kernel
+ *                              of the same rows).  The prepare phase of run k + 1 — a function of the goals alone — then runs beside the
+ *                              joints and chain kernels of run k, in the workspace slots run k does not use (all eight are kept); the
+ *                              start-up kernel, the theta, joints and chain phases of run k + 1 wait for run k's end as before (the
+ *                              trajectory state: control_ik.py:80-83, 276-407 carries it from call to call), and the caller's stream
+ *                              continues behind each run's last kernel as before.  Takes effect behind a run of the same n, block
+ *                              length and stream, issued with value-word edges into the same workspace, on a context no hipGraph
+ *                              points into; otherwise the run is issued as with 0 (rsik_control_continuous_last_form tells). */
+#define RSIK_OPT_CONT_GOALS_RESIDENT 7
+#define RSIK_OPT_COUNT 8
 int rsik_set_option(rsik_ctx *ctx, int option, int value);
 int rsik_get_option(const rsik_ctx *ctx, int option, int *value);
 
@@ -318,7 +333,8 @@ int rsik_control_continuous_step(rsik_ctx *ctx, int64_t n, const double *const m
  *                adds that nobody waits for); only a chunk with an event is walked step by step with the reference's own
  *                sequence of operations (also: steps whose get_joints hit an exact singularity)
  * A run is cut into blocks of steps: three when it is issued launch by launch, two when it is being captured into a
- * hipGraph (RSIK_OPT_CONT_BLOCK_STEPS overrides); the results do not depend on the cut.
+ * hipGraph (RSIK_OPT_CONT_BLOCK_STEPS overrides); the results do not depend on the cut.  Runs of one shape issued one after the
+ * other can overlap: RSIK_OPT_CONT_GOALS_RESIDENT.
  * The phases of neighbouring blocks overlap on four streams (the caller's and three of the context's).  Issued launch by
  * launch the streams are tied by words in device memory (hipStreamWriteValue32 behind the producer, hipStreamWaitValue32
  * ahead of the consumer: a third of an event's latency) and a block's joints kernel is held until the NEXT block's theta
@@ -351,6 +367,21 @@ int rsik_control_continuous_run(rsik_ctx *ctx, int64_t n, int64_t n_steps, const
                                 int constrained_mode, double d_theta_max, const double *current_joints,
                                 double orbita3d_max_angle, double *cont_state, double *joints_steps,
                                 uint8_t *reachable_steps, uint8_t *state_steps);
+
+/*
+ * rsik_control_continuous_last_form — how the last rsik_control_continuous_run of this context was issued (nothing is returned
+ * through the run's own arguments: the results do not depend on the form, the cost does).  RSIK_CONT_FORM_STEPS_NO_LIMITS_CAN_FAIL:
+ * the solver's projection_margin is not positive, so is_reachable_no_limits can fail (symbolic_ik.py:343-345; the reference then
+ * raises on purpose, control_ik.py:385-387, here RSIK_STATE_NOT_REACHABLE_NO_LIMITS) — an outcome the pipeline's phases do not carry:
+ * the run was n_steps launches of the step kernel whatever RSIK_OPT_CONT_RUN_MODE said, 10-30 x the pipeline's time.
+ */
+#define RSIK_CONT_FORM_NONE 0                      /* no run yet */
+#define RSIK_CONT_FORM_PHASED 1                    /* the trajectory pipeline, launch by launch */
+#define RSIK_CONT_FORM_PHASED_OVERLAPPED 2         /* ... its prepare phase started beside the previous run (RSIK_OPT_CONT_GOALS_RESIDENT) */
+#define RSIK_CONT_FORM_PHASED_CAPTURED 3           /* ... recorded into a hipGraph */
+#define RSIK_CONT_FORM_STEPS 4                     /* one launch of the step kernel per control step, as RSIK_OPT_CONT_RUN_MODE asked */
+#define RSIK_CONT_FORM_STEPS_NO_LIMITS_CAN_FAIL 5  /* ... because the arm's projection margin is not positive */
+int rsik_control_continuous_last_form(const rsik_ctx *ctx);
 
 /*
  * rsik_control_continuous_reserve — creates what rsik_control_continuous_run(n, n_steps) would create on first use

@@ -24,7 +24,7 @@ def use_library(path: str) -> None:
     LIB_PATH = os.path.abspath(path)
 
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 RSIK_OK = 0
 RSIK_E_INVALID, RSIK_E_NO_DEVICE, RSIK_E_HIP, RSIK_E_NOT_SET = -1, -2, -3, -4
 
@@ -61,6 +61,7 @@ PROTOTYPES = {
                                                C.c_int, C.c_double, _vp, C.c_double, _vp, _vp, _vp, _vp]),
     "rsik_control_continuous_run": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp, C.POINTER(_vp), _vp, C.c_int, C.c_int, C.c_double, _dp,
                                               C.c_int, C.c_double, _vp, C.c_double, _vp, _vp, _vp, _vp]),
+    "rsik_control_continuous_last_form": (C.c_int, [_vp]),
     "rsik_control_continuous_reserve": (C.c_int, [_vp, C.c_int64, C.c_int64]),
     "rsik_control_continuous_release": (C.c_int, [_vp]),
     "rsik_stage": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_int, _vp, C.c_int, _vp, C.c_int]),
@@ -81,7 +82,11 @@ GOAL_POSE6, GOAL_M12 = 0, 1
  STAGE_CIRCLE_LINE, STAGE_ROTATION_FROM_VECTOR) = range(8)
 STAGE_ROW = {0: (6, 5), 1: (6, 3), 2: (6, 7), 3: (3, 8), 4: (17, 3), 5: (12, 7), 6: (10, 7), 7: (3, 9)}  # doubles in / out per row
 OPT_EULER_ROUNDTRIP, OPT_SWEEP_MODE, OPT_NO_TIPZ, OPT_NO_MIRROR, OPT_CONT_RUN_MODE = 0, 1, 2, 3, 4
-OPT_CONT_BLOCK_STEPS, OPT_CONT_PHASED_VARIANT = 5, 6
+OPT_CONT_BLOCK_STEPS, OPT_CONT_PHASED_VARIANT, OPT_CONT_GOALS_RESIDENT = 5, 6, 7
+(CONT_FORM_NONE, CONT_FORM_PHASED, CONT_FORM_PHASED_OVERLAPPED, CONT_FORM_PHASED_CAPTURED, CONT_FORM_STEPS,
+ CONT_FORM_STEPS_NO_LIMITS_CAN_FAIL) = range(6)
+CONT_FORM_NAMES = {0: "none", 1: "phased", 2: "phased, overlapping the run before", 3: "phased, captured", 4: "steps",
+                   5: "steps (the arm's projection margin lets is_reachable_no_limits fail)"}
 PHASED_EDGES_BY_EVENT, PHASED_NO_THETA_FIRST = 1, 2
 CONT_RUN_AUTO, CONT_RUN_PHASED, CONT_RUN_STEPS = 0, 1, 2
 EMERGENCY_SHOULDER_PITCH, EMERGENCY_ELBOW_YAW, EMERGENCY_WRIST_YAW, EMERGENCY_CONTINUITY = 1, 2, 4, 8

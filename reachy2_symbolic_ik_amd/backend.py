@@ -6,7 +6,7 @@ the hand-written HIP kernels behind include/rsik.h.
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, Optional, Sequence
+from typing import Any, Dict, Optional, Sequence
 
 import numpy as np
 import torch
@@ -20,6 +20,17 @@ _U8 = torch.uint8
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
+
+
+class ContinuousRunResult(dict):
+    """What control_continuous_run returns: the dict of output tensors (joints, reachable, state) with one attribute beside it,
+    `run_form` = how the library issued the run (_abi.CONT_FORM_*; `run_form_name` in words)."""
+
+    run_form: int = _abi.CONT_FORM_NONE
+
+    @property
+    def run_form_name(self) -> str:
+        return _abi.CONT_FORM_NAMES.get(self.run_form, str(self.run_form))
 
 
 class HipSolver:
@@ -335,10 +346,15 @@ class HipSolver:
         current_pose_m12: Optional[torch.Tensor] = None,
         orbita3d_max_angle: float = float(np.deg2rad(42.5)),
         out: Optional[Dict[str, torch.Tensor]] = None,
-    ) -> Dict[str, torch.Tensor]:
+        goals_resident: Optional[bool] = None,
+    ) -> "ContinuousRunResult":
         """m12_steps: [n_steps, 12, n] float64 on the device.  All steps of all trajectories from one C call (the phased
         trajectory pipeline of rsik_control_continuous_run, or a launch of the step kernel per control step under
-        RSIK_CONT_RUN_STEPS); returns joints [n_steps, n, 7], reachable / state [n_steps, n]; `cont_state` is updated in place."""
+        RSIK_CONT_RUN_STEPS); returns joints [n_steps, n, 7], reachable / state [n_steps, n]; `cont_state` is updated in place.
+        The result's attribute `run_form` says how the run was issued (rsik_control_continuous_last_form: _abi.CONT_FORM_*) — in particular
+        when the library fell back to a launch per step because the arm's projection margin lets is_reachable_no_limits fail.
+        `goals_resident` (None: RSIK_OPT_CONT_GOALS_RESIDENT as set on the context): the caller's promise that lets this run's
+        prepare phase start beside the previous run's tail — include/rsik.h."""
         if m12_steps.dim() != 3 or m12_steps.shape[1] != 12:
             raise ValueError("m12_steps must have shape [n_steps, 12, n]")
         n_steps, _, n = (int(v) for v in m12_steps.shape)
@@ -359,13 +375,27 @@ class HipSolver:
         joints = self._out_buf(out, "joints", (n_steps, n, 7), _F64)
         reachable = self._out_buf(out, "reachable", (n_steps, n), _U8)
         state = self._out_buf(out, "state", (n_steps, n), _U8)
-        with torch.cuda.device(self.device):
-            self._bind_stream()
-            self._check(self.lib.rsik_control_continuous_run(
-                self._h, n, n_steps, _ptr(m12_steps), cp, _ptr(arm), int(arm_uniform), int(bool(first_step_timed_out)),
-                float(preferred_theta), pts.ctypes.data_as(C.POINTER(C.c_double)), int(constrained_mode), float(d_theta_max),
-                _ptr(current_joints), float(orbita3d_max_angle), _ptr(cont_state), _ptr(joints), _ptr(reachable), _ptr(state)))
-        return {"joints": joints, "reachable": reachable, "state": state}
+        before = None
+        if goals_resident is not None:
+            before = self.get_option(_abi.OPT_CONT_GOALS_RESIDENT)
+            self.set_option(_abi.OPT_CONT_GOALS_RESIDENT, int(bool(goals_resident)))
+        try:
+            with torch.cuda.device(self.device):
+                self._bind_stream()
+                self._check(self.lib.rsik_control_continuous_run(
+                    self._h, n, n_steps, _ptr(m12_steps), cp, _ptr(arm), int(arm_uniform), int(bool(first_step_timed_out)),
+                    float(preferred_theta), pts.ctypes.data_as(C.POINTER(C.c_double)), int(constrained_mode), float(d_theta_max),
+                    _ptr(current_joints), float(orbita3d_max_angle), _ptr(cont_state), _ptr(joints), _ptr(reachable), _ptr(state)))
+        finally:
+            if before is not None:
+                self.set_option(_abi.OPT_CONT_GOALS_RESIDENT, before)
+        res = ContinuousRunResult({"joints": joints, "reachable": reachable, "state": state})
+        res.run_form = self.continuous_last_form()
+        return res
+
+    def continuous_last_form(self) -> int:
+        """How the last control_continuous_run of this context was issued: _abi.CONT_FORM_* (names: _abi.CONT_FORM_NAMES)."""
+        return int(self.lib.rsik_control_continuous_last_form(self._h))
 
     # ------------------------------------------------------------------ solver-state entry points
     def new_solver_state(self, n: int) -> torch.Tensor:

@@ -481,9 +481,15 @@ class ControlIK:
         d_theta_max: float = 0.01,
         preferred_theta: float = -4 * np.pi / 6,
         out: Optional[Dict[str, torch.Tensor]] = None,
+        goals_resident: Optional[bool] = None,
     ) -> Dict[str, torch.Tensor]:
         """All steps of n parallel trajectories with one host call.  M_steps: [n_steps, n, 4, 4] or packed
-        [n_steps, 12, n].  Returns joints [n_steps, n, 7], reachable / state [n_steps, n]."""
+        [n_steps, 12, n].  Returns joints [n_steps, n, 7], reachable / state [n_steps, n] (a dict with the attribute `run_form`
+        beside its keys: how the library issued the run (_abi.CONT_FORM_*; CONT_FORM_STEPS_NO_LIMITS_CAN_FAIL = a launch per control step because this arm's projection
+        margin lets is_reachable_no_limits fail, symbolic_ik.py:343-345 / control_ik.py:385-387 — correct, 10-30 x slower)).
+        `goals_resident=True`: a promise that lets consecutive runs of one shape overlap (the prepare phase of this run beside the
+        tail of the one before): M_steps was complete on the device before the previous run of this object was issued, and nothing
+        queued since uses this run's `out` buffers — include/rsik.h, RSIK_OPT_CONT_GOALS_RESIDENT."""
         if constrained_mode not in _abi.MODES:
             raise UnboundLocalError("local variable 'interval_limit' referenced before assignment")
         dev = self._solver.device
@@ -501,7 +507,7 @@ class ControlIK:
             m12_steps, cont_state, pts, arm=arm_t, arm_uniform=arm_uniform, first_step_timed_out=first_step_timed_out,
             preferred_theta=float(preferred_theta), constrained_mode=_abi.MODES[constrained_mode],
             d_theta_max=float(d_theta_max), current_joints=current_joints, current_pose_m12=cp,
-            orbita3d_max_angle=float(self.orbita3D_max_angle), out=out)
+            orbita3d_max_angle=float(self.orbita3D_max_angle), out=out, goals_resident=goals_resident)
 
     def capture_continuous_trajectories(
         self,

@@ -30,6 +30,8 @@ struct ContinuousArgs {
     double* joints;
     uint8_t* reachable;
     uint8_t* state;
+    unsigned* started_word;       // cont_init_kernel, launch by launch: started_seq is written here when the kernel's last workgroup has
+    unsigned started_seq;         // been placed (a prepare kernel of the same run is held on it, rsik_control_continuous_run), or NULL
     ArmC arms[2];
 };
 
@@ -226,6 +228,8 @@ __global__ __launch_bounds__(kBlock) void control_continuous_kernel(const Contin
 template <bool MIXED, bool PAIR>
 __global__ __launch_bounds__(kBlock) void cont_init_kernel(const ContinuousArgs K) {
     __builtin_amdgcn_s_setprio(3);  // a few lone waves on the critical path, beside the chip-filling prepare phase
+    if (K.started_word != nullptr && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)  // (the last workgroup runs: all of them have been placed)
+        __hip_atomic_store(K.started_word, K.started_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t i = PAIR ? (gid >> 1) : gid;
     const int half = PAIR ? (int)(gid & 1) : 0;

@@ -97,6 +97,10 @@ struct ContRunArgs {
     int first_block, last_block;
     unsigned* started_word;       // phased pipeline, launch by launch: the theta kernel of a block writes started_seq here when it starts
     unsigned started_seq;         // (the host holds the joints kernel of the block BEFORE on it, see rsik_control_continuous_run), or NULL
+    const unsigned* wait_word;    // theta kernel, launch by launch: the block's "prepared" word, which the kernel itself waits for (wait_seq) —
+    unsigned wait_seq;            // see cont_theta_kernel — or NULL: the stream has waited
+    unsigned* timeout_word;       // ... raised if that wait gives up (rsik_sync reports it)
+    unsigned* chain_started_word; // the same for the chain kernel of a block (the NEXT run's first prepare kernel is held on the last one's), or NULL
     double* st;                   // cont_state
     double* joints;               // [n_steps][n][7]
     uint8_t* reachable;           // [n_steps][n] or NULL
@@ -289,6 +293,27 @@ __global__ __launch_bounds__(kThetaBlock) __attribute__((amdgpu_waves_per_eu(1, 
     static_assert(!MIXED || KIND == kSnapGeneric, "a mixed launch has an interval per lane");
     if (K.started_word != nullptr && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)  // (the last workgroup runs: all of them have been placed)
         __hip_atomic_store(K.started_word, K.started_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // Launch by launch the kernel itself waits for its block's prepare kernel (round 6): a stream wait ahead of it costs 8-17 us
+    // between two theta kernels — the run's critical path once its prepare phase overlaps the run before — and a theta kernel that
+    // only becomes ready while a chip-filling kernel holds the chip cannot get its 276-register waves onto it before that one drains
+    // (docs/experiments.md A.4); launched right behind the theta kernel of the block before, its waves are resident when the word
+    // comes.  Nothing this wait depends on can be behind this kernel in any queue: the prepare kernel, the stream write that raises the
+    // word and everything THEY wait for were issued before this launch (rsik_control_continuous_run's issue order), and what the
+    // waiting waves hold — a wave slot and 276 registers on 64 SIMDs — none of those needs.  Bounded all the same: a second on the
+    // 100 MHz counter, then the walk goes on with whatever is there and the context's timeout word says so.
+    if (K.wait_word != nullptr) {
+        const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+        while ((int)(__hip_atomic_load(K.wait_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - K.wait_seq) < 0) {
+            __builtin_amdgcn_s_sleep(4);
+            if (__builtin_amdgcn_s_memrealtime() - t_begin > 100000000ull) {
+                if (threadIdx.x == 0) __hip_atomic_store(K.timeout_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+        // (what the prepare kernel wrote was released to memory when it ended, before the word was raised: no line of it may be
+        // served from this XCD's L2 as an earlier user of the workspace slot left it)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     // a serial phase: its few waves share their SIMDs with the chip-filling phases of the neighbouring blocks (other
     // streams) and must win the issue arbitration, or every instruction waits behind throughput work
     __builtin_amdgcn_s_setprio(3);
@@ -767,6 +792,8 @@ __device__ __forceinline__ void cont_chain_walk(const ContRunArgs& K, SharedTabl
 template <bool MIXED>
 __global__ __launch_bounds__(kChainBlock) __attribute__((amdgpu_waves_per_eu(1, 1))) void cont_chain_kernel(const ContRunArgs K) {
     RSIK_PIPE_STAMP(K, 3);
+    if (K.chain_started_word != nullptr && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+        __hip_atomic_store(K.chain_started_word, K.started_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // a serial phase beside throughput phases (see cont_theta_kernel), one step below the theta phase, which is the
     // critical path where the two share a SIMD (0.544 -> 0.536 ms per 4096 x 1000 pass)
     __builtin_amdgcn_s_setprio(2);

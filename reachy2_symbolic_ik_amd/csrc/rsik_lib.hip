@@ -51,6 +51,22 @@ struct rsik_ctx {
     unsigned edge_seq;               // runs issued with them: the value a word must reach
     int can_wait_value;              // hipDeviceAttributeCanUseStreamWaitValue
     hipStream_t side[3];             // the pipeline's own streams (prepare / joints / chain), created on first use
+    // Bookkeeping across continuous runs issued launch by launch with value-word edges (RSIK_OPT_CONT_GOALS_RESIDENT, see
+    // rsik_control_continuous_run): which chain kernel used each workspace slot last, and what the last run wrote besides.
+    struct SlotUse { size_t word; unsigned seq; } slot_use[8];  // seq 0: nobody since the streams last met
+    int slot_next;                   // the slot the next overlapped run's first block takes
+    struct LastRun {
+        bool valid;                  // a phased run issued launch by launch with value words; nothing since has made it useless
+        unsigned seq;
+        hipStream_t stream;
+        const void* ws;
+        const unsigned* words;
+        int64_t n, n_steps, T, n_blocks;
+        size_t slot_bytes;
+        int slots;
+        const uint8_t *state_lo, *state_hi, *reach_lo, *reach_hi;  // the rows its prepare and chain kernels wrote
+    } last_run;
+    int last_run_form;               // RSIK_CONT_FORM_* of the last rsik_control_continuous_run (rsik_control_continuous_last_form)
     std::vector<hipEvent_t> events;  // reusable, timing disabled
     bool have_side;
     std::string err;
@@ -116,6 +132,10 @@ int rsik_create(int device_id, rsik_ctx** out) {
     c->can_wait_value = 0;
     (void)hipDeviceGetAttribute(&c->can_wait_value, hipDeviceAttributeCanUseStreamWaitValue, device_id);
     c->have_side = false;
+    for (auto& u : c->slot_use) u = {0, 0};
+    c->slot_next = 0;
+    c->last_run = {};
+    c->last_run_form = RSIK_CONT_FORM_NONE;
     for (auto& st : c->side) st = nullptr;
     *out = c;
     return RSIK_OK;
@@ -148,6 +168,15 @@ int rsik_sync(rsik_ctx* ctx) {
     if (!ctx) return RSIK_E_INVALID;
     RSIK_HIP(ctx, hipSetDevice(ctx->device));
     RSIK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // a theta kernel that gave up waiting for its prepare kernel (cannot happen; the wait is bounded so that it cannot hang either)
+    if (ctx->edge_words) {
+        unsigned gave_up = 0;
+        RSIK_HIP(ctx, hipMemcpy(&gave_up, ctx->edge_words + 3, sizeof gave_up, hipMemcpyDeviceToHost));
+        if (gave_up != 0) {
+            (void)hipMemset(ctx->edge_words + 3, 0, sizeof gave_up);
+            return fail(ctx, RSIK_E_HIP, "rsik_sync: a theta kernel of rsik_control_continuous_run waited a second for its prepare kernel and went on without it: the results of that run are invalid");
+        }
+    }
     // workspaces that continuous runs outgrew: whatever was issued into them has finished now
     if (!ctx->outgrown_ws.empty()) {
         if (ctx->have_run_done) RSIK_HIP(ctx, hipEventSynchronize(ctx->run_done));
@@ -170,7 +199,7 @@ int rsik_set_arm(rsik_ctx* ctx, int arm, const double* consts_host, int count) {
 int rsik_set_option(rsik_ctx* ctx, int option, int value) {
     if (!ctx) return RSIK_E_INVALID;
     if (option < 0 || option >= RSIK_OPT_COUNT) return fail(ctx, RSIK_E_INVALID, "rsik_set_option: unknown option");
-    static const int max_value[RSIK_OPT_COUNT] = {RSIK_EULER_NEVER, 2, 1, 1, RSIK_CONT_RUN_STEPS, 65535, 3};
+    static const int max_value[RSIK_OPT_COUNT] = {RSIK_EULER_NEVER, 2, 1, 1, RSIK_CONT_RUN_STEPS, 65535, 31, 1};
     if (value < 0 || value > max_value[option]) return fail(ctx, RSIK_E_INVALID, "rsik_set_option: value out of range");
     ctx->options[option] = value;
     return RSIK_OK;
@@ -511,13 +540,16 @@ struct ContPlan {
     int slots;
     size_t n_events;
 };
-constexpr int kContSlots = 8;  // workspace slots in flight (block b + 8 reuses the slot of block b once its chain phase has finished)
+constexpr int kContSlots = 8;
+static_assert(kContSlots == sizeof(rsik_ctx::slot_use) / sizeof(rsik_ctx::slot_use[0]), "rsik_ctx::slot_use holds one entry per workspace slot");  // workspace slots in flight (block b + 8 reuses the slot of block b once its chain phase has finished)
 // `capturing`: the call is being recorded into a hipGraph.  A replay executes the dependency DAG with 15-40 us per edge
 // whatever the streams were, so fewer, longer blocks pay there (4096 x 1000 steps replayed: 0.379 ms with two blocks,
 // 0.383 with three, 0.395 with four); launched eagerly four blocks are best (0.43 against 0.46 with two: more overlap for
 // the same host-side issue cost).  Round 5, after the value-word edges and the theta-first hold: three blocks are level with or 1-2 %
 // ahead of four in every sweep (blocks of 256 / 352 steps: 0.370 / 0.363, 0.378 / 0.374, 0.373 / 0.367 ms on three boxes).
-static int cont_plan(rsik_ctx* ctx, const char* who, int64_t n, int64_t n_steps, bool capturing, ContPlan& P) {
+// `all_slots`: the workspace holds kContSlots slots whatever the number of blocks (RSIK_OPT_CONT_GOALS_RESIDENT: the next run's
+// blocks take the slots this run's do not).
+static int cont_plan(rsik_ctx* ctx, const char* who, int64_t n, int64_t n_steps, bool capturing, ContPlan& P, bool all_slots = false) {
     // (the sequential phases address a block's arrays through 2 GB buffer windows: rows of n * 56 bytes, blocks of <= 384 MB
     // of workspace, i.e. <= 1.3 GB of joints; every block costs the host four launches, so blocks are as long as that allows)
     if (n > (int64_t)30 << 20) return fail(ctx, RSIK_E_INVALID, std::string(who) + ": more than 30 Mi trajectories in one call");
@@ -532,6 +564,9 @@ static int cont_plan(rsik_ctx* ctx, const char* who, int64_t n, int64_t n_steps,
     const int64_t parts = capturing ? 2 : 3;
     int64_t T = ctx->options[RSIK_OPT_CONT_BLOCK_STEPS] > 0 ? ctx->options[RSIK_OPT_CONT_BLOCK_STEPS] : (n_steps + parts - 1) / parts;
     if (T < 64 && ctx->options[RSIK_OPT_CONT_BLOCK_STEPS] == 0) T = 64;
+    // (round 6, runs of 2 000 ... 16 000 steps launch by launch: blocks of 512 steps 0.340-0.377 ms per 1000 steps where a third of
+    // the run took 0.362-0.450 and blocks of 256 / 352 0.36-0.41 — profiles/r06/config5_long_runs.txt)
+    if (!capturing && ctx->options[RSIK_OPT_CONT_BLOCK_STEPS] == 0 && T > 512) T = 512;
     T = (T + rsik::kSeqBatch - 1) / rsik::kSeqBatch * rsik::kSeqBatch;
     if (T > T_max) T = T_max >= rsik::kSeqBatch ? T_max / rsik::kSeqBatch * rsik::kSeqBatch : T_max;
     if (T > n_steps) T = n_steps;
@@ -544,10 +579,10 @@ static int cont_plan(rsik_ctx* ctx, const char* who, int64_t n, int64_t n_steps,
     const int64_t n_blocks = (int64_t)P.block_t0.size();
     P.chunks_per_block = ((size_t)T + rsik::kJointChunk - 1) / rsik::kJointChunk;
     P.slot_bytes = (((size_t)T * P.per_step + P.chunks_per_block * (size_t)n + 255) / 256) * 256;
-    P.slots = n_blocks < kContSlots ? (int)n_blocks : kContSlots;
+    P.slots = (n_blocks < kContSlots && !all_slots) ? (int)n_blocks : kContSlots;
     P.carry_bytes = (((size_t)n * 2 * sizeof(double) + 255) / 256) * 256;
     P.need = P.slot_bytes * P.slots + P.carry_bytes;
-    P.n_events = 2 + 4 * (size_t)n_blocks;
+    P.n_events = 4 + 6 * (size_t)n_blocks;  // per run 4, per block: prepared, theta, joints, chain, "theta / chain has started" (words only)
     return RSIK_OK;
 }
 // Workspace, side streams and events for a plan.  Nothing here may happen while the caller's stream is capturing (device
@@ -602,16 +637,26 @@ static int cont_resources(rsik_ctx* ctx, const char* who, size_t need, bool want
 }
 
 #ifdef RSIK_PIPE_TIMING
-// diagnostic builds: the phase kernels' first-start / last-end stamps of the PREVIOUS run are printed (RSIK_PIPE_TIMING_PRINT), the
-// stamp area cleared for this one
+// diagnostic builds: the phase kernels' first-start / last-end stamps of the PREVIOUS run are printed (RSIK_PIPE_TIMING_PRINT).  Two
+// stamp areas take turns, and a run clears the area of the run AFTER it: with RSIK_OPT_CONT_GOALS_RESIDENT a run's prepare kernels
+// can execute before the caller's stream has reached that run's start.
 static unsigned long long* pipe_timing_begin(rsik_ctx* ctx, int64_t n_blocks) {
-    static unsigned long long* pipe_t = nullptr;  // [2][5 * 64]: min stamps, then max stamps
-    static int64_t pipe_prev_blocks = 0;
-    if (!pipe_t) { if (hipMalloc(&pipe_t, 2 * 320 * sizeof(unsigned long long)) != hipSuccess) pipe_t = nullptr; }
-    if (pipe_t && getenv("RSIK_PIPE_TIMING_PRINT") && pipe_prev_blocks > 0) {  // (that run has been synchronised by now)
+    static unsigned long long* pipe_t = nullptr;  // [2 areas][2][5 * 64]: min stamps, then max stamps
+    static int64_t pipe_prev_blocks = 0, pipe_run = 0;
+    auto clear = [&](unsigned long long* area, hipStream_t st) {
+        (void)hipMemsetAsync(area, 0xff, 320 * sizeof(unsigned long long), st);
+        (void)hipMemsetAsync(area + 320, 0, 320 * sizeof(unsigned long long), st);
+    };
+    if (!pipe_t) {
+        if (hipMalloc(&pipe_t, 2 * 640 * sizeof(unsigned long long)) != hipSuccess) pipe_t = nullptr;
+        if (pipe_t) { clear(pipe_t, ctx->stream); clear(pipe_t + 640, ctx->stream); (void)hipStreamSynchronize(ctx->stream); }
+    }
+    if (!pipe_t) return nullptr;
+    unsigned long long* const mine = pipe_t + 640 * (pipe_run & 1), * const other = pipe_t + 640 * ((pipe_run + 1) & 1);
+    if (getenv("RSIK_PIPE_TIMING_PRINT") && pipe_prev_blocks > 0) {  // (that run has been synchronised by now)
         unsigned long long h[640];
         (void)hipDeviceSynchronize();
-        (void)hipMemcpy(h, pipe_t, sizeof h, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(h, other, sizeof h, hipMemcpyDeviceToHost);
         unsigned long long base = ~0ull;
         for (int k = 0; k < 320; k++) if (h[k] < base) base = h[k];
         static const char* names[5] = {"prepare", "theta", "joints", "chain", "turns"};
@@ -620,12 +665,10 @@ static unsigned long long* pipe_timing_begin(rsik_ctx* ctx, int64_t n_blocks) {
                 if (h[b * 5 + ph] != ~0ull)
                     fprintf(stderr, "[pipe] %-8s(%lld) %8.2f -> %8.2f us\n", names[ph], (long long)b, (h[b * 5 + ph] - base) / 100.0, (h[320 + b * 5 + ph] - base) / 100.0);
     }
-    if (pipe_t) {
-        (void)hipMemsetAsync(pipe_t, 0xff, 320 * sizeof(unsigned long long), ctx->stream);
-        (void)hipMemsetAsync(pipe_t + 320, 0, 320 * sizeof(unsigned long long), ctx->stream);
-    }
+    clear(other, ctx->stream);  // (for the run after this one)
     pipe_prev_blocks = n_blocks;
-    return pipe_t;
+    pipe_run += 1;
+    return mine;
 }
 #endif
 
@@ -637,7 +680,7 @@ int rsik_control_continuous_reserve(rsik_ctx* ctx, int64_t n, int64_t n_steps) {
     RSIK_HIP(ctx, hipSetDevice(ctx->device));
     // what an eager run and what a captured run of this size need (their block sizes differ): the larger of each
     ContPlan P, Pc;
-    int rc = cont_plan(ctx, who, n, n_steps, false, P);
+    int rc = cont_plan(ctx, who, n, n_steps, false, P, ctx->options[RSIK_OPT_CONT_GOALS_RESIDENT] != 0);
     if (rc != RSIK_OK) return rc;
     if ((rc = cont_plan(ctx, who, n, n_steps, true, Pc)) != RSIK_OK) return rc;
     if (Pc.need > P.need) P.need = Pc.need;
@@ -657,6 +700,8 @@ int rsik_control_continuous_release(rsik_ctx* ctx) {
     ctx->ws = nullptr;
     ctx->ws_bytes = 0;
     ctx->ws_captured = false;
+    ctx->last_run.valid = false;
+    for (auto& u : ctx->slot_use) u = {0, 0};
     return RSIK_OK;
 }
 
@@ -708,6 +753,10 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     bool no_limits_can_fail = false;
     for (int slot = 0; slot < 2; slot++) no_limits_can_fail = no_limits_can_fail || !(K0.arms[slot].v[RSIK_C_PROJ_MARGIN] > 1e-12);
     if (ctx->options[RSIK_OPT_CONT_RUN_MODE] == RSIK_CONT_RUN_STEPS || no_limits_can_fail) {
+        // (what the run was issued as is the caller's to know: rsik_control_continuous_last_form — a solver whose projection margin
+        // lets is_reachable_no_limits fail gets n_steps launches whatever RSIK_OPT_CONT_RUN_MODE says)
+        ctx->last_run_form = ctx->options[RSIK_OPT_CONT_RUN_MODE] == RSIK_CONT_RUN_STEPS ? RSIK_CONT_FORM_STEPS : RSIK_CONT_FORM_STEPS_NO_LIMITS_CAN_FAIL;
+        ctx->last_run.valid = false;  // (this run's outputs are written on the caller's stream: the next phased run forks behind them)
         for (int64_t k = 0; k < n_steps; k++) {
             rsik::ContinuousArgs K = K0;
             for (int c = 0; c < 12; c++) K.in[c] = m12_steps + ((size_t)k * 12 + c) * (size_t)n;
@@ -744,13 +793,15 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     // got slower, 2.4 ms per pass.)
     // A run is cut into blocks of steps; up to eight workspace slots are in flight (block b + 8 reuses the slot of block b
     // once its last phase has finished).
+    // RSIK_OPT_CONT_GOALS_RESIDENT (rsik.h): the prepare phase of this run need not wait for the previous run's end
+    const bool resident = !capturing && ctx->options[RSIK_OPT_CONT_GOALS_RESIDENT] != 0;
     ContPlan P;
-    if ((rc = cont_plan(ctx, who, n, n_steps, capturing, P)) != RSIK_OK) return rc;
+    if ((rc = cont_plan(ctx, who, n, n_steps, capturing, P, resident)) != RSIK_OK) return rc;
     {
         // the context holds what BOTH forms of a run of this size need, so that a run that was first issued eagerly can be
         // captured afterwards (and the other way round) without creating anything
         ContPlan other, both = P;
-        if ((rc = cont_plan(ctx, who, n, n_steps, !capturing, other)) != RSIK_OK) return rc;
+        if ((rc = cont_plan(ctx, who, n, n_steps, !capturing, other, capturing && ctx->options[RSIK_OPT_CONT_GOALS_RESIDENT] != 0)) != RSIK_OK) return rc;
         if (other.need > both.need) both.need = other.need;
         if (other.n_events > both.n_events) both.n_events = other.n_events;
         if ((rc = cont_resources(ctx, who, both.need, true, both.n_events)) != RSIK_OK) return rc;
@@ -773,8 +824,9 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     const int variant = ctx->options[RSIK_OPT_CONT_PHASED_VARIANT];
     const bool by_value = !capturing && ctx->can_wait_value != 0 && !(variant & RSIK_PHASED_EDGES_BY_EVENT);
     if (by_value) {
-        const size_t need_words = P.n_events + (size_t)n_blocks;  // (+ per block: "theta(b) has started")
+        const size_t need_words = P.n_events;
         if (ctx->edge_count < need_words) {
+            ctx->last_run.valid = false;  // (its words are not these: this run forks behind it)
             // (the old words: runs already issued still wait on them and write them — freed like an outgrown workspace)
             if (ctx->edge_words) { ctx->outgrown_ws.push_back(ctx->edge_words); ctx->edge_words = nullptr; ctx->edge_count = 0; }
             RSIK_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->edge_words), need_words * 2 * sizeof(unsigned)));
@@ -785,7 +837,38 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         ctx->edge_seq += 1;
     }
     const unsigned seq = ctx->edge_seq;
-    auto edge_id = [&](int kind, int64_t b) { return 2 + 4 * (size_t)b + kind; };  // 0 prepared, 1 theta, 2 joints, 3 chain; ids 0, 1: the run's start
+    // (a word's meaning does not depend on the run's number of blocks: a word is only ever written from one stream, in issue order,
+    // so its value never goes back — runs that overlap, below, rely on it)
+    // kinds: 0 prepared, 1 theta, 2 joints, 3 chain, 4 the theta kernel has started, 5 the chain kernel has started; ids 0-3 are the
+    // run's: 0 the start-up kernel is done, 1 the prepare stream may fork, 2 the start-up kernel has started
+    auto edge_id = [&](int kind, int64_t b) { return 4 + 6 * (size_t)b + kind; };
+    constexpr size_t kInitStartedId = 2, kTimeoutId = 3;
+    // Does this run's prepare phase start without waiting for the previous run's end?  Only behind a run of the same shape issued the
+    // same way on the same stream into the same workspace and words (anything else: the streams meet first, as always).
+    rsik_ctx::LastRun& L = ctx->last_run;
+    const bool overlap = resident && by_value && L.valid && L.stream == ctx->stream && L.ws == ctx->ws && L.words == ctx->edge_words &&
+                         L.slot_bytes == P.slot_bytes && L.slots == slots && !ctx->ws_captured;
+    const uint8_t* const st_lo = state_steps, * const st_hi = state_steps ? state_steps + (size_t)n_steps * (size_t)n : nullptr;
+    const uint8_t* const rc_lo = reachable_steps, * const rc_hi = reachable_steps ? reachable_steps + (size_t)n_steps * (size_t)n : nullptr;
+    bool alias_any = false, alias_same = false;
+    if (overlap) {
+        auto meet = [](const uint8_t* a0, const uint8_t* a1, const uint8_t* b0, const uint8_t* b1) { return a0 && b0 && a0 < b1 && b0 < a1; };
+        alias_any = meet(st_lo, st_hi, L.state_lo, L.state_hi) || meet(st_lo, st_hi, L.reach_lo, L.reach_hi) ||
+                    meet(rc_lo, rc_hi, L.state_lo, L.state_hi) || meet(rc_lo, rc_hi, L.reach_lo, L.reach_hi);
+        alias_same = alias_any && st_lo == L.state_lo && rc_lo == L.reach_lo && n == L.n && n_steps == L.n_steps && P.T == L.T;
+    } else {
+        for (auto& u : ctx->slot_use) u = {0, 0};  // the streams meet at this run's start: every slot is free
+    }
+    const int slot_base = overlap ? ctx->slot_next : 0;
+    // A run that overlaps the one before it: its theta kernels wait for their prepare kernels themselves (cont_theta_kernel), and the
+    // joints kernel of a block takes "theta of the NEXT block has started" for "theta of this block is done" (same stream: it is) —
+    // so that nothing stands between two theta kernels on the caller's stream.  Only there: K overlapping 1000-step passes 0.334-0.342
+    // against 0.341-0.346 ms with stream waits, same box; a run on its own is level (0.357-0.371 / 0.363-0.378), a long one — 8 000 /
+    // 16 000 steps in blocks of 512 — slower, 0.348 / 0.425 against 0.340 / 0.377 ms per 1000 steps (profiles/r06/config5_long_runs.txt).
+    // (variant bit 16, timing experiments and the A/B tests: stream waits and writes there too)
+    const bool theta_waits = by_value && overlap && !(variant & 16);
+    const unsigned last_seq = L.seq;
+    const int64_t last_blocks = L.n_blocks;
     auto signal = [&](hipStream_t st, size_t id) -> hipError_t {
         if (by_value) return hipStreamWriteValue32(st, ctx->edge_words + id, seq, 0);
         return hipEventRecord(ctx->events[id], st);
@@ -835,7 +918,7 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         R.T = block_T[b];
         R.first_block = b == 0;
         R.last_block = b == n_blocks - 1;
-        R.ws = reinterpret_cast<double*>(static_cast<char*>(ctx->ws) + slot_bytes * (size_t)(b % slots));
+        R.ws = reinterpret_cast<double*>(static_cast<char*>(ctx->ws) + slot_bytes * (size_t)((slot_base + b) % slots));
         R.gw = R.ws + (size_t)R.T * (size_t)n;
         R.flags = reinterpret_cast<uint8_t*>(R.gw + (size_t)R.T * (size_t)n);
         R.chunk_event = R.flags + (size_t)R.T * (size_t)n;
@@ -844,7 +927,29 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     auto issue_prepare = [&](int64_t b) -> int {
         set_block(b);
         const dim3 grid2(grid.x, (unsigned)R.T);
-        if (b >= slots) RSIK_HIP(ctx, wait_for(s_prep, edge_id(3, b - slots)));  // the slot's previous block is done
+        // the slot's previous block is done (launch by launch: whichever run it belonged to)
+        if (by_value) {
+            const rsik_ctx::SlotUse u = ctx->slot_use[(slot_base + b) % slots];
+            if (u.seq != 0) RSIK_HIP(ctx, hipStreamWaitValue32(s_prep, ctx->edge_words + u.word, u.seq, hipStreamWaitValueGte, 0xffffffffu));
+            ctx->slot_use[(slot_base + b) % slots] = {edge_id(3, b), seq};
+            // a run that overlaps the one before it and writes the same reachable / state rows: behind that run's chain kernel of
+            // the same rows (the same cut), or of its last block
+            // (and not before that run's last joints kernel has finished: started earlier, this run's prepare kernels share the chip
+            // with that run's joints kernels, which its end — and with it this run's start-up — waits for: K passes took 0.39-0.41 ms
+            // each instead of 0.36-0.39; behind it they fill the chip while that run's last chain kernel and this run's start-up
+            // search, lone waves both, have it to themselves)
+            // (variant bits 4 / 8, timing experiments: no such wait / the last chain kernel's END)
+            if (overlap && b == 0 && !(variant & 4)) RSIK_HIP(ctx, hipStreamWaitValue32(s_prep, ctx->edge_words + edge_id((variant & 8) ? 3 : 5, last_blocks - 1), last_seq, hipStreamWaitValueGte, 0xffffffffu));
+            // ... and the later ones leave the chip to the lone waves ahead of them on the critical path — the start-up search, then
+            // theta(0), theta(1) ...: prepare(1) is held until the start-up kernel has started, prepare(b) until theta(b - 2) has (each
+            // issued before this wait, issue_all's order for a run that overlaps)
+            if (overlap && b == 1 && !(variant & 4)) RSIK_HIP(ctx, hipStreamWaitValue32(s_prep, ctx->edge_words + kInitStartedId, seq, hipStreamWaitValueGte, 0xffffffffu));
+            if (overlap && b >= 2 && !(variant & 4)) RSIK_HIP(ctx, hipStreamWaitValue32(s_prep, ctx->edge_words + edge_id(4, b - 2), seq, hipStreamWaitValueGte, 0xffffffffu));
+            if (alias_same) RSIK_HIP(ctx, hipStreamWaitValue32(s_prep, ctx->edge_words + edge_id(3, b), last_seq, hipStreamWaitValueGte, 0xffffffffu));
+            else if (alias_any && b == 0) RSIK_HIP(ctx, hipStreamWaitValue32(s_prep, ctx->edge_words + edge_id(3, last_blocks - 1), last_seq, hipStreamWaitValueGte, 0xffffffffu));
+        } else if (b >= slots) {
+            RSIK_HIP(ctx, wait_for(s_prep, edge_id(3, b - slots)));
+        }
         if (arm) { if (plane_binds) hipLaunchKernelGGL((rsik::cont_prepare_kernel<true, true>), grid2, block, 0, s_prep, R); else hipLaunchKernelGGL((rsik::cont_prepare_kernel<true, false>), grid2, block, 0, s_prep, R); }
         else { if (plane_binds) hipLaunchKernelGGL((rsik::cont_prepare_kernel<false, true>), grid2, block, 0, s_prep, R); else hipLaunchKernelGGL((rsik::cont_prepare_kernel<false, false>), grid2, block, 0, s_prep, R); }
         RSIK_HIP(ctx, signal(s_prep, edge_id(0, b)));
@@ -853,15 +958,22 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     auto issue_theta = [&](int64_t b) -> int {
         set_block(b);
         // (launch by launch: the kernel says when it has started — the joints kernel of the block before is held until then)
-        R.started_word = by_value ? ctx->edge_words + P.n_events + (size_t)b : nullptr;
+        R.started_word = by_value ? ctx->edge_words + edge_id(4, b) : nullptr;
         R.started_seq = seq;
-        RSIK_HIP(ctx, wait_for(s_theta, edge_id(0, b)));
+        if (theta_waits) {
+            R.wait_word = ctx->edge_words + edge_id(0, b);
+            R.wait_seq = seq;
+            R.timeout_word = ctx->edge_words + kTimeoutId;
+        } else {
+            R.wait_word = nullptr;
+            RSIK_HIP(ctx, wait_for(s_theta, edge_id(0, b)));
+        }
         const dim3 grid_t((unsigned)((n + rsik::kThetaBlock - 1) / rsik::kThetaBlock)), block_t(rsik::kThetaBlock);
         if (arm) hipLaunchKernelGGL((rsik::cont_theta_kernel<true, rsik::kSnapGeneric>), grid_t, block_t, 0, s_theta, R);
         else if (snap_kind == rsik::kSnapInner) hipLaunchKernelGGL((rsik::cont_theta_kernel<false, rsik::kSnapInner>), grid_t, block_t, 0, s_theta, R);
         else if (snap_kind == rsik::kSnapWrap) hipLaunchKernelGGL((rsik::cont_theta_kernel<false, rsik::kSnapWrap>), grid_t, block_t, 0, s_theta, R);
         else hipLaunchKernelGGL((rsik::cont_theta_kernel<false, rsik::kSnapGeneric>), grid_t, block_t, 0, s_theta, R);
-        RSIK_HIP(ctx, signal(s_theta, edge_id(1, b)));
+        if (!theta_waits || b == n_blocks - 1) RSIK_HIP(ctx, signal(s_theta, edge_id(1, b)));
         return RSIK_OK;
     };
     auto issue_back = [&](int64_t b) -> int {  // joints(b), chain(b)
@@ -877,15 +989,18 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         // completed, so that the prepare kernels — which every later phase of a block waits for — have the chip to themselves:
         // 0.424 against 0.371 ms per pass, the joints kernels then run one behind the other with a stream operation's ~15 us
         // between them; higher stream priority for the prepare and chain streams: no difference)
-        // (only where theta(b + 1) has been ISSUED before this wait: streams can share a hardware queue, and a wait that sat in one
-        // ahead of the launch it waits for would wait for ever — true for the blocks that have workspace slots of their own)
-        RSIK_HIP(ctx, wait_for(s_joints, edge_id(1, b)));
-        if (by_value && !(variant & RSIK_PHASED_NO_THETA_FIRST) && b + 1 < head)
-            RSIK_HIP(ctx, hipStreamWaitValue32(s_joints, ctx->edge_words + P.n_events + (size_t)(b + 1), seq, hipStreamWaitValueGte, 0xffffffffu));
+        // (theta(b + 1) has been ISSUED before this wait — issue_all's order: streams can share a hardware queue, and a wait that
+        // sat in one ahead of the launch it waits for would wait for ever)
+        if (!theta_waits || b == n_blocks - 1) RSIK_HIP(ctx, wait_for(s_joints, edge_id(1, b)));
+        else RSIK_HIP(ctx, hipStreamWaitValue32(s_joints, ctx->edge_words + edge_id(4, b + 1), seq, hipStreamWaitValueGte, 0xffffffffu));
+        if (by_value && !theta_waits && !(variant & RSIK_PHASED_NO_THETA_FIRST) && b + 1 < n_blocks)
+            RSIK_HIP(ctx, hipStreamWaitValue32(s_joints, ctx->edge_words + edge_id(4, b + 1), seq, hipStreamWaitValueGte, 0xffffffffu));
         if (arm) hipLaunchKernelGGL(rsik::cont_joints_kernel<true>, grid2, block, 0, s_joints, R);
         else hipLaunchKernelGGL(rsik::cont_joints_kernel<false>, grid2, block, 0, s_joints, R);
         RSIK_HIP(ctx, signal(s_joints, edge_id(2, b)));
         RSIK_HIP(ctx, wait_for(s_chain, edge_id(2, b)));
+        R.chain_started_word = by_value ? ctx->edge_words + edge_id(5, b) : nullptr;
+        R.started_seq = seq;
         if (arm) hipLaunchKernelGGL(rsik::cont_chain_kernel<true>, grid8, dim3(rsik::kChainBlock), 0, s_chain, R);
         else hipLaunchKernelGGL(rsik::cont_chain_kernel<false>, grid8, dim3(rsik::kChainBlock), 0, s_chain, R);
         RSIK_HIP(ctx, signal(s_chain, edge_id(3, b)));
@@ -896,21 +1011,32 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     // the trajectory state: its stream forks off BEFORE the initialisation (behind whatever the caller queued ahead of
     // this call), so prepare(0) runs beside it and theta(0) starts when both are done; the joints and chain streams fork
     // behind it.
+    // RSIK_OPT_CONT_GOALS_RESIDENT, behind a run of the same shape: the prepare stream does not fork at all — it carries on behind
+    // the previous run's prepare kernels, so this run's run beside that run's joints and chain kernels (its slots and output rows
+    // are waited for one by one, issue_prepare); the start-up kernel and everything behind it wait for the previous run's end
+    // as they must (the trajectory state).
     auto issue_start = [&]() -> int {
-        RSIK_HIP(ctx, signal(s_main, 1));
-        RSIK_HIP(ctx, wait_for(s_prep, 1));
+        if (!overlap) {
+            RSIK_HIP(ctx, signal(s_main, 1));
+            RSIK_HIP(ctx, wait_for(s_prep, 1));
+        }
         {
             // two lanes per trajectory where get_joints cannot move the solver's state (no elbow projection possible)
             const bool pair = !singularity_plane_binds(K0.arms);
             dim3 grid_init = grid;
             int rc_ = RSIK_OK;
             if (pair && (rc_ = launch_dims(ctx, n * 2, &grid_init, who)) != RSIK_OK) return rc_;
+            K0.started_word = by_value ? ctx->edge_words + kInitStartedId : nullptr;
+            K0.started_seq = seq;
             if (arm) { if (pair) hipLaunchKernelGGL((rsik::cont_init_kernel<true, true>), grid_init, block, 0, s_main, K0); else hipLaunchKernelGGL((rsik::cont_init_kernel<true, false>), grid_init, block, 0, s_main, K0); }
             else { if (pair) hipLaunchKernelGGL((rsik::cont_init_kernel<false, true>), grid_init, block, 0, s_main, K0); else hipLaunchKernelGGL((rsik::cont_init_kernel<false, false>), grid_init, block, 0, s_main, K0); }
-            RSIK_HIP(ctx, signal(s_main, 0));
+            // (the joints and chain streams' first kernels wait for theta(0), which is behind this kernel on its stream)
+            if (!theta_waits) RSIK_HIP(ctx, signal(s_main, 0));
         }
-        RSIK_HIP(ctx, wait_for(s_joints, 0));
-        RSIK_HIP(ctx, wait_for(s_chain, 0));
+        if (!theta_waits) {
+            RSIK_HIP(ctx, wait_for(s_joints, 0));
+            RSIK_HIP(ctx, wait_for(s_chain, 0));
+        }
         return RSIK_OK;
     };
     // Issue order of the blocks that have a workspace slot of their own (it is also the order of the nodes in a captured
@@ -923,15 +1049,28 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         if (rc_ != RSIK_OK) return rc_;
         if ((rc_ = issue_prepare(0)) != RSIK_OK) return rc_;
         if ((rc_ = issue_theta(0)) != RSIK_OK) return rc_;
-        for (int64_t b = 1; b < head; b++)
-            if ((rc_ = issue_prepare(b)) != RSIK_OK) return rc_;
-        for (int64_t b = 1; b < head; b++)
-            if ((rc_ = issue_theta(b)) != RSIK_OK) return rc_;
-        for (int64_t b = 0; b < head; b++)
-            if ((rc_ = issue_back(b)) != RSIK_OK) return rc_;
-        for (int64_t b = head; b < n_blocks; b++) {
-            if ((rc_ = issue_prepare(b)) != RSIK_OK) return rc_;
-            if ((rc_ = issue_theta(b)) != RSIK_OK) return rc_;
+        if (overlap) {
+            // (a run that overlaps the one before it holds prepare(b) until theta(b - 2) has started: that one is issued first)
+            for (int64_t b = 1; b < head; b++) {
+                if ((rc_ = issue_prepare(b)) != RSIK_OK) return rc_;
+                if ((rc_ = issue_theta(b)) != RSIK_OK) return rc_;
+            }
+        } else {
+            for (int64_t b = 1; b < head; b++)
+                if ((rc_ = issue_prepare(b)) != RSIK_OK) return rc_;
+            for (int64_t b = 1; b < head; b++)
+                if ((rc_ = issue_theta(b)) != RSIK_OK) return rc_;
+        }
+        // joints + chain of every block; a block beyond the head (it reuses a workspace slot: its prepare kernel waits for the
+        // chain kernel of the block `slots` before it, issued by then) has its prepare and theta kernels issued just ahead of
+        // the joints kernel of the block BEFORE it, so that that one can be held until the theta kernel has started, like the
+        // head's (round 6: a 16 384-step run in blocks of 512 had its theta kernels start 60-100 us late, behind whichever
+        // chip-filling kernel was draining, profiles/r06/config5_long_runs.txt)
+        for (int64_t b = 0; b < n_blocks; b++) {
+            if (b + 1 >= head && b + 1 < n_blocks) {
+                if ((rc_ = issue_prepare(b + 1)) != RSIK_OK) return rc_;
+                if ((rc_ = issue_theta(b + 1)) != RSIK_OK) return rc_;
+            }
             if ((rc_ = issue_back(b)) != RSIK_OK) return rc_;
         }
         // the caller's stream continues once the last chain (hence every phase of every block) is done
@@ -955,10 +1094,24 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
             (void)hipGetLastError();
             ctx->err = first_error;
         }
+        ctx->last_run.valid = false;
+        for (auto& u : ctx->slot_use) u = {0, 0};
         return rc;
+    }
+    if (capturing) {
+        ctx->last_run_form = RSIK_CONT_FORM_PHASED_CAPTURED;
+    } else {
+        ctx->last_run_form = overlap ? RSIK_CONT_FORM_PHASED_OVERLAPPED : RSIK_CONT_FORM_PHASED;
+        L.valid = by_value;
+        L.seq = seq; L.stream = ctx->stream; L.ws = ctx->ws; L.words = ctx->edge_words;
+        L.n = n; L.n_steps = n_steps; L.T = P.T; L.n_blocks = n_blocks; L.slot_bytes = P.slot_bytes; L.slots = slots;
+        L.state_lo = st_lo; L.state_hi = st_hi; L.reach_lo = rc_lo; L.reach_hi = rc_hi;
+        ctx->slot_next = (int)((slot_base + n_blocks) % slots);
     }
     return cont_run_end(ctx, capturing);
 }
+
+int rsik_control_continuous_last_form(const rsik_ctx* ctx) { return ctx ? ctx->last_run_form : RSIK_CONT_FORM_NONE; }
 
 int rsik_matrix_to_pose(rsik_ctx* ctx, int64_t n, const double* const m12_soa[12], int identity_shortcut,
                         double* const pose_soa[6]) {

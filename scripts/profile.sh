@@ -11,7 +11,7 @@ cd /tmp
 # (config 5 under the counters: issued launch by launch with its streams tied by events, as in round 3 — a profiler that serialises
 # dispatches deadlocks on a replayed multi-stream graph (round 4: every --pmc pass of `--launch graph` sat until its timeout), and
 # waits on device words are not its business either)
-LAUNCH=eager; [ "$CFG" = 5 ] && LAUNCH="eager --phased-variant 1 --no-steady-state"
+LAUNCH="eager --no-steady-state"; [ "$CFG" = 5 ] && LAUNCH="eager --phased-variant 1 --no-steady-state"
 python3 $R/bench.py --config $CFG > $OUT/bench.json 2> $OUT/bench.err
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --config $CFG --no-cpu-baseline --no-extras --no-steady-state --no-live-traffic > $OUT/trace.log 2>&1
 timeout -k 10 150 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --config $CFG --steps 5 --warmup 2 --launch $LAUNCH --no-cpu-baseline --no-extras --no-live-traffic > $OUT/pmc_fetch.log 2>&1

@@ -1440,7 +1440,7 @@ def test_continuous_run_outgrows_its_workspace_without_stopping_the_device(torch
 def test_continuous_run_that_begins_latched(torch_mod, timed_out):
     """ControlIK answers previous_sol, not reachable, with the emergency state for every goal once its emergency stop is latched
     (control_ik.py:205-210), until "unfreeze".  A run whose trajectories — some of them, or all — are latched when it begins: the
-    pipeline fills their steps in without walking them (the joints phase writes previous_sol rows, the chain phase lets them stand);
+    pipeline fills their steps in without walking them (the chain phase's fill_rest writes the previous_sol rows of a block on entry, stores only);
     every output and the carried state against the step kernel, launch per step; the latched trajectories' rows are previous_sol
     bit for bit and their state rows are untouched, whether or not the caller says its first step timed out."""
     A = _abi_mod()
