@@ -528,9 +528,11 @@ def parse_args(argv):
     ap.add_argument("--gather-every-step", action="store_true", help="same as --gather step")
     ap.add_argument("--chunks", type=int, default=4,
                     help="N > 1 with --gather step: stripes per shard; stripe c's all-gather travels while stripe c + 1 is solved")
-    ap.add_argument("--launch", choices=["auto", "eager", "graph"], default="auto",
+    ap.add_argument("--launch", choices=["auto", "eager", "graph", "pipelined"], default="auto",
                     help="N = 1: K pre-bound launches from Python (eager) or one replay of a hipGraph holding the K launches; "
-                         "auto = graph for K <= 32 and K >= 200, eager between (measured: graphs of 33 ... ~150 nodes replay slower than eager launches)")
+                         "auto = graph for K <= 32 and K >= 200, eager between (measured: graphs of 33 ... ~150 nodes replay slower than eager launches).  "
+                         "Config 5: auto = pipelined = the K passes issued launch by launch with RSIK_OPT_CONT_GOALS_RESIDENT (the prepare phase of "
+                         "pass k + 1 beside the tail of pass k); eager = the same without the overlap; graph = one captured pass replayed K times")
     ap.add_argument("--graph", action="store_true", help="same as --launch graph")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--single-device", action="store_true", help="every rank uses GPU 0 (with --backend gloo: rehearsal on a 1-GPU box)")
@@ -615,6 +617,8 @@ def other_config_entry(oc, sub, wall_s):
         e["traffic_bytes_per_pass"] = (r["traffic"] * 1000) if r.get("traffic") else None
         e["traffic_bytes_per_control_step_of_4096_trajectories"] = r.get("traffic")
         e["frac_at_286_bytes_state_round_trip_per_step"] = r.get("frac_at_286_bytes_state_round_trip_per_step")
+        e["value_is"] = sub.get("value_is")
+        e["run_forms_seen"] = sub.get("run_forms_seen")
     e["steady_state"] = sub.get("steady_state")
     return e
 
@@ -770,6 +774,7 @@ def _run(argv):
     rpp = n // chunks  # rows per piece
     plan = ShardPlan(world * n, world, chunks)
     assert plan.rows_per_piece == rpp
+    form0 = (plan, chunks, rpp)
     f64, u8 = torch.float64, torch.uint8
 
     def local_to_global(i):  # row i of this rank's shard -> row of the all-gathered array (block-cyclic over stripes)
@@ -804,8 +809,10 @@ def _run(argv):
         arm_t = None if arm_id is None else torch.as_tensor(arm_id).to(dev)
         sample_local = {"pos": pos, "eul": eul, "arm": arm_id}
 
-        def make_set(soa_t, arm_tt, shared=None):
-            """Output buffers + one pre-bound rsik_solve launch per stripe for one resident copy of the inputs."""
+        def make_set(soa_t, arm_tt, shared=None, form=None):
+            """Output buffers + one pre-bound rsik_solve launch per stripe for one resident copy of the inputs (`form`: another
+            partition of the shard into stripes than the run's own — the other gather form's timed leg)."""
+            plan, chunks, rpp = form or form0
             if world > 1:
                 sb = shared or ShardedBuffers(plan, rank, {"joints": ((7,), f64), "state": ((), u8)}, dev)
                 o = {"interval": torch.empty((n, 2), dtype=f64, device=dev), "reachable": torch.empty((n,), dtype=u8, device=dev)}
@@ -842,7 +849,8 @@ def _run(argv):
         hs = ctrl._solver
         m12 = matrices_to_m12_soa(M, dev)
 
-        def make_set(m12_t, _unused=None, shared=None):
+        def make_set(m12_t, _unused=None, shared=None, form=None):
+            plan, chunks, rpp = form or form0
             if world > 1:
                 sb = shared or ShardedBuffers(plan, rank, {"joints": ((7,), f64), "state": ((), u8)}, dev)
                 o = {"reachable": torch.empty((n,), dtype=u8, device=dev), "emergency": torch.empty((n,), dtype=u8, device=dev)}
@@ -883,9 +891,29 @@ def _run(argv):
                "reachable": torch.empty((n_steps, n_traj), dtype=u8, device=dev),
                "state": torch.empty((n_steps, n_traj), dtype=u8, device=dev)}
 
+        # (round 6) consecutive passes may overlap: the goals are resident for the whole run and nothing but the passes themselves
+        # touches `out` between them — the promise RSIK_OPT_CONT_GOALS_RESIDENT asks for (include/rsik.h).  The passes stay what they
+        # were: each resets the trajectory state, re-initialises every trajectory and writes every output row.
+        pipelined = [args.launch in ("auto", "pipelined") and world == 1 and not args.phased_variant]
+        forms_seen = {}
+
         def one_pass(stream=None):  # one bench "step" = one 1000-step pass over all trajectories
             cont.copy_(cont0)
-            ctrl.run_continuous_trajectories("r_arm", traj, cont, first_step_timed_out=True, current_pose=traj[0], out=out)
+            r = ctrl.run_continuous_trajectories("r_arm", traj, cont, first_step_timed_out=True, current_pose=traj[0], out=out,
+                                                 goals_resident=pipelined[0])
+            forms_seen[r.run_form_name] = forms_seen.get(r.run_form_name, 0) + 1
+
+        # the captured form lives on a context of its own: a context a hipGraph points into does not overlap its launch-by-launch runs
+        # (the library cannot see replays)
+        graph_ctx = {}
+
+        def one_pass_for_capture(stream=None):
+            if "ctrl" not in graph_ctx:
+                graph_ctx["ctrl"] = _quiet(ControlIK, urdf_path=URDF, device=local_rank)
+                graph_ctx["ctrl"]._upload_arms()
+                graph_ctx["ctrl"]._solver.control_continuous_reserve(n_traj, n_steps)
+            cont.copy_(cont0)
+            graph_ctx["ctrl"].run_continuous_trajectories("r_arm", traj, cont, first_step_timed_out=True, current_pose=traj[0], out=out)
 
         launches = [one_pass]
         workload = (f"config5: ControlIK continuous, {n_traj} trajectories x {n_steps} steps per pass, trajectory state carried "
@@ -937,16 +965,22 @@ def _run(argv):
     # cannot hold — 0.41 -> 0.37-0.39 ms eager; the replayed graph is still 1-3 % ahead and steadier (same box, alternating processes,
     # W = 5 / K = 20: 0.380-0.386 against 0.387-0.391; after 60 more passes 0.363-0.373 against 0.369-0.390), so `auto` replays;
     # both forms are timed below (`steady_state.launch_forms_ms`).
-    use_graph = world == 1 and (args.launch == "graph" or (args.launch == "auto" and (cfg == 5 or args.steps <= 32 or args.steps >= 200)))
+    use_graph = world == 1 and (args.launch == "graph" or (args.launch == "auto" and cfg != 5 and (args.steps <= 32 or args.steps >= 200)))
     graph = None
     graph_replays = 1
     if use_graph:
         try:
             graph = torch.cuda.CUDAGraph()
+            if cfg == 5:
+                one_pass_for_capture()  # (creates the capture's own context, its workspace, streams and events: nothing of that inside a capture)
+                fence()
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 cs = torch.cuda.current_stream(dev).cuda_stream  # the pre-bound launches go to the capture stream
-                for _ in range(1 if cfg == 5 else args.steps):
-                    launch_all(cs)
+                if cfg == 5:
+                    one_pass_for_capture(cs)
+                else:
+                    for _ in range(args.steps):
+                        launch_all(cs)
             graph_replays = args.steps if cfg == 5 else 1
             # untimed: the captured graph replayed once (configs 2-4: that is K launches); config 5's graph holds ONE pass, so
             # the W warm-up steps are repeated as replays — the thing that is timed (the eager warm-up above ran another form)
@@ -991,27 +1025,62 @@ def _run(argv):
             fence()
             return e0.elapsed_time(e1) / k
 
-        mine, other = ("graph", "eager") if graph is not None else ("eager", "graph")
-        forms = {mine: timed_passes(graph.replay if graph is not None else step, 60, args.steps)}
-        try:
-            if graph is None:
+        mine = "graph" if graph is not None else ("pipelined" if pipelined[0] else "eager")
+        was_pipelined = pipelined[0]
+
+        def form_fn(name):
+            if name == "graph":
+                if graph is not None:
+                    return graph.replay
+                one_pass_for_capture()
+                fence()
                 g2 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g2, capture_error_mode="thread_local"):
-                    launch_all(torch.cuda.current_stream(dev).cuda_stream)
-                forms[other] = timed_passes(g2.replay, 60, args.steps)
-                del g2
-            else:
-                forms[other] = timed_passes(step, 60, args.steps)
-        except Exception as e:  # the other form is information only
-            forms[other] = None
-            forms["error"] = f"{type(e).__name__}: {e}"
+                    one_pass_for_capture(torch.cuda.current_stream(dev).cuda_stream)
+                graph_ctx["g2"] = g2
+                return g2.replay
+
+            def launch_by_launch():
+                pipelined[0] = name == "pipelined"
+                step()
+
+            return launch_by_launch
+
+        forms = {}
+        for name in [mine] + [f for f in ("pipelined", "eager", "graph") if f != mine and not (f == "pipelined" and args.phased_variant)]:
+            try:
+                forms[name] = timed_passes(form_fn(name), 60, args.steps)
+            except Exception as e:  # the other forms are information only
+                if name == mine:
+                    raise
+                forms[name] = None
+                forms[name + "_error"] = f"{type(e).__name__}: {e}"
+        # a pass on its own: the device idle before it, HIP events around it (launch by launch, no overlap)
+        pipelined[0] = False
+        iso = []
+        for _ in range(max(3, min(args.steps, 10))):
+            fence()
+            e0.record()
+            step()
+            e1.record()
+            fence()
+            iso.append(e0.elapsed_time(e1))
+        pipelined[0] = was_pipelined
         steady = {"after_untimed_passes": args.warmup + args.steps + 60, "steps": args.steps, "ms_per_step": forms[mine],
                   "value": units / (forms[mine] * 1e-3), "unit": "steps/s", "launch": mine,
                   "frac": BYTES_PER_POSE[5] * units / (forms[mine] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                  "launch_forms_ms": forms}
-        if graph is None:  # the results checked below are the timed form's: one more eager pass after the capture's replays
-            step()
-            fence()
+                  "launch_forms_ms": forms,
+                  "launch_forms": {"pipelined": "K passes launch by launch with RSIK_OPT_CONT_GOALS_RESIDENT: the prepare phase of pass k + 1 runs beside "
+                                                "the last chain kernel of pass k and its own start-up search (everything else of pass k + 1 waits for pass k's "
+                                                "end: the trajectory state)",
+                                   "eager": "K passes launch by launch, every pass's four streams meet at its start and at its end (no overlap between passes)",
+                                   "graph": "one captured pass (two blocks, events) replayed K times: replays of one graph do not overlap"},
+                  "isolated_pass_ms": float(np.median(iso)),
+                  "isolated_pass_what": f"median of {len(iso)} passes issued launch by launch, each with the device idle before it (a synchronisation "
+                                        "between passes: the host's issue latency is inside the figure)"}
+        # the results checked below are the timed form's: one more pass in that form
+        (graph.replay if graph is not None else step)()
+        fence()
 
     # ---- configs 2-4 on one GPU: the same K steps again behind >= `--settle-ms` of untimed launches of the same kind (round 6: the
     # first ~25 launches of a process run below the sustained clock — docs/experiments.md A.5 — so the driver's W = 5 / K = 20 figure of a
@@ -1043,6 +1112,46 @@ def _run(argv):
                   "frac": BYTES_PER_POSE[cfg] * units / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                   "what": f"the same K = {args.steps} launches timed again (HIP events, one pair) directly behind {rounds} untimed rounds of K "
                           f"(>= {args.settle_ms:g} ms of back-to-back launches): the kernel at the clock the chip settles to"}
+
+    # ---- N > 1: the OTHER gather form, timed the same way (round 6: `value` is whichever form --gather names — since round 5 the
+    # north star's job shape, K sharded steps + ONE all-gather, by default; rounds 1-4 timed an all-gather inside every step — and both
+    # are measured in every run, each in its own overlapped form, so that lines of different rounds can be compared like for like)
+    other_form = None
+    if world > 1 and gather_mode != "none" and cfg != 5:
+        o_mode = "step" if gather_mode == "final" else "final"
+        o_chunks = max(1, args.chunks) if o_mode == "step" else 1
+        if n % o_chunks == 0:
+            o_form = (ShardPlan(world * n, world, o_chunks), o_chunks, n // o_chunks)
+            o_set = make_set(main_set["inputs"][0], main_set["inputs"][1], form=o_form)
+
+            def o_step():
+                if o_mode == "step":
+                    works = []
+                    for c, f in enumerate(o_set["launches"]):
+                        f()
+                        works += gather_stripe(o_set["bufs"], c, gathered_names, async_op=True)
+                    for w in works:
+                        w.wait()
+                else:
+                    for f in o_set["launches"]:
+                        f()
+
+            for _ in range(max(1, min(args.warmup, 3))):
+                o_step()
+            fence()
+            t_o = time.perf_counter()
+            for _ in range(args.steps):
+                o_step()
+            if o_mode == "final":
+                for c in range(o_chunks):
+                    for w in gather_stripe(o_set["bufs"], c, gathered_names, async_op=True):
+                        w.wait()
+            fence()
+            o_elapsed = time.perf_counter() - t_o
+            t = torch.tensor([o_elapsed], dtype=f64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            other_form = {"mode": o_mode, "chunks": o_chunks, "elapsed_s": float(t[0])}
+            del o_set
 
     # ---- kernel-only and gather-only legs (N > 1), each on its own: same buffers, same launches
     kernel_ms, gather_ms = step_ms_events, 0.0
@@ -1156,8 +1265,9 @@ def _run(argv):
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "launch": (("eager: every pass issues the pipeline's kernels on four streams, tied by stream value waits (hipStreamWriteValue32 / "
-                        "hipStreamWaitValue32)" if graph is None else
+            "launch": (((("pipelined: " if pipelined[0] else "eager: ") + "every pass issues the pipeline's kernels on four streams, tied by stream value "
+                         "waits (hipStreamWriteValue32 / hipStreamWaitValue32)" + ("; consecutive passes overlap (RSIK_OPT_CONT_GOALS_RESIDENT): the prepare phase of "
+                         "pass k + 1 beside the tail of pass k" if pipelined[0] else "")) if graph is None else
                         "K replays of a hipGraph holding one pass (two blocks under capture: 9 kernels on four streams, tied by events)") if cfg == 5
                        else ("eager" if graph is None else "hipGraph replay of K captured launches")),
             "config": {"workload": workload, "poses_per_gpu": n,
@@ -1215,17 +1325,32 @@ def _run(argv):
             mg["scaling_efficiency_vs_n1_same_config"] = eff
             if gather_mode != "none" and gather_ms > 0:
                 # north star: "all-gather ... only for the final joint array": K sharded steps, ONE all-gather of the last result
+                o_ms = other_form["elapsed_s"] * 1e3 if other_form else None
+                o_from = (f"a second timed leg of this run: the same K = {args.steps} steps, the same barrier + synchronise bracket, max over ranks"
+                          + (f", {other_form['chunks']} stripes per shard" if other_form and other_form["mode"] == "step" else "")) if other_form else None
                 if gather_mode == "final":
                     mg["gather_final"] = {"ms_for_K_steps_plus_one_gather": elapsed * 1e3, "solves_per_s": value, "one_all_gather_ms": gather_ms,
                                           "from": "the timed region itself (= value)"}
-                    mg["gather_step"] = {"ms_per_step": kernel_ms + gather_ms, "solves_per_s": units * world / ((kernel_ms + gather_ms) * 1e-3),
-                                         "overlapped": False, "from": "the kernel-only and gather-only legs of this run, one after the other (--gather step times the overlapped form)"}
+                    if other_form:
+                        mg["gather_step"] = {"ms_per_step": o_ms / args.steps, "solves_per_s": units * world * args.steps / (o_ms * 1e-3), "overlapped": True,
+                                             "from": o_from}
+                    else:
+                        mg["gather_step"] = {"ms_per_step": kernel_ms + gather_ms, "solves_per_s": units * world / ((kernel_ms + gather_ms) * 1e-3),
+                                             "overlapped": False, "from": "the kernel-only and gather-only legs of this run, one after the other"}
                 else:
-                    total_final_ms = kernel_ms * args.steps + gather_ms
+                    total_final_ms = o_ms if other_form else kernel_ms * args.steps + gather_ms
                     mg["gather_final"] = {"ms_for_K_steps_plus_one_gather": total_final_ms, "solves_per_s": units * world * args.steps / (total_final_ms * 1e-3),
-                                          "one_all_gather_ms": gather_ms, "from": "the kernel-only and gather-only legs of this run"}
+                                          "one_all_gather_ms": gather_ms, "from": o_from or "the kernel-only and gather-only legs of this run"}
                     mg["gather_step"] = {"ms_per_step": elapsed / args.steps * 1e3, "solves_per_s": value, "overlapped": True,
                                          "from": "the timed region itself (= value)"}
+                # the two job shapes side by side, each with its efficiency against one GPU on this config; which of them `value` is, and
+                # since when (the advisor's round-5 finding: `value` changed its meaning with the default of --gather)
+                mg["value_definition"] = {"value_is": "gather_" + gather_mode,
+                                          "default_since_round_5": "gather_final (K sharded steps + ONE all-gather of the final joints + state: the north star's job shape)",
+                                          "default_in_rounds_1_to_4": "gather_step (an all-gather inside every step, stripe-pipelined): compare those rounds' `value` with gather_step.solves_per_s",
+                                          "changed_in_round": 5}
+                for shape in ("gather_final", "gather_step"):
+                    mg[shape]["efficiency_vs_n1_same_config"] = mg[shape]["solves_per_s"] / (n1 * world)
             mg["group"] = group_info
             # beside `value`: the north star's own job shape (K sharded steps, ONE all-gather of the final joints) end to end, and the
             # efficiency against one GPU on this same config
@@ -1233,6 +1358,10 @@ def _run(argv):
             if "gather_final" in mg:
                 line["gather_final"] = {"solves_per_s": mg["gather_final"]["solves_per_s"], "ms_for_K_steps_plus_one_gather": mg["gather_final"]["ms_for_K_steps_plus_one_gather"],
                                         "efficiency_vs_n1_same_config": mg["gather_final"]["solves_per_s"] / (n1 * world)}
+                line["gather_step"] = {"solves_per_s": mg["gather_step"]["solves_per_s"], "ms_per_step": mg["gather_step"]["ms_per_step"],
+                                       "overlapped": mg["gather_step"]["overlapped"],
+                                       "efficiency_vs_n1_same_config": mg["gather_step"]["solves_per_s"] / (n1 * world)}
+                line["value_definition"] = mg["value_definition"]
         if cfg == 5:
             line["metric"] = "IK control steps/sec (ControlIK continuous, r_arm trajectories)"
             line["unit"] = "steps/s"
@@ -1242,6 +1371,11 @@ def _run(argv):
                 "between the steps of a pass (SURVEY 8d's persistent-loop figure)")
             line["roofline"]["frac_at_286_bytes_state_round_trip_per_step"] = (
                 BYTES_PER_STEP_STATE_ROUND_TRIP * units / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
+            line["run_forms_seen"] = dict(forms_seen)
+            line["value_is"] = ("K passes back to back, consecutive passes overlapping (the next pass's prepare phase beside this pass's tail); every pass "
+                                "resets the trajectory state, re-initialises every trajectory and writes every output row; `steady_state.isolated_pass_ms` "
+                                "is one pass on its own, `steady_state.launch_forms_ms.eager` K passes without the overlap"
+                                if (pipelined[0] and graph is None) else "K passes back to back without overlap between passes")
         if steady is not None:
             line["steady_state"] = steady
 

@@ -110,6 +110,18 @@ def test_sharded_solve_world2_gloo(tmp_path, n):
     assert all(os.path.exists(tmp_path / f"ok_{r}") for r in range(world))
 
 
+@pytest.mark.parametrize("n", [5, 1000, 4099])
+def test_sharded_solve_world8_gloo(tmp_path, n):
+    """The rank count of BASELINE config 4 (8 GPUs of one node), on the CPU: eight ranks, stripes of 8 x rows_per_piece rows, fewer
+    rows than ranks (5: three ranks own nothing), a row count that is no multiple of world x chunks (4099: the last stripe is padded)
+    — every rank ends up with every row, in pose order, equal to the unsharded solve.  (A GPU box of this pool admits six processes
+    on its card: the eight-rank shape cannot be rehearsed there, tests/test_gpu_multi.py rehearses four; the first real eight-rank run
+    is the driver's.)"""
+    world = 8
+    mp.spawn(_worker, args=(world, _free_port(), n, 4321 + n, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f"ok_{r}") for r in range(world))
+
+
 # ------------------------------------------------------------------------------------------ bench.py's own launcher
 def _run_bench(*argv, env=None):
     import subprocess
@@ -127,7 +139,7 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     is the launcher, which is the same code path the GPU run takes."""
     import json
 
-    for n in (2, 3):
+    for n in (2, 3, 8):  # (8: the driver's SCALE command shape — eight children, one rendezvous on 127.0.0.1)
         p = _run_bench("--gpus", str(n), "--rendezvous-only")
         assert p.returncode == 0, p.stderr
         lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]

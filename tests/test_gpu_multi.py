@@ -27,8 +27,8 @@ def _bench(*argv, timeout=900):
     return json.loads(lines[0])
 
 
-def _check_two_rank_line(d, gather):
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["workload"].startswith("config4")
+def _check_two_rank_line(d, gather, world=2):
+    assert d["n_gpus"] == world and d["scaling"] == "weak" and d["config"]["workload"].startswith("config4")
     m = d["multi_gpu"]
     assert m["kernel_only_solves_per_s"] > 0
     if gather == "none":
@@ -37,21 +37,30 @@ def _check_two_rank_line(d, gather):
         assert m["gather_only_ms"] > 0 and m["end_to_end_solves_per_s"] > 0 and m["gathered_rows_checked"]
         # rank 0 re-solved rows taken from BOTH ranks' parts of the gathered array with the CPU checker
         par = d["cpu_baseline"]["parity_on_sample"]
-        assert par["rows"] >= 2 * 1024 and par["max_abs_joint_error_rad"] < 1e-6
+        assert par["rows"] >= world * 1024 and par["max_abs_joint_error_rad"] < 1e-6
     assert abs(m["end_to_end_solves_per_s"] - d["value"]) < 1e-6 * d["value"]
     if gather == "final":
         # the N > 1 default, the north star's job shape: K sharded steps + ONE all-gather of the final arrays inside the timed region
         assert "ONE RCCL all-gather" in d["config"]["collective"] and "north star" in m["value_is"]
         assert m["gather_final"]["from"].startswith("the timed region") and abs(m["gather_final"]["solves_per_s"] - d["value"]) < 1e-6 * d["value"]
-        assert m["gather_step"]["overlapped"] is False and m["gather_step"]["solves_per_s"] < m["kernel_only_solves_per_s"]
+        # (round 6) the other job shape is MEASURED in the same run, in its own overlapped form: a second timed leg, not arithmetic on legs
+        assert m["gather_step"]["overlapped"] is True and m["gather_step"]["from"].startswith("a second timed leg")
+        assert m["gather_step"]["solves_per_s"] < m["kernel_only_solves_per_s"]
     if gather == "step":
         assert m["gather_step"]["from"].startswith("the timed region") and m["gather_step"]["overlapped"] is True
+        assert m["gather_final"]["from"].startswith("a second timed leg")
+    if gather != "none":
+        # `value` says which job shape it is and since when (the default changed in round 5), both shapes carry their own efficiency
+        vd = m["value_definition"]
+        assert vd["value_is"] == "gather_" + gather and vd["changed_in_round"] == 5 and d["value_definition"] == vd
+        for shape in ("gather_final", "gather_step"):
+            assert 0 < m[shape]["efficiency_vs_n1_same_config"] <= 1.0 + 1e-9 and d[shape]["solves_per_s"] == m[shape]["solves_per_s"]
     if gather != "none":  # kernel-only, gather-only and both end-to-end figures are all there, whichever was timed
         assert m["kernel_only_solves_per_s"] > 0 and m["gather_only_solves_per_s"] > 0
         assert m["gather_final"]["solves_per_s"] > 0 and m["gather_step"]["solves_per_s"] > 0
     # what the collective library saw, and the like-for-like reference for the driver's scaling curve
     g = m["group"]
-    assert g["world_size"] == 2 and len(g["ranks"]) == 2 and {r["rank"] for r in g["ranks"]} == {0, 1}
+    assert g["world_size"] == world and len(g["ranks"]) == world and {r["rank"] for r in g["ranks"]} == set(range(world))
     assert all(r["pid"] > 0 and r["name"] for r in g["ranks"]) and g["collective_timeout_s"] > 0
     assert m["n1_same_config"]["solves_per_s"] > 0
     eff = m["scaling_efficiency_vs_n1_same_config"]
@@ -82,12 +91,26 @@ def test_bench_two_ranks_gloo_one_gpu(gather):
     _check_two_rank_line(d, "final" if gather == "default" else gather)
 
 
+@pytest.mark.parametrize("gather", ["final", "step"])
+def test_bench_four_ranks_gloo_one_gpu(gather):
+    """The driver's SCALE command shape rehearsed at the largest rank count a one-GPU box of this pool admits beside the test runner
+    (its process guard stops a seventh process on the card; the eight-rank partition itself is covered on the CPU,
+    tests/test_distributed_gloo.py): four ranks, 131 072 mixed r/l poses each, eight stripes per shard in the every-step form — the
+    rank-0 parity sample is drawn from all four parts of the gathered array, the checksum of every rank's rows is checked on every
+    rank, the group as the collective library sees it has four members."""
+    d = _bench("--gpus", "4", "--backend", "gloo", "--single-device", "--poses", "131072", "--steps", "3", "--warmup", "1",
+               "--cpu-seconds", "2", "--chunks", "8", "--gather", gather)
+    _check_two_rank_line(d, gather, world=4)
+    assert d["config"]["poses_per_gpu"] == 131072 and "rehearsal" in d["config"]["collective"]
+
+
 def test_bench_measures_traffic_in_its_own_run():
     """roofline.traffic comes from THIS run, not from a file the builder committed: after the timed legs bench.py runs itself twice more
     under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, --kernel-trace only) and reads the kernel's counters.  A
     small config-3 batch: the figure is there, says where it came from, and is the algorithmic 154 B per pose to within a few percent
     (tables, constants and partial lines on a batch this small)."""
-    d = _bench("--config", "3", "--poses", "65536", "--steps", "3", "--warmup", "1", "--no-extras", "--cpu-seconds", "1")
+    d = _bench("--config", "3", "--poses", "65536", "--steps", "3", "--warmup", "1", "--no-extras", "--cpu-seconds", "1", "--settle-ms", "0")
+    assert "steady_state" not in d  # (--settle-ms 0: no settled leg)
     r = d["roofline"]
     assert "traffic_live_error" not in r, r.get("traffic_live_error")
     assert r["traffic_source"].startswith("measured in this run") and r["traffic_seconds"] > 0
@@ -103,18 +126,43 @@ def test_bench_two_ranks_gloo_config3_and_config5():
 
 
 def test_bench_config5_line_carries_both_protocols():
-    """Config 5 on one GPU: the line's value is the protocol asked for (W warm-up passes, K timed; one captured pass replayed);
-    `steady_state` holds the same K passes after 60 more untimed ones, in both launch forms; the CPU leg carries the static
-    reference figures."""
+    """Config 5 on one GPU: the line's value is the protocol asked for (W warm-up passes, K timed) in the form it names — by default
+    the K passes issued launch by launch with consecutive passes overlapping (RSIK_OPT_CONT_GOALS_RESIDENT: every pass after the first
+    really was issued that way, `run_forms_seen`); `steady_state` holds the same K passes after 60 more untimed ones in all three
+    launch forms and one pass on its own (`isolated_pass_ms`); the CPU leg — parity of the LAST timed pass's rows against the
+    checker — carries the static reference figures and the host's facts."""
     d = _bench("--config", "5", "--poses", "256", "--steps", "3", "--warmup", "2", "--cpu-seconds", "2")
-    assert d["unit"] == "steps/s" and d["steps"] == 3 and d["warmup"] == 2 and d["launch"].startswith("K replays")
+    assert d["unit"] == "steps/s" and d["steps"] == 3 and d["warmup"] == 2 and d["launch"].startswith("pipelined")
+    assert "overlapping" in d["value_is"] and d["run_forms_seen"].get("phased, overlapping the run before", 0) >= 3 + 2 + 60
     ss = d["steady_state"]
-    assert ss["launch"] == "graph" and ss["steps"] == 3 and ss["after_untimed_passes"] == 65
-    assert ss["launch_forms_ms"]["eager"] > 0 and ss["launch_forms_ms"]["graph"] > 0 and ss["value"] > 0
-    assert d["cpu_baseline"]["parity_on_sample"]["flags_and_states"] == "bit-exact"
-    assert d["cpu_baseline"]["reference_numpy"]["config5_steps_per_s_per_core"] > 0
+    assert ss["launch"] == "pipelined" and ss["steps"] == 3 and ss["after_untimed_passes"] == 65
+    f = ss["launch_forms_ms"]
+    assert f["pipelined"] > 0 and f["eager"] > 0 and f["graph"] > 0 and ss["value"] > 0 and ss["isolated_pass_ms"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["parity_on_sample"]["flags_and_states"] == "bit-exact"
+    assert cb["reference_numpy"]["config5_steps_per_s_per_core"] > 0
+    assert cb["cores_visible"] >= cb["threads_used"] == cb["cores"] >= 1 and cb["cpu_model"] and cb["logical_cpus"] >= cb["cores_visible"]
     g = _bench("--config", "5", "--poses", "256", "--steps", "2", "--warmup", "1", "--launch", "eager", "--no-cpu-baseline", "--no-live-traffic")
     assert g["launch"].startswith("eager") and g["steady_state"]["launch"] == "eager" and g["steady_state"]["launch_forms_ms"]["graph"] > 0
+    assert g["steady_state"]["launch_forms_ms"]["pipelined"] > 0 and "without overlap" in g["value_is"]
+
+
+def test_bench_settled_leg_of_configs_3_and_4():
+    """Configs 2-4 on one GPU carry a `steady_state` leg: the same K launches timed again behind >= --settle-ms of untimed launches of the
+    same kind, so that the driver's own W = 5 / K = 20 run witnesses the figure the kernel settles to (round 5: the driver read 0.325 for
+    config 3 where profiles/ and a longer run read 0.35); the headline figure stays what the protocol says.  And the host's facts sit in
+    every CPU leg: the affinity count, the CPU model, the threads the figure was measured with."""
+    for cfg, n in ((3, 65536), (4, 131072)):
+        d = _bench("--config", str(cfg), "--poses", str(n), "--steps", "4", "--warmup", "2", "--settle-ms", "5", "--no-extras", "--no-live-traffic",
+                   "--cpu-seconds", "1")
+        ss = d["steady_state"]
+        assert ss["steps"] == 4 and ss["untimed_ms_target"] == 5 and ss["untimed_rounds_of_K"] >= 1 and ss["after_untimed_launches"] >= 2 + 4 * 2
+        assert ss["ms_per_step"] > 0 and ss["unit"] == "solves/s" and abs(ss["value"] - n / (ss["ms_per_step"] * 1e-3)) < 1e-3 * ss["value"]
+        assert abs(ss["frac"] - ss["achieved_GBs"] / 8000.0) < 1e-12 and ss["launch"] in ("graph", "eager")
+        assert d["steps"] == 4 and d["warmup"] == 2  # (the headline is the protocol's)
+        cb = d["cpu_baseline"]
+        assert cb["cores_visible"] >= cb["threads_used"] == cb["cores"] >= 1 and isinstance(cb["cpu_model"], str) and cb["cpu_model"]
+        assert str(cb["threads_used"]) in cb["threads_probed"]
 
 
 def test_stage_timers_script():
