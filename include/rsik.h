@@ -414,6 +414,21 @@ int rsik_control_continuous_release(rsik_ctx *ctx);
  *   RSIK_STAGE_NEAREST_APPROACH     points_of_nearest_approach :588-606: p1 3, normal1 3, p2 3, normal2 3 -> q found 0/1 (0 = []), q 3, v 3
  *   RSIK_STAGE_CIRCLE_LINE          intersection_circle_line_3d_vd :608-645: centre 3, radius, direction 3, point on line 3 -> points 0/1/2, point 3, point 3
  *   RSIK_STAGE_ROTATION_FROM_VECTOR utils.rotation_matrix_from_vector utils.py:59-81: vector 3 -> 3 x 3 row-major
+ * and the policy layer's helpers as utils.py exposes them — scalar functions of explicit arguments that callers of the reference import
+ * (src/example/test_ik.py:16-21, test_go_to.py:10-13); `arm` is not read by these (nor by the three stages before them: a context
+ * no arm was uploaded to runs them):
+ *   RSIK_STAGE_ANGLE_DIFF           angle_diff utils.py:486-490: a, b -> the difference in [-pi, pi)
+ *   RSIK_STAGE_IS_VALID_ANGLE       is_valid_angle :468-474: angle, interval 2 -> 0/1
+ *   RSIK_STAGE_LIMIT_THETA_TO_INTERVAL  limit_theta_to_interval :93-112: theta, previous_theta, interval 2 -> theta, "theta in interval" 0/1
+ *   RSIK_STAGE_IS_ELBOW_OK          is_elbow_ok :443-465: elbow 3, side (+1 r / -1 l), singularity_offset, singularity_limit_coeff,
+ *                                   elbow_singularity_position 3 -> 0/1
+ *   RSIK_STAGE_ALLOW_MULTITURN      allow_multiturn :493-505: new joints 7, previous joints 7 -> joints 7
+ *   RSIK_STAGE_LIMIT_ORBITA3D_JOINTS  limit_orbita3d_joints :508-519: roll, pitch, yaw (intrinsic XYZ), max angle -> the three angles in the cone
+ *   RSIK_STAGE_MULTITURN_SAFETY_CHECK  multiturn_safety_check :535-568: joints 7, the three limits -> joints 7, RSIK_EMERGENCY_* bits
+ *   RSIK_STAGE_CONTINUITY_CHECK     continuity_check :571-589: joints 7, previous joints 7, max angular change 7 -> joints 7, stop 0/1
+ *   RSIK_STAGE_BEST_DISCRETE_THETA  get_best_discrete_theta :334-396: previous_theta, interval 2, nb_search_points, preferred_theta, side,
+ *                                   singularity_offset, singularity_limit_coeff, elbow_singularity_position 3, the intersection circle its
+ *                                   get_elbow_position argument reads (centre 3, radius, normal 3) -> found 0/1, theta, preferred worked 0/1
  */
 #define RSIK_STAGE_POSE_IN_REACH 0
 #define RSIK_STAGE_WRIST_POSITION 1
@@ -423,7 +438,16 @@ int rsik_control_continuous_release(rsik_ctx *ctx);
 #define RSIK_STAGE_NEAREST_APPROACH 5
 #define RSIK_STAGE_CIRCLE_LINE 6
 #define RSIK_STAGE_ROTATION_FROM_VECTOR 7
-#define RSIK_STAGE_COUNT 8
+#define RSIK_STAGE_ANGLE_DIFF 8
+#define RSIK_STAGE_IS_VALID_ANGLE 9
+#define RSIK_STAGE_LIMIT_THETA_TO_INTERVAL 10
+#define RSIK_STAGE_IS_ELBOW_OK 11
+#define RSIK_STAGE_ALLOW_MULTITURN 12
+#define RSIK_STAGE_LIMIT_ORBITA3D_JOINTS 13
+#define RSIK_STAGE_MULTITURN_SAFETY_CHECK 14
+#define RSIK_STAGE_CONTINUITY_CHECK 15
+#define RSIK_STAGE_BEST_DISCRETE_THETA 16
+#define RSIK_STAGE_COUNT 17
 int rsik_stage(rsik_ctx *ctx, int op, int64_t n, int arm, const double *in, int in_stride, double *out, int out_stride);
 
 /*

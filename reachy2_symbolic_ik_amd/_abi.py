@@ -79,8 +79,11 @@ PROTOTYPES = {
 
 GOAL_POSE6, GOAL_M12 = 0, 1
 (STAGE_POSE_IN_REACH, STAGE_WRIST_POSITION, STAGE_LIMITATION_CIRCLE, STAGE_INTERSECTION_CIRCLE, STAGE_CIRCLES_LINKED, STAGE_NEAREST_APPROACH,
- STAGE_CIRCLE_LINE, STAGE_ROTATION_FROM_VECTOR) = range(8)
-STAGE_ROW = {0: (6, 5), 1: (6, 3), 2: (6, 7), 3: (3, 8), 4: (17, 3), 5: (12, 7), 6: (10, 7), 7: (3, 9)}  # doubles in / out per row
+ STAGE_CIRCLE_LINE, STAGE_ROTATION_FROM_VECTOR, STAGE_ANGLE_DIFF, STAGE_IS_VALID_ANGLE, STAGE_LIMIT_THETA_TO_INTERVAL, STAGE_IS_ELBOW_OK,
+ STAGE_ALLOW_MULTITURN, STAGE_LIMIT_ORBITA3D_JOINTS, STAGE_MULTITURN_SAFETY_CHECK, STAGE_CONTINUITY_CHECK, STAGE_BEST_DISCRETE_THETA) = range(17)
+STAGE_ROW = {0: (6, 5), 1: (6, 3), 2: (6, 7), 3: (3, 8), 4: (17, 3), 5: (12, 7), 6: (10, 7), 7: (3, 9),  # doubles in / out per row
+             8: (2, 1), 9: (3, 1), 10: (4, 2), 11: (9, 1), 12: (14, 7), 13: (4, 3), 14: (10, 8), 15: (21, 8), 16: (18, 3)}
+STAGE_IN_MAX, STAGE_OUT_MAX = 21, 9
 OPT_EULER_ROUNDTRIP, OPT_SWEEP_MODE, OPT_NO_TIPZ, OPT_NO_MIRROR, OPT_CONT_RUN_MODE = 0, 1, 2, 3, 4
 OPT_CONT_BLOCK_STEPS, OPT_CONT_PHASED_VARIANT, OPT_CONT_GOALS_RESIDENT = 5, 6, 7
 (CONT_FORM_NONE, CONT_FORM_PHASED, CONT_FORM_PHASED_OVERLAPPED, CONT_FORM_PHASED_CAPTURED, CONT_FORM_STEPS,

@@ -53,20 +53,90 @@ __device__ inline void rotation_from_vector_ref(V3 vect, double (&R)[9]) {
         }
 }
 
-// S:588-606 with S:570-586: the line of intersection of the two circles' planes.  The reference's least-squares solve of the 3 x 2
-// system [v1, -v2] t = p2 - p1 through its normal equations (the system is consistent: both lines lie in the plane normal to v).
+// S:588-606 with S:570-586: the line of intersection of the two circles' planes.  The reference's least-squares solve
+// (np.linalg.lstsq, an SVD) of the 3 x 2 system [v1, -v2] t = p2 - p1, here by a thin QR factorisation — Gram-Schmidt with one
+// re-orthogonalisation of the second column — which, like the SVD, works at the system's own condition number: the normal equations
+// (rounds 5's form) square it, and for planes a few 1e-6 apart — just outside normal_vector_margin — lost four more digits of q than the
+// reference does (the advisor's round-5 finding; G18 holds such pairs).
 // false: intersection_point returned [] (np.all(np.isclose(params, params[0])), Q7).
 __device__ inline bool nearest_approach_ref(V3 p1, V3 n1, V3 p2, V3 n2, V3& q, V3& v) {
     const V3 c = cross_d(n1, n2);
     v = div_d(c, sqrt(dot_d(c, c)));
     const V3 v1 = cross_d(v, n1), v2 = cross_d(v, n2);
     const V3 b = p2 - p1;
-    const double a11 = dot_d(v1, v1), a12 = -dot_d(v1, v2), a22 = dot_d(v2, v2);
-    const double r1 = dot_d(v1, b), r2 = -dot_d(v2, b);
-    const double det = a11 * a22 - a12 * a12;
-    const double t0 = (r1 * a22 - a12 * r2) / det, t1 = (a11 * r2 - a12 * r1) / det;
+    const V3 a2 = {-v2.x, -v2.y, -v2.z};
+    const double r11 = sqrt(dot_d(v1, v1));
+    const V3 q1 = div_d(v1, r11);
+    double r12 = dot_d(q1, a2);
+    V3 w = a2 - q1 * r12;
+    const double fix = dot_d(q1, w);  // (second pass: what the first left of q1 in w)
+    w = w - q1 * fix;
+    r12 += fix;
+    const double r22 = sqrt(dot_d(w, w));
+    const V3 q2 = div_d(w, r22);
+    const double t1 = dot_d(q2, b) / r22;
+    const double t0 = (dot_d(q1, b) - r12 * t1) / r11;
     q = {v1.x * t0 + p1.x, v1.y * t0 + p1.y, v1.z * t0 + p1.z};
     return !(np_isclose(t0, t0) && np_isclose(t1, t0));
+}
+
+// ---- the policy layer's helpers as the reference's utils module exposes them (U:93-112, 334-396, 443-589): scalar functions of
+// explicit arguments that callers of the reference import (src/example/test_ik.py:16-21, test_go_to.py:10-13).  The fused control
+// kernels carry specialised forms of the same arithmetic (rsik_device.hpp); these are the general ones — any interval, any limits.
+// U:468-474, for any interval (the fused kernels' form assumes ends in [-pi, pi])
+__device__ inline bool is_valid_angle_ref(double angle, double i0, double i1) {
+    if (pymod_2pi(i0) == pymod_2pi(i1)) return true;
+    if (i0 < i1) return (i0 <= angle) && (angle <= i1);
+    return (i0 <= angle) || (angle <= i1);
+}
+// U:93-112 (previous_theta is normalised there and never used, Q12).  `inside`: "theta in interval" / "theta not in interval"
+__device__ inline double limit_theta_to_interval_ref(double theta, double i0, double i1, bool& inside) {
+    theta = pymod_2pi(theta);
+    if (theta > kPi) theta -= kTwoPi;
+    inside = is_valid_angle_ref(theta, i0, i1);
+    if (inside) return theta;
+    const double posDiff = angle_diff(theta, i1), negDiff = angle_diff(theta, i0);
+    return (fabs(posDiff) < fabs(negDiff)) ? i1 : i0;
+}
+// U:443-465 on explicit arguments
+__device__ inline bool is_elbow_ok_ref(V3 e, double side, double so, double coeff, V3 esp) {
+    bool ok = e.y * side < -0.2;
+    ok = ok && (e.z < (e.x - esp.x) * coeff + esp.z - so);
+    return ok;
+}
+// S:684-695 on an explicit circle (centre, radius, normal)
+__device__ inline V3 elbow_position_ref(V3 centre, double radius, V3 normal, double theta) {
+    double R[9];
+    rotation_from_vector_ref(normal, R);
+    const double y = radius * cos(theta), z = radius * sin(theta);
+    return {R[0] * 0.0 + R[1] * y + R[2] * z + centre.x, R[3] * 0.0 + R[4] * y + R[5] * z + centre.y, R[6] * 0.0 + R[7] * y + R[8] * z + centre.z};
+}
+// U:334-396.  Returns found; `worked`: the preferred theta itself passed (the reference's early return)
+__device__ inline bool best_discrete_theta_ref(double previous_theta, double i0, double i1, int nb, double pref, double side, double so, double coeff,
+                                               V3 esp, V3 centre, double radius, V3 normal, double& theta, bool& worked) {
+    worked = false;
+    if (is_valid_angle_ref(pref, i0, i1) && is_elbow_ok_ref(elbow_position_ref(centre, radius, normal, pref), side, so, coeff, esp)) {
+        theta = pref;
+        worked = true;
+        return true;
+    }
+    double a, b;
+    if (fabs(fabs(i0) + fabs(i1) - 2 * kPi) < 0.00001) { a = kPi / 2; b = kPi / 2 + 2 * kPi; }
+    else if (i0 < i1) { a = i0; b = i1; }
+    else { a = i0; b = i1 + 2 * kPi; }
+    // np.linspace(a, b, nb): k * step + a with step = (b - a) / (nb - 1), the last point b itself (one point: a)
+    const double step = nb > 1 ? (b - a) / (double)(nb - 1) : 0.0;
+    bool found = false;
+    double best_d = __builtin_inf();
+    for (int k = 0; k < nb; k++) {
+        const double th = (k == nb - 1 && nb > 1) ? b : ((double)k * step + a);
+        if (is_elbow_ok_ref(elbow_position_ref(centre, radius, normal, th), side, so, coeff, esp)) {
+            const double d = fabs(angle_diff(th, pref));
+            if (d < best_d) { best_d = d; theta = th; found = true; }
+        }
+    }
+    if (!found) theta = previous_theta;
+    return found;
 }
 
 // S:608-645: 0, 1 or 2 points (the + root first)
@@ -221,6 +291,61 @@ __global__ __launch_bounds__(kBlock) void stage_kernel(const StageArgs K) {
         double R[9];
         rotation_from_vector_ref(V3{x[0], x[1], x[2]}, R);
         for (int k = 0; k < 9; k++) o[k] = R[k];
+        break;
+    }
+    case RSIK_STAGE_ANGLE_DIFF:  // U:486-490.  in: a, b; out: the difference in [-pi, pi)
+        o[0] = angle_diff(x[0], x[1]);
+        break;
+    case RSIK_STAGE_IS_VALID_ANGLE:  // U:468-474.  in: angle, interval 2; out: 0/1
+        o[0] = is_valid_angle_ref(x[0], x[1], x[2]) ? 1.0 : 0.0;
+        break;
+    case RSIK_STAGE_LIMIT_THETA_TO_INTERVAL: {  // U:93-112.  in: theta, previous_theta, interval 2; out: theta, in interval 0/1
+        bool inside;
+        o[0] = limit_theta_to_interval_ref(x[0], x[2], x[3], inside);
+        o[1] = inside ? 1.0 : 0.0;
+        break;
+    }
+    case RSIK_STAGE_IS_ELBOW_OK:  // U:443-465.  in: elbow 3, side (+1 r / -1 l), singularity_offset, singularity_limit_coeff, elbow_singularity_position 3; out: 0/1
+        o[0] = is_elbow_ok_ref(V3{x[0], x[1], x[2]}, x[3], x[4], x[5], V3{x[6], x[7], x[8]}) ? 1.0 : 0.0;
+        break;
+    case RSIK_STAGE_ALLOW_MULTITURN:  // U:493-505.  in: new joints 7, previous joints 7; out: joints 7
+        for (int k = 0; k < 7; k++) o[k] = x[7 + k] + angle_diff(x[k], x[7 + k]);
+        break;
+    case RSIK_STAGE_LIMIT_ORBITA3D_JOINTS: {  // U:508-519.  in: roll, pitch, yaw (intrinsic XYZ), max angle; out: the three angles inside the cone
+        double j[7] = {0, 0, 0, 0, x[0], x[1], x[2]};
+        limit_wrist_cone(A.utab, j, cos(x[0]), sin(x[0]), cos(x[1]), sin(x[1]), cos(x[2]), sin(x[2]), cos(x[3]), sin(x[3]));
+        o[0] = j[4]; o[1] = j[5]; o[2] = j[6];
+        break;
+    }
+    case RSIK_STAGE_MULTITURN_SAFETY_CHECK: {  // U:535-568.  in: joints 7, shoulder pitch / elbow yaw / wrist yaw limits; out: joints 7, RSIK_EMERGENCY_* bits
+        int cause = 0;
+        for (int k = 0; k < 7; k++) o[k] = x[k];
+        const int which[3] = {0, 2, 6}, bit[3] = {RSIK_EMERGENCY_SHOULDER_PITCH, RSIK_EMERGENCY_ELBOW_YAW, RSIK_EMERGENCY_WRIST_YAW};
+        for (int q = 0; q < 3; q++) {
+            const double lim = x[7 + q];
+            if (o[which[q]] > lim) { o[which[q]] = lim; cause |= bit[q]; }
+            if (o[which[q]] < -lim) { o[which[q]] = -lim; cause |= bit[q]; }
+        }
+        o[7] = (double)cause;
+        break;
+    }
+    case RSIK_STAGE_CONTINUITY_CHECK: {  // U:571-589.  in: joints 7, previous joints 7, max angular change 7; out: joints 7 (the previous ones when not continuous), stop 0/1
+        bool disc = false;
+        for (int k = 0; k < 7; k++) disc = disc || (fabs(angle_diff(x[k], x[7 + k])) > x[14 + k]);
+        for (int k = 0; k < 7; k++) o[k] = disc ? x[7 + k] : x[k];
+        o[7] = disc ? 1.0 : 0.0;
+        break;
+    }
+    case RSIK_STAGE_BEST_DISCRETE_THETA: {  // U:334-396.  in: previous_theta, interval 2, nb_search_points, preferred_theta, side, singularity_offset,
+        // singularity_limit_coeff, elbow_singularity_position 3, the intersection circle get_elbow_position reads (centre 3, radius, normal 3);
+        // out: found 0/1, theta, "preferred_theta worked" 0/1
+        double in[18];
+        for (int k = 0; k < 18; k++) in[k] = x[k];
+        double th = in[0];
+        bool worked = false;
+        const bool found = best_discrete_theta_ref(in[0], in[1], in[2], (int)in[3], in[4], in[5], in[6], in[7], V3{in[8], in[9], in[10]}, V3{in[11], in[12], in[13]},
+                                                   in[14], V3{in[15], in[16], in[17]}, th, worked);
+        o[0] = found ? 1.0 : 0.0; o[1] = th; o[2] = worked ? 1.0 : 0.0;
         break;
     }
     default:

@@ -171,9 +171,11 @@ int rsik_sync(rsik_ctx* ctx) {
     // a theta kernel that gave up waiting for its prepare kernel (cannot happen; the wait is bounded so that it cannot hang either)
     if (ctx->edge_words) {
         unsigned gave_up = 0;
-        RSIK_HIP(ctx, hipMemcpy(&gave_up, ctx->edge_words + 3, sizeof gave_up, hipMemcpyDeviceToHost));
+        RSIK_HIP(ctx, hipMemcpyAsync(&gave_up, ctx->edge_words + 3, sizeof gave_up, hipMemcpyDeviceToHost, ctx->stream));
+        RSIK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (gave_up != 0) {
-            (void)hipMemset(ctx->edge_words + 3, 0, sizeof gave_up);
+            (void)hipMemsetAsync(ctx->edge_words + 3, 0, sizeof gave_up, ctx->stream);
+            (void)hipStreamSynchronize(ctx->stream);
             return fail(ctx, RSIK_E_HIP, "rsik_sync: a theta kernel of rsik_control_continuous_run waited a second for its prepare kernel and went on without it: the results of that run are invalid");
         }
     }
@@ -709,6 +711,14 @@ int rsik_control_continuous_release(rsik_ctx* ctx) {
 // waits for that one's end (runs on one stream are ordered by the stream; hipGraphs recorded from one context must not be
 // replayed concurrently: include/rsik.h).
 static int cont_run_begin(rsik_ctx* ctx, bool capturing) {
+    // Workspaces and word arrays that earlier runs outgrew: a caller that synchronises through its own framework never calls
+    // rsik_sync, so they are also let go here, without waiting — when the last run issued is known to have finished (every run
+    // before it has, then: runs of one context are ordered).  Never inside a capture.
+    if (!capturing && !ctx->outgrown_ws.empty() && ctx->have_run_done && hipEventQuery(ctx->run_done) == hipSuccess) {
+        for (void* w : ctx->outgrown_ws) (void)hipFree(w);
+        ctx->outgrown_ws.clear();
+    }
+    (void)hipGetLastError();  // (hipErrorNotReady is not an error)
     if (capturing || !ctx->have_run_done || ctx->run_stream == ctx->stream) return RSIK_OK;
     RSIK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->run_done, 0));
     return RSIK_OK;
@@ -1096,6 +1106,13 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         }
         ctx->last_run.valid = false;
         for (auto& u : ctx->slot_use) u = {0, 0};
+        // (what was issued before the failure is still running: rsik_sync and the next run's housekeeping wait for THIS point)
+        if (!capturing) {
+            const std::string first_error = ctx->err;
+            (void)cont_run_end(ctx, false);
+            (void)hipGetLastError();
+            ctx->err = first_error;
+        }
         return rc;
     }
     if (capturing) {
@@ -1218,11 +1235,17 @@ int rsik_stage(rsik_ctx* ctx, int op, int64_t n, int arm, const double* in, int 
     const char* who = "rsik_stage";
     if (!ctx) return RSIK_E_INVALID;
     // doubles a row takes and gives, by stage (include/rsik.h)
-    static const int need_in[RSIK_STAGE_COUNT] = {6, 6, 6, 3, 17, 12, 10, 3}, need_out[RSIK_STAGE_COUNT] = {5, 3, 7, 8, 3, 7, 7, 9};
+    static const int need_in[RSIK_STAGE_COUNT] = {6, 6, 6, 3, 17, 12, 10, 3, 2, 3, 4, 9, 14, 4, 10, 21, 18},
+                     need_out[RSIK_STAGE_COUNT] = {5, 3, 7, 8, 3, 7, 7, 9, 1, 1, 2, 1, 7, 3, 8, 8, 3};
+    // (stages 5 on read no arm constant: they do not need an arm to have been set)
     if (op < 0 || op >= RSIK_STAGE_COUNT) return fail(ctx, RSIK_E_INVALID, std::string(who) + ": unknown stage");
     if (n < 0) return fail(ctx, RSIK_E_INVALID, std::string(who) + ": n < 0");
-    int rc = check_arms(ctx, nullptr, arm, who);
-    if (rc != RSIK_OK) return rc;
+    int rc = RSIK_OK;
+    if (op <= RSIK_STAGE_CIRCLES_LINKED) {  // (the stages that read arm constants; the others run on a context no arm was uploaded to)
+        if ((rc = check_arms(ctx, nullptr, arm, who)) != RSIK_OK) return rc;
+    } else if (arm != RSIK_ARM_R && arm != RSIK_ARM_L) {
+        return fail(ctx, RSIK_E_INVALID, std::string(who) + ": arm must be 0 (r) or 1 (l)");
+    }
     if (n == 0) return RSIK_OK;
     if (!in || !out) return fail(ctx, RSIK_E_INVALID, std::string(who) + ": NULL buffer");
     if (in_stride < need_in[op] || out_stride < need_out[op])
@@ -1231,7 +1254,7 @@ int rsik_stage(rsik_ctx* ctx, int op, int64_t n, int arm, const double* in, int 
     rsik::StageArgs K;
     std::memset(&K, 0, sizeof K);
     K.n = n; K.op = op; K.in = in; K.out = out; K.in_stride = in_stride; K.out_stride = out_stride;
-    K.arms[0] = K.arms[1] = ctx->arms[arm];
+    if (ctx->have_arm[arm]) K.arms[0] = K.arms[1] = ctx->arms[arm];  // (else zeros: the utils helpers read none of it)
     RSIK_HIP(ctx, hipSetDevice(ctx->device));
     dim3 grid, block(rsik::kBlock);
     rc = launch_dims(ctx, n, &grid, who);

@@ -191,8 +191,8 @@ class SymbolicIK:
         need_in, need_out = _abi.STAGE_ROW[op]
         io = getattr(self, "_stage_io", None)
         if io is None:
-            io = self._stage_io = {"in": torch.empty((1, 17), dtype=torch.float64).pin_memory(),
-                                   "out": torch.empty((1, 9), dtype=torch.float64).pin_memory()}
+            io = self._stage_io = {"in": torch.empty((1, _abi.STAGE_IN_MAX), dtype=torch.float64).pin_memory(),
+                                   "out": torch.empty((1, _abi.STAGE_OUT_MAX), dtype=torch.float64).pin_memory()}
             io["in_np"], io["out_np"] = io["in"].numpy(), io["out"].numpy()
         flat = np.concatenate([np.asarray(a, dtype=np.float64).reshape(-1) for a in operands])
         if flat.size != need_in:
@@ -202,7 +202,7 @@ class SymbolicIK:
         self._upload()
         with torch.cuda.device(sv.device):
             sv._bind_stream()
-            sv._check(sv.lib.rsik_stage(sv._h, int(op), 1, self.arm_id, io["in"].data_ptr(), 17, io["out"].data_ptr(), 9))
+            sv._check(sv.lib.rsik_stage(sv._h, int(op), 1, self.arm_id, io["in"].data_ptr(), _abi.STAGE_IN_MAX, io["out"].data_ptr(), _abi.STAGE_OUT_MAX))
             torch.cuda.current_stream(sv.device).synchronize()
         return io["out_np"][0, :need_out].copy()
 

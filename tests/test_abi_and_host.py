@@ -197,18 +197,27 @@ def test_packing_helpers():
 
 
 def test_utils_format_helpers():
-    """README.md:96-110 builds its goal matrix with these two helpers."""
+    """README.md:96-110 builds its goal matrix with these two helpers.  The first is packing; the second — like every helper of the
+    utils module that computes anything — runs on the device (rsik_matrix_to_pose; tests/test_gpu_utils.py checks its numbers): without
+    a GPU it fails loudly instead of answering from the host.  The module itself imports without one, and carries the reference's
+    names (utils.py:12-694, less the matplotlib helpers and dead code)."""
+    import torch
     from scipy.spatial.transform import Rotation as R
 
-    from reachy2_symbolic_ik_amd.utils import get_euler_from_homogeneous_matrix, make_homogenous_matrix_from_rotation_matrix
+    import reachy2_symbolic_ik_amd.utils as U
 
     rot = R.from_euler("xyz", [0.3, -0.7, 1.1]).as_matrix()
-    M = make_homogenous_matrix_from_rotation_matrix([0.55, -0.3, -0.15], rot)
+    M = U.make_homogenous_matrix_from_rotation_matrix([0.55, -0.3, -0.15], rot)
     assert M.shape == (4, 4) and np.array_equal(M[3], [0, 0, 0, 1]) and np.array_equal(M[:3, :3], rot)
-    pos, eul = get_euler_from_homogeneous_matrix(M)
-    np.testing.assert_allclose(pos, [0.55, -0.3, -0.15])
-    np.testing.assert_allclose(eul, [0.3, -0.7, 1.1], atol=1e-14)
-    assert np.allclose(get_euler_from_homogeneous_matrix(M, degrees=True)[1], np.degrees([0.3, -0.7, 1.1]))
+    for name in ("rotation_matrix_from_vector", "get_euler_from_homogeneous_matrix", "limit_theta_to_interval", "get_best_discrete_theta",
+                 "is_elbow_ok", "is_valid_angle", "angle_diff", "allow_multiturn", "limit_orbita3d_joints", "limit_orbita3d_joints_wrist",
+                 "multiturn_safety_check", "continuity_check", "get_ik_parameters_from_urdf", "parse_vector"):
+        assert callable(getattr(U, name)), name
+    if not torch.cuda.is_available():
+        for call in (lambda: U.get_euler_from_homogeneous_matrix(M), lambda: U.angle_diff(1.0, 2.0), lambda: U.rotation_matrix_from_vector(np.ones(3))):
+            with pytest.raises(Exception):
+                call()
+        U.set_default_solver(None)
 
 
 def test_header_is_plain_c_and_links(tmp_path):

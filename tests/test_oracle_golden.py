@@ -701,8 +701,9 @@ def test_golden_fixtures_reproduce_from_the_reference():
         pytest.skip("/root/reference is not mounted here")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
-    p = subprocess.run([sys.executable, os.path.join(root, "oracle", "gen_golden.py"), "--check", "--only", "g1,g6,g15"],
+    p = subprocess.run([sys.executable, os.path.join(root, "oracle", "gen_golden.py"), "--check", "--only", "g1,g6,g15,g18"],
                        capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "CHECK g1_catalogue.npz: identical" in p.stdout and "CHECK g6_control_continuous.npz: identical" in p.stdout
     assert "CHECK g15_stages.npz: identical" in p.stdout
+    assert "CHECK g18_utils.npz: identical" in p.stdout
