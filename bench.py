@@ -948,10 +948,16 @@ def _run(argv):
             dist.barrier()
         torch.cuda.synchronize()
 
+    def progress(what):  # N > 1: a line per leg on rank 0's stderr (a rehearsal over gloo at full size is minutes of silence otherwise)
+        if world > 1 and rank == 0:
+            print(f"[bench] {time.strftime('%H:%M:%S')} {what}", file=sys.stderr, flush=True)
+
+    progress(f"config {cfg}: {world} ranks, {n} rows per rank resident, launches bound; warm-up")
     yield "ready"
     for _ in range(args.warmup):
         step()
     fence()
+    progress(f"warm-up done; timing {args.steps} steps (--gather {gather_mode})")
 
     # ---- timed region: exactly K steps, bracketed by barrier + synchronize on both sides
     # auto: replay the K launches from a hipGraph where that is the faster way to issue them.  Measured per step on 1 M-pose
@@ -1009,21 +1015,32 @@ def _run(argv):
     fence()
     elapsed = time.perf_counter() - t0
     step_ms_events = e0.elapsed_time(e1) / args.steps
+    progress(f"timed region done: {elapsed * 1e3:.1f} ms")
 
     # ---- config 5: the same K passes again after 60 more untimed ones (the clock has settled: the driver's W = 5 protocol above is the
     # headline, this is the steady state), in the form timed above and in the other one (eager <-> one captured pass replayed)
     steady = None
     if cfg == 5 and world == 1 and not args.no_steady_state:
-        def timed_passes(fn, w, k):
+        # (three windows of K passes, the median reported: issued launch by launch a pass is ~18 launches and ~30 stream operations, and
+        # the HIP runtime's host side hiccups now and then — 1-2 ms around the 1100th launch of a process, 38-49 ms every ~3800 launches,
+        # scripts/probes/c5_pass_sequence.py — which one window of 20 passes either contains or not)
+        windows_ms = {}
+
+        def timed_passes(fn, w, k, name=None):
             for _ in range(w):
                 fn()
-            fence()
-            e0.record()
-            for _ in range(k):
-                fn()
-            e1.record()
-            fence()
-            return e0.elapsed_time(e1) / k
+            got = []
+            for _ in range(3):
+                fence()
+                e0.record()
+                for _ in range(k):
+                    fn()
+                e1.record()
+                fence()
+                got.append(e0.elapsed_time(e1) / k)
+            if name:
+                windows_ms[name] = got
+            return float(np.median(got))
 
         mine = "graph" if graph is not None else ("pipelined" if pipelined[0] else "eager")
         was_pipelined = pipelined[0]
@@ -1049,7 +1066,7 @@ def _run(argv):
         forms = {}
         for name in [mine] + [f for f in ("pipelined", "eager", "graph") if f != mine and not (f == "pipelined" and args.phased_variant)]:
             try:
-                forms[name] = timed_passes(form_fn(name), 60, args.steps)
+                forms[name] = timed_passes(form_fn(name), 60, args.steps, name)
             except Exception as e:  # the other forms are information only
                 if name == mine:
                     raise
@@ -1070,6 +1087,8 @@ def _run(argv):
                   "value": units / (forms[mine] * 1e-3), "unit": "steps/s", "launch": mine,
                   "frac": BYTES_PER_POSE[5] * units / (forms[mine] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                   "launch_forms_ms": forms,
+                  "launch_forms_windows_ms": windows_ms,
+                  "windows": "every form: 60 untimed passes, then three windows of K timed passes (HIP events, a synchronisation between windows); the median is quoted",
                   "launch_forms": {"pipelined": "K passes launch by launch with RSIK_OPT_CONT_GOALS_RESIDENT: the prepare phase of pass k + 1 runs beside "
                                                 "the last chain kernel of pass k and its own start-up search (everything else of pass k + 1 waits for pass k's "
                                                 "end: the trajectory state)",
@@ -1152,6 +1171,7 @@ def _run(argv):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             other_form = {"mode": o_mode, "chunks": o_chunks, "elapsed_s": float(t[0])}
             del o_set
+            progress(f"the other gather form (--gather {o_mode}) timed: {other_form['elapsed_s'] * 1e3:.1f} ms")
 
     # ---- kernel-only and gather-only legs (N > 1), each on its own: same buffers, same launches
     kernel_ms, gather_ms = step_ms_events, 0.0
@@ -1164,6 +1184,7 @@ def _run(argv):
         e1.record()
         fence()
         kernel_ms = e0.elapsed_time(e1) / k2
+        progress(f"kernel-only leg done: {kernel_ms * 1e3:.1f} us per step")
         if gather_mode != "none":
             for w in gather_all():
                 w.wait()
@@ -1175,6 +1196,7 @@ def _run(argv):
             e1.record()
             fence()
             gather_ms = e0.elapsed_time(e1) / k2
+            progress(f"gather-only leg done: {gather_ms:.1f} ms per all-gather")
             # every rank's rows must have arrived where the partition says: a checksum of checksums over the ranks
             launch_all()
             for w in gather_all():

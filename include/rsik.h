@@ -332,9 +332,12 @@ int rsik_control_continuous_step(rsik_ctx *ctx, int64_t n, const double *const m
  *                turns the chunk sits away from it, which it adds to the chunk's rows where they are not zero (fp64 atomic
  *                adds that nobody waits for); only a chunk with an event is walked step by step with the reference's own
  *                sequence of operations (also: steps whose get_joints hit an exact singularity)
- * A run is cut into blocks of steps: three when it is issued launch by launch, two when it is being captured into a
- * hipGraph (RSIK_OPT_CONT_BLOCK_STEPS overrides); the results do not depend on the cut.  Runs of one shape issued one after the
- * other can overlap: RSIK_OPT_CONT_GOALS_RESIDENT.
+ * A run is cut into blocks of steps: three — of at most 512 steps — when it is issued launch by launch, two when it is being captured
+ * into a hipGraph (RSIK_OPT_CONT_BLOCK_STEPS overrides).  Flags, state codes, the carried theta and the latch do not depend on the cut,
+ * nor do the joints of a run of up to eight blocks; beyond that the joints can differ in their last bits from cut to cut (each is
+ * within 2 ulp of the step kernel's: from the ninth block on phase 3 writes a wound trajectory's rows where phase 4 left previous_sol
+ * eight blocks earlier, one rounding instead of two).  Runs of one shape issued one after the other can overlap:
+ * RSIK_OPT_CONT_GOALS_RESIDENT.
  * The phases of neighbouring blocks overlap on four streams (the caller's and three of the context's).  Issued launch by
  * launch the streams are tied by words in device memory (hipStreamWriteValue32 behind the producer, hipStreamWaitValue32
  * ahead of the consumer: a third of an event's latency) and a block's joints kernel is held until the NEXT block's theta

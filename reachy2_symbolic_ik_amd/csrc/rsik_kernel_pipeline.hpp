@@ -94,6 +94,13 @@ struct ContRunArgs {
     uint8_t* chunk_event;         // [ceil(T / kJointChunk)][n]: phase 3 -> phase 4, see cont_joints_kernel
     double snap_tdag;             // phase 2, single-arm launches: see continuous_next_theta_lean (the kind is a template argument)
     double* theta_carry;          // [2][n]: previous_theta between the blocks of one run (phase 2's own state); row 1: see cont_theta_kernel
+    int no_turn_hint;             // (timing experiments: RSIK_OPT_CONT_PHASED_VARIANT bit 64 — the hint is written as "no turns")
+    unsigned* turn_hint;          // [n]: whole turns previous_sol sits away from [-pi, pi], joints 0, 2, 4, 6 as four biased bytes: what this block's
+                                  // joints kernel reads (cont_joints_chunk) — the run's own array, written by the first block's theta kernel from the
+                                  // state the run begins with, or, from the ninth block on, the workspace slot's, which the chain kernel of the block
+                                  // that used the slot before (eight blocks earlier) left there
+    unsigned* run_turn_hint;      // the run's own array (the first block's theta kernel writes it)
+    uint8_t* slot_turn_hint;      // [n][4]: the slot's array (this block's chain kernel writes it at its end)
     int first_block, last_block;
     unsigned* started_word;       // phased pipeline, launch by launch: the theta kernel of a block writes started_seq here when it starts
     unsigned started_seq;         // (the host holds the joints kernel of the block BEFORE on it, see rsik_control_continuous_run), or NULL
@@ -323,6 +330,22 @@ __global__ __launch_bounds__(kThetaBlock) __attribute__((amdgpu_waves_per_eu(1, 
     // previous_theta travels from block to block in theta_carry: this phase runs ahead of phase 4 (other streams), which
     // alone decides what ends up in the state's row 0 — the theta of the last step, or of the step that latched the
     // emergency stop (C:205-210; what this phase computes for a latched trajectory is never looked at).
+    if (K.first_block) {
+        // Round 6: where previous_sol stands when the run begins (the start-up kernel, ahead of this one on its stream, has had its say),
+        // in whole turns, for the four joints that can wind (shoulder pitch, elbow yaw, wrist roll, wrist yaw): the joints phase writes
+        // its rows that many turns up, so that a trajectory that ARRIVES wound — the later chunks of a streamed trajectory, the survivors
+        // of an emergency stop — finds its chunks standing where the chain phase looks for them instead of having every element of every
+        // chunk moved there by an atomic add (a pass of such trajectories: 1.12 -> ms, profiles/r06/config5_latched_passes.txt).  A
+        // hint only: the chain phase judges every chunk against previous_sol as before, and adds what is still missing.
+        unsigned packed = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const double p = K.st[(1 + 2 * q) * K.n + i];
+            const double h = (fabs(p) < 600.0 && !K.no_turn_hint) ? rint(p * 0.15915494309189535) : 0.0;  // (|turns| <= 100 is all the chain phase takes as quiet)
+            packed |= (unsigned)((int)h + 128) << (8 * q);
+        }
+        K.run_turn_hint[i] = packed;
+    }
     const double prev_theta = K.first_block ? K.st[0 * K.n + i] : K.theta_carry[i];
     K.theta_carry[i] = cont_theta_walk<KIND, kThetaBatch>(K, i, K.lim[slot][0], K.lim[slot][1], K.ws, K.gw, K.T, K.first_block != 0,
                                                                  prev_theta, K.theta_carry + K.n);
@@ -413,6 +436,7 @@ __device__ __forceinline__ void cont_joints_chunk(const ContRunArgs& K, SharedTa
         for (int k = 9; k < 12; k++) m[k] = src[k * n];
     }
     const double theta = RSIK_WS(K, tt, ii);
+    const unsigned hint = K.turn_hint[ii];  // (whole turns previous_sol stood away from the raw angles when the run began: cont_theta_kernel)
     int flag = (int)K.flags[tt * n + ii];
     const bool special = (flag & 8) != 0;
     if (RSIK_RARE(special)) {
@@ -476,11 +500,11 @@ __device__ __forceinline__ void cont_joints_chunk(const ContRunArgs& K, SharedTa
 #pragma unroll
     for (int k = 0; k < 7; k++) turn[k] = 0.0;
     {
-        const int bias = 8 * (sl + 1);
-        turn[0] = (double)((int)(word & 0xffu) - bias);
-        turn[2] = (double)((int)((word >> 8) & 0xffu) - bias);
-        turn[4] = (double)((int)((word >> 16) & 0xffu) - bias);
-        turn[6] = (double)((int)(word >> 24) - bias);
+        const int bias = 8 * (sl + 1) + 128;  // (+ the hint's own bias)
+        turn[0] = (double)((int)(word & 0xffu) + (int)(hint & 0xffu) - bias);
+        turn[2] = (double)((int)((word >> 8) & 0xffu) + (int)((hint >> 8) & 0xffu) - bias);
+        turn[4] = (double)((int)((word >> 16) & 0xffu) + (int)((hint >> 16) & 0xffu) - bias);
+        turn[6] = (double)((int)(word >> 24) + (int)(hint >> 24) - bias);
     }
     double out[7];
 #pragma unroll
@@ -781,6 +805,9 @@ __device__ __forceinline__ void cont_chain_walk(const ContRunArgs& K, SharedTabl
         }
     }
     if (owner) K.st[(1 + j) * n + i] = prev;
+    // (where previous_sol stands now, in whole turns: the hint of the joints kernel that takes this workspace slot next)
+    if (owner && (j & 1) == 0)
+        K.slot_turn_hint[4 * i + (j >> 1)] = (uint8_t)((int)((fabs(prev) < 600.0 && !K.no_turn_hint) ? rint(prev * 0.15915494309189535) : 0.0) + 128);
     if (live && j == 7) {
         K.st[8 * n + i] = init ? 1.0 : 0.0;
         K.st[9 * n + i] = emergency ? 1.0 : 0.0;

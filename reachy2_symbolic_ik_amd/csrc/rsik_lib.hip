@@ -201,7 +201,7 @@ int rsik_set_arm(rsik_ctx* ctx, int arm, const double* consts_host, int count) {
 int rsik_set_option(rsik_ctx* ctx, int option, int value) {
     if (!ctx) return RSIK_E_INVALID;
     if (option < 0 || option >= RSIK_OPT_COUNT) return fail(ctx, RSIK_E_INVALID, "rsik_set_option: unknown option");
-    static const int max_value[RSIK_OPT_COUNT] = {RSIK_EULER_NEVER, 2, 1, 1, RSIK_CONT_RUN_STEPS, 65535, 31, 1};
+    static const int max_value[RSIK_OPT_COUNT] = {RSIK_EULER_NEVER, 2, 1, 1, RSIK_CONT_RUN_STEPS, 65535, 127, 1};
     if (value < 0 || value > max_value[option]) return fail(ctx, RSIK_E_INVALID, "rsik_set_option: value out of range");
     ctx->options[option] = value;
     return RSIK_OK;
@@ -580,9 +580,9 @@ static int cont_plan(rsik_ctx* ctx, const char* who, int64_t n, int64_t n_steps,
     }
     const int64_t n_blocks = (int64_t)P.block_t0.size();
     P.chunks_per_block = ((size_t)T + rsik::kJointChunk - 1) / rsik::kJointChunk;
-    P.slot_bytes = (((size_t)T * P.per_step + P.chunks_per_block * (size_t)n + 255) / 256) * 256;
+    P.slot_bytes = (((size_t)T * P.per_step + P.chunks_per_block * (size_t)n + 255) / 256) * 256 + (((size_t)n * sizeof(unsigned) + 255) / 256) * 256;  // (+ the slot's turn hints)
     P.slots = (n_blocks < kContSlots && !all_slots) ? (int)n_blocks : kContSlots;
-    P.carry_bytes = (((size_t)n * 2 * sizeof(double) + 255) / 256) * 256;
+    P.carry_bytes = (((size_t)n * 2 * sizeof(double) + 255) / 256) * 256 + (((size_t)n * sizeof(unsigned) + 255) / 256) * 256;  // theta_carry, turn_hint
     P.need = P.slot_bytes * P.slots + P.carry_bytes;
     P.n_events = 4 + 6 * (size_t)n_blocks;  // per run 4, per block: prepared, theta, joints, chain, "theta / chain has started" (words only)
     return RSIK_OK;
@@ -903,6 +903,8 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
     R.max_angle = K0.max_angle; R.cos_max = K0.cos_max; R.sin_max = K0.sin_max;
     R.st = cont_state; R.joints = joints_steps; R.reachable = reachable_steps; R.state = state_steps;
     R.theta_carry = reinterpret_cast<double*>(static_cast<char*>(ctx->ws) + slot_bytes * slots);
+    R.no_turn_hint = (variant & 64) ? 1 : 0;
+    R.run_turn_hint = reinterpret_cast<unsigned*>(static_cast<char*>(ctx->ws) + slot_bytes * slots + (((size_t)n * 2 * sizeof(double) + 255) / 256) * 256);
     const dim3 grid8((unsigned)((n * 8 + rsik::kChainBlock - 1) / rsik::kChainBlock));  // (n <= 30 Mi: fits)
     // What a pass really looks like was measured with in-kernel stamps (a -DRSIK_PIPE_TIMING build,
     // scripts/probes/c5_untraced_timeline.py; the profiler's kernel trace delays launches and shows another schedule): a
@@ -932,6 +934,10 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         R.gw = R.ws + (size_t)R.T * (size_t)n;
         R.flags = reinterpret_cast<uint8_t*>(R.gw + (size_t)R.T * (size_t)n);
         R.chunk_event = R.flags + (size_t)R.T * (size_t)n;
+        // (the slot's turn hints sit at its end, whatever the block's length; a block that is the first to use its slot in this run
+        // reads the run's own)
+        R.slot_turn_hint = reinterpret_cast<uint8_t*>(R.ws) + slot_bytes - (((size_t)n * sizeof(unsigned) + 255) / 256) * 256;
+        R.turn_hint = b < slots ? R.run_turn_hint : reinterpret_cast<unsigned*>(R.slot_turn_hint);
     };
     const int64_t head = n_blocks < slots ? n_blocks : slots;  // blocks with a workspace slot of their own: issued phase by phase
     auto issue_prepare = [&](int64_t b) -> int {

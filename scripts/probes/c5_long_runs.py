@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--blocks", default="0,352")
     ap.add_argument("--reps", type=int, default=4)
     ap.add_argument("--graph", action="store_true", help="also time the run captured once and replayed")
-    ap.add_argument("--variants", default="0", help="RSIK_OPT_CONT_PHASED_VARIANT values, comma-separated (16 = stream waits instead of in-kernel waits)")
+    ap.add_argument("--variants", default="0", help="RSIK_OPT_CONT_PHASED_VARIANT values, comma-separated (64 = the joints phase without its turn hints)")
     args = ap.parse_args()
     n = args.n_traj
     lengths = [int(v) for v in args.steps.split(",")]

@@ -59,13 +59,21 @@ def main():
 
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-    def timed(fn, k):
+    host_ms = {}
+
+    def timed(fn, k, name=None):
+        import time
+
         torch.cuda.synchronize()
         e0.record()
+        t0 = time.perf_counter()
         for i in range(k):
             fn(i)
+        host = (time.perf_counter() - t0) * 1e3 / k  # what the host needs to ISSUE a pass (its calls return: nothing waits for the device)
         e1.record()
         torch.cuda.synchronize()
+        if name:
+            host_ms.setdefault(name, []).append(host)
         return e0.elapsed_time(e1) / k
 
     def snapshot(out):
@@ -103,7 +111,7 @@ def main():
     iso = []
     for rnd in range(args.rounds):
         for name, fn in forms.items():
-            ms = timed(fn, K)
+            ms = timed(fn, K, name)
             results[name].append(ms)
             snap = snapshot(outs[(K - 1) & 1] if name == "resident2" else outs[0])
             if name == "serial" and ref is None:
@@ -120,6 +128,7 @@ def main():
             t += e0.elapsed_time(e1)
         iso.append(t / K)
         print(f"round {rnd}  isolated   {t / K:7.4f} ms per pass (a device synchronisation behind every pass)", flush=True)
+    print("host issue time per pass (ms, best):", {k: round(min(v), 4) for k, v in host_ms.items()})
     print("run forms seen:", forms_seen)
     print("best per form:", {k: round(min(v), 4) for k, v in results.items()}, "isolated", round(min(iso), 4))
 

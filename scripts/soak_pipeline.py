@@ -4,7 +4,8 @@ winding joints, unreachable stretches, exact repeats = "stay" steps) through rsi
 pipeline and as one launch of the step kernel per control step, for both arms x both constrained modes x two rate
 limits: flags, state codes, the carried theta, the latch / init rows and the emergency cause bits must be the same bits,
 joints and previous_sol equal to 1e-9 (the pipeline writes a quiet step as raw joint + whole turns instead of previous +
-angle_diff(raw, previous): the last bits differ, amplified where the arm is stretched out).
+angle_diff(raw, previous): the last bits differ, amplified where the arm is stretched out); and — round 6 — as three
+overlapping runs (RSIK_OPT_CONT_GOALS_RESIDENT), which must be the pipeline's bits exactly.
 usage: soak_pipeline.py [trajectories] [steps]"""
 import os
 import sys
@@ -64,18 +65,34 @@ for ai, arm in enumerate(("r_arm", "l_arm")):
                 torch.cuda.synchronize()
                 res[name] = {k: v.clone() for k, v in out.items()}
                 res[name]["cont_state"] = st.clone()
+            # round 6: the same run issued three times back to back with RSIK_OPT_CONT_GOALS_RESIDENT — the second and third overlap the
+            # run before them (prepare phase beside its tail, slots taking turns, theta kernels waiting for their prepare kernels
+            # themselves) — must give the pipeline's bits every time
+            ctrl._solver.set_option(A.OPT_CONT_RUN_MODE, A.CONT_RUN_PHASED)
+            outs = [None, None]
+            forms = []
+            for rep in range(3):
+                st = ctrl.new_continuous_state(arm, n_traj)
+                outs[rep & 1] = ctrl.run_continuous_trajectories(arm, traj, st, first_step_timed_out=True, current_pose=traj[0],
+                                                                 constrained_mode=mode, d_theta_max=dmax, out=outs[rep & 1], goals_resident=True)
+                forms.append(outs[rep & 1].run_form)
+            torch.cuda.synchronize()
+            over = {k: v for k, v in outs[0].items()}
+            over["cont_state"] = st
+            overlapped_same = forms[1:] == [A.CONT_FORM_PHASED_OVERLAPPED] * 2 and all(
+                torch.equal(over[k].contiguous().view(torch.uint8), res["pipeline"][k].contiguous().view(torch.uint8)) for k in over)
             a, b = res["steps"], res["pipeline"]
             same = all(torch.equal(a[k], b[k]) for k in ("reachable", "state"))
             sa, sb = a["cont_state"], b["cont_state"]
             same = same and torch.equal(sa[0].view(torch.uint8), sb[0].view(torch.uint8)) and torch.equal(sa[8:12], sb[8:12])
             worst = max(float((a["joints"] - b["joints"]).abs().max()), float((sa[1:8] - sb[1:8]).abs().max()),
                         float((sa[12:19] - sb[12:19]).abs().max()))
-            same = same and worst <= 1e-9
+            same = same and worst <= 1e-9 and overlapped_same
             st = res["steps"]["cont_state"]
             j = res["steps"]["joints"]
             print(f"{arm} {mode:13s} d_theta_max {dmax}: {n_traj} x {n_steps} steps, reachable {float(res['steps']['reachable'].float().mean()):.2f}, "
                   f"latched {int((st[9] != 0).sum())}, joints beyond pi in {float((j.abs() > np.pi).any(dim=2).float().mean()):.3f} of the steps, "
-                  f"max |joint| {float(j[torch.isfinite(j)].abs().max()):.2f}: {'flags / states / theta / latch identical, joints to %.1e' % worst if same else 'MISMATCH (joints %.3e)' % worst}")
+                  f"max |joint| {float(j[torch.isfinite(j)].abs().max()):.2f}: {'flags / states / theta / latch identical, joints to %.1e; overlapped runs bit-identical to the pipeline' % worst if same else 'MISMATCH (joints %.3e, overlapped runs %s)' % (worst, 'identical' if overlapped_same else 'DIFFER')}")
             bad += 0 if same else 1
 ctrl._solver.set_option(A.OPT_CONT_RUN_MODE, A.CONT_RUN_AUTO)
 print("TOTAL", "0 mismatches" if bad == 0 else f"{bad} configurations differ")

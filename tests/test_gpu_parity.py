@@ -1371,7 +1371,12 @@ def test_continuous_run_forms_are_bit_identical(torch_mod, n_traj, n_steps, arm,
     its variants — events instead of stream value words, no theta-first hold, other block sizes).  They run the same device
     code on the same data: every output and
     the carried state must be the same BITS, on eventful trajectories (jumps, wound wrists, unreachable stretches, repeats)
-    that take the sequential phases through their rare paths; the step kernel, launch per step, bounds them all (_same_run)."""
+    that take the sequential phases through their rare paths; the step kernel, launch per step, bounds them all (_same_run).
+    One exception since round 6: a cut into MORE than eight blocks (blocks of 16 here: 13 of them).  From the ninth block on the joints
+    phase writes its rows as many whole turns up as the chain phase found previous_sol to be when it finished the block that used the
+    workspace slot before — a hint that saves the chain phase its atomic adds on trajectories that have wound up (long runs: -5 ... -9 %)
+    — and a quiet step's value is then raw + turns x 2 pi in ONE rounding instead of two: flags, states, the carried theta and the
+    latch are still the same bits, joints and previous_sol the same to 1e-12 (observed: 2 ulp)."""
     A = _abi_mod()
     traj = _eventful_trajectories(torch_mod, n_traj, n_steps, 7000 + n_traj, arm)
     c = make_control()
@@ -1397,6 +1402,13 @@ def test_continuous_run_forms_are_bit_identical(torch_mod, n_traj, n_steps, arm,
     _same_run(torch_mod, {k: (v[:11] if k == "cont_state" else v) for k, v in got["steps"].items()},
               {k: (v[:11] if k == "cont_state" else v) for k, v in ref.items()}, "steps vs phased")
     for name, _, _, blk in forms[2:]:
+        if blk and (n_steps + blk - 1) // blk > 8:
+            # (rows 11 ... 18 of the state — the cause bits and the joints the continuity check rejected — exactly / to the same bar)
+            _same_run(torch_mod, {k: (v[:11] if k == "cont_state" else v) for k, v in ref.items()},
+                      {k: (v[:11] if k == "cont_state" else v) for k, v in got[name].items()}, name, joint_tol=1e-12)
+            a, b = ref["cont_state"], got[name]["cont_state"]
+            assert torch_mod.equal(a[11], b[11]) and float((a[12:19] - b[12:19]).abs().nan_to_num().max()) <= 1e-12, name
+            continue
         for k, v in ref.items():
             a, b = v, got[name][k]
             same = torch_mod.equal(a.view(torch_mod.uint8), b.view(torch_mod.uint8))
