@@ -49,7 +49,7 @@ BYTES_PER_STEP_STATE_ROUND_TRIP = 96 + 58 + 2 * 66
 GATHER_BYTES_PER_POSE = 56 + 1  # joints [7] f64 + state u8 (reachable == (state == 0) for rsik_solve)
 URDF = "config_files/reachy2_ik_minimal.urdf"
 SHOULDER_R = np.array([0.0, -0.2, 0.0])
-PROFILE_COUNTERS = os.path.join(ROOT, "profiles", "r05", "counters.json")
+PROFILE_COUNTERS = os.path.join(ROOT, "profiles", "r06", "counters.json")
 
 
 def _quiet(fn, *a, **k):
@@ -368,7 +368,7 @@ def committed_counters(cfg, n, build_id):
         t = doc.get(str(cfg))
         if t and t["poses_per_gpu"] == n and doc.get("build_id") == build_id:
             return t
-        return {"stale": f"profiles/r05/counters.json was collected with another build or size (library {build_id})"}
+        return {"stale": f"profiles/r06/counters.json was collected with another build or size (library {build_id})"}
     except (OSError, ValueError, KeyError):
         return None
 
@@ -1407,7 +1407,7 @@ def _run(argv):
         cnt = committed_counters(cfg, n, build_id)
         if cnt and "bytes" in cnt:
             line["roofline"]["traffic"] = cnt["bytes"]
-            line["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) / WRITE_SIZE of this build (profiles/r05/counters.json)"
+            line["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) / WRITE_SIZE of this build (profiles/r06/counters.json)"
             if "bytes_per_pass_by_kernel" in cnt:  # config 5: `traffic` is per control step like `achieved`; the pass by kernel:
                 line["roofline"]["traffic_per_pass_by_kernel"] = cnt["bytes_per_pass_by_kernel"]
         elif cnt and "stale" in cnt:

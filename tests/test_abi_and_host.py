@@ -315,3 +315,15 @@ def test_bench_default_protocol_times_every_gpu_leg_before_any_cpu_leg():
     assert five["traffic_bytes_per_pass"] == 2000.0 and five["traffic_bytes_per_control_step_of_4096_trajectories"] == 2.0
     assert [o[:2] for o in order] == [["setup", 2], ["setup", 3], ["setup", 4], ["setup", 5], ["gpu", 2], ["gpu", 3], ["gpu", 4], ["gpu", 5],
                                       ["cpu", 2], ["cpu", 3], ["cpu", 5]]
+
+
+def test_bench_defaults():
+    """bench.py's defaults, without a GPU: N > 1 times the north star's job shape (K sharded steps + ONE all-gather) unless told otherwise,
+    config 5 the pipelined launch form, the settled leg of configs 2-4 takes 50 ms of untimed launches."""
+    import bench
+
+    a = bench.parse_args([])
+    assert a.gather == "final" and a.launch == "auto" and a.settle_ms == 50.0 and a.gpus == 1 and a.chunks == 4
+    assert bench.parse_args(["--gather-every-step"]).gather == "step" and bench.parse_args(["--graph"]).launch == "graph"
+    h = bench.host_facts()
+    assert h["cores_visible"] >= 1 and h["logical_cpus"] >= h["cores_visible"] and isinstance(h["cpu_model"], str) and h["cpu_model"]

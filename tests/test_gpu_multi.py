@@ -81,7 +81,7 @@ def _check_two_rank_line(d, gather, world=2):
         assert "gather_final" not in d
 
 
-@pytest.mark.parametrize("gather", ["default", "step", "final", "none"])
+@pytest.mark.parametrize("gather", ["default", "step", "none"])
 def test_bench_two_ranks_gloo_one_gpu(gather):
     """`bench.py --gpus 2` starts its own ranks; config 4 (mixed r/l) is the N > 1 default, and so is `--gather final`: the
     all-gather the north star names, once, after the K sharded steps."""
