@@ -896,10 +896,17 @@ def _run(argv):
         # were: each resets the trajectory state, re-initialises every trajectory and writes every output row.
         pipelined = [args.launch in ("auto", "pipelined") and world == 1 and not args.phased_variant]
         forms_seen = {}
+        # overlapping passes write two sets of output buffers in turn, as a caller that consumes pass k while pass k + 1 runs has to
+        # (the promise covers a run's output rows too); every other form writes `out`.  `last_out`: what the last pass issued wrote.
+        out_sets = [out, {k: torch.empty_like(v) for k, v in out.items()}] if pipelined[0] else [out]
+        last_out, passes_issued = [out], [0]
 
         def one_pass(stream=None):  # one bench "step" = one 1000-step pass over all trajectories
             cont.copy_(cont0)
-            r = ctrl.run_continuous_trajectories("r_arm", traj, cont, first_step_timed_out=True, current_pose=traj[0], out=out,
+            o = out_sets[passes_issued[0] % len(out_sets)] if pipelined[0] else out
+            passes_issued[0] += 1
+            last_out[0] = o
+            r = ctrl.run_continuous_trajectories("r_arm", traj, cont, first_step_timed_out=True, current_pose=traj[0], out=o,
                                                  goals_resident=pipelined[0])
             forms_seen[r.run_form_name] = forms_seen.get(r.run_form_name, 0) + 1
 
@@ -913,6 +920,7 @@ def _run(argv):
                 graph_ctx["ctrl"]._upload_arms()
                 graph_ctx["ctrl"]._solver.control_continuous_reserve(n_traj, n_steps)
             cont.copy_(cont0)
+            last_out[0] = out
             graph_ctx["ctrl"].run_continuous_trajectories("r_arm", traj, cont, first_step_timed_out=True, current_pose=traj[0], out=out)
 
         launches = [one_pass]
@@ -1091,7 +1099,7 @@ def _run(argv):
                   "windows": "every form: 60 untimed passes, then three windows of K timed passes (HIP events, a synchronisation between windows); the median is quoted",
                   "launch_forms": {"pipelined": "K passes launch by launch with RSIK_OPT_CONT_GOALS_RESIDENT: the prepare phase of pass k + 1 runs beside "
                                                 "the last chain kernel of pass k and its own start-up search (everything else of pass k + 1 waits for pass k's "
-                                                "end: the trajectory state)",
+                                                "end: the trajectory state); two sets of output buffers in turn",
                                    "eager": "K passes launch by launch, every pass's four streams meet at its start and at its end (no overlap between passes)",
                                    "graph": "one captured pass (two blocks, events) replayed K times: replays of one graph do not overlap"},
                   "isolated_pass_ms": float(np.median(iso)),
@@ -1220,6 +1228,7 @@ def _run(argv):
         jj = bufs.full["joints"] if bufs is not None else out["joints"]
         assert bool(torch.isfinite(jj).all()), "non-finite joints"
     if cfg == 5:  # every step of every trajectory produced joints; the reachable / fallback mix is the generator's
+        out = last_out[0]  # (the set the last pass wrote: overlapping passes take two in turn)
         assert bool(torch.isfinite(out["joints"]).all()), "non-finite joints in the trajectory batch"
         frac_ok = float(out["reachable"].to(torch.float32).mean().item())
         assert 0.05 < frac_ok < 0.95, f"unexpected reachable fraction {frac_ok}"

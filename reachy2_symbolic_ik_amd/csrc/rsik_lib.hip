@@ -723,13 +723,16 @@ static int cont_run_begin(rsik_ctx* ctx, bool capturing) {
     RSIK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->run_done, 0));
     return RSIK_OK;
 }
-static int cont_run_end(rsik_ctx* ctx, bool capturing) {
+// `where`: the stream whose last operation marks the run's end — the chain stream behind the last chain kernel (every phase of every
+// block is ahead of it), so that the record is not one more operation between this run's end and the next run's first kernel on the
+// caller's stream (round 6: that stretch is on the critical path of runs that overlap); the caller's stream where a run failed part-way.
+static int cont_run_end(rsik_ctx* ctx, bool capturing, hipStream_t where) {
     if (capturing) return RSIK_OK;
     if (!ctx->have_run_done) {
         RSIK_HIP(ctx, hipEventCreateWithFlags(&ctx->run_done, hipEventDisableTiming));
         ctx->have_run_done = true;
     }
-    RSIK_HIP(ctx, hipEventRecord(ctx->run_done, ctx->stream));
+    RSIK_HIP(ctx, hipEventRecord(ctx->run_done, where));
     ctx->run_stream = ctx->stream;
     return RSIK_OK;
 }
@@ -1115,7 +1118,7 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         // (what was issued before the failure is still running: rsik_sync and the next run's housekeeping wait for THIS point)
         if (!capturing) {
             const std::string first_error = ctx->err;
-            (void)cont_run_end(ctx, false);
+            (void)cont_run_end(ctx, false, ctx->stream);
             (void)hipGetLastError();
             ctx->err = first_error;
         }
@@ -1131,7 +1134,7 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
         L.state_lo = st_lo; L.state_hi = st_hi; L.reach_lo = rc_lo; L.reach_hi = rc_hi;
         ctx->slot_next = (int)((slot_base + n_blocks) % slots);
     }
-    return cont_run_end(ctx, capturing);
+    return cont_run_end(ctx, capturing, s_chain);
 }
 
 int rsik_control_continuous_last_form(const rsik_ctx* ctx) { return ctx ? ctx->last_run_form : RSIK_CONT_FORM_NONE; }
