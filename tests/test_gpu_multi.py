@@ -95,13 +95,14 @@ def test_bench_two_ranks_gloo_one_gpu(gather):
 def test_bench_four_ranks_gloo_one_gpu(gather):
     """The driver's SCALE command shape rehearsed at the largest rank count a one-GPU box of this pool admits beside the test runner
     (its process guard stops a seventh process on the card; the eight-rank partition itself is covered on the CPU,
-    tests/test_distributed_gloo.py): four ranks, 131 072 mixed r/l poses each, eight stripes per shard in the every-step form — the
+    tests/test_distributed_gloo.py; six ranks at BASELINE's 1 048 576 poses per rank are on record under profiles/r06/): four ranks,
+    32 768 mixed r/l poses each (gloo moves the gathered arrays through host memory: minutes at full size), eight stripes per shard in the every-step form — the
     rank-0 parity sample is drawn from all four parts of the gathered array, the checksum of every rank's rows is checked on every
     rank, the group as the collective library sees it has four members."""
-    d = _bench("--gpus", "4", "--backend", "gloo", "--single-device", "--poses", "131072", "--steps", "3", "--warmup", "1",
+    d = _bench("--gpus", "4", "--backend", "gloo", "--single-device", "--poses", "32768", "--steps", "2", "--warmup", "1",
                "--cpu-seconds", "2", "--chunks", "8", "--gather", gather)
     _check_two_rank_line(d, gather, world=4)
-    assert d["config"]["poses_per_gpu"] == 131072 and "rehearsal" in d["config"]["collective"]
+    assert d["config"]["poses_per_gpu"] == 32768 and "rehearsal" in d["config"]["collective"]
 
 
 def test_bench_measures_traffic_in_its_own_run():
