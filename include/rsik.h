@@ -432,6 +432,7 @@ int rsik_control_continuous_release(rsik_ctx *ctx);
  *   RSIK_STAGE_BEST_DISCRETE_THETA  get_best_discrete_theta :334-396: previous_theta, interval 2, nb_search_points, preferred_theta, side,
  *                                   singularity_offset, singularity_limit_coeff, elbow_singularity_position 3, the intersection circle its
  *                                   get_elbow_position argument reads (centre 3, radius, normal 3) -> found 0/1, theta, preferred worked 0/1
+ *                                   (nb_search_points outside [0, 2^20] or not a number: an empty grid)
  */
 #define RSIK_STAGE_POSE_IN_REACH 0
 #define RSIK_STAGE_WRIST_POSITION 1

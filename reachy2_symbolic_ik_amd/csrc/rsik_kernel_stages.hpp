@@ -343,7 +343,9 @@ __global__ __launch_bounds__(kBlock) void stage_kernel(const StageArgs K) {
         for (int k = 0; k < 18; k++) in[k] = x[k];
         double th = in[0];
         bool worked = false;
-        const bool found = best_discrete_theta_ref(in[0], in[1], in[2], (int)in[3], in[4], in[5], in[6], in[7], V3{in[8], in[9], in[10]}, V3{in[11], in[12], in[13]},
+        // (the grid size is data: a NaN, a negative number or an absurd one must not become the trip count of a loop on the device)
+        const int nb = (in[3] >= 0.0 && in[3] <= 1048576.0) ? (int)in[3] : 0;
+        const bool found = best_discrete_theta_ref(in[0], in[1], in[2], nb, in[4], in[5], in[6], in[7], V3{in[8], in[9], in[10]}, V3{in[11], in[12], in[13]},
                                                    in[14], V3{in[15], in[16], in[17]}, th, worked);
         o[0] = found ? 1.0 : 0.0; o[1] = th; o[2] = worked ? 1.0 : 0.0;
         break;

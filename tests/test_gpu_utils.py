@@ -50,6 +50,13 @@ def test_utils_stages_against_reference(golden_dir, torch_mod):
     np.testing.assert_array_equal(o[:, 0] != 0, g["bd_found"] != 0)
     np.testing.assert_array_equal(o[:, 2] != 0, g["bd_worked"] != 0)
     assert np.max(np.abs(o[:, 1] - g["bd_theta"])) < 1e-12  # (a grid point, the preferred theta, or previous_theta handed back)
+    # a grid size that is not a sane number is an empty grid (nothing found, previous_theta handed back), never a loop count
+    pick = np.nonzero(np.abs(g["bd_interval"]).sum(axis=1) < 6.0)[0][:4]  # (not the whole circle: NaN is in no other interval)
+    bad = np.column_stack([a[pick, 0], g["bd_interval"][pick], a[pick, 1:], g["bd_circle"][pick]])
+    bad[:, 3] = [np.nan, -5.0, 1e300, np.inf]
+    bad[:, 4] = np.nan  # (a preferred theta that is in no interval: the shortcut cannot answer)
+    o = run(A.STAGE_BEST_DISCRETE_THETA, torch_mod.as_tensor(np.ascontiguousarray(bad)).cuda())
+    assert np.all(o[:, 0] == 0) and np.array_equal(o[:, 1], bad[:, 0])
     with pytest.raises(Exception):
         hs.stage(A.STAGE_ANGLE_DIFF, T(g["ad_a"]), 0)  # a row of the wrong length is refused on the host
 
