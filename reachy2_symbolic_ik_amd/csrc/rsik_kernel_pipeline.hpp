@@ -335,8 +335,9 @@ __global__ __launch_bounds__(kThetaBlock) __attribute__((amdgpu_waves_per_eu(1, 
         // in whole turns, for the four joints that can wind (shoulder pitch, elbow yaw, wrist roll, wrist yaw): the joints phase writes
         // its rows that many turns up, so that a trajectory that ARRIVES wound — the later chunks of a streamed trajectory, the survivors
         // of an emergency stop — finds its chunks standing where the chain phase looks for them instead of having every element of every
-        // chunk moved there by an atomic add (a pass of such trajectories: 1.12 -> ms, profiles/r06/config5_latched_passes.txt).  A
-        // hint only: the chain phase judges every chunk against previous_sol as before, and adds what is still missing.
+        // chunk moved there by an atomic add (a run that continues config 5's batch, 95 % of whose steps have a joint beyond pi by then:
+        // 0.50 -> 0.43 ms, profiles/r06/config5_continuing_runs_s1.txt).  A hint only: the chain phase judges every chunk against
+        // previous_sol as before, and adds what is still missing.
         unsigned packed = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
