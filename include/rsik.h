@@ -169,7 +169,9 @@ int rsik_destroy(rsik_ctx *ctx);
 const char *rsik_last_error(const rsik_ctx *ctx);
 /* Use the caller's hipStream_t (e.g. torch's current stream) for all launches; NULL = default stream. */
 int rsik_set_stream(rsik_ctx *ctx, void *hip_stream);
-/* Waits for the context's stream; also frees the workspaces that continuous runs have outgrown since the last call. */
+/* Waits for the context's stream; also frees the workspaces that continuous runs have outgrown since the last call, and reports
+ * (RSIK_E_HIP) a theta kernel of an overlapping continuous run that gave up its bounded wait for its prepare kernel (cannot happen:
+ * everything it waits for is issued before it; bounded so that it cannot hang the device either). */
 int rsik_sync(rsik_ctx *ctx);
 /* Uploads one arm's constant block (host pointer).  Replaces SymbolicIK.__init__ (symbolic_ik.py:26-83). */
 int rsik_set_arm(rsik_ctx *ctx, int arm, const double *consts_host, int count);
@@ -209,7 +211,11 @@ int rsik_set_arm(rsik_ctx *ctx, int arm, const double *consts_host, int count);
 /*   RSIK_OPT_CONT_PHASED_VARIANT  phased pipeline issued launch by launch, a bit mask (0 = the default form; results do not depend on it):
  *                              1  its streams tied by hipEvents (as a run recorded into a hipGraph always is) instead of by
  *                                 hipStreamWriteValue32 / hipStreamWaitValue32 on words in device memory
- *                              2  the joints kernel of a block NOT held until the theta kernel of the next block has started */
+ *                              2  the joints kernel of a block NOT held until the theta kernel of the next block has started
+ *                              4 / 8 / 16  (runs that overlap, RSIK_OPT_CONT_GOALS_RESIDENT) the next run's prepare kernels not held at all /
+ *                                 held until the previous run's last chain kernel has FINISHED / its theta kernels behind stream waits
+ *                                 instead of waiting for their prepare kernels themselves — the steps docs/experiments.md R6.2 measures
+ *                              64 the joints phase without its turn hints (R6.3; joints then differ in their last bits) */
 #define RSIK_OPT_CONT_PHASED_VARIANT 6
 #define RSIK_PHASED_EDGES_BY_EVENT 1
 #define RSIK_PHASED_NO_THETA_FIRST 2
