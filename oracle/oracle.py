@@ -68,6 +68,19 @@ def _bind(L):
     L.orc_euler_from_matrix_xyz.argtypes = [_dp, _dp]
     L.orc_get_best_discrete_theta.restype = C.c_int
     L.orc_get_best_discrete_theta.argtypes = [_dp, _dp, C.c_double, _dp, C.c_int, C.c_double, _dp]
+    L.orc_is_elbow_ok_args.restype = C.c_int
+    L.orc_is_elbow_ok_args.argtypes = [_dp, C.c_double, C.c_double, C.c_double, _dp]
+    L.orc_allow_multiturn.argtypes = [_dp, _dp, _dp]
+    L.orc_multiturn_safety_check.restype = C.c_int
+    L.orc_multiturn_safety_check.argtypes = [_dp, _dp, _dp]
+    L.orc_continuity_check.restype = C.c_int
+    L.orc_continuity_check.argtypes = [_dp, _dp, _dp, _dp]
+    L.orc_best_discrete_theta_circle.restype = C.c_int
+    L.orc_best_discrete_theta_circle.argtypes = [C.c_double, _dp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, _dp, _dp, _dp, _ip]
+    L.orc_points_of_nearest_approach.restype = C.c_int
+    L.orc_points_of_nearest_approach.argtypes = [_dp] * 6
+    L.orc_intersection_circle_line.restype = C.c_int
+    L.orc_intersection_circle_line.argtypes = [_dp, C.c_double, _dp, _dp, _dp]
     L.orc_control_discrete.restype = C.c_int
     L.orc_control_discrete.argtypes = [_dp, _dp, C.c_int, C.c_double, C.c_int, _dp, _dp, C.c_double, C.c_double, _dp, _ip, _ip]
     L.orc_control_continuous_step.restype = C.c_int

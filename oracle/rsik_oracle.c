@@ -427,7 +427,7 @@ static void get_limitation_wrist_circle(const orc_arm_t *arm, const orc_solver_t
 }
 
 /* S:570-586 intersection_point via np.linalg.lstsq on the 3x2 system [v1, -v2] t = p02 - p01.
- * Restated as a thin QR (modified Gram-Schmidt) least-squares solve.  Returns 0 if "empty". */
+ * Restated as a thin QR (Gram-Schmidt with one re-orthogonalisation) least-squares solve.  Returns 0 if "empty". */
 static int intersection_point(const double v1[3], const double p01[3], const double v2[3], const double p02[3],
                               double out[3]) {
     double a1[3] = {v1[0], v1[1], v1[2]}, a2[3] = {-v2[0], -v2[1], -v2[2]};
@@ -436,6 +436,11 @@ static int intersection_point(const double v1[3], const double p01[3], const dou
     double q1[3] = {a1[0] / r11, a1[1] / r11, a1[2] / r11};
     double r12 = dot3(q1, a2);
     double a2p[3] = {a2[0] - r12 * q1[0], a2[1] - r12 * q1[1], a2[2] - r12 * q1[2]};
+    /* one re-orthogonalisation (planes a few 1e-6 apart, just outside normal_vector_margin: the system's condition number is
+     * 1 / that, and a single Gram-Schmidt pass leaves that much of q1 in the second column — G18's nearly parallel pairs) */
+    double fix = dot3(q1, a2p);
+    for (int i = 0; i < 3; i++) a2p[i] -= fix * q1[i];
+    r12 += fix;
     double r22 = norm3(a2p);
     double q2[3] = {a2p[0] / r22, a2p[1] / r22, a2p[2] / r22};
     double t2 = dot3(q2, b) / r22;
@@ -850,6 +855,71 @@ int orc_get_best_discrete_theta(const orc_arm_t *arm, const orc_solver_t *sv, do
     if (found) { *theta_out = best_theta; return 1; }
     *theta_out = previous_theta;
     return 0;
+}
+
+/* ---- the same helpers on explicit arguments, as utils.py exposes them (G18: tests/test_oracle_golden.py) ---- */
+/* U:443-465 */
+int orc_is_elbow_ok_args(const double e[3], double side, double singularity_offset, double singularity_limit_coeff, const double esp[3]) {
+    int ok = e[1] * side < -0.2;
+    ok = ok && (e[2] < (e[0] - esp[0]) * singularity_limit_coeff + esp[2] - singularity_offset);
+    return ok;
+}
+/* U:493-505 */
+void orc_allow_multiturn(const double new_joints[7], const double prev_joints[7], double out[7]) {
+    for (int i = 0; i < 7; i++) out[i] = prev_joints[i] + orc_angle_diff(new_joints[i], prev_joints[i]);
+}
+/* U:535-568.  Returns the cause bits of include/rsik.h's RSIK_EMERGENCY_* (1 shoulder pitch, 2 elbow yaw, 4 wrist yaw). */
+int orc_multiturn_safety_check(const double joints[7], const double limits[3], double out[7]) {
+    const int idx[3] = {0, 2, 6};
+    int cause = 0;
+    memcpy(out, joints, 7 * sizeof(double));
+    for (int k = 0; k < 3; k++) {
+        if (out[idx[k]] > limits[k]) { out[idx[k]] = limits[k]; cause |= 1 << k; }
+        if (out[idx[k]] < -limits[k]) { out[idx[k]] = -limits[k]; cause |= 1 << k; }
+    }
+    return cause;
+}
+/* U:571-589.  Returns emergency_stop; out = joints, or previous_joints when not continuous. */
+int orc_continuity_check(const double joints[7], const double previous_joints[7], const double max_change[7], double out[7]) {
+    int disc = 0;
+    for (int i = 0; i < 7; i++)
+        if (fabs(orc_angle_diff(joints[i], previous_joints[i])) > max_change[i]) disc = 1;
+    memcpy(out, disc ? previous_joints : joints, 7 * sizeof(double));
+    return disc;
+}
+/* U:334-396 on an explicit intersection circle (what the get_elbow_position argument reads, S:684-695).  Returns found;
+ * *worked: "preferred_theta worked!". */
+int orc_best_discrete_theta_circle(double previous_theta, const double interval[2], int nb, double preferred_theta, double side,
+                                   double singularity_offset, double singularity_limit_coeff, const double esp[3], const double circle[7],
+                                   double *theta_out, int *worked) {
+    orc_solver_t sv;
+    memset(&sv, 0, sizeof sv);
+    memcpy(sv.circle_center, circle, 3 * sizeof(double));
+    sv.circle_radius = circle[3];
+    memcpy(sv.circle_normal, circle + 4, 3 * sizeof(double));
+    orc_arm_t arm;
+    memset(&arm, 0, sizeof arm);
+    arm.side = side;
+    arm.singularity_offset = singularity_offset;
+    arm.singularity_limit_coeff = singularity_limit_coeff;
+    memcpy(arm.elbow_singularity_position, esp, 3 * sizeof(double));
+    *worked = 0;
+    if (orc_is_valid_angle(preferred_theta, interval)) {
+        double e[3];
+        orc_get_elbow_position(&sv, preferred_theta, e);
+        if (is_elbow_ok(&arm, e)) *worked = 1;
+    }
+    return orc_get_best_discrete_theta(&arm, &sv, previous_theta, interval, nb, preferred_theta, theta_out);
+}
+/* S:588-606 / S:608-645 on explicit operands */
+int orc_points_of_nearest_approach(const double p1[3], const double n1[3], const double p2[3], const double n2[3], double q[3], double v[3]) {
+    return points_of_nearest_approach(p1, n1, p2, n2, q, v);
+}
+int orc_intersection_circle_line(const double center[3], double radius, const double direction[3], const double point_on_line[3], double pts[6]) {
+    double p[2][3];
+    const int k = intersection_circle_line_3d_vd(center, radius, direction, point_on_line, p);
+    for (int i = 0; i < k; i++) memcpy(pts + 3 * i, p[i], 3 * sizeof(double));
+    return k;
 }
 
 /* ------------------------------------------------------------------ ControlIK */

@@ -707,3 +707,57 @@ def test_golden_fixtures_reproduce_from_the_reference():
     assert "CHECK g1_catalogue.npz: identical" in p.stdout and "CHECK g6_control_continuous.npz: identical" in p.stdout
     assert "CHECK g15_stages.npz: identical" in p.stdout
     assert "CHECK g18_utils.npz: identical" in p.stdout
+
+
+def test_utils_helpers_on_explicit_arguments(golden_dir):
+    """G18 (round 6): the policy layer's helpers as the reference's utils module exposes them — utils.py:93-112, 334-396, 443-589 —
+    and points_of_nearest_approach / intersection_circle_line_3d_vd on nearly parallel planes, what the reference returned for explicit
+    arguments against the checker's restatement of each (the HIP stages of the same names are checked against the same vectors on the
+    GPU, tests/test_gpu_utils.py): outcomes exact, numbers to 1e-12 (1e-9 through the two Euler conversions of the Orbita3D cone;
+    a relative ~1e-14 / delta for the 3 x 2 least-squares solve of planes delta apart)."""
+    import ctypes as C
+
+    g = load(golden_dir, "g18_utils.npz")
+    L = orc.lib()
+    D = lambda a: np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    got = np.array([L.orc_angle_diff(float(a), float(b)) for a, b in zip(g["ad_a"], g["ad_b"])])
+    assert np.array_equal(got, g["ad_out"])  # (Python's % restated: the same doubles)
+    ok = [bool(L.orc_is_valid_angle(float(t), D(iv))) for t, iv in zip(g["iv_angle"], g["iv_interval"])]
+    np.testing.assert_array_equal(ok, g["iv_valid"] != 0)
+    th = np.array([L.orc_limit_theta_to_interval(float(t), float(p), D(iv)) for t, p, iv in zip(g["iv_angle"], g["iv_prev"], g["iv_interval"])])
+    assert np.max(np.abs(th - g["lt_theta"])) < 1e-12
+    ok = [bool(L.orc_is_elbow_ok_args(D(e), float(s), float(o), float(c), D(p))) for e, s, o, c, p in
+          zip(g["eo_elbow"], g["eo_side"], g["eo_so"], g["eo_coeff"], g["eo_esp"])]
+    np.testing.assert_array_equal(ok, g["eo_ok"] != 0)
+    out = np.zeros(7)
+    for k in range(len(g["mt_new"])):
+        L.orc_allow_multiturn(D(g["mt_new"][k]), D(g["mt_prev"][k]), D(out))
+        assert np.array_equal(out, g["mt_out"][k]), k
+        cause = L.orc_multiturn_safety_check(D(g["ms_joints"][k]), D(g["ms_limits"][k]), D(out))
+        assert np.array_equal(out, g["ms_out"][k]) and (cause != 0) == bool(g["ms_stop"][k]), k
+        assert str(g["ms_text"][k]).count("EMERGENCY STOP") >= bin(cause).count("1")
+        stop = L.orc_continuity_check(D(g["cc_joints"][k]), D(g["cc_prev"][k]), D(g["cc_max"]), D(out))
+        assert np.array_equal(out, g["cc_out"][k]) and bool(stop) == bool(g["cc_stop"][k]), k
+    w = np.zeros(3)
+    worst = 0.0
+    for j, m, want in zip(g["lo_joints"], g["lo_max"], g["lo_out"]):
+        L.orc_limit_orbita3d_joints(D(j), float(m), D(w))
+        worst = max(worst, float(np.max(np.abs((w - want + np.pi) % (2 * np.pi) - np.pi))))
+    assert worst < 1e-9, worst
+    theta, worked = C.c_double(), C.c_int()
+    for k in range(len(g["bd_found"])):
+        a = g["bd_args"][k]
+        found = L.orc_best_discrete_theta_circle(float(a[0]), D(g["bd_interval"][k]), int(a[1]), float(a[2]), float(a[3]), float(a[4]), float(a[5]),
+                                                 D(a[6:9]), D(g["bd_circle"][k]), C.byref(theta), C.byref(worked))
+        assert bool(found) == bool(g["bd_found"][k]) and bool(worked.value) == bool(g["bd_worked"][k]), k
+        assert abs(theta.value - g["bd_theta"][k]) < 1e-12, (k, theta.value, g["bd_theta"][k])
+    q, v, pts = np.zeros(3), np.zeros(3), np.zeros(6)
+    for k, row in enumerate(g["np_in"]):
+        found = L.orc_points_of_nearest_approach(D(row[0:3]), D(row[3:6]), D(row[6:9]), D(row[9:12]), D(q), D(v))
+        assert bool(found) == bool(g["np_found"][k]) and np.max(np.abs(v - g["np_v"][k])) < 1e-9, k
+        if found:
+            rel = np.linalg.norm(q - g["np_q"][k]) / max(1.0, np.linalg.norm(g["np_q"][k]))
+            assert rel < max(2e-14 / g["np_delta"][k], 1e-12), (k, rel)
+            n = L.orc_intersection_circle_line(D(row[0:3]), float(row[12]), D(g["np_v"][k]), D(g["np_q"][k]), D(pts))
+            assert n == int(g["np_cl_count"][k])
+            assert np.max(np.abs(pts[: 3 * n] - g["np_cl_points"][k][: 3 * n]), initial=0.0) < 1e-9
