@@ -22,6 +22,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import bench  # noqa: E402
 from reachy2_symbolic_ik_amd import ControlIK, _abi  # noqa: E402
 
+if os.environ.get("C5_LIB"):  # another build of the library (scripts/build_variant.py)
+    _abi.use_library(os.path.abspath(os.environ["C5_LIB"]))
+
 
 def main():
     ap = argparse.ArgumentParser()
