@@ -349,3 +349,24 @@ def test_scalar_drop_in_raises_like_the_reference(torch_mod):
     j2, ok2, s2 = twin.symbolic_inverse_kinematics("r_arm", M, "continuous")
     assert ok1 == ok2 and s1 == s2 and np.max(np.abs(np.array(j1) - np.array(j2))) < 1e-9
     assert abs(c.previous_theta["r_arm"] - twin.previous_theta["r_arm"]) < 1e-12
+
+
+def test_arrays_past_two_and_four_gib(torch_mod):
+    """Maximum sizes: 80 Mi poses / goal matrices through ONE rsik_solve / rsik_control_discrete launch (joints 4.4 GiB, the
+    matrices 7.5 GiB) and 1 Mi trajectories x 96 steps through one continuous run (joints 5.3 GiB; the sequential phases address a
+    block through 2 GiB buffer windows, cont_plan sizes the blocks for that): the same 1 Mi poses / 4096 trajectories tiled, every
+    tile's rows bit-identical to the first tile's and to the same rows solved as a batch of their own — a 32-bit offset anywhere
+    would show as a tile that differs or was never written (scripts/probes/large_batches.py)."""
+    import os
+    import subprocess
+    import sys
+
+    free, _total = torch_mod.cuda.mem_get_info()
+    if free < 64 * 2**30:
+        pytest.skip("needs 64 GiB of free device memory")
+    torch_mod.cuda.empty_cache()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "probes", "large_batches.py"), "80", "1048576"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "TOTAL ok" in r.stdout and r.stdout.count("every tile identical to the first") == 12, r.stdout[-3000:]
