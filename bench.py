@@ -536,6 +536,9 @@ def parse_args(argv):
     ap.add_argument("--graph", action="store_true", help="same as --launch graph")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--single-device", action="store_true", help="every rank uses GPU 0 (with --backend gloo: rehearsal on a 1-GPU box)")
+    ap.add_argument("--grouped", action="store_true",
+                    help="--gpus 1 through the N > 1 code path: a ONE-rank process group (RCCL by default) — group set-up, barriers, the "
+                         "all-gather forms, max-over-ranks timing, the multi_gpu block; what a one-GPU box can rehearse of the RCCL path")
     ap.add_argument("--collective-timeout", type=float, default=120.0, help="N > 1: seconds before a stuck collective fails its rank")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="ranks only meet, all-reduce their rank numbers on the CPU and print the line's skeleton (launcher self-test, no GPU)")
@@ -695,8 +698,15 @@ def main(argv=None, return_line=False):
     in_group = "WORLD_SIZE" in os.environ and "RANK" in os.environ
     if not in_group and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus, argv))
+    if args.grouped and not in_group:  # a one-rank group in this process
+        import socket
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1 and args.config == 0 and not args.no_other_configs and not args.rendezvous_only:
+    if world == 1 and args.config == 0 and not args.no_other_configs and not args.rendezvous_only and not args.grouped:
         others_argv = ["--steps", "20", "--warmup", "5", "--no-extras", "--no-valu-calibration", "--no-other-configs", "--cpu-seconds", "2"]
         if args.lib:
             others_argv += ["--lib", args.lib]
@@ -734,10 +744,11 @@ def _run(argv):
     if args.rendezvous_only:
         rendezvous_only(args, world, rank)
         return None
+    grouped = world > 1 or args.grouped  # (the N > 1 code path; --grouped: with one rank)
 
-    cfg = args.config or (4 if world > 1 else 2)
+    cfg = args.config or (4 if grouped else 2)
     if not args.steps:
-        args.steps = 20 if (cfg == 5 or world > 1) else 1000
+        args.steps = 20 if (cfg == 5 or grouped) else 1000
     if args.lib:
         from reachy2_symbolic_ik_amd import _abi
 
@@ -754,7 +765,7 @@ def _run(argv):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if grouped:
         import torch.distributed as dist
 
         import datetime
@@ -767,7 +778,7 @@ def _run(argv):
             dist.init_process_group(backend=args.backend, timeout=timeout)
         group_info = describe_group(torch, dist, dev, world, rank, args)
     n = args.poses or {2: 1 << 20, 3: 1 << 18, 4: 1 << 20, 5: 4096}[cfg]
-    gather_mode = args.gather if (world > 1 and cfg != 5) else "none"
+    gather_mode = args.gather if (grouped and cfg != 5) else "none"
     chunks = max(1, args.chunks) if gather_mode == "step" else 1
     if n % chunks:
         raise SystemExit(f"--poses {n} must be a multiple of --chunks {chunks}")
@@ -813,7 +824,7 @@ def _run(argv):
             """Output buffers + one pre-bound rsik_solve launch per stripe for one resident copy of the inputs (`form`: another
             partition of the shard into stripes than the run's own — the other gather form's timed leg)."""
             plan, chunks, rpp = form or form0
-            if world > 1:
+            if grouped:
                 sb = shared or ShardedBuffers(plan, rank, {"joints": ((7,), f64), "state": ((), u8)}, dev)
                 o = {"interval": torch.empty((n, 2), dtype=f64, device=dev), "reachable": torch.empty((n,), dtype=u8, device=dev)}
             else:
@@ -851,7 +862,7 @@ def _run(argv):
 
         def make_set(m12_t, _unused=None, shared=None, form=None):
             plan, chunks, rpp = form or form0
-            if world > 1:
+            if grouped:
                 sb = shared or ShardedBuffers(plan, rank, {"joints": ((7,), f64), "state": ((), u8)}, dev)
                 o = {"reachable": torch.empty((n,), dtype=u8, device=dev), "emergency": torch.empty((n,), dtype=u8, device=dev)}
             else:
@@ -894,7 +905,7 @@ def _run(argv):
         # (round 6) consecutive passes may overlap: the goals are resident for the whole run and nothing but the passes themselves
         # touches `out` between them — the promise RSIK_OPT_CONT_GOALS_RESIDENT asks for (include/rsik.h).  The passes stay what they
         # were: each resets the trajectory state, re-initialises every trajectory and writes every output row.
-        pipelined = [args.launch in ("auto", "pipelined") and world == 1 and not args.phased_variant]
+        pipelined = [args.launch in ("auto", "pipelined") and not grouped and not args.phased_variant]
         forms_seen = {}
         # overlapping passes write two sets of output buffers in turn, as a caller that consumes pass k while pass k + 1 runs has to
         # (the promise covers a run's output rows too); every other form writes `out`.  `last_out`: what the last pass issued wrote.
@@ -952,12 +963,12 @@ def _run(argv):
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
     def progress(what):  # N > 1: a line per leg on rank 0's stderr (a rehearsal over gloo at full size is minutes of silence otherwise)
-        if world > 1 and rank == 0:
+        if grouped and rank == 0:
             print(f"[bench] {time.strftime('%H:%M:%S')} {what}", file=sys.stderr, flush=True)
 
     progress(f"config {cfg}: {world} ranks, {n} rows per rank resident, launches bound; warm-up")
@@ -979,7 +990,7 @@ def _run(argv):
     # cannot hold — 0.41 -> 0.37-0.39 ms eager; the replayed graph is still 1-3 % ahead and steadier (same box, alternating processes,
     # W = 5 / K = 20: 0.380-0.386 against 0.387-0.391; after 60 more passes 0.363-0.373 against 0.369-0.390), so `auto` replays;
     # both forms are timed below (`steady_state.launch_forms_ms`).
-    use_graph = world == 1 and (args.launch == "graph" or (args.launch == "auto" and cfg != 5 and (args.steps <= 32 or args.steps >= 200)))
+    use_graph = not grouped and (args.launch == "graph" or (args.launch == "auto" and cfg != 5 and (args.steps <= 32 or args.steps >= 200)))
     graph = None
     graph_replays = 1
     if use_graph:
@@ -1028,7 +1039,7 @@ def _run(argv):
     # ---- config 5: the same K passes again after 60 more untimed ones (the clock has settled: the driver's W = 5 protocol above is the
     # headline, this is the steady state), in the form timed above and in the other one (eager <-> one captured pass replayed)
     steady = None
-    if cfg == 5 and world == 1 and not args.no_steady_state:
+    if cfg == 5 and not grouped and not args.no_steady_state:
         # (three windows of K passes, the median reported: issued launch by launch a pass is ~18 launches and ~30 stream operations, and
         # the HIP runtime's host side hiccups now and then — 1-2 ms around the 1100th launch of a process, 38-49 ms every ~3800 launches,
         # scripts/probes/c5_pass_sequence.py — which one window of 20 passes either contains or not)
@@ -1113,7 +1124,7 @@ def _run(argv):
     # first ~25 launches of a process run below the sustained clock — docs/experiments.md A.5 — so the driver's W = 5 / K = 20 figure of a
     # 14 us kernel reads 10 % under what profiles/ and a longer run show; this leg lets the driver's own run witness the settled figure,
     # next to the headline it does not replace)
-    if cfg != 5 and world == 1 and not args.no_steady_state and args.settle_ms > 0:
+    if cfg != 5 and not grouped and not args.no_steady_state and args.settle_ms > 0:
         per_round_ms = max(step_ms_events * args.steps, 1e-3)
         rounds = max(1, int(np.ceil(args.settle_ms / per_round_ms)))
 
@@ -1144,7 +1155,7 @@ def _run(argv):
     # north star's job shape, K sharded steps + ONE all-gather, by default; rounds 1-4 timed an all-gather inside every step — and both
     # are measured in every run, each in its own overlapped form, so that lines of different rounds can be compared like for like)
     other_form = None
-    if world > 1 and gather_mode != "none" and cfg != 5:
+    if grouped and gather_mode != "none" and cfg != 5:
         o_mode = "step" if gather_mode == "final" else "final"
         o_chunks = max(1, args.chunks) if o_mode == "step" else 1
         if n % o_chunks == 0:
@@ -1183,7 +1194,7 @@ def _run(argv):
 
     # ---- kernel-only and gather-only legs (N > 1), each on its own: same buffers, same launches
     kernel_ms, gather_ms = step_ms_events, 0.0
-    if world > 1:
+    if grouped:
         k2 = max(5, min(args.steps, 50))
         fence()
         e0.record()
@@ -1235,7 +1246,7 @@ def _run(argv):
 
     # ---- the rows the CPU-baseline leg re-solves, and the GPU's results for them
     sample, gpu_rows = None, None
-    if not args.no_cpu_baseline and cfg == 5 and world == 1:
+    if not args.no_cpu_baseline and cfg == 5 and not grouped:
         # 64 of the trajectories (evenly spread), all their steps: what the CPU leg re-walks
         sub = torch.arange(0, n, max(1, n // 64), device=dev)[:64]
         m12 = traj[:, :, sub].cpu().numpy()                         # [n_steps, 12, n_sub]
@@ -1249,7 +1260,7 @@ def _run(argv):
         gpu_rows = {k: out[k][:, sub].cpu().numpy() for k in ("joints", "state", "reachable")}
     elif not args.no_cpu_baseline and cfg != 5:
         m = min(n, 1 << 18 if cfg in (2, 4) else 1 << 17)
-        if world == 1:
+        if not grouped:
             sample = {k: (None if v is None else v[:m]) for k, v in sample_local.items()}
             gpu_rows = {k: out[k][:m].cpu().numpy() for k in ("joints", "state", "reachable")}
         elif gather_mode != "none":
@@ -1275,7 +1286,7 @@ def _run(argv):
         bpp = BYTES_PER_POSE[cfg]
         achieved = bpp * units / (kernel_ms * 1e-3) / 1e9
         collective = "none"
-        if world > 1:
+        if grouped:
             collective = {"step": f"RCCL all-gather of joints [n,7] f64 + state u8 inside every step, {chunks} stripes per shard, "
                                   "stripe c in flight while stripe c + 1 is solved",
                           "final": "none in the K sharded steps; ONE RCCL all-gather of joints [n,7] f64 + state u8 after the last of them, "
@@ -1314,13 +1325,13 @@ def _run(argv):
                 "traffic": None,
                 "algorithmic_bytes_per_pose": bpp,
                 "kernel_ms": kernel_ms,
-                "kernel_timing": ("HIP events on the launch stream around the K timed steps (one pair)" if world == 1 else
+                "kernel_timing": ("HIP events on the launch stream around the K timed steps (one pair)" if not grouped else
                                   "HIP events around a kernel-only replay of the same launches, no collective in flight"),
                 "kernel_only_solves_per_s_per_gpu": units / (kernel_ms * 1e-3),
                 "note": "fp64 VALU-bound path (DESIGN.md section 4): the HBM fraction is reported as the contract asks; `compute` holds the binding limit",
             },
         }
-        if world > 1:
+        if grouped:
             recv = GATHER_BYTES_PER_POSE * n * (world - 1)
             links = min(world - 1, XGMI_LINKS)
             line["multi_gpu"] = {
@@ -1335,7 +1346,7 @@ def _run(argv):
                 "gather_bytes_received_per_gpu": recv,
                 "xgmi": {"achieved": (recv / (gather_ms * 1e-3) / 1e9) if gather_ms > 0 else None, "unit": "GB/s received per GPU",
                          "peak": links * XGMI_LINK_GBS, "links_usable": links,
-                         "frac": (recv / (gather_ms * 1e-3) / 1e9 / (links * XGMI_LINK_GBS)) if gather_ms > 0 else None},
+                         "frac": (recv / (gather_ms * 1e-3) / 1e9 / (links * XGMI_LINK_GBS)) if (gather_ms > 0 and links > 0) else None},
                 "gathered_rows_checked": "checksum of every rank's rows against the solving rank's own checksum" if gather_mode != "none" else None,
             }
             mg = line["multi_gpu"]
@@ -1421,7 +1432,7 @@ def _run(argv):
                 line["roofline"]["traffic_per_pass_by_kernel"] = cnt["bytes_per_pass_by_kernel"]
         elif cnt and "stale" in cnt:
             line["roofline"]["traffic_note"] = cnt["stale"]
-        if not args.no_extras and world == 1 and cfg != 5:
+        if not args.no_extras and not grouped and cfg != 5:
             extras = {}
             # (a) cold HBM: rotate over distinct resident copies of the batch whose combined footprint exceeds the
             # 256 MiB Infinity Cache, so that every launch's inputs and outputs really come from / go to HBM
@@ -1480,7 +1491,7 @@ def _run(argv):
     yield "timed"
     if rank == 0 and sample is not None:
         line["cpu_baseline"] = cpu_baseline(cfg, sample, args.cpu_seconds, gpu=gpu_rows)
-    if rank == 0 and world == 1 and not args.no_live_traffic:
+    if rank == 0 and not grouped and not args.no_live_traffic:
         # roofline.traffic from THIS run (behind every timed leg: the children have the GPU to themselves)
         lt = live_traffic(cfg, n, args.lib)
         r = line["roofline"]
@@ -1494,7 +1505,7 @@ def _run(argv):
                 r["traffic_per_pass_by_kernel"] = lt["by_kernel"]
         else:
             r["traffic_live_error"] = lt["error"]
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
     return line

@@ -92,17 +92,36 @@ def test_bench_two_ranks_gloo_one_gpu(gather):
 
 
 @pytest.mark.parametrize("gather", ["final", "step"])
+def test_bench_one_rank_rccl_group(gather):
+    """`bench.py --gpus 1 --grouped`: the N > 1 code path of the bench on a ONE-rank RCCL group (backend "nccl": what the driver's SCALE runs
+    use, and all a one-GPU box can run of it — RCCL refuses two ranks on a device): init_process_group with device_id, describe_group's
+    object all-gather, barriers, the in-place stripe all-gathers of both job shapes, the max-over-ranks all-reduce of the timing, the
+    checksum exchange, destroy.  With one rank nothing crosses a link; every call is made."""
+    d = _bench("--gpus", "1", "--grouped", "--poses", "65536", "--steps", "3", "--warmup", "1", "--cpu-seconds", "2", "--chunks", "4", "--gather", gather)
+    assert d["n_gpus"] == 1 and d["config"]["workload"].startswith("config4")
+    m = d["multi_gpu"]
+    g = m["group"]
+    assert g["backend"] == "nccl" and g["world_size"] == 1 and g["collective_library"].startswith("RCCL") and "rehearsal" not in d["config"]["collective"]
+    assert m["gather_only_ms"] > 0 and m["gather_final"]["solves_per_s"] > 0 and m["gather_step"]["solves_per_s"] > 0
+    assert m["value_definition"]["value_is"] == "gather_" + gather and m["gathered_rows_checked"]
+    assert m["xgmi"]["links_usable"] == 0 and m["xgmi"]["frac"] is None
+    par = d["cpu_baseline"]["parity_on_sample"]
+    assert par["flags_and_states"] == "bit-exact" and par["max_abs_joint_error_rad"] < 1e-9
+
+
+@pytest.mark.parametrize("gather", ["final", "step"])
 def test_bench_four_ranks_gloo_one_gpu(gather):
     """The driver's SCALE command shape rehearsed at the largest rank count a one-GPU box of this pool admits beside the test runner
     (its process guard stops a seventh process on the card; the eight-rank partition itself is covered on the CPU,
     tests/test_distributed_gloo.py; six ranks at BASELINE's 1 048 576 poses per rank are on record under profiles/r06/): four ranks,
-    32 768 mixed r/l poses each (gloo moves the gathered arrays through host memory: minutes at full size), eight stripes per shard in the every-step form — the
+    16 384 mixed r/l poses each (gloo moves the gathered arrays through host memory: minutes at full size, and on a busy host even
+    32 768 poses in eight stripes took 160 s once), four stripes per shard in the every-step form — the
     rank-0 parity sample is drawn from all four parts of the gathered array, the checksum of every rank's rows is checked on every
     rank, the group as the collective library sees it has four members."""
-    d = _bench("--gpus", "4", "--backend", "gloo", "--single-device", "--poses", "32768", "--steps", "2", "--warmup", "1",
-               "--cpu-seconds", "2", "--chunks", "8", "--gather", gather)
+    d = _bench("--gpus", "4", "--backend", "gloo", "--single-device", "--poses", "16384", "--steps", "2", "--warmup", "1",
+               "--cpu-seconds", "2", "--chunks", "4", "--gather", gather)
     _check_two_rank_line(d, gather, world=4)
-    assert d["config"]["poses_per_gpu"] == 32768 and "rehearsal" in d["config"]["collective"]
+    assert d["config"]["poses_per_gpu"] == 16384 and "rehearsal" in d["config"]["collective"]
 
 
 def test_bench_measures_traffic_in_its_own_run():
@@ -266,6 +285,22 @@ def test_solve_sharded_rccl_two_gpus(tmp_path):
         port = s.getsockname()[1]
     mp.spawn(_rccl_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert all(os.path.exists(tmp_path / f"ok_{r}") for r in range(2))
+
+
+def test_solve_sharded_rccl_one_rank(tmp_path):
+    """The same worker as the two-GPU test on a ONE-rank RCCL group (what a one-GPU box allows: RCCL refuses two ranks on a device):
+    torch's "nccl" backend initialised with device_id, the in-place all_gather_into_tensor of a stripe (input = this rank's rows of the
+    output), async work handles, chunks = 1 and 4 with a padded last stripe, destroy — every RCCL call of the sharded path except the
+    transport between devices."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_rccl_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    assert os.path.exists(tmp_path / "ok_0")
 
 
 def test_c_abi_allgather_single_rank():
