@@ -1461,6 +1461,34 @@ def _run(argv):
                 line["roofline"]["cold_note"] = (f"{sets_needed} distinct resident batches ({sets_needed * footprint / 2**20:.0f} MiB of inputs + outputs) "
                                                  "solved round-robin: nothing a launch touches is still in the 256 MiB Infinity Cache")
                 del sets
+            # (a2) SURVEY 8(d): the vendor's 8 TB/s confirmed by a stream copy on THIS box — 1 GiB read + 1 GiB written per copy (four
+            # times the Infinity Cache), device to device, and a read-modify-write of the same size; `frac` is reported against both
+            try:
+                src_c = torch.empty(1 << 27, dtype=f64, device=dev).normal_()
+                dst_c = torch.empty_like(src_c)
+                for _ in range(3):
+                    dst_c.copy_(src_c)
+                torch.cuda.synchronize()
+                reps_c = 20
+                e0.record()
+                for _ in range(reps_c):
+                    dst_c.copy_(src_c)
+                e1.record()
+                torch.cuda.synchronize()
+                copy_gbs = 2 * src_c.numel() * 8 / (e0.elapsed_time(e1) / reps_c * 1e-3) / 1e9
+                e0.record()
+                for _ in range(reps_c):
+                    dst_c.add_(1.0)
+                e1.record()
+                torch.cuda.synchronize()
+                rmw_gbs = 2 * src_c.numel() * 8 / (e0.elapsed_time(e1) / reps_c * 1e-3) / 1e9
+                del src_c, dst_c
+                extras["hbm_copy"] = {"copy_GBs": copy_gbs, "read_modify_write_GBs": rmw_gbs, "bytes_per_copy": 2 << 30,
+                                      "what": "torch copy_ / add_ of a 1 GiB fp64 tensor, read + written bytes over the HIP-event time of 20 back to back"}
+                line["roofline"]["peak_measured_copy"] = max(copy_gbs, rmw_gbs)
+                line["roofline"]["frac_of_measured_copy"] = line["roofline"]["achieved"] / max(copy_gbs, rmw_gbs)
+            except Exception as e:
+                extras["hbm_copy"] = {"error": f"{type(e).__name__}: {e}"}
             # (b) the shader clock the chip holds under this kernel (s_memtime / s_memrealtime in a monitor wave on a side
             # stream, no stamp in the product kernel), after >= 2 s of back-to-back launches, and over a short burst
             try:

@@ -124,6 +124,19 @@ def test_bench_four_ranks_gloo_one_gpu(gather):
     assert d["config"]["poses_per_gpu"] == 16384 and "rehearsal" in d["config"]["collective"]
 
 
+def test_bench_extras_confirm_the_hbm_peak_with_a_copy():
+    """the vendor's 8 TB/s is confirmed by a stream copy on the box and the fraction reported against both.  A small config-2
+    batch with the extras on: `extras.hbm_copy` holds the copy and read-modify-write rates of a 1 GiB tensor, `roofline` the fraction of
+    the better of the two beside the fraction of 8 TB/s."""
+    d = _bench("--config", "2", "--poses", "131072", "--steps", "5", "--warmup", "2", "--cpu-seconds", "1", "--settle-ms", "0",
+               "--no-live-traffic", "--no-valu-calibration")
+    hc = d["extras"]["hbm_copy"]
+    assert "error" not in hc and 1000.0 < hc["copy_GBs"] < 8000.0 and 1000.0 < hc["read_modify_write_GBs"] < 8000.0
+    r = d["roofline"]
+    assert r["peak"] == 8000.0 and r["peak_measured_copy"] == max(hc["copy_GBs"], hc["read_modify_write_GBs"])
+    assert abs(r["frac_of_measured_copy"] - r["achieved"] / r["peak_measured_copy"]) < 1e-12 and r["frac_of_measured_copy"] > r["frac"]
+
+
 def test_bench_measures_traffic_in_its_own_run():
     """roofline.traffic comes from THIS run, not from a file the builder committed: after the timed legs bench.py runs itself twice more
     under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, --kernel-trace only) and reads the kernel's counters.  A
