@@ -360,7 +360,8 @@ int rsik_control_continuous_step(rsik_ctx *ctx, int64_t n, const double *const m
  * first — otherwise the call fails with RSIK_E_INVALID instead of allocating inside the capture.  A captured graph
  * stays valid after later, larger calls (the workspace it points into is kept until rsik_destroy / _release; an
  * outgrown workspace that only runs already issued can use is freed by the next rsik_sync).  The call never waits for
- * the device.  A solver whose
+ * the device — with one exception in 4e9 launch-by-launch runs of a context: the words carry a 32-bit run number, and before it
+ * wraps the call drains what the context has issued and starts them over.  A solver whose
  * projection_margin is not positive (RSIK_STATE_NOT_REACHABLE_NO_LIMITS possible) is run step by step.  At most 30 Mi
  * trajectories per call.  4096 trajectories x 1000 steps: see DESIGN.md section 4.
  * A goal that is not numbers: see "Rows that are not numbers" above (the step is reported, the trajectory goes on).

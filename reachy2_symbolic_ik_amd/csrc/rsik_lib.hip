@@ -88,6 +88,11 @@ static int hip_fail(rsik_ctx* ctx, hipError_t e, const char* what) {
         if (e_ != hipSuccess) return hip_fail(ctx, e_, #call); \
     } while (0)
 
+// the run number at which the words that tie the streams of rsik_control_continuous_run start over (a test build sets it to a handful)
+#ifndef RSIK_EDGE_SEQ_WRAP
+#define RSIK_EDGE_SEQ_WRAP 0xfffffff0u
+#endif
+
 extern "C" {
 
 int rsik_abi_version(void) { return RSIK_ABI_VERSION; }
@@ -846,6 +851,18 @@ int rsik_control_continuous_run(rsik_ctx* ctx, int64_t n, int64_t n_steps, const
             RSIK_HIP(ctx, hipMemset(ctx->edge_words, 0, need_words * 2 * sizeof(unsigned)));
             ctx->edge_count = need_words * 2;
             ctx->edge_seq = 0;
+        }
+        if (ctx->edge_seq >= RSIK_EDGE_SEQ_WRAP) {
+            // A word only ever grows and every wait is "word >= a run's number": before the 32-bit number wraps (4e9 runs: weeks of a
+            // control loop that issues a run per tick) everything issued drains, the words start over from zero and this run forks
+            // behind the caller's stream like a first one.
+            RSIK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            for (auto& st : ctx->side) RSIK_HIP(ctx, hipStreamSynchronize(st));
+            // (word 3 is not a sequence number: a theta kernel's "gave up waiting" mark, rsik_sync's to read and clear)
+            RSIK_HIP(ctx, hipMemset(ctx->edge_words, 0, 3 * sizeof(unsigned)));
+            RSIK_HIP(ctx, hipMemset(ctx->edge_words + 4, 0, (ctx->edge_count - 4) * sizeof(unsigned)));
+            ctx->edge_seq = 0;
+            ctx->last_run.valid = false;
         }
         ctx->edge_seq += 1;
     }

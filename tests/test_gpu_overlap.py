@@ -222,3 +222,46 @@ def test_last_form_says_when_a_run_fell_back_to_a_launch_per_step(torch_mod):
     for mode in (A.CONT_RUN_AUTO, A.CONT_RUN_PHASED):
         for k in ref:
             assert torch.equal(ref[k].contiguous().view(torch.uint8), runs[mode][k].contiguous().view(torch.uint8)), (mode, k)
+
+
+def test_run_numbers_start_over_before_they_wrap(torch_mod, tmp_path):
+    """The stream-ordering words of rsik_control_continuous_run hold a 32-bit run number and every wait is "word >= number": the library
+    drains and starts them over before the number wraps (4e9 runs — weeks of a control loop issuing a run per tick).  A build with that
+    point at run 5 (-DRSIK_EDGE_SEQ_WRAP=5) against the product library: 14 overlapping runs continuing one eventful trajectory batch,
+    every run's outputs and the carried state bit for bit; the runs right behind a restart are issued as first runs (not overlapping)."""
+    import os
+    import subprocess
+    import sys
+
+    torch = torch_mod
+    A = _abi_mod()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from reachy2_symbolic_ik_amd import build as B
+
+    lib = os.path.join(root, "build", "variants", "seqwrap.so")
+
+    def stale(path):
+        code = "import ctypes as C,sys; l=C.CDLL(sys.argv[1]); l.rsik_build_id.restype=C.c_char_p; print(l.rsik_build_id().decode())"
+        p = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True)
+        return p.returncode != 0 or B.source_hash() not in p.stdout
+
+    if not os.path.exists(lib) or stale(lib):
+        subprocess.run([sys.executable, os.path.join(root, "scripts", "build_variant.py"), "seqwrap", "-DRSIK_EDGE_SEQ_WRAP=5"],
+                       check=True, stdout=subprocess.DEVNULL, timeout=900)
+    got = {}
+    for name, arg in (("product", "-"), ("wraps", lib)):
+        out = str(tmp_path / f"{name}.pt")
+        p = subprocess.run([sys.executable, os.path.join(root, "scripts", "probes", "seq_wrap_check.py"), arg, out],
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+        got[name] = torch.load(out)
+    a, b = got["product"], got["wraps"]
+    assert a["forms"] == [A.CONT_FORM_PHASED] + [A.CONT_FORM_PHASED_OVERLAPPED] * 13
+    # the test build: runs 1-5 carry the numbers 1-5; run 6 finds the number at its limit, starts over and forks like a first run; so do
+    # runs 11 (and 16 ...)
+    assert b["forms"] == [A.CONT_FORM_PHASED if k in (0, 5, 10) else A.CONT_FORM_PHASED_OVERLAPPED for k in range(14)], b["forms"]
+    assert int((a["runs"][-1]["cont_state"][9] != 0).sum()) > 0, "the trajectories were meant to trip the continuity check"
+    for k, (ra, rb) in enumerate(zip(a["runs"], b["runs"])):
+        for key in ra:
+            assert torch.equal(ra[key].contiguous().view(torch.uint8), rb[key].contiguous().view(torch.uint8)), (k, key)
