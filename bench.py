@@ -13,13 +13,17 @@ One "step" = one pass of the hot path over one resident batch:
     joints [n,7], interval [n,2], reachable, state -> 122 algorithmic B/pose.
   config 3: ControlIK discrete mode, 64-point elbow sweep, 262 144 wrist-reachable goal matrices per GPU -> 154 B/pose.
   config 4 (default at N > 1, BASELINE.json's multi-GPU configuration): r_arm + l_arm mixed batch (per-pose arm byte),
-    1 048 576 poses per GPU = 8 M poses at N = 8, each GPU solves its shard and the joint array (+ state byte) is
-    all-gathered over xGMI with RCCL INSIDE every step, stripe by stripe behind the kernel (`--chunks`), so `value` is
-    the end-to-end rate of "shard, solve, all-gather"; kernel-only, gather-only and end-to-end figures are all in the
-    line.  `--gather final` keeps the collective out of the K timed steps (one final all-gather, timed on its own).
-  config 5: ControlIK continuous mode, 4096 trajectories x 1000 control steps per pass.
+    1 048 576 poses per GPU = 8 M poses at N = 8; each GPU solves its shard K times and the joint array (+ state byte) is
+    all-gathered over xGMI with RCCL ONCE, after the last step, inside the timed region (`--gather final`, the default since
+    round 5: the north star's job shape); `--gather step` puts a stripe-pipelined all-gather inside EVERY step (`--chunks`; the
+    default of rounds 1-4), `--gather none` none.  Both job shapes are timed in every N > 1 run (`multi_gpu.gather_final` /
+    `gather_step`, `value_definition` says which one `value` is), beside kernel-only and gather-only figures.
+    `--gpus 1 --grouped` takes this code path on a one-rank RCCL group (all a one-GPU box can run of it).
+  config 5: ControlIK continuous mode, 4096 trajectories x 1000 control steps per pass; consecutive passes overlap
+    (RSIK_OPT_CONT_GOALS_RESIDENT; `steady_state.launch_forms_ms` holds the other launch forms).
 
-Prints ONE JSON line on rank 0 (the repo prompt's bench contract) carrying `roofline` and `cpu_baseline`.
+Prints ONE JSON line on rank 0 (the repo prompt's bench contract) carrying `roofline` (traffic measured in the run; `extras.hbm_copy`
+confirms the 8 TB/s it is priced against) and `cpu_baseline`.
 """
 import argparse
 import json
