@@ -305,11 +305,12 @@ __global__ __launch_bounds__(kDiscBlock, RSIK_DISC_MIN_WAVES) RSIK_DISC_ATTR voi
     // 16 the grid search was needed (the preferred-theta shortcut failed), 32 a theta was found, 64 it took the cooperative sweep
     em = (need ? 16 : 0) | (found ? 32 : 0) | (coop ? 64 : 0);
 #endif
-    store_rows<7>(K.joints, wave_base, K.n, lane, &lds_slab[wave][0][0], jv);
+    // (written through: the launch is one round of waves, its end is a fifth of it — rsik_kernel_solve.hpp, kStoreThrough)
+    store_rows<7, kStoreThrough>(K.joints, wave_base, K.n, lane, &lds_slab[wave][0][0], jv);
     if (live) {
-        if (K.reachable) K.reachable[i] = found ? 1 : 0;
-        if (K.state) K.state[i] = (uint8_t)st_code;
-        if (K.emergency) K.emergency[i] = (uint8_t)em;  // RSIK_EMERGENCY_* cause bits
+        if (K.reachable) st_stream<kStoreThrough>(K.reachable + i, (uint8_t)(found ? 1 : 0));
+        if (K.state) st_stream<kStoreThrough>(K.state + i, (uint8_t)st_code);
+        if (K.emergency) st_stream<kStoreThrough>(K.emergency + i, (uint8_t)em);  // RSIK_EMERGENCY_* cause bits
     }
 #ifdef RSIK_TIMELINE_PROBE
     // diagnostic build only (scripts/disc_timeline_probe.py): lane 0 of every wave overwrites its joints row with the six

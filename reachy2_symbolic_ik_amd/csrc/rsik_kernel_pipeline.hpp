@@ -115,6 +115,13 @@ struct ContRunArgs {
     ArmC arms[2];
 };
 #define RSIK_WS(K, t, i) (K).ws[(int64_t)(t) * (K).n + (i)]
+// The pipeline's bulk stores are written through to system scope (st_stream<kStoreThrough>, rsik_kernel_solve.hpp): the end of each of
+// its kernels is what a hand-over waits for, and nothing of its output is then left dirty in the L2s for the write-back at that end
+// (-1.3 ... -1.5 % per pass in every launch form, bit-identical; non-temporal LOADS of the goal matrices cost 1-3 %: the joints phase reads
+// what the prepare phase read).  kRowStoreAux: the same policy for the raw buffer stores (sc0 | sc1).
+constexpr int kRowStoreAux = 17;
+template <class T>
+__device__ __forceinline__ void pipe_store(T* p, T v) { st_stream<kStoreThrough>(p, v); }
 
 // phase 1, one (step, trajectory): `m` the step's twelve matrix entries, `t` the step's row in the workspace arrays, `t_abs`
 // its row in the run's outputs.
@@ -136,13 +143,13 @@ __device__ __forceinline__ void cont_prepare_step(const ContRunArgs& K, const Ac
     // the step's goal for the theta phase: the search's theta, NaN = nothing found, stay (U:252-264 with goal =
     // previous_theta), or the preferred theta of an unreachable pose (U:115-127)
     const double goal = T.ok_limits ? (T.found ? T.theta : __builtin_nan("")) : K.pref_arg[slot];
-    RSIK_WS(K, t, i) = goal;
+    pipe_store(&RSIK_WS(K, t, i), goal);
     // what limit_theta_to_interval makes of theta = goal before it looks at the interval (U:93-97): this phase has the
     // issue slots for it, the theta phase (a lone wave per SIMD) has not
-    K.gw[t * K.n + i] = wrap_theta_to_pi(goal);
-    K.flags[t * K.n + i] = (uint8_t)((T.ok_limits ? 1 : 0) | (T.found ? 2 : 0) | (special ? 8 : 0) | (invalid ? 16 : 0));
-    if (K.state) K.state[t_abs * K.n + i] = (uint8_t)T.code;
-    if (K.reachable) K.reachable[t_abs * K.n + i] = (T.ok_limits && T.found) ? 1 : 0;
+    pipe_store(&K.gw[t * K.n + i], wrap_theta_to_pi(goal));
+    pipe_store(&K.flags[t * K.n + i], (uint8_t)((T.ok_limits ? 1 : 0) | (T.found ? 2 : 0) | (special ? 8 : 0) | (invalid ? 16 : 0)));
+    if (K.state) pipe_store(&K.state[t_abs * K.n + i], (uint8_t)T.code);
+    if (K.reachable) pipe_store(&K.reachable[t_abs * K.n + i], (uint8_t)((T.ok_limits && T.found) ? 1 : 0));
 }
 
 // phase 1: one thread per (trajectory, step of the block)
@@ -178,7 +185,7 @@ __device__ __forceinline__ double ld_row_f64(__amdgpu_buffer_rsrc_t buf, unsigne
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(buf, lane, row, 0));
 }
 __device__ __forceinline__ void st_row_f64(__amdgpu_buffer_rsrc_t buf, unsigned lane, unsigned row, double v) {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(RowWords2, v), buf, lane, row, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(RowWords2, v), buf, lane, row, kRowStoreAux);
 }
 __device__ __forceinline__ int ld_row_u8(__amdgpu_buffer_rsrc_t buf, unsigned lane, unsigned row) {
     return (int)__builtin_amdgcn_raw_buffer_load_b8(buf, lane, row, 0);
@@ -517,7 +524,7 @@ __device__ __forceinline__ void cont_joints_chunk(const ContRunArgs& K, SharedTa
     if (live && sing) K.flags[t * n + i] = (uint8_t)(flag | 4);
     // one event byte per (chunk, trajectory): OR over the chunk's steps
     const unsigned long long evm = __ballot(ev && live);
-    if (live && sl == 0) K.chunk_event[c * n + i] = ((evm >> tl) & 0x0101010101010101ull) != 0 ? 1 : 0;
+    if (live && sl == 0) pipe_store(&K.chunk_event[c * n + i], (uint8_t)(((evm >> tl) & 0x0101010101010101ull) != 0 ? 1 : 0));
     // rows out: the wave's 64 rows are 8 runs (one per step) of 8 x 7 consecutive doubles; 32-bit offsets from the chunk's
     // first row (a block's joints stay below 2 GB, see rsik_control_continuous_run)
 #pragma unroll

@@ -146,10 +146,17 @@ __device__ __forceinline__ Acc<MIXED> make_acc(const ArmC* arms, bool isl, Share
 #define RSIK_NT_LOAD 0
 #endif
 typedef double f64x2 __attribute__((ext_vector_type(2)));
-template <class T>
+// kStoreStream: non-temporal.  kStoreThrough: written through to system scope (sc0 sc1) — nothing of the kernel's output is left dirty in
+// the eight L2s for the write-back at its end, which the next launch of a stream (and every launch that waits for this one) sits behind.
+// Round 6, same box, interleaved: the discrete kernel 15.0 -> 14.6 us per 262 144 matrices, the trajectory pipeline -1.3 ... -1.5 % per pass
+// in every launch form (its kernels' ends are what its hand-overs wait for); the solve kernel, four rounds of waves long, 31.3 -> 31.7 us
+// with it: that one keeps the non-temporal form (docs/experiments.md R6.8).
+constexpr int kStoreStream = 1, kStoreThrough = 2;
+template <int POLICY = kStoreStream, class T>
 __device__ __forceinline__ void st_stream(T* p, T v) {
 #if RSIK_NT_STORE
-    __builtin_nontemporal_store(v, p);
+    if constexpr (POLICY == kStoreThrough && sizeof(T) <= 8) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else __builtin_nontemporal_store(v, p);
 #else
     *p = v;
 #endif
@@ -164,7 +171,7 @@ __device__ __forceinline__ T ld_stream(const T* p) {
 }
 
 // Writes ROWxW doubles per lane as a contiguous [64*W] slab per wave (row-major [n,W] output).
-template <int W>
+template <int W, int POLICY = kStoreStream>
 __device__ __forceinline__ void store_rows(double* __restrict__ out, int64_t wave_base, int64_t n, int lane,
                                            double* __restrict__ lds_wave, const double (&vals)[W]) {
 #pragma unroll
@@ -180,13 +187,13 @@ __device__ __forceinline__ void store_rows(double* __restrict__ out, int64_t wav
 #pragma unroll
         for (int k = 0; k < W; k++) v[k] = lds_wave[k * 64 + lane];
 #pragma unroll
-        for (int k = 0; k < W; k++) st_stream(dst + k * 64 + lane, v[k]);
+        for (int k = 0; k < W; k++) st_stream<POLICY>(dst + k * 64 + lane, v[k]);
     } else {
         const int64_t total = rows * W;
 #pragma unroll
         for (int k = 0; k < W; k++) {
             int idx = k * 64 + lane;
-            if (idx < total) st_stream(dst + idx, lds_wave[idx]);
+            if (idx < total) st_stream<POLICY>(dst + idx, lds_wave[idx]);
         }
     }
     __builtin_amdgcn_wave_barrier();
